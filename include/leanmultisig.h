@@ -1,0 +1,105 @@
+/* leanmultisig.h — C ABI of the MI355X-native proving hot path of leanMultisig.
+ *
+ * Drop-in boundary: the reference has no FFI; the entry points below are what a Rust `extern "C"`
+ * shim inside crates/whir, crates/sub_protocols and crates/backend/{sumcheck,fiat-shamir} would bind to replace the
+ * bodies of the cited Rust functions (citations are relative to the reference checkout).  INTEGRATION.md shows the shim.
+ *
+ * Conventions
+ *   - every field value is a u32 in Montgomery form (R = 2^32) of KoalaBear p = 0x7f000001 — the in-memory
+ *     representation of the reference (crates/backend/koala-bear/src/monty_31/monty_31.rs:33-41);
+ *   - an extension element (EF) handed over on the HOST is 5 consecutive u32 (quintic_extension/extension.rs:25-35);
+ *   - a DEVICE array of EF of length n is SoA: 5 planes of n u32 (plane k = coefficient of X^k); lm_ef_aos_to_soa /
+ *     lm_ef_soa_to_aos convert on the device;
+ *   - pointers named d_* are device (HBM) pointers, everything else is host memory;
+ *   - multilinear convention of the reference: point[0] <-> most significant index bit (poly/src/evals.rs:142-347);
+ *   - one lm_ctx per GPU/stream, not re-entrant; calls are serialised by the (single) prover thread, like the single
+ *     `&mut impl FSProver` of the reference (fiat-shamir/src/traits.rs:15-44);
+ *   - every function returns 0 on success, a negative LM_E_* code otherwise; nothing unwinds across the ABI;
+ *   - integers derived from f64 maths in WhirConfig::new (query counts, PoW bits, folding factors;
+ *     whir/src/config.rs:146-334) are inputs, never re-derived here.
+ */
+#ifndef LEANMULTISIG_H
+#define LEANMULTISIG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_OK 0
+#define LM_E_INVALID (-1)  /* bad argument */
+#define LM_E_DEVICE (-2)   /* HIP runtime error (see lm_last_error) */
+#define LM_E_NOMEM (-3)
+
+#define LM_DIGEST_WORDS 8 /* symetric/src/merkle.rs:11 */
+#define LM_EF_DIM 5
+
+typedef struct lm_ctx lm_ctx;
+typedef struct lm_tree lm_tree;
+
+/* ---- context, memory ------------------------------------------------------------------------------------------- */
+int lm_ctx_create(int device, lm_ctx** out);
+void lm_ctx_destroy(lm_ctx* ctx);
+const char* lm_last_error(void);
+int lm_sync(lm_ctx* ctx);
+/* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing by the caller */
+void* lm_ctx_stream(lm_ctx* ctx);
+
+int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
+int lm_free(lm_ctx* ctx, uint32_t* d_ptr);
+int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words);
+int lm_download(lm_ctx* ctx, uint32_t* dst, const uint32_t* d_src, uint64_t n_words);
+int lm_memset_zero(lm_ctx* ctx, uint32_t* d_dst, uint64_t n_words);
+int lm_ef_aos_to_soa(lm_ctx* ctx, const uint32_t* d_aos, uint32_t* d_soa, uint64_t n);
+int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64_t n);
+
+/* ---- hash ------------------------------------------------------------------------------------------------------ */
+/* n independent Poseidon1-16 permutations / compressions (perm(x)+x) of 16-word states, d_states = n x 16 words,
+ * in place.  Replaces Poseidon1KoalaBear16::{permute_mut,compress_in_place}
+ * (crates/backend/koala-bear/src/poseidon1_koalabear_16.rs:873-912,1018-1030). */
+int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
+int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
+
+/* ---- WHIR commitment: LDE + Merkle tree -------------------------------------------------------------------------
+ * lm_commit replaces reorder_and_dft (crates/whir/src/utils.rs:69-98: prepare_evals_for_fft_unpacked :128-150 +
+ * EvalsDft::dft_algebra_batch_by_evals crates/whir/src/dft.rs:79-155) followed by MerkleData::build
+ * (crates/whir/src/commit.rs:17-32 -> merkle_commit/build_merkle_tree_koalabear crates/whir/src/merkle.rs:28-88).
+ *
+ *   d_evals        2^n_vars evaluations of the multilinear polynomial; base words, or (is_ext) SoA EF
+ *   folding_factor k: the matrix has 2^k columns, column c = c-th contiguous 2^(n_vars-k) slice
+ *   log_inv_rate   each value repeated 2^log_inv_rate times before the transform; h = 2^(n_vars+log_inv_rate-k) rows
+ *   actual_len     d_evals[actual_len..] is all zero (WhirConfig::commit, commit.rs:64-99); columns that are
+ *                  entirely zero are neither transformed nor stored, and are absorbed through the zero-suffix sponge
+ *                  state like first_digest_layer_with_initial_state (merkle.rs:251-287).  Pass 2^n_vars if unknown.
+ *   root           8 words (host)
+ * The LDE matrix and all digest layers stay resident in HBM inside *out until lm_tree_free. */
+int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t folding_factor,
+              uint32_t log_inv_rate, uint64_t actual_len, lm_tree** out, uint32_t root[LM_DIGEST_WORDS]);
+void lm_tree_free(lm_ctx* ctx, lm_tree* tree);
+uint32_t lm_tree_log_height(const lm_tree* tree);
+/* number of base words of one (zero-padded) leaf: 2^k, or 5 * 2^k for EF */
+uint32_t lm_tree_leaf_words(const lm_tree* tree);
+/* Batched MerkleData::open (commit.rs:34-46 -> WhirMerkleTree::open merkle.rs:205-211 + open_siblings
+ * symetric/src/merkle.rs:43-47).  leaves: n_idx x leaf_words (EF leaves flattened coefficient-minor exactly like
+ * flatten_to_base); siblings: n_idx x log_height x 8, bottom-up. */
+int lm_tree_open(lm_ctx* ctx, const lm_tree* tree, const uint64_t* indices, uint32_t n_idx, uint32_t* leaves,
+                 uint32_t* siblings);
+/* test/debug access: copy the device-resident LDE matrix out in the reference's row-major order (h x leaf_words) */
+int lm_tree_download_matrix(lm_ctx* ctx, const lm_tree* tree, uint32_t* rows);
+/* test/debug access: all digest layers bottom-up, (2h - 1) x 8 words */
+int lm_tree_download_digests(lm_ctx* ctx, const lm_tree* tree, uint32_t* digests);
+
+/* ---- multilinear evaluation --------------------------------------------------------------------------------------
+ * EvaluationsList::evaluate (crates/backend/poly/src/evals.rs:26,142-347): out = sum_i v[i] * eq(point, i).
+ * n_polys polynomials of 2^n_vars values each at d_evals + p * stride_words (base) — or SoA EF with plane stride
+ * 2^n_vars at d_evals + p * stride_words (is_ext) — all at the same point (n_vars x 5 host words).
+ * out: n_polys x 5 host words. */
+int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
+                uint64_t stride_words, const uint32_t* point, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEANMULTISIG_H */

@@ -1,0 +1,9 @@
+"""leanmultisig_amd — MI355X-native proving hot path of leanMultisig (WHIR commitment, sumchecks, logup/GKR).
+
+The product is the HIP shared library `libleanmultisig_hip.so` (C ABI: include/leanmultisig.h).  This package is the
+ctypes binding used by the tests and bench; it never falls back to a CPU implementation: if the library is missing
+`load()` raises.
+"""
+from .capi import Context, load, LIB_PATH, LmError  # noqa: F401
+
+__all__ = ["Context", "load", "LIB_PATH", "LmError"]

@@ -1,0 +1,397 @@
+// WHIR commitment on gfx950: LDE (gather/replicate + evaluation-domain radix-2 NTT), Poseidon1-16 leaf sponge,
+// Merkle levels, batched openings.
+//
+// HBM layout: the LDE matrix is COLUMN-major (one column = h contiguous words) — column c of the reference's
+// row-major matrix (crates/whir/src/utils.rs:128-150) is the c-th contiguous slice of the committed polynomial, so
+// the gather is a replicate-on-load, every NTT pass streams whole columns, and the leaf sponge (one row per lane)
+// reads 64 consecutive rows of a column per wave instruction: fully coalesced.  An EF matrix of C columns is stored
+// as 5*C base columns in plane-major order (k*C + c); the reference's leaf word 5c+k maps to that column.
+#include "lm_common.h"
+
+using namespace kb;
+
+// =====================================================================================================
+// NTT.  Layer l (1-based) of the reference (crates/whir/src/dft.rs:79-144,548-568): blocks of 2^l rows, j < 2^(l-1):
+//   a = v[j], b = v[j + 2^(l-1)], d = (b - a) * w_{2^l}^j, v[j] = a + d, v[j + 2^(l-1)] = a - d.
+// One pass executes layers S+1 .. S+K on an LDS tile of 2^K "hi" values x 2^m consecutive "lo" values:
+//   element e = blk * 2^(S+K) + hi * 2^S + lo.
+// Twiddle of layer S+q+1 for (hi, lo):  w_{2^(q+1)}^(hi mod 2^q) * w_{2^(S+q+1)}^lo ; the first factor comes from the
+// small layered table (LDS), the second depends only on (q, lo) and is staged once per workgroup.
+// =====================================================================================================
+struct NttArgs {
+    u32 log_h, S, K, m;
+    u32 first;      // 1: read (replicated) input, 0: in place
+    u32 log_rate;   // replicate factor of the first pass
+    u64 in_col_len; // input words per column (first pass)
+};
+
+__global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u32* __restrict__ out,
+                                                  const u32* __restrict__ tw_big, const u32* __restrict__ tw_small,
+                                                  NttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u32 K = a.K, m = a.m, S = a.S;
+    const u32 tile = 1u << (K + m);
+    u32* data = lds;
+    u32* tws = lds + tile;              // 2^K words
+    u32* twlo = tws + (1u << K);        // K * 2^m words (S > 0 only)
+    const u32 tid = threadIdx.x;
+    const u64 h = 1ull << a.log_h;
+    const u64 col = blockIdx.y;
+    const u32 t = blockIdx.x;
+    const u32 lo_tiles_log = S - m;  // S >= m
+    const u64 blk = t >> lo_tiles_log;
+    const u32 lo_tile = t & ((1u << lo_tiles_log) - 1);
+    const u64 base = (blk << (S + K)) + ((u64)lo_tile << m);
+
+    for (u32 x = tid; x < (1u << K); x += 256) tws[x] = tw_small[x];
+    if (S > 0) {
+        for (u32 x = tid; x < (K << m); x += 256) {
+            u32 q = x >> m, lo_l = x & ((1u << m) - 1);
+            u32 l = S + q + 1;
+            u64 lo = ((u64)lo_tile << m) + lo_l;
+            twlo[x] = tw_big[lo << (LM_TW_LOG - l)];
+        }
+    }
+    if (a.first) {
+        const u32* src = in + col * a.in_col_len;
+        for (u32 x = tid; x < tile; x += 256) {
+            u32 hi = x >> m, lo_l = x & ((1u << m) - 1);
+            u64 e = base + ((u64)hi << S) + lo_l;
+            data[x] = src[e >> a.log_rate];
+        }
+    } else {
+        const u32* src = out + col * h;
+        for (u32 x = tid; x < tile; x += 256) {
+            u32 hi = x >> m, lo_l = x & ((1u << m) - 1);
+            u64 e = base + ((u64)hi << S) + lo_l;
+            data[x] = src[e];
+        }
+    }
+    for (u32 q = 0; q < K; q++) {
+        __syncthreads();
+        const u32 bp = q + m;
+        for (u32 b = tid; b < (tile >> 1); b += 256) {
+            u32 x0 = ((b >> bp) << (bp + 1)) | (b & ((1u << bp) - 1));
+            u32 x1 = x0 | (1u << bp);
+            u32 hi = x0 >> m;
+            u32 w = tws[(1u << q) + (hi & ((1u << q) - 1))];
+            if (S > 0) w = mul(w, twlo[(q << m) + (x0 & ((1u << m) - 1))]);
+            u32 va = data[x0], vb = data[x1];
+            u32 d = mul(sub(vb, va), w);
+            data[x0] = add(va, d);
+            data[x1] = sub(va, d);
+        }
+    }
+    __syncthreads();
+    u32* dst = out + col * h;
+    for (u32 x = tid; x < tile; x += 256) {
+        u32 hi = x >> m, lo_l = x & ((1u << m) - 1);
+        u64 e = base + ((u64)hi << S) + lo_l;
+        dst[e] = data[x];
+    }
+}
+
+// columns: n_cols contiguous inputs of in_col_len = h >> log_rate words at d_in; output column-major n_cols x h.
+static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 n_cols, u32 log_h, u32 log_rate) {
+    LM_REQUIRE(log_h <= LM_TW_LOG);
+    if (log_h == 0) {
+        LM_HIP(hipMemcpyAsync(d_out, d_in, (u64)n_cols * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return LM_OK;
+    }
+    const u32 K1 = log_h < 12 ? log_h : 12;
+    u32 done = 0;
+    {
+        NttArgs a{log_h, 0, K1, 0, 1, log_rate, (1ull << log_h) >> log_rate};
+        dim3 grid(1u << (log_h - K1), n_cols);
+        size_t sh = ((1u << K1) * 2) * 4;
+        hipLaunchKernelGGL(k_ntt_pass, grid, dim3(256), sh, ctx->stream, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        done = K1;
+    }
+    u32 rem = log_h - done;
+    u32 n_pass = (rem + 8) / 9;
+    for (u32 p = 0; p < n_pass; p++) {
+        u32 K = (rem + (n_pass - p) - 1) / (n_pass - p);
+        u32 m = 13 - K;
+        if (m > done) m = done;
+        NttArgs a{log_h, done, K, m, 0, 0, 0};
+        dim3 grid(1u << (log_h - K - m), n_cols);
+        size_t sh = ((1u << (K + m)) + (1u << K) + (K << m)) * 4;
+        hipLaunchKernelGGL(k_ntt_pass, grid, dim3(256), sh, ctx->stream, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        done += K;
+        rem -= K;
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+// =====================================================================================================
+// Leaf sponge: digest(row) = hash_slice(row zero-padded to the full leaf width)
+// (crates/backend/symetric/src/sponge.rs:7-24; crates/whir/src/merkle.rs:215-287).  One row per lane.
+// =====================================================================================================
+struct LeafArgs {
+    u64 h;
+    u32 is_ext;
+    u32 stored_cols;   // EF: number of EF columns stored (plane stride); base: number of base columns stored
+    u32 eff_words;     // words of the leaf that are backed by stored columns; the rest are zero
+    u32 total_chunks;  // leaf_words / 8
+    u32 data_chunks;   // chunks 0 .. data_chunks-1 may hold data
+    u32 has_init;      // state after the all-zero suffix chunks was precomputed on the host
+    u32 init[16];
+};
+
+__device__ __forceinline__ void load_chunk(const u32* __restrict__ mat, const LeafArgs& a, u64 row, u32 c, u32* dst) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 w = c * 8 + i;
+        u32 v = 0;
+        if (w < a.eff_words) {
+            u32 colidx = a.is_ext ? (w % 5) * a.stored_cols + w / 5 : w;
+            v = mat[(u64)colidx * a.h + row];
+        }
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_leaf_sponge(const u32* __restrict__ mat, u32* __restrict__ digests, LeafArgs a) {
+    u64 row = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.h) return;
+    u32 s[16];
+    int c;
+    if (a.has_init) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = a.init[i];
+        c = (int)a.data_chunks - 1;
+    } else {
+        load_chunk(mat, a, row, a.total_chunks - 2, s);
+        load_chunk(mat, a, row, a.total_chunks - 1, s + 8);
+        poseidon16_compress(s);
+        c = (int)a.total_chunks - 3;
+    }
+    for (; c >= 0; c--) {
+        load_chunk(mat, a, row, (u32)c, s + 8);
+        poseidon16_compress(s);
+    }
+    uint4* o = reinterpret_cast<uint4*>(digests + row * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// one Merkle level: next[i] = compress(prev[2i] || prev[2i+1])  (symetric/src/merkle.rs:50-90, compression.rs:5-15)
+__global__ __launch_bounds__(256) void k_compress_layer(const u32* __restrict__ prev, u32* __restrict__ next, u64 n) {
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4* p = reinterpret_cast<const uint4*>(prev + i * 16);
+    uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    u32 s[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    poseidon16_compress(s);
+    uint4* o = reinterpret_cast<uint4*>(next + i * 8);
+    o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__global__ __launch_bounds__(256) void k_poseidon_batch(u32* __restrict__ states, u64 n, int compress) {
+    u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4* p = reinterpret_cast<uint4*>(states + i * 16);
+    uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    u32 s[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    if (compress)
+        poseidon16_compress(s);
+    else
+        poseidon16_permute(s);
+    p[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    p[1] = make_uint4(s[4], s[5], s[6], s[7]);
+    p[2] = make_uint4(s[8], s[9], s[10], s[11]);
+    p[3] = make_uint4(s[12], s[13], s[14], s[15]);
+}
+
+// batched opening: block b serves indices[b]
+__global__ __launch_bounds__(256) void k_tree_open(const u32* __restrict__ mat, const u32* __restrict__ digests,
+                                                   const u64* __restrict__ indices, u32* __restrict__ leaves,
+                                                   u32* __restrict__ siblings, u64 h, u32 log_h, u32 is_ext,
+                                                   u32 stored_cols, u32 eff_words, u32 leaf_words) {
+    const u64 idx = indices[blockIdx.x];
+    for (u32 w = threadIdx.x; w < leaf_words; w += 256) {
+        u32 v = 0;
+        if (w < eff_words) {
+            u32 colidx = is_ext ? (w % 5) * stored_cols + w / 5 : w;
+            v = mat[(u64)colidx * h + idx];
+        }
+        leaves[(u64)blockIdx.x * leaf_words + w] = v;
+    }
+    for (u32 x = threadIdx.x; x < log_h * 8; x += 256) {
+        u32 lvl = x >> 3, k = x & 7;
+        // layer lvl starts at offset sum_{i<lvl} (h >> i) = 2h - (h >> (lvl-1)) ... computed incrementally
+        u64 off = 2 * h - (2 * h >> lvl);
+        u64 node = (idx >> lvl) ^ 1;
+        siblings[(u64)blockIdx.x * log_h * 8 + x] = digests[(off + node) * 8 + k];
+    }
+}
+
+extern "C" {
+
+int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n) {
+    LM_REQUIRE(ctx && d_states);
+    if (n == 0) return LM_OK;
+    hipLaunchKernelGGL(k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n, 0);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n) {
+    LM_REQUIRE(ctx && d_states);
+    if (n == 0) return LM_OK;
+    hipLaunchKernelGGL(k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n, 1);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t folding_factor,
+              uint32_t log_inv_rate, uint64_t actual_len, lm_tree** out, uint32_t root[LM_DIGEST_WORDS]) {
+    LM_REQUIRE(ctx && d_evals && out && root);
+    LM_REQUIRE(folding_factor >= 1 && folding_factor <= n_vars);
+    LM_REQUIRE(n_vars + log_inv_rate - folding_factor <= LM_TW_LOG);
+    const u64 len = 1ull << n_vars;
+    LM_REQUIRE(actual_len >= 1 && actual_len <= len);
+    const u32 n_cols = 1u << folding_factor;
+    const u32 dim = is_ext ? 5 : 1;
+    LM_REQUIRE((n_cols * dim) % 8 == 0 && n_cols * dim >= 16);
+    const u64 col_len = len >> folding_factor;
+    const u32 log_h = n_vars + log_inv_rate - folding_factor;
+    const u64 h = 1ull << log_h;
+    // WhirConfig::commit, commit.rs:70-73
+    const u32 eff_cols = (u32)((actual_len + col_len - 1) / col_len);
+
+    lm_tree* t = new lm_tree();
+    t->log_h = log_h;
+    t->is_ext = is_ext ? 1 : 0;
+    t->n_cols = n_cols;
+    t->eff_cols = eff_cols;
+    t->stored_words = eff_cols * dim;
+    t->leaf_words = n_cols * dim;
+    if (hipMalloc(&t->d_matrix, (u64)t->stored_words * h * 4) != hipSuccess ||
+        hipMalloc(&t->d_digests, (2 * h - 1) * 8 * 4) != hipSuccess) {
+        lm_set_error("lm_commit: hipMalloc failed (%llu + %llu bytes)", (unsigned long long)t->stored_words * h * 4,
+                     (unsigned long long)(2 * h - 1) * 32);
+        if (t->d_matrix) (void)hipFree(t->d_matrix);
+        delete t;
+        return LM_E_NOMEM;
+    }
+    int rc;
+    if (!is_ext) {
+        rc = lde_columns(ctx, d_evals, t->d_matrix, eff_cols, log_h, log_inv_rate);
+    } else {
+        // SoA planes: plane k holds 2^n_vars words; its first eff_cols column slices are stored at k*eff_cols + c
+        rc = LM_OK;
+        for (u32 k = 0; k < 5 && rc == LM_OK; k++)
+            rc = lde_columns(ctx, d_evals + (u64)k * len, t->d_matrix + (u64)k * eff_cols * h, eff_cols, log_h,
+                             log_inv_rate);
+    }
+    if (rc != LM_OK) {
+        lm_tree_free(ctx, t);
+        return rc;
+    }
+    // leaf digests
+    LeafArgs la;
+    memset(&la, 0, sizeof la);
+    la.h = h;
+    la.is_ext = t->is_ext;
+    la.stored_cols = eff_cols;
+    la.eff_words = t->stored_words;
+    la.total_chunks = t->leaf_words / 8;
+    const u32 zero_chunks = (t->leaf_words - t->stored_words) / 8;  // merkle.rs:65
+    if (zero_chunks >= 2) {
+        // precompute_zero_suffix_state, sponge.rs:27-49 (host Poseidon, row independent)
+        u32 st[16];
+        memset(st, 0, sizeof st);
+        poseidon16_compress(st);
+        for (u32 i = 0; i + 2 < zero_chunks; i++) {
+            for (int j = 8; j < 16; j++) st[j] = 0;
+            poseidon16_compress(st);
+        }
+        la.has_init = 1;
+        memcpy(la.init, st, sizeof st);
+        la.data_chunks = la.total_chunks - zero_chunks;
+    } else {
+        la.has_init = 0;
+        la.data_chunks = la.total_chunks;
+    }
+    hipLaunchKernelGGL(k_leaf_sponge, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, t->d_matrix,
+                       t->d_digests, la);
+    // levels
+    u64 off = 0;
+    for (u64 n = h; n > 1; n >>= 1) {
+        u64 next_n = n >> 1;
+        hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           t->d_digests + off * 8, t->d_digests + (off + n) * 8, next_n);
+        off += n;
+    }
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(root, t->d_digests + (2 * h - 2) * 8, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        lm_set_error("lm_commit: kernel launch / sync failed: %s", hipGetErrorString(hipGetLastError()));
+        lm_tree_free(ctx, t);
+        return LM_E_DEVICE;
+    }
+    *out = t;
+    return LM_OK;
+}
+
+void lm_tree_free(lm_ctx* ctx, lm_tree* t) {
+    (void)ctx;
+    if (!t) return;
+    if (t->d_matrix) (void)hipFree(t->d_matrix);
+    if (t->d_digests) (void)hipFree(t->d_digests);
+    delete t;
+}
+uint32_t lm_tree_log_height(const lm_tree* t) { return t ? t->log_h : 0; }
+uint32_t lm_tree_leaf_words(const lm_tree* t) { return t ? t->leaf_words : 0; }
+
+int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_t n_idx, uint32_t* leaves,
+                 uint32_t* siblings) {
+    LM_REQUIRE(ctx && t && indices && leaves && siblings);
+    if (n_idx == 0) return LM_OK;
+    const u64 h = 1ull << t->log_h;
+    for (u32 i = 0; i < n_idx; i++) LM_REQUIRE(indices[i] < h);
+    const u64 leaf_total = (u64)n_idx * t->leaf_words, sib_total = (u64)n_idx * t->log_h * 8;
+    u32* d_tmp;
+    int rc = lm_scratch(ctx, 2ull * n_idx + leaf_total + sib_total, &d_tmp);
+    if (rc) return rc;
+    u64* d_idx = reinterpret_cast<u64*>(d_tmp);
+    u32* d_leaves = d_tmp + 2ull * n_idx;
+    u32* d_sib = d_leaves + leaf_total;
+    LM_HIP(hipMemcpyAsync(d_idx, indices, (u64)n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_tree_open, dim3(n_idx), dim3(256), 0, ctx->stream, t->d_matrix, t->d_digests, d_idx, d_leaves,
+                       d_sib, h, t->log_h, t->is_ext, t->eff_cols, t->stored_words, t->leaf_words);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(leaves, d_leaves, leaf_total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (sib_total) LM_HIP(hipMemcpyAsync(siblings, d_sib, sib_total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+int lm_tree_download_matrix(lm_ctx* ctx, const lm_tree* t, uint32_t* rows) {
+    LM_REQUIRE(ctx && t && rows);
+    const u64 h = 1ull << t->log_h;
+    std::vector<u32> cm((u64)t->stored_words * h);
+    LM_HIP(hipMemcpyAsync(cm.data(), t->d_matrix, cm.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    for (u64 r = 0; r < h; r++)
+        for (u32 w = 0; w < t->leaf_words; w++) {
+            u32 v = 0;
+            if (w < t->stored_words) {
+                u32 colidx = t->is_ext ? (w % 5) * t->eff_cols + w / 5 : w;
+                v = cm[(u64)colidx * h + r];
+            }
+            rows[r * t->leaf_words + w] = v;
+        }
+    return LM_OK;
+}
+int lm_tree_download_digests(lm_ctx* ctx, const lm_tree* t, uint32_t* digests) {
+    LM_REQUIRE(ctx && t && digests);
+    const u64 h = 1ull << t->log_h;
+    LM_HIP(hipMemcpyAsync(digests, t->d_digests, (2 * h - 1) * 32, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// Shared internals of the HIP library (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/leanmultisig.h"
+#include "kb.h"
+#include "poseidon16.h"
+
+using kb::EF;
+using kb::u32;
+using kb::u64;
+
+// generator of the 2^24-th roots of unity, canonical value (reference koala_bear.rs:50-54, last entry);
+// every smaller two-adic generator is a repeated square of it.
+static constexpr u32 LM_G24_CANON = 0x6ac49f88u;
+static constexpr int LM_TW_LOG = 24;        // big table: w_{2^24}^j for j < 2^23   (32 MiB of HBM)
+static constexpr int LM_TW_SMALL_LOG = 13;  // layered table: entry (1 << q) + j = w_{2^(q+1)}^j, q < 13
+
+void lm_set_error(const char* fmt, ...);
+
+#define LM_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            lm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return LM_E_DEVICE;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define LM_REQUIRE(cond)                                                   \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            lm_set_error("%s:%d requirement failed: %s", __FILE__, __LINE__, #cond); \
+            return LM_E_INVALID;                                           \
+        }                                                                  \
+    } while (0)
+
+struct lm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
+    u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
+    u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
+    u64 scratch_words = 0;
+    u32* h_pinned = nullptr;    // pinned host staging
+    u64 pinned_words = 0;
+};
+
+struct lm_tree {
+    u32* d_matrix = nullptr;   // column-major: stored_cols x h words
+    u32* d_digests = nullptr;  // all layers bottom-up, (2h - 1) x 8 words
+    u32 log_h = 0;
+    u32 is_ext = 0;
+    u32 n_cols = 0;          // 2^folding_factor (in EF or base elements)
+    u32 eff_cols = 0;        // effective (non-zero) columns, same unit
+    u32 stored_words = 0;    // base columns stored per row (eff_cols or 5 * eff_cols)
+    u32 leaf_words = 0;      // n_cols or 5 * n_cols
+};
+
+int lm_scratch(lm_ctx* ctx, u64 words, u32** out);
+int lm_pinned(lm_ctx* ctx, u64 words, u32** out);

@@ -1,0 +1,310 @@
+// Context, memory helpers, twiddle tables, multilinear evaluation.
+#include <stdarg.h>
+#include "lm_common.h"
+
+using namespace kb;
+
+static thread_local char g_err[512] = "";
+void lm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// tw_big[j] = w_{2^24}^j ; tw_small[(1 << q) + j] = w_{2^(q+1)}^j
+__global__ void k_init_twiddles(u32* tw_big, u32* tw_small, u32 g24) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1ull << (LM_TW_LOG - 1))) tw_big[i] = kb::pow(g24, i);
+    if (i >= 1 && i < (1ull << LM_TW_SMALL_LOG)) {
+        u32 q = 31 - __clz((u32)i);
+        u64 j = i - (1ull << q);
+        tw_small[i] = kb::pow(g24, j << (LM_TW_LOG - (q + 1)));
+    }
+    if (i == 0) tw_small[0] = ONE;
+}
+
+__global__ void k_aos_to_soa(const u32* __restrict__ aos, u32* __restrict__ soa, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 5; k++) soa[(u64)k * n + i] = aos[i * 5 + k];
+}
+__global__ void k_soa_to_aos(const u32* __restrict__ soa, u32* __restrict__ aos, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 5; k++) aos[i * 5 + k] = soa[(u64)k * n + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// eq table (SoA, n_out = 2^n entries): out[i] = prod_j (i_j p_j + (1 - i_j)(1 - p_j)), point[0] <-> MSB of i.
+// One entry per thread: n EF multiplications.  Only used for small tables (<= 2^16).
+// point: device, n x 5 words AoS.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_eq_table_small(const u32* __restrict__ point, u32 n, u32* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 len = 1u << n;
+    if (i >= len) return;
+    EF acc = ef_one();
+    for (u32 j = 0; j < n; j++) {
+        EF p;
+#pragma unroll
+        for (int k = 0; k < 5; k++) p.v[k] = point[j * 5 + k];
+        u32 bit = (i >> (n - 1 - j)) & 1;
+        EF f = bit ? p : ef_sub(ef_one(), p);
+        acc = ef_mul(acc, f);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) out[(u64)k * len + i] = acc.v[k];
+}
+
+__device__ __forceinline__ EF wave_reduce_ef(EF v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        EF o;
+#pragma unroll
+        for (int k = 0; k < 5; k++) o.v[k] = __shfl_down(v.v[k], off, 64);
+        v = ef_add(v, o);
+    }
+    return v;
+}
+// result valid in thread 0
+__device__ __forceinline__ EF block_reduce_ef(EF v, u32* lds /* >= 20 words */) {
+    v = wave_reduce_ef(v);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) lds[wave * 5 + k] = v.v[k];
+    }
+    __syncthreads();
+    EF r = ef_zero();
+    if (threadIdx.x == 0) {
+        for (u32 w = 0; w < (blockDim.x >> 6); w++) {
+            EF o;
+#pragma unroll
+            for (int k = 0; k < 5; k++) o.v[k] = lds[w * 5 + k];
+            r = ef_add(r, o);
+        }
+    }
+    return r;
+}
+
+// partial[(poly * n_hi + hi)] = eq_hi[hi] * sum_lo v[hi * 2^k_lo + lo] * eq_lo[lo]
+// base values: 5 u64 accumulators with a fold every product (acc < 2^32 p, product < p^2, sum < 2^64).
+__global__ __launch_bounds__(256) void k_mle_partial_base(const u32* __restrict__ evals, u64 stride_words, u32 k_lo,
+                                                          const u32* __restrict__ eq_lo, const u32* __restrict__ eq_hi,
+                                                          u32 n_hi, u32* __restrict__ partial) {
+    __shared__ u32 red[32];
+    const u32 hi = blockIdx.x, poly = blockIdx.y;
+    const u32 len_lo = 1u << k_lo;
+    const u32* v = evals + (u64)poly * stride_words + (u64)hi * len_lo;
+    u64 acc[5] = {0, 0, 0, 0, 0};
+    for (u32 i = threadIdx.x; i < len_lo; i += 256) {
+        u32 x = v[i];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            u64 t = acc[k] + (u64)x * eq_lo[(u64)k * len_lo + i];
+            u64 y = t - P_SHL32;
+            acc[k] = t >= P_SHL32 ? y : t;
+        }
+    }
+    EF s;
+#pragma unroll
+    for (int k = 0; k < 5; k++) s.v[k] = reduce(acc[k]);
+    EF r = block_reduce_ef(s, red);
+    if (threadIdx.x == 0) {
+        EF e;
+#pragma unroll
+        for (int k = 0; k < 5; k++) e.v[k] = eq_hi[(u64)k * n_hi + hi];
+        r = ef_mul(r, e);
+#pragma unroll
+        for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_mle_partial_ext(const u32* __restrict__ evals, u64 stride_words, u64 plane,
+                                                         u32 k_lo, const u32* __restrict__ eq_lo,
+                                                         const u32* __restrict__ eq_hi, u32 n_hi,
+                                                         u32* __restrict__ partial) {
+    __shared__ u32 red[32];
+    const u32 hi = blockIdx.x, poly = blockIdx.y;
+    const u32 len_lo = 1u << k_lo;
+    const u32* v = evals + (u64)poly * stride_words + (u64)hi * len_lo;
+    EF s = ef_zero();
+    for (u32 i = threadIdx.x; i < len_lo; i += 256) {
+        EF x, e;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            x.v[k] = v[(u64)k * plane + i];
+            e.v[k] = eq_lo[(u64)k * len_lo + i];
+        }
+        s = ef_add(s, ef_mul(x, e));
+    }
+    EF r = block_reduce_ef(s, red);
+    if (threadIdx.x == 0) {
+        EF e;
+#pragma unroll
+        for (int k = 0; k < 5; k++) e.v[k] = eq_hi[(u64)k * n_hi + hi];
+        r = ef_mul(r, e);
+#pragma unroll
+        for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
+    }
+}
+// out[poly] = sum_hi partial[poly][hi]   (AoS EF)
+__global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ partial, u32 n_hi, u32* __restrict__ out) {
+    __shared__ u32 red[32];
+    const u32 poly = blockIdx.x;
+    EF s = ef_zero();
+    for (u32 i = threadIdx.x; i < n_hi; i += 256) {
+        EF x;
+#pragma unroll
+        for (int k = 0; k < 5; k++) x.v[k] = partial[((u64)poly * n_hi + i) * 5 + k];
+        s = ef_add(s, x);
+    }
+    EF r = block_reduce_ef(s, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) out[poly * 5 + k] = r.v[k];
+    }
+}
+
+int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {
+    if (words > ctx->scratch_words) {
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) LM_HIP(hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_words = 0;
+        u64 w = words < (1ull << 20) ? (1ull << 20) : words;
+        if (hipMalloc(&ctx->d_scratch, w * 4) != hipSuccess) {
+            lm_set_error("scratch hipMalloc of %llu bytes failed", (unsigned long long)w * 4);
+            return LM_E_NOMEM;
+        }
+        ctx->scratch_words = w;
+    }
+    *out = ctx->d_scratch;
+    return LM_OK;
+}
+
+extern "C" {
+
+const char* lm_last_error(void) { return g_err; }
+
+int lm_ctx_create(int device, lm_ctx** out) {
+    LM_REQUIRE(out);
+    LM_HIP(hipSetDevice(device));
+    lm_ctx* c = new lm_ctx();
+    c->device = device;
+    LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
+    LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
+    const u64 n = 1ull << (LM_TW_LOG - 1);
+    hipLaunchKernelGGL(k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->stream, c->d_tw, c->d_tw_small,
+                       to_monty(LM_G24_CANON));
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(c->stream));
+    *out = c;
+    return LM_OK;
+}
+void lm_ctx_destroy(lm_ctx* c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_tw) (void)hipFree(c->d_tw);
+    if (c->d_tw_small) (void)hipFree(c->d_tw_small);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+int lm_sync(lm_ctx* ctx) {
+    LM_REQUIRE(ctx);
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+void* lm_ctx_stream(lm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out) {
+    LM_REQUIRE(ctx && d_out && n_words > 0);
+    if (hipMalloc(d_out, n_words * 4) != hipSuccess) {
+        lm_set_error("hipMalloc of %llu bytes failed", (unsigned long long)n_words * 4);
+        return LM_E_NOMEM;
+    }
+    return LM_OK;
+}
+int lm_free(lm_ctx* ctx, uint32_t* d_ptr) {
+    LM_REQUIRE(ctx);
+    if (d_ptr) {
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+        LM_HIP(hipFree(d_ptr));
+    }
+    return LM_OK;
+}
+int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words) {
+    LM_REQUIRE(ctx && d_dst && src);
+    LM_HIP(hipMemcpyAsync(d_dst, src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+int lm_download(lm_ctx* ctx, uint32_t* dst, const uint32_t* d_src, uint64_t n_words) {
+    LM_REQUIRE(ctx && dst && d_src);
+    LM_HIP(hipMemcpyAsync(dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+int lm_memset_zero(lm_ctx* ctx, uint32_t* d_dst, uint64_t n_words) {
+    LM_REQUIRE(ctx && d_dst);
+    LM_HIP(hipMemsetAsync(d_dst, 0, n_words * 4, ctx->stream));
+    return LM_OK;
+}
+int lm_ef_aos_to_soa(lm_ctx* ctx, const uint32_t* d_aos, uint32_t* d_soa, uint64_t n) {
+    LM_REQUIRE(ctx && d_aos && d_soa);
+    if (!n) return LM_OK;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_aos, d_soa, n);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64_t n) {
+    LM_REQUIRE(ctx && d_aos && d_soa);
+    if (!n) return LM_OK;
+    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_soa, d_aos, n);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
+                uint64_t stride_words, const uint32_t* point, uint32_t* out) {
+    LM_REQUIRE(ctx && d_evals && out && n_polys >= 1 && n_vars <= 40);
+    LM_REQUIRE(n_vars == 0 || point);
+    const u32 k_lo = n_vars < 12 ? n_vars : 12;
+    const u32 k_hi = n_vars - k_lo;
+    LM_REQUIRE(k_hi <= 20);
+    const u32 n_hi = 1u << k_hi, len_lo = 1u << k_lo;
+    // scratch: point (n*5) | eq_lo (5*len_lo) | eq_hi (5*n_hi) | partial (n_polys*n_hi*5) | out (n_polys*5)
+    const u64 need = (u64)n_vars * 5 + 5ull * len_lo + 5ull * n_hi + (u64)n_polys * n_hi * 5 + (u64)n_polys * 5 + 64;
+    u32* s;
+    int rc = lm_scratch(ctx, need, &s);
+    if (rc) return rc;
+    u32* d_point = s;
+    u32* d_eq_lo = d_point + ((n_vars * 5 + 15) & ~15u);
+    u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
+    u32* d_partial = d_eq_hi + 5ull * n_hi;
+    u32* d_out = d_partial + (u64)n_polys * n_hi * 5;
+    if (n_vars) LM_HIP(hipMemcpyAsync(d_point, point, (u64)n_vars * 20, hipMemcpyHostToDevice, ctx->stream));
+    // point = (hi part: first k_hi coordinates) ++ (lo part: last k_lo coordinates)
+    hipLaunchKernelGGL(k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, ctx->stream, d_point, k_hi, d_eq_hi);
+    hipLaunchKernelGGL(k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, ctx->stream, d_point + k_hi * 5, k_lo,
+                       d_eq_lo);
+    if (!is_ext)
+        hipLaunchKernelGGL(k_mle_partial_base, dim3(n_hi, n_polys), dim3(256), 0, ctx->stream, d_evals, stride_words, k_lo,
+                           d_eq_lo, d_eq_hi, n_hi, d_partial);
+    else
+        hipLaunchKernelGGL(k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, ctx->stream, d_evals, stride_words,
+                           1ull << n_vars, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(n_polys), dim3(256), 0, ctx->stream, d_partial, n_hi, d_out);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// Poseidon1-16 over KoalaBear (x^3, 4 + 20 + 4 rounds, circulant MDS) for gfx950 lanes and for the host transcript.
+// Same permutation as the reference (crates/backend/koala-bear/src/poseidon1_koalabear_16.rs:873-912): the partial
+// rounds run in the sparse form derived by gen_poseidon_consts.py; the full rounds use the small-integer circulant
+// directly (entries <= 101, row sum 371), accumulated in 64 bits and folded with 2^31 = 2^24 - 1 (mod p).
+// One permutation = one lane; the 16-word state lives in VGPRs, every constant is wave-uniform (scalar loads).
+#pragma once
+#include "kb.h"
+
+namespace kb {
+
+struct PoseidonConsts {
+    u32 rc_init[4][16];
+    u32 rc_term[4][16];
+    u32 dm[16][16];   // D * MDS (fused linear layer of the 4th full round and the partial-block entry)
+    u32 dbias[16];    // D * first_rc
+    u32 prow[20][16]; // sparse first row per partial round
+    u32 pcol[20][16]; // sparse first column (rows 1..15) per partial round
+    u32 pscalar[20];  // lane-0 constant added after the S-box of partial round r (r < 19)
+};
+
+static const PoseidonConsts kPoseidonHost =
+#include "poseidon16_consts.inc"
+    ;
+
+#if defined(__HIPCC__)
+static __constant__ PoseidonConsts kPoseidonDev =
+#include "poseidon16_consts.inc"
+    ;
+#endif
+
+KB_HD const PoseidonConsts& poseidon_consts() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return kPoseidonDev;
+#else
+    return kPoseidonHost;
+#endif
+}
+
+// x < 2^40  ->  [0, p).   2^31 = 2^24 - 1 (mod p), applied twice.
+KB_HD u32 reduce40(u64 s) {
+    u32 a = (u32)(s >> 31);
+    u32 b = (u32)s & 0x7fffffffu;
+    u64 r1 = (u64)a * 0x00ffffffu + b;  // < 2^34
+    u32 a2 = (u32)(r1 >> 31);           // < 8
+    u32 b2 = (u32)r1 & 0x7fffffffu;
+    u32 r2 = b2 + a2 * 0x00ffffffu;     // < 2^31 + 2^27 < 2p
+    return umin(r2, r2 - P);
+}
+
+// s <- C * s with C[i][j] = col[(i - j) mod 16], col = {1,3,13,22,67,2,15,63,101,1,2,17,11,1,51,1}
+// (poseidon1_koalabear_16.rs:22,580-581).  Plain small integers act directly on Montgomery-form values.
+KB_HD void mds_circ16(u32 s[16]) {
+    constexpr u32 C[16] = {1, 3, 13, 22, 67, 2, 15, 63, 101, 1, 2, 17, 11, 1, 51, 1};
+    u32 o[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        u64 acc = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc += (u64)s[j] * C[(16 + i - j) & 15];
+        o[i] = reduce40(acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = o[i];
+}
+
+// 16-term dot product with delayed reduction (4 products per fold).
+KB_HD u32 dot16(const u32 s[16], const u32 c[16]) {
+    u64 acc = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        u64 x = (u64)s[4 * g] * c[4 * g] + (u64)s[4 * g + 1] * c[4 * g + 1] + (u64)s[4 * g + 2] * c[4 * g + 2] +
+                (u64)s[4 * g + 3] * c[4 * g + 3];  // < 4p^2 < 2^64
+        u64 y = x - P_SHL32;
+        x = x >= P_SHL32 ? y : x;                 // < 2^32 p
+        acc += x;                                 // acc < 2^32 p before this add -> < 2^33 p < 2^64
+        y = acc - P_SHL32;
+        acc = acc >= P_SHL32 ? y : acc;
+    }
+    return reduce(acc);
+}
+
+KB_HD void poseidon16_permute(u32 s[16]) {
+    const PoseidonConsts& K = poseidon_consts();
+    // 3 plain initial full rounds
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_init[r][i]));
+        mds_circ16(s);
+    }
+    // 4th full round: S-box, then fused (D * MDS) and bias
+    {
+        u32 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t[i] = cube(add(s[i], K.rc_init[3][i]));
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = add(dot16(t, K.dm[i]), K.dbias[i]);
+    }
+    // 20 partial rounds, sparse form
+#pragma unroll 1
+    for (int r = 0; r < 20; r++) {
+        u32 s0 = cube(s[0]);
+        if (r < 19) s0 = add(s0, K.pscalar[r]);
+        s[0] = s0;
+        u32 n0 = dot16(s, K.prow[r]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) s[i] = add(s[i], mul(s0, K.pcol[r][i - 1]));
+        s[0] = n0;
+    }
+    // 4 terminal full rounds
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_term[r][i]));
+        mds_circ16(s);
+    }
+}
+
+// compression mode: perm(x) + x (poseidon1_koalabear_16.rs:1018-1030)
+KB_HD void poseidon16_compress(u32 s[16]) {
+    u32 in[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) in[i] = s[i];
+    poseidon16_permute(s);
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = add(s[i], in[i]);
+}
+
+}  // namespace kb

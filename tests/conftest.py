@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from tests import oracle_binding
+    return oracle_binding.load()
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import leanmultisig_amd
+    c = leanmultisig_amd.Context(0)
+    yield c
+    c.close()

@@ -47,6 +47,12 @@ int lm_sync(lm_ctx* ctx);
 /* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing by the caller */
 void* lm_ctx_stream(lm_ctx* ctx);
 
+/* Per-kernel HIP-event timing on the context's stream (bench.py's roofline leg).  lm_profile_select(ctx, "k_name")
+ * brackets every later launch of that kernel with a pair of events ("*" = every kernel, NULL/"" = off);
+ * lm_profile_read synchronises, returns launch count and summed duration for one kernel and clears its records. */
+int lm_profile_select(lm_ctx* ctx, const char* kernel_name);
+int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms);
+
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr);
 int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words);
@@ -98,6 +104,41 @@ int lm_tree_download_digests(lm_ctx* ctx, const lm_tree* tree, uint32_t* digests
  * out: n_polys x 5 host words. */
 int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
                 uint64_t stride_words, const uint32_t* point, uint32_t* out);
+
+/* ---- weight polynomial of the WHIR sumcheck -----------------------------------------------------------------------
+ * combine_statement (crates/whir/src/open.rs:518-584), SumcheckSingle::add_new_equality / add_new_base_equality
+ * (open.rs:337-382 -> compute_eval_eq_packed / compute_eval_eq_base_packed_batched, crates/backend/poly/src/eq_mle.rs):
+ *     W[offset_j + i] += scalar_j * w_j(i),  i < 2^inner_j,
+ * with w_j = eq(point_j, .) or (is_next) matrix_next_mle_folded(point_j) (crates/backend/poly/src/next_mle.rs:35-53).
+ * offset_j = selector << inner_j.  Items that share (offset, inner) are summed in registers and W is touched once.
+ * d_W: SoA EF of 2^n_vars.  points: concatenated host EF coordinates, item j uses inner_j of them starting at
+ * point_offset_j (in EF elements).  scalars: n_items x 5 host words. */
+typedef struct {
+    uint64_t offset;       /* selector << inner_n */
+    uint32_t inner_n;      /* number of coordinates of the point */
+    uint32_t is_next;      /* 0: eq, 1: next */
+    uint64_t point_offset; /* index of the first coordinate in `points` */
+} lm_weight_item;
+int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                          const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars);
+
+/* ---- product sumcheck (WHIR) --------------------------------------------------------------------------------------
+ * One round of run_product_sumcheck / sumcheck_prove_many_rounds with ProductComputation
+ * (crates/backend/sumcheck/src/product_computation.rs:37-315): pairs (i, i + 2^(n_vars-1)) — MSB-first —
+ *     c0 = sum f[i] W[i],   c2 = sum (f[i+half] - f[i]) (W[i+half] - W[i]);   out = c0 || c2 (10 host words).
+ * d_f is base words or SoA EF, d_W is SoA EF. */
+int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars,
+                  uint32_t out_c0_c2[10]);
+/* fold_multilinear (crates/backend/poly/src/utils.rs:161-186): out[i] = in[i] + r (in[i + half] - in[i]), out is SoA
+ * EF of 2^(n_vars-1) (d_out may not alias d_in). */
+int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
+            uint32_t* d_out);
+
+/* ---- proof-of-work ------------------------------------------------------------------------------------------------
+ * FSProver::pow_grinding (crates/backend/fiat-shamir/src/prover.rs:120-177): smallest canonical w such that
+ * permute(capacity[0..8] || w || 0^7)[8], read canonically, has `bits` low zero bits.  *witness is Montgomery form.
+ * (The reference takes whichever witness rayon finds first; every verifier accepts the smallest.) */
+int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_t* witness);
 
 #ifdef __cplusplus
 }

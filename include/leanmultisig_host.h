@@ -1,0 +1,85 @@
+/* leanmultisig_host.h — host-side mirror (C++ behind a C ABI) of the reference's transcript and WHIR driver.
+ *
+ * The reference is Rust; no Rust toolchain exists in the build image, so the layer that in the reference sits ABOVE
+ * the kernels — ProverState (crates/backend/fiat-shamir/src/prover.rs), WhirConfig::commit (crates/whir/src/commit.rs)
+ * and WhirConfig::prove (crates/whir/src/open.rs) — is written in C++ over the device ABI of leanmultisig.h, with the
+ * same names, argument meaning and transcript order.  A Rust caller can either bind this coarse layer, or keep its own
+ * Rust driver and bind the fine-grained device entry points of leanmultisig.h (INTEGRATION.md shows both).
+ */
+#ifndef LEANMULTISIG_HOST_H
+#define LEANMULTISIG_HOST_H
+
+#include "leanmultisig.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_MAX_WHIR_ROUNDS 8
+
+/* The integers of WhirConfig (crates/whir/src/config.rs:118-134) — derived by the caller (f64 maths stays on the
+ * caller's side). */
+typedef struct {
+    uint32_t num_variables;
+    uint32_t starting_log_inv_rate;
+    uint32_t folding_factor_first, folding_factor_subsequent; /* FoldingFactor */
+    uint32_t rs_domain_initial_reduction_factor;
+    uint32_t commitment_ood_samples;
+    uint32_t starting_folding_pow_bits;
+    uint32_t n_rounds;
+    uint32_t final_queries, final_query_pow_bits, final_sumcheck_rounds;
+    struct {
+        uint32_t query_pow_bits, folding_pow_bits, num_queries, ood_samples;
+    } rounds[LM_MAX_WHIR_ROUNDS]; /* RoundConfig, config.rs:104-116 */
+} lm_whir_config;
+
+/* SparseStatement / SparseValue (crates/whir/src/lib.rs:31-108), flattened:
+ * statement s uses point coordinates points[point_offset .. +point_len) and values [values_offset .. +n_values) of
+ * the parallel arrays selectors[] / values[] (EF = 5 words). */
+typedef struct {
+    uint32_t point_len;
+    uint32_t is_next;
+    uint32_t n_values;
+    uint32_t reserved;
+    uint64_t point_offset;
+    uint64_t values_offset;
+} lm_sparse_statement;
+
+/* ---- ProverState (fiat-shamir/src/prover.rs:27-177; challenger.rs:9-76) ------------------------------------------ */
+typedef struct lmh_prover lmh_prover;
+lmh_prover* lmh_prover_new(void);
+void lmh_prover_free(lmh_prover* p);
+void lmh_add_base_scalars(lmh_prover* p, const uint32_t* scalars, uint64_t n);          /* FSProver::add_base_scalars */
+void lmh_observe_scalars(lmh_prover* p, const uint32_t* scalars, uint64_t n);           /* FSProver::observe_scalars */
+void lmh_add_extension_scalars(lmh_prover* p, const uint32_t* ef, uint64_t n_ef);       /* add_extension_scalars */
+void lmh_duplex(lmh_prover* p);
+int lmh_sample_vec(lmh_prover* p, uint64_t n_ef, uint32_t* out_ef);                     /* ChallengeSampler::sample_vec */
+int lmh_sample_in_range(lmh_prover* p, uint32_t bits, uint64_t n, uint64_t* out);
+/* add_sumcheck_polynomial(coeffs, eq_alpha): eq_alpha may be NULL */
+void lmh_add_sumcheck_polynomial(lmh_prover* p, const uint32_t* coeffs_ef, uint32_t n_coeffs, const uint32_t* eq_alpha);
+/* pow_grinding on the GPU with the canonical (smallest) witness */
+int lmh_pow_grinding(lm_ctx* ctx, lmh_prover* p, uint32_t bits);
+void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]);
+/* Proof = transcript + un-pruned Merkle hints (RawProof, fiat-shamir/src/transcript.rs:20-31), serialised as u32 words:
+ *   [T][transcript x T][M] then M x { index_lo, index_hi, leaf_len, path_len, leaf x leaf_len, path x path_len } */
+uint64_t lmh_proof_words(const lmh_prover* p);
+void lmh_proof_copy(const lmh_prover* p, uint32_t* out);
+
+/* ---- WHIR ------------------------------------------------------------------------------------------------------- */
+typedef struct lmh_witness lmh_witness; /* Witness, commit.rs:49-57: device-resident tree + OOD points/answers */
+/* WhirConfig::commit (commit.rs:64-99): d_poly = 2^num_variables base words in HBM. */
+int lmh_whir_commit(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* cfg, const uint32_t* d_poly, uint64_t actual_len,
+                    lmh_witness** out);
+void lmh_witness_free(lm_ctx* ctx, lmh_witness* w);
+void lmh_witness_root(const lmh_witness* w, uint32_t root[8]);
+/* WhirConfig::prove (open.rs:37-56).  Consumes the witness.  out_point: num_variables x 5 words (the folding
+ * randomness, MultilinearPoint). */
+int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* cfg, const lm_sparse_statement* statements,
+                   uint32_t n_statements, const uint32_t* points, uint64_t n_point_coords, const uint64_t* selectors,
+                   const uint32_t* values, uint64_t n_values, lmh_witness* witness, const uint32_t* d_poly,
+                   uint32_t* out_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libleanmultisig_hip.so")
-SOURCES = ["lm_core.hip", "lm_commit.hip"]
+SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "host/lm_host.cpp"]
 
 
 def _sources():
@@ -20,6 +20,7 @@ def _deps():
             if f.endswith((".h", ".inc", ".hpp")):
                 deps.append(os.path.join(root, f))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "leanmultisig.h"))
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "leanmultisig_host.h"))
     return deps
 
 

@@ -26,6 +26,8 @@ _SIGS = {
     "lm_last_error": (C.c_char_p, []),
     "lm_sync": (C.c_int, [vp]),
     "lm_ctx_stream": (vp, [vp]),
+    "lm_profile_select": (C.c_int, [vp, C.c_char_p]),
+    "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lm_free": (C.c_int, [vp, vp]),
     "lm_upload": (C.c_int, [vp, vp, vp, C.c_uint64]),
@@ -43,7 +45,82 @@ _SIGS = {
     "lm_tree_download_matrix": (C.c_int, [vp, vp, vp]),
     "lm_tree_download_digests": (C.c_int, [vp, vp, vp]),
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
+    "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
+    "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
+    "lm_fold": (C.c_int, [vp, vp, C.c_int, C.c_uint32, vp, vp]),
+    "lm_pow_grind": (C.c_int, [vp, vp, C.c_uint32, u32p]),
 }
+
+# include/leanmultisig_host.h
+_HOST_SIGS = {
+    "lmh_prover_new": (vp, []),
+    "lmh_prover_free": (None, [vp]),
+    "lmh_add_base_scalars": (None, [vp, vp, C.c_uint64]),
+    "lmh_observe_scalars": (None, [vp, vp, C.c_uint64]),
+    "lmh_add_extension_scalars": (None, [vp, vp, C.c_uint64]),
+    "lmh_duplex": (None, [vp]),
+    "lmh_sample_vec": (C.c_int, [vp, C.c_uint64, vp]),
+    "lmh_sample_in_range": (C.c_int, [vp, C.c_uint32, C.c_uint64, vp]),
+    "lmh_add_sumcheck_polynomial": (None, [vp, vp, C.c_uint32, vp]),
+    "lmh_pow_grinding": (C.c_int, [vp, vp, C.c_uint32]),
+    "lmh_challenger_state": (None, [vp, vp]),
+    "lmh_proof_words": (C.c_uint64, [vp]),
+    "lmh_proof_copy": (None, [vp, vp]),
+    "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
+    "lmh_witness_free": (None, [vp, vp]),
+    "lmh_witness_root": (None, [vp, vp]),
+    "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
+}
+
+LM_MAX_WHIR_ROUNDS = 8
+
+
+class WhirRound(C.Structure):
+    _fields_ = [("query_pow_bits", C.c_uint32), ("folding_pow_bits", C.c_uint32), ("num_queries", C.c_uint32),
+                ("ood_samples", C.c_uint32)]
+
+
+class WhirConfig(C.Structure):
+    """lm_whir_config"""
+    _fields_ = [("num_variables", C.c_uint32), ("starting_log_inv_rate", C.c_uint32),
+                ("folding_factor_first", C.c_uint32), ("folding_factor_subsequent", C.c_uint32),
+                ("rs_domain_initial_reduction_factor", C.c_uint32), ("commitment_ood_samples", C.c_uint32),
+                ("starting_folding_pow_bits", C.c_uint32), ("n_rounds", C.c_uint32), ("final_queries", C.c_uint32),
+                ("final_query_pow_bits", C.c_uint32), ("final_sumcheck_rounds", C.c_uint32),
+                ("rounds", WhirRound * LM_MAX_WHIR_ROUNDS)]
+
+    @classmethod
+    def from_dict(cls, d):
+        c = cls()
+        c.num_variables = d["num_variables"]
+        c.starting_log_inv_rate = d["starting_log_inv_rate"]
+        c.folding_factor_first = d["fold_first"]
+        c.folding_factor_subsequent = d["fold_sub"]
+        c.rs_domain_initial_reduction_factor = d["rs_red"]
+        c.commitment_ood_samples = d["commitment_ood_samples"]
+        c.starting_folding_pow_bits = d["starting_folding_pow_bits"]
+        c.n_rounds = d["n_rounds"]
+        c.final_queries = d["final_queries"]
+        c.final_query_pow_bits = d["final_query_pow_bits"]
+        c.final_sumcheck_rounds = d["final_sumcheck_rounds"]
+        for i, r in enumerate(d["rounds"]):
+            c.rounds[i].query_pow_bits = r["query_pow_bits"]
+            c.rounds[i].folding_pow_bits = r["folding_pow_bits"]
+            c.rounds[i].num_queries = r["num_queries"]
+            c.rounds[i].ood_samples = r["ood_samples"]
+        return c
+
+
+class SparseStatement(C.Structure):
+    """lm_sparse_statement"""
+    _fields_ = [("point_len", C.c_uint32), ("is_next", C.c_uint32), ("n_values", C.c_uint32), ("reserved", C.c_uint32),
+                ("point_offset", C.c_uint64), ("values_offset", C.c_uint64)]
+
+
+class WeightItem(C.Structure):
+    """lm_weight_item"""
+    _fields_ = [("offset", C.c_uint64), ("inner_n", C.c_uint32), ("is_next", C.c_uint32), ("point_offset", C.c_uint64)]
+
 
 _lib = None
 
@@ -57,10 +134,11 @@ def load():
         raise LmError(f"{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; "
                       "leanmultisig_amd has no CPU fallback")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGS.items():
-        fn = getattr(lib, name)
-        fn.restype = res
-        fn.argtypes = args
+    for sigs in (_SIGS, _HOST_SIGS):
+        for name, (res, args) in sigs.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -171,6 +249,15 @@ class Context:
     def stream(self):
         return self.lib.lm_ctx_stream(self.h)
 
+    def profile_select(self, kernel_name):
+        self._check(self.lib.lm_profile_select(self.h, kernel_name.encode() if kernel_name else None))
+
+    def profile_read(self, kernel_name):
+        """-> (n_launches, total_ms) of the selected kernel since the last read"""
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        self._check(self.lib.lm_profile_read(self.h, kernel_name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     # ---- memory -------------------------------------------------------------------------------------
     def alloc(self, n_words):
         return DeviceBuffer(self, n_words)
@@ -211,4 +298,98 @@ class Context:
         ptr = d_evals.ptr if isinstance(d_evals, DeviceBuffer) else int(d_evals)
         self._check(self.lib.lm_mle_eval(self.h, ptr, int(bool(is_ext)), n_vars, n_polys, int(stride_words),
                                          _ptr(pt) if pt.size else None, _ptr(out)))
+        return out
+
+
+    def weights_accumulate(self, d_W, n_vars, items, points, scalars):
+        """items: list of (offset, inner_n, is_next, point_offset); points (k,5); scalars (n_items,5)"""
+        arr = (WeightItem * len(items))()
+        for i, (off, inner, nxt, poff) in enumerate(items):
+            arr[i].offset, arr[i].inner_n, arr[i].is_next, arr[i].point_offset = off, inner, int(nxt), poff
+        pts = _u32(points).reshape(-1)
+        sc = _u32(scalars).reshape(-1)
+        self._check(self.lib.lm_weights_accumulate(self.h, d_W.ptr, n_vars, C.cast(arr, vp), len(items),
+                                                   _ptr(pts) if pts.size else None, pts.size // 5, _ptr(sc)))
+
+    def prod_round(self, d_f, f_is_ext, d_W, n_vars):
+        out = np.empty(10, dtype=np.uint32)
+        self._check(self.lib.lm_prod_round(self.h, d_f.ptr, int(bool(f_is_ext)), d_W.ptr, n_vars, _ptr(out)))
+        return out[:5].copy(), out[5:].copy()
+
+    def fold(self, d_in, in_is_ext, n_vars, r):
+        out = self.alloc(5 << (n_vars - 1))
+        r = _u32(r)
+        self._check(self.lib.lm_fold(self.h, d_in.ptr, int(bool(in_is_ext)), n_vars, _ptr(r), out.ptr))
+        return out
+
+    def pow_grind(self, capacity, bits):
+        cap = _u32(capacity)
+        w = C.c_uint32(0)
+        self._check(self.lib.lm_pow_grind(self.h, _ptr(cap), bits, C.byref(w)))
+        return w.value
+
+
+class Prover:
+    """lmh_prover: ProverState of the reference (transcript + challenger) driving the device."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.h = self.lib.lmh_prover_new()
+
+    def close(self):
+        if self.h:
+            self.lib.lmh_prover_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_base_scalars(self, s):
+        s = _u32(s).reshape(-1)
+        self.lib.lmh_add_base_scalars(self.h, _ptr(s), s.size)
+
+    def proof(self):
+        n = self.lib.lmh_proof_words(self.h)
+        out = np.empty(n, dtype=np.uint32)
+        self.lib.lmh_proof_copy(self.h, _ptr(out))
+        return out
+
+    def state(self):
+        out = np.empty(16, dtype=np.uint32)
+        self.lib.lmh_challenger_state(self.h, _ptr(out))
+        return out
+
+    def whir_commit(self, cfg, d_poly, actual_len):
+        w = vp()
+        self.ctx._check(self.lib.lmh_whir_commit(self.ctx.h, self.h, C.byref(cfg), d_poly.ptr, int(actual_len), C.byref(w)))
+        return w.value
+
+    def whir_prove(self, cfg, statements, witness, d_poly):
+        """statements: list of dict(point=(k,5), is_next, values=[(selector, ef5)])"""
+        arr = (SparseStatement * max(len(statements), 1))()
+        pts, sels, vals = [], [], []
+        for i, s in enumerate(statements):
+            pt = np.asarray(s["point"], dtype=np.uint32).reshape(-1, 5)
+            arr[i].point_len = pt.shape[0]
+            arr[i].is_next = int(bool(s.get("is_next", False)))
+            arr[i].n_values = len(s["values"])
+            arr[i].point_offset = sum(p.shape[0] for p in pts)
+            arr[i].values_offset = len(sels)
+            pts.append(pt)
+            for sel, v in s["values"]:
+                sels.append(sel)
+                vals.append(np.asarray(v, dtype=np.uint32))
+        pts = np.concatenate(pts).reshape(-1) if pts else np.zeros(0, dtype=np.uint32)
+        pts = np.ascontiguousarray(pts, dtype=np.uint32)
+        sels = np.array(sels or [0], dtype=np.uint64)
+        vals = np.ascontiguousarray(np.array(vals or [[0] * 5], dtype=np.uint32))
+        out = np.empty((cfg.num_variables, 5), dtype=np.uint32)
+        self.ctx._check(self.lib.lmh_whir_prove(self.ctx.h, self.h, C.byref(cfg), C.cast(arr, vp), len(statements),
+                                                _ptr(pts) if pts.size else None, pts.size // 5, _ptr(sels), _ptr(vals),
+                                                len(statements) and sum(len(s["values"]) for s in statements),
+                                                witness, d_poly.ptr, _ptr(out)))
         return out

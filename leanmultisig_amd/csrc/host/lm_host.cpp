@@ -1,0 +1,534 @@
+// Host-side mirror of the reference's transcript and WHIR driver (see include/leanmultisig_host.h).
+// Everything heavy goes through the device ABI (include/leanmultisig.h); this file only sequences the protocol:
+// Fiat–Shamir state, round polynomials, query sampling, tiny leaf evaluations.
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../../include/leanmultisig_host.h"
+#include "../kb.h"
+#include "../poseidon16.h"
+
+using kb::EF;
+using kb::u32;
+using kb::u64;
+
+namespace {
+
+// ---- Challenger (crates/backend/fiat-shamir/src/challenger.rs:9-76): overwrite-mode duplex, plain permutation -----
+struct Challenger {
+    u32 state[16];
+    bool rate_fresh = false;
+    Challenger() { memset(state, 0, sizeof state); }
+    void observe(const u32 v[8]) {
+        memcpy(state + 8, v, 32);
+        kb::poseidon16_permute(state);
+        rate_fresh = true;
+    }
+    void observe_many(const u32* s, u64 n) {
+        for (u64 off = 0; off < n; off += 8) {
+            u32 buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            memcpy(buf, s + off, (size_t)std::min<u64>(8, n - off) * 4);
+            observe(buf);
+        }
+    }
+    void duplex() {
+        const u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        observe(z);
+    }
+    bool sample(u32 out[8]) {
+        if (!rate_fresh) return false;  // "stale rate. insert a duplex() before."
+        memcpy(out, state + 8, 32);
+        rate_fresh = false;
+        return true;
+    }
+    bool sample_many(u64 n_blocks, std::vector<u32>& out) {
+        out.clear();
+        for (u64 i = 0; i < n_blocks; i++) {
+            if (i) duplex();
+            u32 b[8];
+            if (!sample(b)) return false;
+            out.insert(out.end(), b, b + 8);
+        }
+        return true;
+    }
+};
+
+struct Opening {
+    u64 index;
+    std::vector<u32> leaf, path;
+};
+
+EF ef_load(const u32* p) {
+    EF r;
+    memcpy(r.v, p, 20);
+    return r;
+}
+
+std::vector<EF> expand_from_univariate(EF a, u32 n) {  // poly/src/point.rs:51-61
+    std::vector<EF> r(n);
+    for (u32 i = 0; i < n; i++) {
+        r[i] = a;
+        a = kb::ef_sqr(a);
+    }
+    return r;
+}
+
+// evals (2^k values, base or AoS EF) at an EF point, point[0] <-> MSB (poly/src/evals.rs:142-347)
+EF eval_leaf(const u32* leaf, bool is_ext, u32 k, const EF* point) {
+    u64 len = 1ull << k;
+    std::vector<EF> cur(len);
+    for (u64 i = 0; i < len; i++) cur[i] = is_ext ? ef_load(leaf + 5 * i) : kb::ef_from_base(leaf[i]);
+    for (u32 j = 0; j < k; j++) {
+        u64 half = len >> 1;
+        for (u64 i = 0; i < half; i++) cur[i] = kb::ef_add(cur[i], kb::ef_mul(point[j], kb::ef_sub(cur[i + half], cur[i])));
+        len = half;
+    }
+    return cur[0];
+}
+
+u32 ilog2(u64 x) {
+    u32 l = 0;
+    while ((1ull << (l + 1)) <= x) l++;
+    return l;
+}
+
+}  // namespace
+
+struct lmh_prover {
+    Challenger ch;
+    std::vector<u32> transcript;
+    std::vector<Opening> openings;
+};
+struct lmh_witness {
+    lm_tree* tree = nullptr;
+    u32 root[8];
+    std::vector<EF> ood_points, ood_answers;
+};
+
+namespace {
+
+void add_base(lmh_prover* p, const u32* s, u64 n) {
+    p->ch.observe_many(s, n);
+    p->transcript.insert(p->transcript.end(), s, s + n);
+}
+void add_ext(lmh_prover* p, const std::vector<EF>& v) {
+    std::vector<u32> f(v.size() * 5);
+    for (size_t i = 0; i < v.size(); i++) memcpy(&f[5 * i], v[i].v, 20);
+    add_base(p, f.data(), f.size());
+}
+bool sample_vec(lmh_prover* p, u64 n, std::vector<EF>& out) {  // fiat-shamir/src/utils.rs:43-58
+    std::vector<u32> fe;
+    if (!p->ch.sample_many((n * 5 + 7) / 8, fe)) return false;
+    out.resize(n);
+    for (u64 i = 0; i < n; i++) memcpy(out[i].v, &fe[5 * i], 20);
+    return true;
+}
+bool sample_in_range(lmh_prover* p, u32 bits, u64 n, std::vector<u64>& out) {  // challenger.rs:66-75
+    std::vector<u32> fe;
+    if (!p->ch.sample_many((n + 7) / 8, fe)) return false;
+    out.resize(n);
+    for (u64 i = 0; i < n; i++) out[i] = (u64)kb::from_monty(fe[i]) & ((1ull << bits) - 1);
+    return true;
+}
+// prover.rs:100-114 + utils.rs:30-41
+void add_sumcheck_poly(lmh_prover* p, const std::vector<EF>& coeffs, const EF* eq_alpha) {
+    std::vector<u32> bare(coeffs.size() * 5);
+    for (size_t i = 0; i < coeffs.size(); i++) memcpy(&bare[5 * i], coeffs[i].v, 20);
+    if (!eq_alpha) {
+        p->ch.observe_many(bare.data(), bare.size());
+    } else {
+        EF oma = kb::ef_sub(kb::ef_one(), *eq_alpha);
+        EF tam = kb::ef_sub(kb::ef_dbl(*eq_alpha), kb::ef_one());
+        size_t d = coeffs.size() - 1;
+        std::vector<EF> full;
+        full.push_back(kb::ef_mul(oma, coeffs[0]));
+        for (size_t k = 1; k <= d; k++) full.push_back(kb::ef_add(kb::ef_mul(oma, coeffs[k]), kb::ef_mul(tam, coeffs[k - 1])));
+        full.push_back(kb::ef_mul(tam, coeffs[d]));
+        std::vector<u32> f(full.size() * 5);
+        for (size_t i = 0; i < full.size(); i++) memcpy(&f[5 * i], full[i].v, 20);
+        p->ch.observe_many(f.data(), f.size());
+    }
+    p->transcript.insert(p->transcript.end(), bare.begin() + 5, bare.end());
+}
+int pow_grinding(lm_ctx* ctx, lmh_prover* p, u32 bits) {  // prover.rs:120-177
+    if (bits == 0) return LM_OK;
+    u32 w;
+    int rc = lm_pow_grind(ctx, p->ch.state, bits, &w);
+    if (rc) return rc;
+    p->ch.observe_many(&w, 1);
+    if ((kb::from_monty(p->ch.state[8]) & ((1u << bits) - 1)) != 0) return LM_E_INVALID;
+    p->transcript.push_back(w);
+    return LM_OK;
+}
+
+struct Sumcheck {  // SumcheckSingle, open.rs:322-330 — device resident
+    lm_ctx* ctx = nullptr;
+    const u32* f = nullptr;  // current evals (base at the very beginning, SoA EF afterwards)
+    bool f_is_ext = false;
+    u32* W = nullptr;        // current weights (SoA EF)
+    u32 n_vars = 0;
+    EF sum;
+    u32 *f_buf[2] = {nullptr, nullptr}, *w_buf[2] = {nullptr, nullptr};
+    int f_cur = -1, w_cur = 0;
+    ~Sumcheck() {
+        for (int i = 0; i < 2; i++) {
+            if (f_buf[i]) lm_free(ctx, f_buf[i]);
+            if (w_buf[i]) lm_free(ctx, w_buf[i]);
+        }
+    }
+};
+
+// run_product_sumcheck / run_sumcheck_many_rounds (product_computation.rs:37-125, open.rs:384-409)
+int sumcheck_rounds(lm_ctx* ctx, lmh_prover* p, Sumcheck& sc, u32 n_rounds, u32 pow_bits, std::vector<EF>& challenges) {
+    for (u32 r = 0; r < n_rounds; r++) {
+        u32 c[10];
+        int rc = lm_prod_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, c);
+        if (rc) return rc;
+        EF c0 = ef_load(c), c2 = ef_load(c + 5);
+        EF c1 = kb::ef_sub(kb::ef_sub(sc.sum, kb::ef_dbl(c0)), c2);
+        add_sumcheck_poly(p, {c0, c1, c2}, nullptr);
+        rc = pow_grinding(ctx, p, pow_bits);
+        if (rc) return rc;
+        std::vector<EF> chv;
+        if (!sample_vec(p, 1, chv)) return LM_E_INVALID;
+        EF ch = chv[0];
+        challenges.push_back(ch);
+        sc.sum = kb::ef_add(c0, kb::ef_mul(ch, kb::ef_add(c1, kb::ef_mul(ch, c2))));
+        int fn = sc.f_cur < 0 ? 0 : 1 - sc.f_cur, wn = 1 - sc.w_cur;
+        rc = lm_fold(ctx, sc.f, sc.f_is_ext, sc.n_vars, ch.v, sc.f_buf[fn]);
+        if (rc) return rc;
+        rc = lm_fold(ctx, sc.W, 1, sc.n_vars, ch.v, sc.w_buf[wn]);
+        if (rc) return rc;
+        sc.f = sc.f_buf[fn];
+        sc.f_is_ext = true;
+        sc.f_cur = fn;
+        sc.W = sc.w_buf[wn];
+        sc.w_cur = wn;
+        sc.n_vars -= 1;
+    }
+    return LM_OK;
+}
+
+int open_and_hint(lm_ctx* ctx, lmh_prover* p, const lm_tree* tree, const std::vector<u64>& idx, std::vector<u32>& leaves,
+                  u32& leaf_words) {
+    leaf_words = lm_tree_leaf_words(tree);
+    u32 log_h = lm_tree_log_height(tree);
+    leaves.resize((u64)idx.size() * leaf_words);
+    std::vector<u32> sib((u64)idx.size() * log_h * 8 + 1);
+    int rc = lm_tree_open(ctx, tree, idx.data(), (u32)idx.size(), leaves.data(), sib.data());
+    if (rc) return rc;
+    for (size_t q = 0; q < idx.size(); q++) {
+        Opening o;
+        o.index = idx[q];
+        o.leaf.assign(leaves.begin() + q * leaf_words, leaves.begin() + (q + 1) * leaf_words);
+        o.path.assign(sib.begin() + q * log_h * 8, sib.begin() + (q + 1) * log_h * 8);
+        p->openings.push_back(std::move(o));
+    }
+    return LM_OK;
+}
+
+u32 fold_at(const lm_whir_config* c, u32 round) { return round == 0 ? c->folding_factor_first : c->folding_factor_subsequent; }
+u32 total_fold(const lm_whir_config* c, u32 n_rounds) { return c->folding_factor_first + c->folding_factor_subsequent * n_rounds; }
+
+// sample_ood_points (whir/src/utils.rs:30-57) on a device polynomial
+int sample_ood(lm_ctx* ctx, lmh_prover* p, u32 n_samples, u32 num_variables, const u32* d_poly, bool is_ext,
+               std::vector<EF>& pts, std::vector<EF>& ans) {
+    pts.clear();
+    ans.clear();
+    if (!n_samples) return LM_OK;
+    if (!sample_vec(p, n_samples, pts)) return LM_E_INVALID;
+    for (EF z : pts) {
+        std::vector<EF> pt = expand_from_univariate(z, num_variables);
+        EF a;
+        int rc = lm_mle_eval(ctx, d_poly, is_ext, num_variables, 1, 0, num_variables ? pt[0].v : nullptr, a.v);
+        if (rc) return rc;
+        ans.push_back(a);
+    }
+    add_ext(p, ans);
+    return LM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+lmh_prover* lmh_prover_new(void) { return new lmh_prover(); }
+void lmh_prover_free(lmh_prover* p) { delete p; }
+void lmh_add_base_scalars(lmh_prover* p, const uint32_t* s, uint64_t n) { add_base(p, s, n); }
+void lmh_observe_scalars(lmh_prover* p, const uint32_t* s, uint64_t n) { p->ch.observe_many(s, n); }
+void lmh_add_extension_scalars(lmh_prover* p, const uint32_t* ef, uint64_t n) { add_base(p, ef, n * 5); }
+void lmh_duplex(lmh_prover* p) { p->ch.duplex(); }
+int lmh_sample_vec(lmh_prover* p, uint64_t n, uint32_t* out) {
+    std::vector<EF> v;
+    if (!sample_vec(p, n, v)) return LM_E_INVALID;
+    for (u64 i = 0; i < n; i++) memcpy(out + 5 * i, v[i].v, 20);
+    return LM_OK;
+}
+int lmh_sample_in_range(lmh_prover* p, uint32_t bits, uint64_t n, uint64_t* out) {
+    std::vector<u64> v;
+    if (bits >= 31 || !sample_in_range(p, bits, n, v)) return LM_E_INVALID;
+    memcpy(out, v.data(), n * 8);
+    return LM_OK;
+}
+void lmh_add_sumcheck_polynomial(lmh_prover* p, const uint32_t* coeffs, uint32_t n, const uint32_t* eq_alpha) {
+    std::vector<EF> c(n);
+    for (u32 i = 0; i < n; i++) c[i] = ef_load(coeffs + 5 * i);
+    if (eq_alpha) {
+        EF a = ef_load(eq_alpha);
+        add_sumcheck_poly(p, c, &a);
+    } else {
+        add_sumcheck_poly(p, c, nullptr);
+    }
+}
+int lmh_pow_grinding(lm_ctx* ctx, lmh_prover* p, uint32_t bits) { return pow_grinding(ctx, p, bits); }
+void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]) { memcpy(out16, p->ch.state, 64); }
+
+uint64_t lmh_proof_words(const lmh_prover* p) {
+    u64 n = 2 + p->transcript.size();
+    for (const Opening& o : p->openings) n += 4 + o.leaf.size() + o.path.size();
+    return n;
+}
+void lmh_proof_copy(const lmh_prover* p, uint32_t* out) {
+    u64 k = 0;
+    out[k++] = (u32)p->transcript.size();
+    memcpy(out + k, p->transcript.data(), p->transcript.size() * 4);
+    k += p->transcript.size();
+    out[k++] = (u32)p->openings.size();
+    for (const Opening& o : p->openings) {
+        out[k++] = (u32)o.index;
+        out[k++] = (u32)(o.index >> 32);
+        out[k++] = (u32)o.leaf.size();
+        out[k++] = (u32)o.path.size();
+        memcpy(out + k, o.leaf.data(), o.leaf.size() * 4);
+        k += o.leaf.size();
+        memcpy(out + k, o.path.data(), o.path.size() * 4);
+        k += o.path.size();
+    }
+}
+
+int lmh_whir_commit(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const uint32_t* d_poly, uint64_t actual_len,
+                    lmh_witness** out) {
+    if (!ctx || !p || !c || !d_poly || !out) return LM_E_INVALID;
+    lmh_witness* w = new lmh_witness();
+    int rc = lm_commit(ctx, d_poly, 0, c->num_variables, c->folding_factor_first, c->starting_log_inv_rate, actual_len,
+                       &w->tree, w->root);
+    if (rc) {
+        delete w;
+        return rc;
+    }
+    add_base(p, w->root, 8);
+    rc = sample_ood(ctx, p, c->commitment_ood_samples, c->num_variables, d_poly, false, w->ood_points, w->ood_answers);
+    if (rc) {
+        lmh_witness_free(ctx, w);
+        return rc;
+    }
+    *out = w;
+    return LM_OK;
+}
+void lmh_witness_free(lm_ctx* ctx, lmh_witness* w) {
+    if (!w) return;
+    if (w->tree) lm_tree_free(ctx, w->tree);
+    delete w;
+}
+void lmh_witness_root(const lmh_witness* w, uint32_t root[8]) { memcpy(root, w->root, 32); }
+
+int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm_sparse_statement* statements,
+                   uint32_t n_statements, const uint32_t* points, uint64_t n_point_coords, const uint64_t* selectors,
+                   const uint32_t* values, uint64_t n_values, lmh_witness* witness, const uint32_t* d_poly,
+                   uint32_t* out_point) {
+    if (!ctx || !p || !c || !witness || !d_poly || !out_point) return LM_E_INVALID;
+    const u32 n = c->num_variables;
+    if (c->n_rounds > LM_MAX_WHIR_ROUNDS) return LM_E_INVALID;
+    // validate_parameters, open.rs:18-20
+    if (n != total_fold(c, c->n_rounds) + c->final_sumcheck_rounds) return LM_E_INVALID;
+    int rc;
+
+    // ---- initialize_first_round_state (open.rs:467-510): OOD statements first, then the caller's --------------
+    std::vector<lm_weight_item> items;
+    std::vector<u32> pts;      // EF coordinates
+    std::vector<u32> scalars;  // EF per item
+    p->ch.duplex();
+    std::vector<EF> gv;
+    if (!sample_vec(p, 1, gv)) return LM_E_INVALID;
+    const EF gamma = gv[0];
+    EF gp = kb::ef_one(), sum = kb::ef_zero();
+    auto push_item = [&](u64 offset, u32 inner, u32 is_next, u64 point_off, const EF& scalar) {
+        lm_weight_item it;
+        it.offset = offset;
+        it.inner_n = inner;
+        it.is_next = is_next;
+        it.point_offset = point_off;
+        items.push_back(it);
+        scalars.insert(scalars.end(), scalar.v, scalar.v + 5);
+    };
+    for (size_t i = 0; i < witness->ood_points.size(); i++) {
+        std::vector<EF> pt = expand_from_univariate(witness->ood_points[i], n);
+        u64 off = pts.size() / 5;
+        for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
+        push_item(0, n, 0, off, gp);
+        sum = kb::ef_add(sum, kb::ef_mul(witness->ood_answers[i], gp));
+        gp = kb::ef_mul(gp, gamma);
+    }
+    const u64 user_pt_base = pts.size() / 5;
+    if (n_point_coords) pts.insert(pts.end(), points, points + n_point_coords * 5);
+    for (u32 s = 0; s < n_statements; s++) {
+        const lm_sparse_statement& st = statements[s];
+        if (st.point_len > n || st.n_values == 0 || st.point_offset + st.point_len > n_point_coords ||
+            st.values_offset + st.n_values > n_values)
+            return LM_E_INVALID;  // validate_statement, open.rs:22-28
+        for (u32 v = 0; v < st.n_values; v++) {
+            u64 sel = selectors[st.values_offset + v];
+            if (sel >= (1ull << (n - st.point_len))) return LM_E_INVALID;
+            push_item(sel << st.point_len, st.point_len, st.is_next, user_pt_base + st.point_offset, gp);
+            sum = kb::ef_add(sum, kb::ef_mul(ef_load(values + (st.values_offset + v) * 5), gp));
+            gp = kb::ef_mul(gp, gamma);
+        }
+    }
+
+    Sumcheck sc;
+    sc.ctx = ctx;
+    const u64 len = 1ull << n;
+    if ((rc = lm_malloc(ctx, 5 * len, &sc.w_buf[0]))) return rc;
+    if ((rc = lm_malloc(ctx, 5 * (len / 2) + 8, &sc.w_buf[1]))) return rc;
+    if ((rc = lm_malloc(ctx, 5 * (len / 2) + 8, &sc.f_buf[0]))) return rc;
+    if ((rc = lm_malloc(ctx, 5 * (len / 4) + 8, &sc.f_buf[1]))) return rc;
+    if ((rc = lm_memset_zero(ctx, sc.w_buf[0], 5 * len))) return rc;
+    // combine_statement, open.rs:518-584
+    rc = lm_weights_accumulate(ctx, sc.w_buf[0], n, items.data(), (u32)items.size(), pts.data(), pts.size() / 5, scalars.data());
+    if (rc) return rc;
+    sc.f = d_poly;
+    sc.f_is_ext = false;
+    sc.W = sc.w_buf[0];
+    sc.w_cur = 0;
+    sc.n_vars = n;
+    sc.sum = sum;
+    // f_buf[1] must hold the second fold (len/4) and later ones; f_buf[0] the first (len/2): ping-pong sizes shrink.
+
+    std::vector<EF> randomness;
+    if ((rc = sumcheck_rounds(ctx, p, sc, fold_at(c, 0), c->starting_folding_pow_bits, randomness))) return rc;
+
+    u64 domain_size = 1ull << (n + c->starting_log_inv_rate);
+    u32 next_domain_gen_log = ilog2(domain_size) - fold_at(c, 0);  // two_adic_generator(bits)
+    lm_tree* tree = witness->tree;
+    witness->tree = nullptr;
+    bool tree_is_ext = false;
+    const u32 g24 = kb::to_monty(0x6ac49f88u);  // generator of the 2^24-th roots (koala_bear.rs:50-54)
+    auto two_adic_generator = [&](u32 bits) {
+        u32 g = g24;
+        for (u32 i = bits; i < 24; i++) g = kb::sqr(g);
+        return g;
+    };
+    auto fail = [&](int code) {
+        if (tree) lm_tree_free(ctx, tree);
+        lmh_witness_free(ctx, witness);
+        return code;
+    };
+
+    for (u32 round = 0; round <= c->n_rounds; round++) {
+        const u32 num_variables = n - total_fold(c, round);
+        if (round == c->n_rounds) {
+            // ---- final_round (open.rs:182-248) ----
+            const u64 m = 1ull << num_variables;
+            std::vector<u32> soa(5 * m);
+            if ((rc = lm_download(ctx, soa.data(), sc.f, 5 * m))) return fail(rc);
+            std::vector<EF> coeffs(m);
+            for (u64 i = 0; i < m; i++)
+                for (int k = 0; k < 5; k++) coeffs[i].v[k] = soa[(u64)k * m + i];
+            // evals_to_coeffs, poly/src/evals.rs:44-56
+            for (u64 half = 1; half < m; half <<= 1)
+                for (u64 i = 0; i < m; i += 2 * half)
+                    for (u64 j = 0; j < half; j++) coeffs[i + j + half] = kb::ef_sub(coeffs[i + j + half], coeffs[i + j]);
+            for (u64 i = 0; i < m; i++) {
+                u64 j = 0;
+                for (u32 b = 0; b < num_variables; b++)
+                    if ((i >> b) & 1) j |= 1ull << (num_variables - 1 - b);
+                if (i < j) std::swap(coeffs[i], coeffs[j]);
+            }
+            add_ext(p, coeffs);
+            if ((rc = pow_grinding(ctx, p, c->final_query_pow_bits))) return fail(rc);
+            std::vector<u64> idx;
+            if (!sample_in_range(p, ilog2(domain_size >> fold_at(c, round)), c->final_queries, idx)) return fail(LM_E_INVALID);
+            std::vector<u32> leaves;
+            u32 lw;
+            if ((rc = open_and_hint(ctx, p, tree, idx, leaves, lw))) return fail(rc);
+            if (c->final_sumcheck_rounds > 0)
+                if ((rc = sumcheck_rounds(ctx, p, sc, c->final_sumcheck_rounds, 0, randomness))) return fail(rc);
+            break;
+        }
+        const u32 fnext = fold_at(c, round + 1);
+        const u32 rs_red = round == 0 ? c->rs_domain_initial_reduction_factor : 1;
+        const u64 new_domain_size = domain_size >> rs_red;
+        const u64 inv_rate = new_domain_size >> num_variables;
+        // reorder_and_dft + MerkleData::build on the folded polynomial (open.rs:75-90)
+        lm_tree* new_tree = nullptr;
+        u32 root[8];
+        rc = lm_commit(ctx, sc.f, 1, num_variables, fnext, ilog2(inv_rate), 1ull << num_variables, &new_tree, root);
+        if (rc) return fail(rc);
+        add_base(p, root, 8);
+        std::vector<EF> ood_points, ood_answers;
+        rc = sample_ood(ctx, p, c->rounds[round].ood_samples, num_variables, sc.f, true, ood_points, ood_answers);
+        if (!rc) rc = pow_grinding(ctx, p, c->rounds[round].query_pow_bits);
+        std::vector<u64> idx;
+        if (!rc && !sample_in_range(p, ilog2(domain_size >> fold_at(c, round)), c->rounds[round].num_queries, idx)) rc = LM_E_INVALID;
+        std::vector<u32> leaves;
+        u32 lw = 0;
+        if (!rc) rc = open_and_hint(ctx, p, tree, idx, leaves, lw);
+        if (rc) {
+            lm_tree_free(ctx, new_tree);
+            return fail(rc);
+        }
+        const u32 ff = fold_at(c, round);
+        const EF* folding_randomness = randomness.data() + (randomness.size() - ff);
+        std::vector<EF> stir_evals(idx.size());
+        for (size_t q = 0; q < idx.size(); q++) stir_evals[q] = eval_leaf(&leaves[q * lw], tree_is_ext, ff, folding_randomness);
+        p->ch.duplex();
+        std::vector<EF> g1;
+        if (!sample_vec(p, 1, g1)) {
+            lm_tree_free(ctx, new_tree);
+            return fail(LM_E_INVALID);
+        }
+        const EF g = g1[0];
+        // add_new_equality + add_new_base_equality (open.rs:337-382)
+        items.clear();
+        pts.clear();
+        scalars.clear();
+        EF gpw = kb::ef_one();
+        for (size_t i = 0; i < ood_points.size(); i++) {
+            std::vector<EF> pt = expand_from_univariate(ood_points[i], num_variables);
+            u64 off = pts.size() / 5;
+            for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
+            push_item(0, num_variables, 0, off, gpw);
+            sc.sum = kb::ef_add(sc.sum, kb::ef_mul(gpw, ood_answers[i]));
+            gpw = kb::ef_mul(gpw, g);
+        }
+        const u32 dom_gen = two_adic_generator(next_domain_gen_log);
+        for (size_t q = 0; q < idx.size(); q++) {
+            u32 z = kb::pow(dom_gen, idx[q]);
+            std::vector<EF> pt = expand_from_univariate(kb::ef_from_base(z), num_variables);
+            u64 off = pts.size() / 5;
+            for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
+            push_item(0, num_variables, 0, off, gpw);
+            sc.sum = kb::ef_add(sc.sum, kb::ef_mul(gpw, stir_evals[q]));
+            gpw = kb::ef_mul(gpw, g);
+        }
+        rc = lm_weights_accumulate(ctx, sc.W, num_variables, items.data(), (u32)items.size(), pts.data(), pts.size() / 5,
+                                   scalars.data());
+        if (!rc) rc = sumcheck_rounds(ctx, p, sc, fnext, c->rounds[round].folding_pow_bits, randomness);
+        if (rc) {
+            lm_tree_free(ctx, new_tree);
+            return fail(rc);
+        }
+        domain_size = new_domain_size;
+        next_domain_gen_log = ilog2(new_domain_size) - fnext;
+        lm_tree_free(ctx, tree);
+        tree = new_tree;
+        tree_is_ext = true;
+    }
+    if (tree) lm_tree_free(ctx, tree);
+    lmh_witness_free(ctx, witness);
+    if (randomness.size() != n) return LM_E_INVALID;
+    for (u32 i = 0; i < n; i++) memcpy(out_point + 5 * i, randomness[i].v, 20);
+    return LM_OK;
+}
+
+}  // extern "C"

@@ -104,7 +104,7 @@ static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 n_cols, u32
         NttArgs a{log_h, 0, K1, 0, 1, log_rate, (1ull << log_h) >> log_rate};
         dim3 grid(1u << (log_h - K1), n_cols);
         size_t sh = ((1u << K1) * 2) * 4;
-        hipLaunchKernelGGL(k_ntt_pass, grid, dim3(256), sh, ctx->stream, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
         done = K1;
     }
     u32 rem = log_h - done;
@@ -116,7 +116,7 @@ static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 n_cols, u32
         NttArgs a{log_h, done, K, m, 0, 0, 0};
         dim3 grid(1u << (log_h - K - m), n_cols);
         size_t sh = ((1u << (K + m)) + (1u << K) + (K << m)) * 4;
-        hipLaunchKernelGGL(k_ntt_pass, grid, dim3(256), sh, ctx->stream, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
         done += K;
         rem -= K;
     }
@@ -233,14 +233,14 @@ extern "C" {
 int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n) {
     LM_REQUIRE(ctx && d_states);
     if (n == 0) return LM_OK;
-    hipLaunchKernelGGL(k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n, 0);
+    LM_LAUNCH(ctx, k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_states, n, 0);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
 int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n) {
     LM_REQUIRE(ctx && d_states);
     if (n == 0) return LM_OK;
-    hipLaunchKernelGGL(k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, n, 1);
+    LM_LAUNCH(ctx, k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_states, n, 1);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -315,13 +315,13 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
         la.has_init = 0;
         la.data_chunks = la.total_chunks;
     }
-    hipLaunchKernelGGL(k_leaf_sponge, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, t->d_matrix,
+    LM_LAUNCH(ctx, k_leaf_sponge, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, t->d_matrix,
                        t->d_digests, la);
     // levels
     u64 off = 0;
     for (u64 n = h; n > 1; n >>= 1) {
         u64 next_n = n >> 1;
-        hipLaunchKernelGGL(k_compress_layer, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0, ctx->stream,
+        LM_LAUNCH(ctx, k_compress_layer, dim3((unsigned)((next_n + 255) / 256)), dim3(256), 0,
                            t->d_digests + off * 8, t->d_digests + (off + n) * 8, next_n);
         off += n;
     }
@@ -360,7 +360,7 @@ int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_
     u32* d_leaves = d_tmp + 2ull * n_idx;
     u32* d_sib = d_leaves + leaf_total;
     LM_HIP(hipMemcpyAsync(d_idx, indices, (u64)n_idx * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_tree_open, dim3(n_idx), dim3(256), 0, ctx->stream, t->d_matrix, t->d_digests, d_idx, d_leaves,
+    LM_LAUNCH(ctx, k_tree_open, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, d_leaves,
                        d_sib, h, t->log_h, t->is_ext, t->eff_cols, t->stored_words, t->leaf_words);
     LM_HIP(hipGetLastError());
     LM_HIP(hipMemcpyAsync(leaves, d_leaves, leaf_total * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <string>
+#include <map>
+#include <utility>
 #include "../../include/leanmultisig.h"
 #include "kb.h"
 #include "poseidon16.h"
@@ -47,7 +50,27 @@ struct lm_ctx {
     u64 scratch_words = 0;
     u32* h_pinned = nullptr;    // pinned host staging
     u64 pinned_words = 0;
+    // optional per-kernel HIP-event timing (bench.py roofline leg): only launches whose kernel name is selected
+    std::string prof_select;    // empty = profiling off; "*" = every kernel
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
+
+#define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                                  \
+    do {                                                                                                 \
+        lm_ctx* c__ = (ctx);                                                                             \
+        const bool p__ = !c__->prof_select.empty() && (c__->prof_select == "*" || c__->prof_select == #kernel); \
+        hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                       \
+        if (p__) {                                                                                       \
+            (void)hipEventCreate(&e0__);                                                                 \
+            (void)hipEventCreate(&e1__);                                                                 \
+            (void)hipEventRecord(e0__, c__->stream);                                                     \
+        }                                                                                                \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, c__->stream, __VA_ARGS__);                        \
+        if (p__) {                                                                                       \
+            (void)hipEventRecord(e1__, c__->stream);                                                     \
+            c__->prof_events[#kernel].emplace_back(e0__, e1__);                                          \
+        }                                                                                                \
+    } while (0)
 
 struct lm_tree {
     u32* d_matrix = nullptr;   // column-major: stored_cols x h words

@@ -199,7 +199,7 @@ int lm_ctx_create(int device, lm_ctx** out) {
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
     const u64 n = 1ull << (LM_TW_LOG - 1);
-    hipLaunchKernelGGL(k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->stream, c->d_tw, c->d_tw_small,
+    LM_LAUNCH(c, k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->d_tw, c->d_tw_small,
                        to_monty(LM_G24_CANON));
     LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(c->stream));
@@ -222,6 +222,30 @@ int lm_sync(lm_ctx* ctx) {
     return LM_OK;
 }
 void* lm_ctx_stream(lm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int lm_profile_select(lm_ctx* ctx, const char* kernel_name) {
+    LM_REQUIRE(ctx);
+    ctx->prof_select = kernel_name ? kernel_name : "";
+    return LM_OK;
+}
+int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms) {
+    LM_REQUIRE(ctx && kernel_name && n_launches && total_ms);
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    *n_launches = 0;
+    *total_ms = 0.0;
+    auto it = ctx->prof_events.find(kernel_name);
+    if (it == ctx->prof_events.end()) return LM_OK;
+    for (auto& pr : it->second) {
+        float ms = 0.f;
+        LM_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        *total_ms += ms;
+        *n_launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->prof_events.erase(it);
+    return LM_OK;
+}
 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out) {
     LM_REQUIRE(ctx && d_out && n_words > 0);
@@ -259,14 +283,14 @@ int lm_memset_zero(lm_ctx* ctx, uint32_t* d_dst, uint64_t n_words) {
 int lm_ef_aos_to_soa(lm_ctx* ctx, const uint32_t* d_aos, uint32_t* d_soa, uint64_t n) {
     LM_REQUIRE(ctx && d_aos && d_soa);
     if (!n) return LM_OK;
-    hipLaunchKernelGGL(k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_aos, d_soa, n);
+    LM_LAUNCH(ctx, k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_aos, d_soa, n);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
 int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64_t n) {
     LM_REQUIRE(ctx && d_aos && d_soa);
     if (!n) return LM_OK;
-    hipLaunchKernelGGL(k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_soa, d_aos, n);
+    LM_LAUNCH(ctx, k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_soa, d_aos, n);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -291,16 +315,16 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     u32* d_out = d_partial + (u64)n_polys * n_hi * 5;
     if (n_vars) LM_HIP(hipMemcpyAsync(d_point, point, (u64)n_vars * 20, hipMemcpyHostToDevice, ctx->stream));
     // point = (hi part: first k_hi coordinates) ++ (lo part: last k_lo coordinates)
-    hipLaunchKernelGGL(k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, ctx->stream, d_point, k_hi, d_eq_hi);
-    hipLaunchKernelGGL(k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, ctx->stream, d_point + k_hi * 5, k_lo,
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, d_point, k_hi, d_eq_hi);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, d_point + k_hi * 5, k_lo,
                        d_eq_lo);
     if (!is_ext)
-        hipLaunchKernelGGL(k_mle_partial_base, dim3(n_hi, n_polys), dim3(256), 0, ctx->stream, d_evals, stride_words, k_lo,
+        LM_LAUNCH(ctx, k_mle_partial_base, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words, k_lo,
                            d_eq_lo, d_eq_hi, n_hi, d_partial);
     else
-        hipLaunchKernelGGL(k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, ctx->stream, d_evals, stride_words,
+        LM_LAUNCH(ctx, k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words,
                            1ull << n_vars, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
-    hipLaunchKernelGGL(k_sum_partials, dim3(n_polys), dim3(256), 0, ctx->stream, d_partial, n_hi, d_out);
+    LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, d_partial, n_hi, d_out);
     LM_HIP(hipGetLastError());
     LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));

@@ -1,0 +1,398 @@
+// Device side of WhirConfig::prove: weight-polynomial construction, product-sumcheck rounds, folds, PoW grinding.
+#include <algorithm>
+#include "lm_common.h"
+
+using namespace kb;
+
+// =====================================================================================================
+// Weights.  W[offset + i] += sum_{items of the group} scalar_j * w_j(i)
+//   eq   : w(i) = eq(point, i) = T_hi[i >> k_lo] * T_lo[i & mask]   (scalar folded into T_hi)
+//   next : w(i) = eq(point, i - 1) for i >= 1, plus eq(point, 2^n - 1) at i = 2^n - 1
+//          (matrix_next_mle_folded, crates/backend/poly/src/next_mle.rs:35-53: weight of x = i - 1, wrap-around at the
+//          all-ones index)
+// =====================================================================================================
+static constexpr u32 W_KLO = 10;
+static constexpr u32 W_CHUNK = 1u << W_KLO;
+
+struct WItem {
+    u64 thi_off, tlo_off;  // word offsets into the table arena (SoA tables)
+    u32 inner_n, is_next;
+    u64 point_off;         // EF index into the points array
+};
+struct WGroup {
+    u64 offset;
+    u64 chunk_begin;
+    u32 inner_n, item_begin, item_end, pad;
+};
+
+// grid: (ceil(max_table/256), n_items, 2).  z = 0: T_hi over the first inner-k_lo coordinates, times the scalar;
+// z = 1: T_lo over the last k_lo coordinates.
+__global__ __launch_bounds__(256) void k_weight_tables(const WItem* __restrict__ items, const u32* __restrict__ points,
+                                                       const u32* __restrict__ scalars, u32* __restrict__ arena) {
+    const WItem it = items[blockIdx.y];
+    const u32 k_lo = it.inner_n < W_KLO ? it.inner_n : W_KLO;
+    const u32 k_hi = it.inner_n - k_lo;
+    const bool lo = blockIdx.z == 1;
+    const u32 nb = lo ? k_lo : k_hi;
+    const u32 len = 1u << nb;
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const u32* pt = points + (it.point_off + (lo ? k_hi : 0)) * 5;
+    EF acc;
+    if (lo) {
+        acc = ef_one();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc.v[k] = scalars[blockIdx.y * 5 + k];
+    }
+    for (u32 j = 0; j < nb; j++) {
+        EF p;
+#pragma unroll
+        for (int k = 0; k < 5; k++) p.v[k] = pt[j * 5 + k];
+        u32 bit = (i >> (nb - 1 - j)) & 1;
+        acc = ef_mul(acc, bit ? p : ef_sub(ef_one(), p));
+    }
+    u32* dst = arena + (lo ? it.tlo_off : it.thi_off);
+#pragma unroll
+    for (int k = 0; k < 5; k++) dst[(u64)k * len + i] = acc.v[k];
+}
+
+__device__ __forceinline__ EF weight_eq_at(const u32* __restrict__ arena, const WItem& it, u32 k_lo, u64 j) {
+    const u64 hi_len = 1ull << (it.inner_n - k_lo);
+    const u32 lo_len = 1u << k_lo;
+    const u64 jh = j >> k_lo;
+    const u32 jl = (u32)j & (lo_len - 1);
+    EF a, b;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        a.v[k] = arena[it.thi_off + (u64)k * hi_len + jh];
+        b.v[k] = arena[it.tlo_off + (u64)k * lo_len + jl];
+    }
+    return ef_mul(a, b);
+}
+
+__global__ __launch_bounds__(256) void k_weights_accumulate(u32* __restrict__ W, u64 plane, const WGroup* __restrict__ groups,
+                                                            u32 n_groups, const WItem* __restrict__ items,
+                                                            const u32* __restrict__ arena) {
+    // find the group of this block
+    u32 lo = 0, hi = n_groups - 1;
+    const u64 b = blockIdx.x;
+    while (lo < hi) {
+        u32 mid = (lo + hi + 1) >> 1;
+        if (groups[mid].chunk_begin <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const WGroup g = groups[lo];
+    const u64 len = 1ull << g.inner_n;
+    const u64 i_base = (b - g.chunk_begin) * W_CHUNK;
+    const u32 k_lo = g.inner_n < W_KLO ? g.inner_n : W_KLO;
+#pragma unroll 1
+    for (u32 u = 0; u < W_CHUNK / 256; u++) {
+        const u64 i = i_base + u * 256 + threadIdx.x;
+        if (i >= len) break;
+        EF acc = ef_zero();
+        for (u32 j = g.item_begin; j < g.item_end; j++) {
+            const WItem it = items[j];
+            if (!it.is_next) {
+                acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i));
+            } else {
+                if (i >= 1) acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i - 1));
+                if (i == len - 1) acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i));
+            }
+        }
+        u32* w = W + g.offset + i;
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[(u64)k * plane] = add(w[(u64)k * plane], acc.v[k]);
+    }
+}
+
+// =====================================================================================================
+// Product sumcheck round: partial sums per block, then one reducing block.
+// =====================================================================================================
+__device__ __forceinline__ u64 fold64(u64 t) {
+    u64 y = t - P_SHL32;
+    return t >= P_SHL32 ? y : t;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = add(v, (u32)__shfl_down(v, off, 64));
+    return v;
+}
+// sums 10 field values across the block; thread 0 writes them to dst[0..10)
+__device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, u32* dst) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 10; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) lds[wave * 10 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        u32 s = 0;
+        for (u32 w = 0; w < (blockDim.x >> 6); w++) s = add(s, lds[w * 10 + threadIdx.x]);
+        dst[threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
+                                                         u32* __restrict__ partial) {
+    __shared__ u32 red[40];
+    const u64 plane = 2 * half;
+    u64 a0[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0};
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
+        const u32 f0 = f[i], f1 = f[i + half];
+        const u32 df = sub(f1, f0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u32 w0 = W[(u64)k * plane + i], w1 = W[(u64)k * plane + i + half];
+            a0[k] = fold64(a0[k] + (u64)f0 * w0);
+            a2[k] = fold64(a2[k] + (u64)df * sub(w1, w0));
+        }
+    }
+    u32 v[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        v[k] = reduce(a0[k]);
+        v[5 + k] = reduce(a2[k]);
+    }
+    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+}
+__global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
+                                                        u32* __restrict__ partial) {
+    __shared__ u32 red[40];
+    const u64 plane = 2 * half;
+    EF c0 = ef_zero(), c2 = ef_zero();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
+        EF f0, f1, w0, w1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            f0.v[k] = f[(u64)k * plane + i];
+            f1.v[k] = f[(u64)k * plane + i + half];
+            w0.v[k] = W[(u64)k * plane + i];
+            w1.v[k] = W[(u64)k * plane + i + half];
+        }
+        c0 = ef_add(c0, ef_mul(f0, w0));
+        c2 = ef_add(c2, ef_mul(ef_sub(f1, f0), ef_sub(w1, w0)));
+    }
+    u32 v[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        v[k] = c0.v[k];
+        v[5 + k] = c2.v[k];
+    }
+    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+}
+__global__ __launch_bounds__(256) void k_sum10(const u32* __restrict__ partial, u32 n, u32* __restrict__ out) {
+    __shared__ u32 red[40];
+    u32 v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (u32 i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int k = 0; k < 10; k++) v[k] = add(v[k], partial[(u64)i * 10 + k]);
+    block_sum10(v, red, out);
+}
+
+__global__ __launch_bounds__(256) void k_fold_base(const u32* __restrict__ in, u64 half, EF r, u32* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
+        const u32 a = in[i], d = sub(in[i + half], a);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            u32 t = mul(r.v[k], d);
+            out[(u64)k * half + i] = k == 0 ? add(t, a) : t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fold_ext(const u32* __restrict__ in, u64 half, EF r, u32* __restrict__ out) {
+    const u64 plane = 2 * half;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
+        EF a, b;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            a.v[k] = in[(u64)k * plane + i];
+            b.v[k] = in[(u64)k * plane + i + half];
+        }
+        EF o = ef_add(a, ef_mul(r, ef_sub(b, a)));
+#pragma unroll
+        for (int k = 0; k < 5; k++) out[(u64)k * half + i] = o.v[k];
+    }
+}
+
+// =====================================================================================================
+// PoW: candidates base .. base + n; result = min hit (or 0xffffffff)
+// =====================================================================================================
+struct PowArgs {
+    u32 cap[8];
+    u32 base, n, mask, r2;
+};
+__global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ result) {
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const u32 w = a.base + i;
+    if (w >= P) return;
+    u32 s[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = a.cap[k];
+    s[8] = mul(w, a.r2);  // Montgomery form of the canonical candidate
+#pragma unroll
+    for (int k = 9; k < 16; k++) s[k] = 0;
+    poseidon16_permute(s);
+    if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
+}
+
+extern "C" {
+
+int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                          const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars) {
+    LM_REQUIRE(ctx && d_W && n_vars <= 40);
+    if (n_items == 0) return LM_OK;
+    LM_REQUIRE(items && scalars && (points || n_point_coords == 0));
+    const u64 plane = 1ull << n_vars;
+    // order items by (inner_n, offset): groups (same region) are contiguous, and all groups of one inner_n — which are
+    // pairwise disjoint aligned blocks — form one launch.  Regions of different sizes may nest, so they must not be
+    // updated by the same launch (read-modify-write of W).
+    std::vector<u32> order(n_items);
+    for (u32 i = 0; i < n_items; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+        if (items[a].inner_n != items[b].inner_n) return items[a].inner_n < items[b].inner_n;
+        return items[a].offset < items[b].offset;
+    });
+    std::vector<WItem> hit(n_items);
+    std::vector<WGroup> hgr;
+    std::vector<u32> hsc((u64)n_items * 5);
+    u64 arena_words = 0, chunks = 0;
+    u32 max_table = 1;
+    for (u32 k = 0; k < n_items; k++) {
+        const lm_weight_item& s = items[order[k]];
+        LM_REQUIRE(s.inner_n <= n_vars && s.inner_n <= 36);
+        LM_REQUIRE(s.offset + (1ull << s.inner_n) <= plane && (s.offset & ((1ull << s.inner_n) - 1)) == 0);
+        LM_REQUIRE(s.point_offset + s.inner_n <= n_point_coords);
+        const u32 k_lo = s.inner_n < W_KLO ? s.inner_n : W_KLO;
+        WItem& w = hit[k];
+        w.inner_n = s.inner_n;
+        w.is_next = s.is_next ? 1 : 0;
+        w.point_off = s.point_offset;
+        w.thi_off = arena_words;
+        arena_words += 5ull << (s.inner_n - k_lo);
+        w.tlo_off = arena_words;
+        arena_words += 5ull << k_lo;
+        max_table = std::max(max_table, std::max(1u << (s.inner_n - k_lo), 1u << k_lo));
+        memcpy(&hsc[(u64)k * 5], scalars + (u64)order[k] * 5, 20);
+        if (hgr.empty() || hgr.back().offset != s.offset || hgr.back().inner_n != s.inner_n) {
+            WGroup g;
+            g.offset = s.offset;
+            g.inner_n = s.inner_n;
+            g.item_begin = k;
+            g.item_end = k + 1;
+            if (!hgr.empty() && hgr.back().inner_n != s.inner_n) chunks = 0;  // chunk numbering restarts per launch
+            g.chunk_begin = chunks;
+            g.pad = 0;
+            chunks += ((1ull << s.inner_n) + W_CHUNK - 1) / W_CHUNK;
+            LM_REQUIRE(chunks < (1ull << 31));
+            hgr.push_back(g);
+        } else {
+            hgr.back().item_end = k + 1;
+        }
+    }
+    // scratch layout (words): items | groups | scalars | points | arena
+    const u64 w_items = (sizeof(WItem) * n_items + 3) / 4, w_groups = (sizeof(WGroup) * hgr.size() + 3) / 4;
+    const u64 w_sc = (u64)n_items * 5, w_pts = n_point_coords * 5;
+    auto al = [](u64 x) { return (x + 15) & ~15ull; };
+    const u64 o_items = 0, o_groups = al(o_items + w_items), o_sc = al(o_groups + w_groups), o_pts = al(o_sc + w_sc),
+              o_arena = al(o_pts + w_pts);
+    u32* s;
+    int rc = lm_scratch(ctx, o_arena + arena_words, &s);
+    if (rc) return rc;
+    LM_HIP(hipMemcpyAsync(s + o_items, hit.data(), sizeof(WItem) * n_items, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemcpyAsync(s + o_groups, hgr.data(), sizeof(WGroup) * hgr.size(), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemcpyAsync(s + o_sc, hsc.data(), w_sc * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (w_pts) LM_HIP(hipMemcpyAsync(s + o_pts, points, w_pts * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the host vectors must outlive the async copies
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    LM_LAUNCH(ctx, k_weight_tables, dim3((max_table + 255) / 256, n_items, 2), dim3(256), 0, (const WItem*)(s + o_items),
+              s + o_pts, s + o_sc, s + o_arena);
+    for (size_t g0 = 0; g0 < hgr.size();) {
+        size_t g1 = g0;
+        while (g1 < hgr.size() && hgr[g1].inner_n == hgr[g0].inner_n) g1++;
+        const WGroup& last = hgr[g1 - 1];
+        const u64 n_chunks = last.chunk_begin + ((1ull << last.inner_n) + W_CHUNK - 1) / W_CHUNK;
+        LM_LAUNCH(ctx, k_weights_accumulate, dim3((unsigned)n_chunks), dim3(256), 0, d_W, plane,
+                  (const WGroup*)(s + o_groups) + g0, (u32)(g1 - g0), (const WItem*)(s + o_items), s + o_arena);
+        g0 = g1;
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars,
+                  uint32_t out_c0_c2[10]) {
+    LM_REQUIRE(ctx && d_f && d_W && out_c0_c2 && n_vars >= 1 && n_vars <= 40);
+    const u64 half = 1ull << (n_vars - 1);
+    u32 blocks = (u32)std::min<u64>((half + 255) / 256, 2048);
+    u32* s;
+    int rc = lm_scratch(ctx, (u64)blocks * 10 + 16, &s);
+    if (rc) return rc;
+    u32* d_out = s + (u64)blocks * 10;
+    if (f_is_ext)
+        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
+    else
+        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
+    LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, d_out);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(out_c0_c2, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
+            uint32_t* d_out) {
+    LM_REQUIRE(ctx && d_in && d_out && r && n_vars >= 1 && n_vars <= 40);
+    const u64 half = 1ull << (n_vars - 1);
+    u32 blocks = (u32)std::min<u64>((half + 255) / 256, 4096);
+    EF rr;
+    memcpy(rr.v, r, 20);
+    if (in_is_ext)
+        LM_LAUNCH(ctx, k_fold_ext, dim3(blocks), dim3(256), 0, d_in, half, rr, d_out);
+    else
+        LM_LAUNCH(ctx, k_fold_base, dim3(blocks), dim3(256), 0, d_in, half, rr, d_out);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_t* witness) {
+    LM_REQUIRE(ctx && capacity && witness && bits < 31);
+    if (bits == 0) {
+        *witness = 0;
+        return LM_OK;
+    }
+    u32* s;
+    int rc = lm_scratch(ctx, 16, &s);
+    if (rc) return rc;
+    PowArgs a;
+    memcpy(a.cap, capacity, 32);
+    a.mask = (1u << bits) - 1;
+    a.r2 = to_monty(to_monty(1));  // 2^64 mod p
+    // batch sized to the expected work (2^bits candidates), at least one full wave of the chip
+    u64 batch = std::max<u64>(1ull << 16, std::min<u64>(1ull << bits, 1ull << 22));
+    for (u64 base = 0; base < P; base += batch) {
+        LM_HIP(hipMemsetAsync(s, 0xff, 4, ctx->stream));
+        a.base = (u32)base;
+        a.n = (u32)std::min<u64>(batch, (u64)P - base);
+        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, s);
+        LM_HIP(hipGetLastError());
+        u32 res;
+        LM_HIP(hipMemcpyAsync(&res, s, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+        if (res != 0xffffffffu) {
+            *witness = to_monty(res);
+            return LM_OK;
+        }
+    }
+    lm_set_error("lm_pow_grind: no witness");
+    return LM_E_INVALID;
+}
+
+}  // extern "C"

@@ -91,3 +91,160 @@ void orc_eq_table(const uint32_t* point, uint32_t n, const uint32_t* scalar5, ui
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// WHIR (whir_oracle.hpp)
+// ================================================================================================
+#include "whir_oracle.hpp"
+
+namespace {
+WhirConfigBuilder make_builder(const uint32_t* b) {
+    // b = [starting_log_inv_rate, max_num_variables_to_send_coeffs, rs_domain_initial_reduction_factor,
+    //      fold_first, fold_subsequent, soundness_type, security_level, pow_bits]
+    WhirConfigBuilder w;
+    w.starting_log_inv_rate = b[0];
+    w.max_num_variables_to_send_coeffs = b[1];
+    w.rs_domain_initial_reduction_factor = b[2];
+    w.folding_factor = FoldingFactor{b[3], b[4]};
+    w.soundness_type = (SecurityAssumption)b[5];
+    w.security_level = b[6];
+    w.pow_bits = b[7];
+    return w;
+}
+// statements blob (u32 words): [n_statements] then per statement:
+//   [point_len, is_next, n_values] [point: 5*point_len] then n_values x [selector_lo, selector_hi, value x5]
+std::vector<SparseStatement> parse_statements(const uint32_t* blob, size_t total_vars) {
+    std::vector<SparseStatement> out;
+    size_t k = 0;
+    uint32_t n = blob[k++];
+    for (uint32_t s = 0; s < n; s++) {
+        SparseStatement st;
+        st.total_num_variables = total_vars;
+        uint32_t pl = blob[k++];
+        st.is_next = blob[k++] != 0;
+        uint32_t nv = blob[k++];
+        st.point.resize(pl);
+        for (uint32_t i = 0; i < pl; i++) {
+            std::memcpy(st.point[i].v, blob + k, 20);
+            k += 5;
+        }
+        for (uint32_t i = 0; i < nv; i++) {
+            SparseValue v;
+            v.selector = (size_t)blob[k] | ((size_t)blob[k + 1] << 32);
+            k += 2;
+            std::memcpy(v.value.v, blob + k, 20);
+            k += 5;
+            st.values.push_back(v);
+        }
+        out.push_back(std::move(st));
+    }
+    return out;
+}
+std::vector<uint32_t> serialize_proof(const ProverState& ps) {
+    std::vector<uint32_t> o;
+    o.push_back((uint32_t)ps.transcript.size());
+    o.insert(o.end(), ps.transcript.begin(), ps.transcript.end());
+    o.push_back((uint32_t)ps.merkle_openings.size());
+    for (const MerkleOpening& m : ps.merkle_openings) {
+        o.push_back((uint32_t)m.leaf_index);
+        o.push_back((uint32_t)((uint64_t)m.leaf_index >> 32));
+        o.push_back((uint32_t)m.leaf_data.size());
+        o.push_back((uint32_t)m.path.size());
+        o.insert(o.end(), m.leaf_data.begin(), m.leaf_data.end());
+        o.insert(o.end(), m.path.begin(), m.path.end());
+    }
+    return o;
+}
+void parse_proof(const uint32_t* blob, VerifierState& vs) {
+    size_t k = 0;
+    uint32_t t = blob[k++];
+    vs.transcript.assign(blob + k, blob + k + t);
+    k += t;
+    uint32_t m = blob[k++];
+    for (uint32_t i = 0; i < m; i++) {
+        MerkleOpening o;
+        o.leaf_index = (size_t)blob[k] | ((size_t)blob[k + 1] << 32);
+        uint32_t ll = blob[k + 2], pl = blob[k + 3];
+        k += 4;
+        o.leaf_data.assign(blob + k, blob + k + ll);
+        k += ll;
+        o.path.assign(blob + k, blob + k + pl);
+        k += pl;
+        vs.merkle_openings.push_back(std::move(o));
+    }
+}
+std::vector<uint32_t> g_last_proof;
+}  // namespace
+
+extern "C" {
+
+// out: [commitment_ood_samples, starting_folding_pow_bits, n_rounds, final_queries, final_query_pow_bits,
+//       final_sumcheck_rounds, final_log_inv_rate] then per round [query_pow_bits, folding_pow_bits, num_queries,
+//       ood_samples, log_inv_rate, num_variables]; returns number of words written
+uint32_t orc_whir_config(const uint32_t* builder, uint32_t num_variables, uint32_t* out) {
+    WhirConfig c = WhirConfig::make(make_builder(builder), num_variables);
+    uint32_t k = 0;
+    out[k++] = (uint32_t)c.commitment_ood_samples;
+    out[k++] = (uint32_t)c.starting_folding_pow_bits;
+    out[k++] = (uint32_t)c.n_rounds();
+    out[k++] = (uint32_t)c.final_queries;
+    out[k++] = (uint32_t)c.final_query_pow_bits;
+    out[k++] = (uint32_t)c.final_sumcheck_rounds;
+    out[k++] = (uint32_t)c.final_log_inv_rate;
+    for (const RoundConfig& r : c.round_parameters) {
+        out[k++] = (uint32_t)r.query_pow_bits;
+        out[k++] = (uint32_t)r.folding_pow_bits;
+        out[k++] = (uint32_t)r.num_queries;
+        out[k++] = (uint32_t)r.ood_samples;
+        out[k++] = (uint32_t)r.log_inv_rate;
+        out[k++] = (uint32_t)r.num_variables;
+    }
+    return k;
+}
+
+// commit + prove.  `prefix` words are absorbed with add_base_scalars first (binds the test transcript to its context).
+// Returns the proof size in words (fetch with orc_last_proof); out_point = num_variables x 5.
+uint64_t orc_whir_prove(const uint32_t* builder, uint32_t num_variables, const uint32_t* poly, uint64_t actual_len,
+                        const uint32_t* statements_blob, const uint32_t* prefix, uint32_t n_prefix, uint32_t* out_point,
+                        uint64_t* out_pow_perms) {
+    WhirConfig c = WhirConfig::make(make_builder(builder), num_variables);
+    ProverState ps;
+    if (n_prefix) ps.add_base_scalars(prefix, n_prefix);
+    Witness w = whir_commit(c, ps, poly, actual_len);
+    std::vector<SparseStatement> st = parse_statements(statements_blob, num_variables);
+    std::vector<EF> pt = whir_prove(c, ps, st, std::move(w), poly);
+    std::memcpy(out_point, pt.data(), pt.size() * 20);
+    if (out_pow_perms) *out_pow_perms = ps.pow_permutations;
+    g_last_proof = serialize_proof(ps);
+    return g_last_proof.size();
+}
+void orc_last_proof(uint32_t* out) { std::memcpy(out, g_last_proof.data(), g_last_proof.size() * 4); }
+
+// returns 1 if the proof verifies (and writes the folding randomness), 0 otherwise (message in orc_last_error)
+static char g_verr[256];
+const char* orc_last_error() { return g_verr; }
+int orc_whir_verify(const uint32_t* builder, uint32_t num_variables, const uint32_t* proof_blob,
+                    const uint32_t* statements_blob, const uint32_t* prefix, uint32_t n_prefix, uint32_t* out_point) {
+    try {
+        WhirConfig c = WhirConfig::make(make_builder(builder), num_variables);
+        VerifierState vs;
+        parse_proof(proof_blob, vs);
+        if (n_prefix) {
+            std::vector<uint32_t> got = vs.next_base_scalars_vec(n_prefix);
+            if (std::memcmp(got.data(), prefix, n_prefix * 4) != 0) throw std::runtime_error("prefix mismatch");
+        }
+        ParsedCommitment pc = parse_commitment(vs, num_variables, c.commitment_ood_samples);
+        std::vector<SparseStatement> st = parse_statements(statements_blob, num_variables);
+        std::vector<EF> pt = whir_verify(c, vs, pc, st);
+        if (vs.off != vs.transcript.size()) throw std::runtime_error("trailing transcript data");
+        if (vs.merkle_idx != vs.merkle_openings.size()) throw std::runtime_error("unused merkle openings");
+        if (out_point) std::memcpy(out_point, pt.data(), pt.size() * 20);
+        g_verr[0] = 0;
+        return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+
+}  // extern "C"

@@ -146,3 +146,100 @@ def load():
 def rand_field(rng, shape):
     """i.i.d. uniform F_p elements as Montgomery-form words (any word < p is a valid Montgomery value)."""
     return rng.integers(0, P, size=shape, dtype=np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# WHIR helpers (oracle side)
+# ------------------------------------------------------------------------------------------------------------
+JOHNSON, CAPACITY = 1, 2
+
+
+def whir_builder(log_inv_rate=1, max_send=8, rs_red=5, fold_first=7, fold_sub=5, soundness=JOHNSON, security=124,
+                 pow_bits=16):
+    """WhirConfigBuilder as 8 ints (default = lean_prover::default_whir_config, lean_prover/src/lib.rs:22-50)."""
+    return np.array([log_inv_rate, max_send, rs_red, fold_first, fold_sub, soundness, security, pow_bits], dtype=np.uint32)
+
+
+def whir_config(orc, builder, num_variables):
+    out = np.zeros(7 + 6 * 16, dtype=np.uint32)
+    n = orc.lib.orc_whir_config(_p(builder), C.c_uint32(num_variables), _p(out))
+    out = out[:n]
+    cfg = dict(num_variables=num_variables, starting_log_inv_rate=int(builder[0]), fold_first=int(builder[3]),
+               fold_sub=int(builder[4]), rs_red=int(builder[2]), commitment_ood_samples=int(out[0]),
+               starting_folding_pow_bits=int(out[1]), n_rounds=int(out[2]), final_queries=int(out[3]),
+               final_query_pow_bits=int(out[4]), final_sumcheck_rounds=int(out[5]), final_log_inv_rate=int(out[6]), rounds=[])
+    for r in range(cfg["n_rounds"]):
+        q = out[7 + 6 * r: 13 + 6 * r]
+        cfg["rounds"].append(dict(query_pow_bits=int(q[0]), folding_pow_bits=int(q[1]), num_queries=int(q[2]),
+                                  ood_samples=int(q[3]), log_inv_rate=int(q[4]), num_variables=int(q[5])))
+    return cfg
+
+
+def statements_blob(statements):
+    """statements: list of dict(point=(k,5) uint32, is_next=bool, values=[(selector, ef5), ...])"""
+    words = [len(statements)]
+    for s in statements:
+        pt = np.asarray(s["point"], dtype=np.uint32).reshape(-1, 5)
+        words += [pt.shape[0], int(bool(s.get("is_next", False))), len(s["values"])]
+        words += [int(x) for x in pt.reshape(-1)]
+        for sel, val in s["values"]:
+            words += [sel & 0xFFFFFFFF, sel >> 32] + [int(x) for x in val]
+    return np.array(words, dtype=np.uint32)
+
+
+def whir_prove(orc, builder, num_variables, poly, statements, actual_len=None, prefix=()):
+    poly = np.ascontiguousarray(poly, dtype=np.uint32)
+    blob = statements_blob(statements)
+    pre = np.array(list(prefix) or [0], dtype=np.uint32)
+    pt = np.empty((num_variables, 5), dtype=np.uint32)
+    perms = C.c_uint64(0)
+    orc.lib.orc_whir_prove.restype = C.c_uint64
+    n = orc.lib.orc_whir_prove(_p(builder), C.c_uint32(num_variables), _p(poly),
+                               C.c_uint64(poly.size if actual_len is None else actual_len), _p(blob), _p(pre),
+                               C.c_uint32(len(prefix)), _p(pt), C.byref(perms))
+    proof = np.empty(n, dtype=np.uint32)
+    orc.lib.orc_last_proof(_p(proof))
+    return proof, pt, perms.value
+
+
+def whir_verify(orc, builder, num_variables, proof, statements, prefix=()):
+    blob = statements_blob(statements)
+    pre = np.array(list(prefix) or [0], dtype=np.uint32)
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    pt = np.empty((num_variables, 5), dtype=np.uint32)
+    orc.lib.orc_last_error.restype = C.c_char_p
+    ok = orc.lib.orc_whir_verify(_p(builder), C.c_uint32(num_variables), _p(proof), _p(blob), _p(pre),
+                                 C.c_uint32(len(prefix)), _p(pt))
+    return bool(ok), pt, orc.lib.orc_last_error().decode()
+
+
+def evaluate_sparse(orc, poly, selector, point):
+    """polynomial.evaluate_sparse(selector, point) (poly/src/evals.rs:41-43)"""
+    k = np.asarray(point).reshape(-1, 5).shape[0]
+    return orc.mle_eval_base(poly[selector << k:(selector + 1) << k], point)
+
+
+def random_statements(orc, rng, poly, num_variables, n_points=7, with_next=False):
+    """Same shape of workload as whir/tests/run_whir.rs:63-96: random sparse points + the all-selector statement."""
+    sts = []
+    pts = []
+    for _ in range(n_points):
+        sel_len = int(rng.integers(0, num_variables // 2))
+        pts.append((sel_len, rand_field(rng, (num_variables - sel_len, 5))))
+    pts.append((num_variables, np.zeros((0, 5), dtype=np.uint32)))
+    for sel_len, pt in pts:
+        n_sel = int(rng.integers(1, 5))
+        sels = []
+        for _ in range(n_sel):
+            s = int(rng.integers(0, 1 << sel_len))
+            if s not in sels:
+                sels.append(s)
+        vals = []
+        for s in sels:
+            if pt.shape[0] == 0:
+                v = np.array([poly[s], 0, 0, 0, 0], dtype=np.uint32)
+            else:
+                v = evaluate_sparse(orc, poly, s, pt)
+            vals.append((s, v))
+        sts.append(dict(point=pt, is_next=False, values=vals))
+    return sts

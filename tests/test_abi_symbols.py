@@ -6,10 +6,10 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "leanmultisig.h")).read()
+def declared_symbols(header="leanmultisig.h", prefix="lm_"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(lm_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -17,8 +17,8 @@ def test_library_exports_every_declared_symbol():
     __graft_entry__.build()
     from leanmultisig_amd import LIB_PATH
     lib = ctypes.CDLL(LIB_PATH)
-    syms = declared_symbols()
-    assert len(syms) >= 20
+    syms = declared_symbols() + declared_symbols("leanmultisig_host.h", "lmh_")
+    assert len(syms) >= 40
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
 
@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_header():
     from leanmultisig_amd import capi
     assert sorted(capi._SIGS) == declared_symbols()
+    assert sorted(capi._HOST_SIGS) == declared_symbols("leanmultisig_host.h", "lmh_")
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -134,6 +134,25 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
 int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
             uint32_t* d_out);
 
+/* ---- GKR for a sum of fractions (logup) -----------------------------------------------------------------------------
+ * prove_gkr_quotient (crates/sub_protocols/src/quotient_gkr/mod.rs:31-78).  The transcript stays with the caller; the
+ * device holds the layers and runs the per-round kernels.  d_nums: 2^n_vars base words, d_dens: SoA EF of 2^n_vars,
+ * NATURAL index order, already padded with (0, 1) to the power of two (the reference's chunk-bit-reversed packing and
+ * symbolic padding — logup.rs:61-86, sumcheck_utils.rs:136 — are CPU layout choices; transcript values are identical).
+ *   lm_gkr_build        sum_quotients_2_by_2 down to 2^5 entries (layers.rs:124-189); inputs must stay alive
+ *   lm_gkr_top          the 32 + 32 values sent first (mod.rs:64-66), host AoS EF
+ *   lm_gkr_layer_begin  start prove_gkr_layer (mod.rs:80-141) for the layer with 2^(K+1) entries: claim point (K x 5), alpha
+ *   lm_gkr_round        one sumcheck round, LSB first: out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109);
+ *                       prev_r = NULL for the first round, else the previous challenge (fold_and_compute_round)
+ *   lm_gkr_layer_end    fold by the last challenge; inner_evals = [n_l, n_r, d_l, d_r] (4 EF) */
+typedef struct lm_gkr lm_gkr;
+int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out);
+void lm_gkr_free(lm_ctx* ctx, lm_gkr* g);
+int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32);
+int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point, const uint32_t alpha[LM_EF_DIM]);
+int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]);
+int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[LM_EF_DIM], uint32_t inner_evals[20]);
+
 /* ---- proof-of-work ------------------------------------------------------------------------------------------------
  * FSProver::pow_grinding (crates/backend/fiat-shamir/src/prover.rs:120-177): smallest canonical w such that
  * permute(capacity[0..8] || w || 0^7)[8], read canonically, has `bits` low zero bits.  *witness is Montgomery form.

@@ -79,6 +79,12 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* cfg, const 
                    const uint32_t* values, uint64_t n_values, lmh_witness* witness, const uint32_t* d_poly,
                    uint32_t* out_point);
 
+/* ---- logup GKR ---------------------------------------------------------------------------------------------------
+ * prove_gkr_quotient (crates/sub_protocols/src/quotient_gkr/mod.rs:31-78): returns the quotient sum n_i/d_i, the claim
+ * point (n_vars x 5) and the two final claims (numerators MLE, denominators MLE at the point; mod.rs:74-77). */
+int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
+                           uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]);
+
 #ifdef __cplusplus
 }
 #endif

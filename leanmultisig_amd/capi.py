@@ -49,6 +49,12 @@ _SIGS = {
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
     "lm_fold": (C.c_int, [vp, vp, C.c_int, C.c_uint32, vp, vp]),
     "lm_pow_grind": (C.c_int, [vp, vp, C.c_uint32, u32p]),
+    "lm_gkr_build": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(vp)]),
+    "lm_gkr_free": (None, [vp, vp]),
+    "lm_gkr_top": (C.c_int, [vp, vp, vp, vp]),
+    "lm_gkr_layer_begin": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
+    "lm_gkr_round": (C.c_int, [vp, vp, vp, vp]),
+    "lm_gkr_layer_end": (C.c_int, [vp, vp, vp, vp]),
 }
 
 # include/leanmultisig_host.h
@@ -69,6 +75,7 @@ _HOST_SIGS = {
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
+    "lmh_prove_gkr_quotient": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
 }
 
@@ -362,6 +369,14 @@ class Prover:
         out = np.empty(16, dtype=np.uint32)
         self.lib.lmh_challenger_state(self.h, _ptr(out))
         return out
+
+    def prove_gkr_quotient(self, d_nums, d_dens, n_vars):
+        q = np.empty(5, dtype=np.uint32)
+        pt = np.empty((n_vars, 5), dtype=np.uint32)
+        cl = np.empty((2, 5), dtype=np.uint32)
+        self.ctx._check(self.lib.lmh_prove_gkr_quotient(self.ctx.h, self.h, d_nums.ptr, d_dens.ptr, n_vars, _ptr(q), _ptr(pt),
+                                                        _ptr(cl)))
+        return q, pt, cl
 
     def whir_commit(self, cfg, d_poly, actual_len):
         w = vp()

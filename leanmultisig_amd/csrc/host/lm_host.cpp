@@ -531,4 +531,82 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
     return LM_OK;
 }
 
+
+// prove_gkr_quotient (quotient_gkr/mod.rs:31-141) — transcript order of SURVEY.md App. B step 4.
+int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
+                           uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]) {
+    if (!ctx || !p || !d_nums || !d_dens || !out_quotient || !out_point || !out_claims) return LM_E_INVALID;
+    lm_gkr* g = nullptr;
+    int rc = lm_gkr_build(ctx, d_nums, d_dens, n_vars, &g);
+    if (rc) return rc;
+    auto fail = [&](int code) {
+        lm_gkr_free(ctx, g);
+        return code;
+    };
+    u32 tn[160], td[160];
+    if ((rc = lm_gkr_top(ctx, g, tn, td))) return fail(rc);
+    add_base(p, tn, 160);
+    add_base(p, td, 160);
+    std::vector<EF> top_n(32), top_d(32);
+    EF quotient = kb::ef_zero();
+    for (int i = 0; i < 32; i++) {
+        top_n[i] = ef_load(tn + 5 * i);
+        top_d[i] = ef_load(td + 5 * i);
+        quotient = kb::ef_add(quotient, kb::ef_mul(top_n[i], kb::ef_inv(top_d[i])));  // compute_quotient, mod.rs:143-145
+    }
+    std::vector<EF> point;
+    if (!sample_vec(p, 5, point)) return fail(LM_E_INVALID);
+    EF claim_num = eval_leaf(tn, true, 5, point.data());
+    EF claim_den = eval_leaf(td, true, 5, point.data());
+    for (u32 K = 5; K < n_vars; K++) {
+        // prove_gkr_layer
+        p->ch.duplex();
+        std::vector<EF> av;
+        if (!sample_vec(p, 1, av)) return fail(LM_E_INVALID);
+        const EF alpha = av[0];
+        EF sum = kb::ef_add(claim_num, kb::ef_mul(alpha, claim_den));
+        EF mmf = kb::ef_one();
+        if ((rc = lm_gkr_layer_begin(ctx, g, K, point[0].v, alpha.v))) return fail(rc);
+        std::vector<EF> q;
+        EF r_prev;
+        for (u32 t = 0; t < K; t++) {
+            u32 c[10];
+            if ((rc = lm_gkr_round(ctx, g, t == 0 ? nullptr : r_prev.v, c))) return fail(rc);
+            const EF eq_alpha = point[K - 1 - t];
+            // build_bare_from_coeffs, sumcheck_utils.rs:491-503
+            const EF c0 = kb::ef_mul(ef_load(c), mmf), c2 = kb::ef_mul(ef_load(c + 5), mmf);
+            const EF h1 = kb::ef_mul(kb::ef_sub(sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), c0)), kb::ef_inv(eq_alpha));
+            const EF c1 = kb::ef_sub(kb::ef_sub(h1, c0), c2);
+            add_sumcheck_poly(p, {c0, c1, c2}, &eq_alpha);
+            std::vector<EF> rv;
+            if (!sample_vec(p, 1, rv)) return fail(LM_E_INVALID);
+            const EF r = rv[0];
+            const EF eq_eval = kb::ef_add(kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), kb::ef_sub(kb::ef_one(), r)),
+                                          kb::ef_mul(eq_alpha, r));
+            const EF bare_r = kb::ef_add(c0, kb::ef_mul(r, kb::ef_add(c1, kb::ef_mul(r, c2))));
+            sum = kb::ef_mul(eq_eval, bare_r);
+            mmf = kb::ef_mul(mmf, eq_eval);
+            q.push_back(r);
+            r_prev = r;
+        }
+        u32 ie[20];
+        if ((rc = lm_gkr_layer_end(ctx, g, r_prev.v, ie))) return fail(rc);
+        add_base(p, ie, 20);
+        std::vector<EF> bv;
+        if (!sample_vec(p, 1, bv)) return fail(LM_E_INVALID);
+        const EF beta = bv[0], omb = kb::ef_sub(kb::ef_one(), beta);
+        claim_num = kb::ef_add(kb::ef_mul(omb, ef_load(ie)), kb::ef_mul(beta, ef_load(ie + 5)));
+        claim_den = kb::ef_add(kb::ef_mul(omb, ef_load(ie + 10)), kb::ef_mul(beta, ef_load(ie + 15)));
+        std::vector<EF> np(q.rbegin(), q.rend());
+        np.push_back(beta);
+        point = np;
+    }
+    lm_gkr_free(ctx, g);
+    memcpy(out_quotient, quotient.v, 20);
+    for (u32 i = 0; i < n_vars; i++) memcpy(out_point + 5 * i, point[i].v, 20);
+    memcpy(out_claims, claim_num.v, 20);
+    memcpy(out_claims + 5, claim_den.v, 20);
+    return LM_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,509 @@
+// GKR for a sum of fractions sum n_i / d_i  (reference: crates/sub_protocols/src/quotient_gkr/{mod,layers,sumcheck_utils}.rs).
+//
+// Device layout: natural index order (the reference's chunk-bit-reversed SIMD packing is a CPU artefact; all
+// transcript values are layout independent).  A layer with 2^v entries is {nums, dens}: nums is one base plane for the
+// input layer and SoA EF above it, dens is SoA EF.  Children of parent j are entries 2j (left) and 2j+1 (right), so one
+// sumcheck pair (parents 2j', 2j'+1) is 4 consecutive entries: one 16-byte load per plane.
+// During a layer's sumcheck the four multilinears (n_l, n_r, d_l, d_r) live as 4 SoA EF arrays that halve every round
+// (LSB-first folding, sumcheck_utils.rs:278-357).
+#include <algorithm>
+#include "lm_common.h"
+
+using namespace kb;
+
+struct lm_gkr {
+    u32 n_vars = 0;
+    const u32* d_nums0 = nullptr;  // caller's input layer (base)
+    const u32* d_dens0 = nullptr;  // caller's input layer (SoA EF)
+    std::vector<u32*> nums, dens;  // layers n_vars-1 .. 5 (index 0 = 2^(n_vars-1) entries), SoA EF, owned
+    u32* work[2] = {nullptr, nullptr};  // ping-pong: 4 arrays x 5 planes
+    u64 work_words = 0;
+    u32* tables = nullptr;  // prefix eq tables of the current layer
+    // state of the layer being proven
+    u32 K = 0;        // number of rounds = number of coordinates of the claim point
+    u32 round = 0;
+    int cur = -1;     // which work buffer holds the current arrays (-1: still in layer storage)
+    u64 m = 0;        // current length of each of the 4 arrays
+    EF alpha;
+    std::vector<u64> th_off, tl_off;  // table offsets (words) per prefix length
+    u32 H = 0;
+};
+
+// ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
+template <bool BASE>
+__global__ __launch_bounds__(256) void k_gkr_layer_up(const u32* __restrict__ n_in, const u32* __restrict__ d_in, u64 m_out,
+                                                      u32* __restrict__ n_out, u32* __restrict__ d_out) {
+    const u64 plane_in = 2 * m_out;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < m_out; i += (u64)gridDim.x * 256) {
+        EF d0, d1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint2 v = *reinterpret_cast<const uint2*>(d_in + (u64)k * plane_in + 2 * i);
+            d0.v[k] = v.x;
+            d1.v[k] = v.y;
+        }
+        EF no;
+        if (BASE) {
+            uint2 v = *reinterpret_cast<const uint2*>(n_in + 2 * i);
+            no = ef_add(ef_mul_base(d1, v.x), ef_mul_base(d0, v.y));
+        } else {
+            EF n0, n1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                uint2 v = *reinterpret_cast<const uint2*>(n_in + (u64)k * plane_in + 2 * i);
+                n0.v[k] = v.x;
+                n1.v[k] = v.y;
+            }
+            no = ef_add(ef_mul(d1, n0), ef_mul(d0, n1));
+        }
+        EF dd = ef_mul(d0, d1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            n_out[(u64)k * m_out + i] = no.v[k];
+            d_out[(u64)k * m_out + i] = dd.v[k];
+        }
+    }
+}
+
+// ---- prefix eq tables -------------------------------------------------------------------------------------------------
+// table t (t < n_tables): eq over coordinates point[c0 .. c0 + nb), written SoA at arena + off.
+struct GkrTableDesc {
+    u64 off;
+    u32 c0, nb;
+};
+__global__ __launch_bounds__(256) void k_gkr_tables(const GkrTableDesc* __restrict__ descs, const u32* __restrict__ point,
+                                                    u32* __restrict__ arena) {
+    const GkrTableDesc d = descs[blockIdx.y];
+    const u32 len = 1u << d.nb;
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    EF acc = ef_one();
+    for (u32 j = 0; j < d.nb; j++) {
+        EF p;
+#pragma unroll
+        for (int k = 0; k < 5; k++) p.v[k] = point[(d.c0 + j) * 5 + k];
+        u32 bit = (i >> (d.nb - 1 - j)) & 1;
+        acc = ef_mul(acc, bit ? p : ef_sub(ef_one(), p));
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) arena[d.off + (u64)k * len + i] = acc.v[k];
+}
+
+struct EqSplit {
+    const u32* th;  // hi table (SoA, len_hi entries)
+    const u32* tl;  // lo table (SoA, len_lo entries) or nullptr
+    u32 len_hi, log_lo;
+};
+__device__ __forceinline__ EF eq_split_at(const EqSplit& e, u64 j) {
+    EF a;
+    const u64 jh = j >> e.log_lo;
+#pragma unroll
+    for (int k = 0; k < 5; k++) a.v[k] = e.th[(u64)k * e.len_hi + jh];
+    if (e.tl) {
+        EF b;
+        const u32 len_lo = 1u << e.log_lo;
+        const u32 jl = (u32)j & (len_lo - 1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) b.v[k] = e.tl[(u64)k * len_lo + jl];
+        a = ef_mul(a, b);
+    }
+    return a;
+}
+
+// pair_coeffs (sumcheck_utils.rs:65-79) accumulated with weight w into acc[0..4) = (c0_num, c2_num, c0_den, c2_den)
+__device__ __forceinline__ void pair_accumulate(const EF& nl0, const EF& nl1, const EF& nr0, const EF& nr1, const EF& dl0,
+                                                const EF& dl1, const EF& dr0, const EF& dr1, const EF& w, EF acc[4]) {
+    const EF ddl = ef_sub(dl1, dl0), ddr = ef_sub(dr1, dr0);
+    const EF c0d = ef_mul(dl0, dr0);
+    const EF c2d = ef_mul(ddl, ddr);
+    const EF c0n = ef_add(ef_mul(nl0, dr0), ef_mul(nr0, dl0));
+    const EF c2n = ef_add(ef_mul(ef_sub(nl1, nl0), ddr), ef_mul(ef_sub(nr1, nr0), ddl));
+    acc[0] = ef_add(acc[0], ef_mul(c0n, w));
+    acc[1] = ef_add(acc[1], ef_mul(c2n, w));
+    acc[2] = ef_add(acc[2], ef_mul(c0d, w));
+    acc[3] = ef_add(acc[3], ef_mul(c2d, w));
+}
+__device__ __forceinline__ void pair_accumulate_base(u32 nl0, u32 nl1, u32 nr0, u32 nr1, const EF& dl0, const EF& dl1,
+                                                     const EF& dr0, const EF& dr1, const EF& w, EF acc[4]) {
+    const EF ddl = ef_sub(dl1, dl0), ddr = ef_sub(dr1, dr0);
+    const EF c0d = ef_mul(dl0, dr0);
+    const EF c2d = ef_mul(ddl, ddr);
+    const EF c0n = ef_add(ef_mul_base(dr0, nl0), ef_mul_base(dl0, nr0));
+    const EF c2n = ef_add(ef_mul_base(ddr, sub(nl1, nl0)), ef_mul_base(ddl, sub(nr1, nr0)));
+    acc[0] = ef_add(acc[0], ef_mul(c0n, w));
+    acc[1] = ef_add(acc[1], ef_mul(c2n, w));
+    acc[2] = ef_add(acc[2], ef_mul(c0d, w));
+    acc[3] = ef_add(acc[3], ef_mul(c2d, w));
+}
+
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = add(v, (u32)__shfl_down(v, off, 64));
+    return v;
+}
+// block-sum of 4 EF accumulators -> partial[block][20]
+__device__ __forceinline__ void block_store_acc(const EF acc[4], u32* lds /* 80 words */, u32* dst) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 v[20];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[a * 5 + k] = wave_sum_u32(acc[a].v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 20; k++) lds[wave * 20 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 20) {
+        u32 s = 0;
+        for (u32 w = 0; w < (blockDim.x >> 6); w++) s = add(s, lds[w * 20 + threadIdx.x]);
+        dst[threadIdx.x] = s;
+    }
+}
+// out[0..5) = c0_num + alpha c0_den ; out[5..10) = c2_num + alpha c2_den
+__global__ __launch_bounds__(256) void k_gkr_reduce(const u32* __restrict__ partial, u32 n, EF alpha, u32* __restrict__ out) {
+    __shared__ u32 lds[80];
+    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
+    for (u32 i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[a].v[k] = add(acc[a].v[k], partial[(u64)i * 20 + a * 5 + k]);
+    __shared__ u32 tot[20];
+    block_store_acc(acc, lds, tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        EF c0n, c2n, c0d, c2d;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            c0n.v[k] = tot[k];
+            c2n.v[k] = tot[5 + k];
+            c0d.v[k] = tot[10 + k];
+            c2d.v[k] = tot[15 + k];
+        }
+        EF a = ef_add(c0n, ef_mul(alpha, c0d)), b = ef_add(c2n, ef_mul(alpha, c2d));
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            out[k] = a.v[k];
+            out[5 + k] = b.v[k];
+        }
+    }
+}
+
+// ---- round 0 of a layer straight from layer storage: pairs j' < n_pairs, entries 4j' .. 4j'+3 ------------------------
+template <bool BASE>
+__global__ __launch_bounds__(256) void k_gkr_round_storage(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
+                                                           u64 n_pairs, EqSplit eq, u32* __restrict__ partial) {
+    __shared__ u32 lds[80];
+    const u64 plane = 4 * n_pairs;
+    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
+        EF dl0, dr0, dl1, dr1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint4 v = *reinterpret_cast<const uint4*>(d_in + (u64)k * plane + 4 * j);
+            dl0.v[k] = v.x;
+            dr0.v[k] = v.y;
+            dl1.v[k] = v.z;
+            dr1.v[k] = v.w;
+        }
+        const EF w = eq_split_at(eq, j);
+        if (BASE) {
+            uint4 v = *reinterpret_cast<const uint4*>(n_in + 4 * j);
+            pair_accumulate_base(v.x, v.z, v.y, v.w, dl0, dl1, dr0, dr1, w, acc);
+        } else {
+            EF nl0, nr0, nl1, nr1;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                uint4 v = *reinterpret_cast<const uint4*>(n_in + (u64)k * plane + 4 * j);
+                nl0.v[k] = v.x;
+                nr0.v[k] = v.y;
+                nl1.v[k] = v.z;
+                nr1.v[k] = v.w;
+            }
+            pair_accumulate(nl0, nl1, nr0, nr1, dl0, dl1, dr0, dr1, w, acc);
+        }
+    }
+    block_store_acc(acc, lds, partial + (u64)blockIdx.x * 20);
+}
+
+// ---- fold by r then compute the next round.  MODE 0: input = layer storage with base nums, 1: layer storage with EF
+// nums, 2: four SoA arrays of length m_in.  Output: four SoA arrays of length m_out = m_in / 2 at `out`
+// (array a at out + a * 5 * m_out).  Thread j' produces outputs 2j', 2j'+1 and (if m_out >= 2) their pair coefficients.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gkr_fold_round(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
+                                                        const u32* __restrict__ arr_in, u64 m_out, EF r, EqSplit eq,
+                                                        u32* __restrict__ out, u32* __restrict__ partial) {
+    __shared__ u32 lds[80];
+    const u64 m_in = 2 * m_out;
+    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
+    const u64 n_threads_work = m_out >= 2 ? m_out / 2 : 1;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_threads_work; j += (u64)gridDim.x * 256) {
+        EF o[2][4];  // [which output][array]
+        const int n_out = m_out >= 2 ? 2 : 1;
+        for (int t = 0; t < n_out; t++) {
+            const u64 i = 2 * j + t;  // output index; inputs 2i, 2i+1 of each array
+            EF a[4], b[4];
+            if (MODE == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        uint2 v = *reinterpret_cast<const uint2*>(arr_in + ((u64)q * 5 + k) * m_in + 2 * i);
+                        a[q].v[k] = v.x;
+                        b[q].v[k] = v.y;
+                    }
+            } else {
+                // storage: n_l(x) = n[2x], n_r(x) = n[2x+1]; inputs x = 2i, 2i+1 -> entries 4i .. 4i+3
+                const u64 plane = 2 * m_in;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    uint4 v = *reinterpret_cast<const uint4*>(d_in + (u64)k * plane + 4 * i);
+                    a[2].v[k] = v.x;
+                    a[3].v[k] = v.y;
+                    b[2].v[k] = v.z;
+                    b[3].v[k] = v.w;
+                }
+                if (MODE == 0) {
+                    uint4 v = *reinterpret_cast<const uint4*>(n_in + 4 * i);
+                    a[0] = ef_from_base(v.x);
+                    a[1] = ef_from_base(v.y);
+                    b[0] = ef_from_base(v.z);
+                    b[1] = ef_from_base(v.w);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        uint4 v = *reinterpret_cast<const uint4*>(n_in + (u64)k * plane + 4 * i);
+                        a[0].v[k] = v.x;
+                        a[1].v[k] = v.y;
+                        b[0].v[k] = v.z;
+                        b[1].v[k] = v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (MODE == 0 && q < 2) {
+                    // base numerators: r * (b - a) is EF x base
+                    EF t2 = ef_mul_base(r, sub(b[q].v[0], a[q].v[0]));
+                    t2.v[0] = add(t2.v[0], a[q].v[0]);
+                    o[t][q] = t2;
+                } else {
+                    o[t][q] = ef_add(a[q], ef_mul(r, ef_sub(b[q], a[q])));
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) out[((u64)q * 5 + k) * m_out + i] = o[t][q].v[k];
+            }
+        }
+        if (m_out >= 2) {
+            const EF w = eq_split_at(eq, j);
+            pair_accumulate(o[0][0], o[1][0], o[0][1], o[1][1], o[0][2], o[1][2], o[0][3], o[1][3], w, acc);
+        }
+    }
+    if (m_out >= 2) block_store_acc(acc, lds, partial + (u64)blockIdx.x * 20);
+}
+
+extern "C" {
+
+void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
+    if (!g) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (u32* p : g->nums) (void)hipFree(p);
+    for (u32* p : g->dens) (void)hipFree(p);
+    for (int i = 0; i < 2; i++)
+        if (g->work[i]) (void)hipFree(g->work[i]);
+    if (g->tables) (void)hipFree(g->tables);
+    delete g;
+}
+
+int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out) {
+    LM_REQUIRE(ctx && d_nums && d_dens && out && n_vars > 5 && n_vars <= 30);
+    lm_gkr* g = new lm_gkr();
+    g->n_vars = n_vars;
+    g->d_nums0 = d_nums;
+    g->d_dens0 = d_dens;
+    const u32* n_in = d_nums;
+    const u32* d_in = d_dens;
+    for (u32 v = n_vars - 1; v >= 5; v--) {
+        const u64 m = 1ull << v;
+        u32 *nn = nullptr, *dd = nullptr;
+        if (hipMalloc(&nn, 5 * m * 4) != hipSuccess || hipMalloc(&dd, 5 * m * 4) != hipSuccess) {
+            lm_set_error("lm_gkr_build: hipMalloc failed");
+            if (nn) (void)hipFree(nn);
+            lm_gkr_free(ctx, g);
+            return LM_E_NOMEM;
+        }
+        g->nums.push_back(nn);
+        g->dens.push_back(dd);
+        const u32 blocks = (u32)std::min<u64>((m + 255) / 256, 4096);
+        if (v == n_vars - 1)
+            LM_LAUNCH(ctx, k_gkr_layer_up<true>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd);
+        else
+            LM_LAUNCH(ctx, k_gkr_layer_up<false>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd);
+        n_in = nn;
+        d_in = dd;
+    }
+    // work buffers: first fold of the biggest layer yields 4 arrays of 2^(n_vars-2) EF
+    g->work_words = 20ull << (n_vars - 2);
+    const u64 w1 = std::max<u64>(g->work_words / 2, 64);
+    if (hipMalloc(&g->work[0], g->work_words * 4) != hipSuccess || hipMalloc(&g->work[1], w1 * 4) != hipSuccess ||
+        hipMalloc(&g->tables, (20ull << ((n_vars + 1) / 2 + 1)) * 4 + 4096) != hipSuccess) {
+        lm_set_error("lm_gkr_build: hipMalloc failed (work)");
+        lm_gkr_free(ctx, g);
+        return LM_E_NOMEM;
+    }
+    LM_HIP(hipGetLastError());
+    *out = g;
+    return LM_OK;
+}
+
+int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32) {
+    LM_REQUIRE(ctx && g && nums32 && dens32);
+    u32 soa[2][160];
+    LM_HIP(hipMemcpyAsync(soa[0], g->nums.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipMemcpyAsync(soa[1], g->dens.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 32; i++)
+        for (int k = 0; k < 5; k++) {
+            nums32[i * 5 + k] = soa[0][k * 32 + i];
+            dens32[i * 5 + k] = soa[1][k * 32 + i];
+        }
+    return LM_OK;
+}
+
+// Start the sumcheck of the layer with 2^(K+1) entries (K = number of coordinates of the claim point, 5 <= K < n_vars).
+int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point, const uint32_t alpha[5]) {
+    LM_REQUIRE(ctx && g && point && alpha && K >= 5 && K < g->n_vars);
+    g->K = K;
+    g->round = 0;
+    g->cur = -1;
+    g->m = 1ull << K;  // length of each of n_l, n_r, d_l, d_r
+    memcpy(g->alpha.v, alpha, 20);
+    // prefix tables: round t uses eq over point[0 .. p), p = K-1-t.  hi part: first min(p, H) coords; lo: [H, p).
+    const u32 P1 = K - 1;
+    const u32 H = (P1 + 1) / 2;
+    g->H = H;
+    std::vector<GkrTableDesc> descs;
+    g->th_off.assign(H + 1, 0);
+    g->tl_off.assign(P1 + 1, 0);
+    u64 off = 0;
+    u32 max_len = 1;
+    for (u32 q = 0; q <= H; q++) {
+        g->th_off[q] = off;
+        descs.push_back({off, 0, q});
+        off += 5ull << q;
+        max_len = std::max(max_len, 1u << q);
+    }
+    for (u32 p = H + 1; p <= P1; p++) {
+        g->tl_off[p] = off;
+        descs.push_back({off, H, p - H});
+        off += 5ull << (p - H);
+        max_len = std::max(max_len, 1u << (p - H));
+    }
+    // descriptors + point go to the tail of the table buffer
+    const u64 tail = (off + 15) & ~15ull;
+    const u64 desc_words = (descs.size() * sizeof(GkrTableDesc) + 3) / 4;
+    LM_REQUIRE(tail + desc_words + K * 5 + 16 <= (20ull << ((g->n_vars + 1) / 2 + 1)) + 1024);
+    LM_HIP(hipMemcpyAsync(g->tables + tail, descs.data(), descs.size() * sizeof(GkrTableDesc), hipMemcpyHostToDevice,
+                          ctx->stream));
+    const u64 pt_off = (tail + desc_words + 15) & ~15ull;
+    LM_HIP(hipMemcpyAsync(g->tables + pt_off, point, (u64)K * 20, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    LM_LAUNCH(ctx, k_gkr_tables, dim3((max_len + 255) / 256, (u32)descs.size()), dim3(256), 0,
+              (const GkrTableDesc*)(g->tables + tail), (const u32*)(g->tables + pt_off), g->tables);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+static EqSplit make_eq(const lm_gkr* g, u32 p) {
+    EqSplit e;
+    const u32 H = g->H;
+    if (p <= H) {
+        e.th = g->tables + g->th_off[p];
+        e.len_hi = 1u << p;
+        e.tl = nullptr;
+        e.log_lo = 0;
+    } else {
+        e.th = g->tables + g->th_off[H];
+        e.len_hi = 1u << H;
+        e.tl = g->tables + g->tl_off[p];
+        e.log_lo = p - H;
+    }
+    return e;
+}
+
+// One round.  prev_r = NULL on the first round of the layer; afterwards the challenge of the previous round (the
+// arrays are folded by it first).  out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109), padding included
+// because the vectors are fully materialised.
+int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
+    LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
+    LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
+    const u32 t = g->round;
+    const u32 p = g->K - 1 - t;  // prefix coordinates of this round's eq table
+    const u64 n_pairs = 1ull << p;
+    const u32 blocks = (u32)std::min<u64>((n_pairs + 255) / 256, 1024);
+    u32* s;
+    int rc = lm_scratch(ctx, (u64)blocks * 20 + 32, &s);
+    if (rc) return rc;
+    u32* d_out = s + (u64)blocks * 20;
+    const EqSplit eq = make_eq(g, p);
+    // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
+    // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
+    const bool input_layer = g->K == g->n_vars - 1;
+    const u32* n_st = input_layer ? g->d_nums0 : g->nums[g->n_vars - g->K - 2];
+    const u32* d_st = input_layer ? g->d_dens0 : g->dens[g->n_vars - g->K - 2];
+    if (t == 0) {
+        if (input_layer)
+            LM_LAUNCH(ctx, k_gkr_round_storage<true>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s);
+        else
+            LM_LAUNCH(ctx, k_gkr_round_storage<false>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s);
+    } else {
+        EF r;
+        memcpy(r.v, prev_r, 20);
+        const u64 m_out = g->m / 2;
+        const int dst = g->cur < 0 ? 0 : 1 - g->cur;
+        if (g->cur < 0) {
+            if (input_layer)
+                LM_LAUNCH(ctx, k_gkr_fold_round<0>, dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
+                          g->work[dst], s);
+            else
+                LM_LAUNCH(ctx, k_gkr_fold_round<1>, dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
+                          g->work[dst], s);
+        } else {
+            LM_LAUNCH(ctx, k_gkr_fold_round<2>, dim3(blocks), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
+                      (const u32*)g->work[g->cur], m_out, r, eq, g->work[dst], s);
+        }
+        g->cur = dst;
+        g->m = m_out;
+    }
+    LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, d_out);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(out_c0_c2, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    g->round++;
+    return LM_OK;
+}
+
+// After the last round: fold by the last challenge and return [n_l, n_r, d_l, d_r] (4 EF, mod.rs:129).
+int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[5], uint32_t inner_evals[20]) {
+    LM_REQUIRE(ctx && g && last_r && inner_evals && g->round == g->K && g->m == 2);
+    EF r;
+    memcpy(r.v, last_r, 20);
+    const int dst = 1 - g->cur;
+    EqSplit eq = make_eq(g, 0);
+    u32* s;
+    int rc = lm_scratch(ctx, 64, &s);
+    if (rc) return rc;
+    LM_REQUIRE(g->cur >= 0);  // K >= 5 rounds, so at least one fold happened
+    LM_LAUNCH(ctx, k_gkr_fold_round<2>, dim3(1), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
+              (const u32*)g->work[g->cur], (u64)1, r, eq, g->work[dst], s);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(inner_evals, g->work[dst], 80, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    g->cur = dst;
+    g->m = 1;
+    return LM_OK;
+}
+
+}  // extern "C"

@@ -248,3 +248,44 @@ int orc_whir_verify(const uint32_t* builder, uint32_t num_variables, const uint3
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// GKR quotient (gkr_oracle.hpp)
+// ================================================================================================
+#include "gkr_oracle.hpp"
+extern "C" {
+// nums: 2^n base words; dens: 2^n x 5.  out: quotient[5], point[n*5], claims[10].  Returns proof words (orc_last_proof).
+uint64_t orc_gkr_prove(const uint32_t* nums, const uint32_t* dens, uint32_t n_vars, uint32_t* out_quotient,
+                       uint32_t* out_point, uint32_t* out_claims) {
+    ProverState ps;
+    EF q, cn, cd;
+    std::vector<EF> pt;
+    gkr_prove(ps, nums, (const EF*)dens, n_vars, q, pt, cn, cd);
+    std::memcpy(out_quotient, q.v, 20);
+    std::memcpy(out_point, pt.data(), pt.size() * 20);
+    std::memcpy(out_claims, cn.v, 20);
+    std::memcpy(out_claims + 5, cd.v, 20);
+    g_last_proof = serialize_proof(ps);
+    return g_last_proof.size();
+}
+int orc_gkr_verify(const uint32_t* proof_blob, uint32_t n_vars, uint32_t* out_quotient, uint32_t* out_point,
+                   uint32_t* out_claims) {
+    try {
+        VerifierState vs;
+        parse_proof(proof_blob, vs);
+        EF q, cn, cd;
+        std::vector<EF> pt;
+        gkr_verify(vs, n_vars, q, pt, cn, cd);
+        if (vs.off != vs.transcript.size()) throw std::runtime_error("trailing transcript data");
+        std::memcpy(out_quotient, q.v, 20);
+        std::memcpy(out_point, pt.data(), pt.size() * 20);
+        std::memcpy(out_claims, cn.v, 20);
+        std::memcpy(out_claims + 5, cd.v, 20);
+        g_verr[0] = 0;
+        return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+}

@@ -243,3 +243,46 @@ def random_statements(orc, rng, poly, num_variables, n_points=7, with_next=False
             vals.append((s, v))
         sts.append(dict(point=pt, is_next=False, values=vals))
     return sts
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GKR quotient helpers (oracle side)
+# ------------------------------------------------------------------------------------------------------------
+def gkr_prove(orc, nums, dens):
+    nums = np.ascontiguousarray(nums, dtype=np.uint32)
+    dens = np.ascontiguousarray(dens, dtype=np.uint32).reshape(-1, 5)
+    n_vars = int(nums.size).bit_length() - 1
+    q = np.empty(5, dtype=np.uint32)
+    pt = np.empty((n_vars, 5), dtype=np.uint32)
+    cl = np.empty((2, 5), dtype=np.uint32)
+    orc.lib.orc_gkr_prove.restype = C.c_uint64
+    n = orc.lib.orc_gkr_prove(_p(nums), _p(dens), C.c_uint32(n_vars), _p(q), _p(pt), _p(cl))
+    proof = np.empty(n, dtype=np.uint32)
+    orc.lib.orc_last_proof(_p(proof))
+    return proof, q, pt, cl
+
+
+def gkr_verify(orc, proof, n_vars):
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    q = np.empty(5, dtype=np.uint32)
+    pt = np.empty((n_vars, 5), dtype=np.uint32)
+    cl = np.empty((2, 5), dtype=np.uint32)
+    orc.lib.orc_last_error.restype = C.c_char_p
+    ok = orc.lib.orc_gkr_verify(_p(proof), C.c_uint32(n_vars), _p(q), _p(pt), _p(cl))
+    return bool(ok), q, pt, cl, orc.lib.orc_last_error().decode()
+
+
+def gkr_instance(orc, rng, log_n, active_frac=1.0):
+    """Same instance family as quotient_gkr/mod.rs:222-239: random numerators, denominators c - (small base value),
+    (0, 1) padding after the active prefix."""
+    n = 1 << log_n
+    active = max(1, int(n * active_frac))
+    nums = rand_field(rng, n)
+    nums[active:] = 0
+    c = rand_field(rng, 5)
+    dens = np.tile(c, (n, 1))
+    sub = orc.to_monty(rng.integers(0, n, size=n))
+    dens[:, 0] = ((dens[:, 0].astype(np.int64) - sub) % P).astype(np.uint32)
+    dens[active:] = 0
+    dens[active:, 0] = 0x01FFFFFE
+    return nums, dens

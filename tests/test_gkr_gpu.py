@@ -1,0 +1,39 @@
+"""GPU parity: logup GKR (sum of fractions) through the C ABI vs the CPU oracle — transcripts must be word-identical —
+with the instance family and checks of the reference's own test (quotient_gkr/mod.rs:222-301)."""
+import numpy as np
+import pytest
+
+import leanmultisig_amd as lm
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n,frac", [(6, 1.0), (7, 0.7), (11, 0.51), (11, 2 / 3), (13, 0.75), (13, 7 / 8), (15, 1.0)])
+def test_gkr_matches_oracle(ctx, orc, log_n, frac):
+    rng = np.random.default_rng(log_n * 7 + int(frac * 100))
+    nums, dens = ob.gkr_instance(orc, rng, log_n, frac)
+    ref_proof, rq, rpt, rcl = ob.gkr_prove(orc, nums, dens)
+    pr = lm.Prover(ctx)
+    q, pt, cl = pr.prove_gkr_quotient(ctx.to_device(nums), ctx.ef_to_device_soa(dens), log_n)
+    proof = pr.proof()
+    assert np.array_equal(q, rq) and np.array_equal(pt, rpt) and np.array_equal(cl, rcl)
+    assert np.array_equal(proof, ref_proof)
+    ok, vq, vpt, vcl, err = ob.gkr_verify(orc, proof, log_n)
+    assert ok, err
+
+
+def test_gkr_large_verifies_and_claims_match_mle(ctx, orc):
+    """2^20 entries: too slow for the oracle prover; checked by the oracle verifier + device MLE evaluations of the
+    inputs at the returned point (the two checks of the reference test, mod.rs:276-279)."""
+    log_n = 20
+    rng = np.random.default_rng(1)
+    nums, dens = ob.gkr_instance(orc, rng, log_n, 0.8)
+    d_n, d_d = ctx.to_device(nums), ctx.ef_to_device_soa(dens)
+    pr = lm.Prover(ctx)
+    q, pt, cl = pr.prove_gkr_quotient(d_n, d_d, log_n)
+    ok, vq, vpt, vcl, err = ob.gkr_verify(orc, pr.proof(), log_n)
+    assert ok, err
+    assert np.array_equal(vq, q) and np.array_equal(vpt, pt) and np.array_equal(vcl, cl)
+    assert list(ctx.mle_eval(d_n, False, log_n, pt)[0]) == list(cl[0])
+    assert list(ctx.mle_eval(d_d, True, log_n, pt)[0]) == list(cl[1])

@@ -153,6 +153,31 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
 int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]);
 int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[LM_EF_DIM], uint32_t inner_evals[20]);
 
+/* ---- AIR sumcheck sessions ----------------------------------------------------------------------------------------
+ * The OuterSumcheckSession trait object of the reference (crates/sub_protocols/src/air_sumcheck.rs:34-42, implemented by
+ * AirSumcheckSession :45-296) as an opaque handle.  table: 0 = execution, 1 = extension_op, 2 = poseidon16
+ * (constraint bodies: crates/lean_vm/src/tables/{execution/air.rs, extension_op/air.rs, poseidon_16/mod.rs}).
+ *   lm_air_new         AirSumcheckSession::new: d_cols = host array of n_columns DEVICE pointers to the committed base
+ *                      columns (2^log_rows words each, natural row order — the chunk-bit-reversal of :87-111 is a CPU
+ *                      layout); the next-row ("shift") views of the first n_shift columns are derived on the device
+ *                      (compute_shifted_columns :683-694).  eq_point = eq_factor (log_rows x 5), alpha = air_alpha
+ *                      (powers are taken on the device side), logup_eq16 = logup_alphas_eq_poly (16 x 5), bus_beta.
+ *   lm_air_round       the raw sums of compute_bare_round_poly before missing_mul_factor / padding handling:
+ *                      out[zi] = sum_pairs eq_prefix * sum_k alpha^k C_k(lo + z (hi - lo)), z = 0, 2, 3, .., degree
+ *                      (degree x 5 words); the full padded domain is summed, which equals the reference's active
+ *                      prefix + constraints_eval_at_padding shortcut (:236-240)
+ *   lm_air_bind        process_challenge's fold (:268-292)
+ *   lm_air_final_evals final_column_evals (:294-296): (n_columns + n_shift) x 5 words */
+typedef struct lm_air lm_air;
+int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint32_t log_rows, const uint32_t* eq_point,
+               const uint32_t alpha[LM_EF_DIM], const uint32_t* logup_eq16, const uint32_t bus_beta[LM_EF_DIM], lm_air** out);
+void lm_air_free(lm_ctx* ctx, lm_air* a);
+uint32_t lm_air_degree(const lm_air* a);
+uint32_t lm_air_n_evals(const lm_air* a);
+int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw);
+int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[LM_EF_DIM]);
+int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out);
+
 /* ---- proof-of-work ------------------------------------------------------------------------------------------------
  * FSProver::pow_grinding (crates/backend/fiat-shamir/src/prover.rs:120-177): smallest canonical w such that
  * permute(capacity[0..8] || w || 0^7)[8], read canonically, has `bits` low zero bits.  *witness is Montgomery form.

@@ -85,6 +85,22 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* cfg, const 
 int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
                            uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]);
 
+/* ---- batched AIR sumcheck -----------------------------------------------------------------------------------------
+ * prove_batched_air_sumcheck (crates/sub_protocols/src/air_sumcheck.rs:636-681) over one session per table, followed by
+ * sending every table's final column evaluations (crates/lean_prover/src/prove_execution.rs:212-214).  Tables must be
+ * given in the reference's order (sort_tables_by_height: descending height, stable).  out_point: n_max x 5 challenges
+ * in sumcheck order (LSB first); out_col_evals: concatenation over tables of (n_columns + n_shift) x 5 words. */
+typedef struct {
+    uint32_t table;                /* 0 execution, 1 extension_op, 2 poseidon16 */
+    uint32_t log_rows;
+    const uint32_t* const* d_cols; /* host array of device column pointers */
+    const uint32_t* eq_point;      /* log_rows x 5 (from_end(gkr_point, log_rows)) */
+    uint32_t sum[5];               /* bus_final_value */
+} lm_air_table;
+int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_table* tables, uint32_t n_tables,
+                                   const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5],
+                                   const uint32_t eta[5], uint32_t* out_point, uint32_t* out_col_evals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,13 @@ _SIGS = {
     "lm_gkr_layer_begin": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
     "lm_gkr_round": (C.c_int, [vp, vp, vp, vp]),
     "lm_gkr_layer_end": (C.c_int, [vp, vp, vp, vp]),
+    "lm_air_new": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(vp)]),
+    "lm_air_free": (None, [vp, vp]),
+    "lm_air_degree": (C.c_uint32, [vp]),
+    "lm_air_n_evals": (C.c_uint32, [vp]),
+    "lm_air_round": (C.c_int, [vp, vp, vp]),
+    "lm_air_bind": (C.c_int, [vp, vp, vp]),
+    "lm_air_final_evals": (C.c_int, [vp, vp, vp]),
 }
 
 # include/leanmultisig_host.h
@@ -76,6 +83,7 @@ _HOST_SIGS = {
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
     "lmh_prove_gkr_quotient": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
+    "lmh_prove_batched_air_sumcheck": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
 }
 
@@ -122,6 +130,16 @@ class SparseStatement(C.Structure):
     """lm_sparse_statement"""
     _fields_ = [("point_len", C.c_uint32), ("is_next", C.c_uint32), ("n_values", C.c_uint32), ("reserved", C.c_uint32),
                 ("point_offset", C.c_uint64), ("values_offset", C.c_uint64)]
+
+
+class AirTable(C.Structure):
+    """lm_air_table"""
+    _fields_ = [("table", C.c_uint32), ("log_rows", C.c_uint32), ("d_cols", vp), ("eq_point", vp), ("sum", C.c_uint32 * 5)]
+
+
+AIR_N_COLUMNS = {0: 20, 1: 29, 2: 109}
+AIR_N_SHIFT = {0: 2, 1: 13, 2: 0}
+AIR_DEGREE = {0: 5, 1: 6, 2: 10}
 
 
 class WeightItem(C.Structure):
@@ -377,6 +395,38 @@ class Prover:
         self.ctx._check(self.lib.lmh_prove_gkr_quotient(self.ctx.h, self.h, d_nums.ptr, d_dens.ptr, n_vars, _ptr(q), _ptr(pt),
                                                         _ptr(cl)))
         return q, pt, cl
+
+    def prove_batched_air_sumcheck(self, tables, alpha, logup_eq16, bus_beta, eta):
+        """tables: list of dict(table=int, log_rows=int, cols=[DeviceBuffer or device ptr per column], eq_point=(n,5),
+        sum=ef5), already in the reference's order (descending height).  Returns (point (n_max,5), [col_evals per table])."""
+        arr = (AirTable * len(tables))()
+        keep = []
+        n_max = 0
+        total = 0
+        for i, t in enumerate(tables):
+            ptrs = np.array([c.ptr if isinstance(c, DeviceBuffer) else int(c) for c in t["cols"]], dtype=np.uint64)
+            assert ptrs.size == AIR_N_COLUMNS[t["table"]]
+            eqp = _u32(t["eq_point"]).reshape(-1)
+            assert eqp.size == 5 * t["log_rows"]
+            keep += [ptrs, eqp]
+            arr[i].table, arr[i].log_rows = t["table"], t["log_rows"]
+            arr[i].d_cols, arr[i].eq_point = ptrs.ctypes.data, eqp.ctypes.data
+            for k in range(5):
+                arr[i].sum[k] = int(t["sum"][k])
+            n_max = max(n_max, t["log_rows"])
+            total += AIR_N_COLUMNS[t["table"]] + AIR_N_SHIFT[t["table"]]
+        al, eq16, bb, et = _u32(alpha), _u32(logup_eq16).reshape(-1), _u32(bus_beta), _u32(eta)
+        assert eq16.size == 80
+        pt = np.empty((n_max, 5), dtype=np.uint32)
+        ev = np.empty((total, 5), dtype=np.uint32)
+        self.ctx._check(self.lib.lmh_prove_batched_air_sumcheck(self.ctx.h, self.h, C.cast(arr, vp), len(tables), _ptr(al),
+                                                                _ptr(eq16), _ptr(bb), _ptr(et), _ptr(pt), _ptr(ev)))
+        out, k = [], 0
+        for t in tables:
+            n = AIR_N_COLUMNS[t["table"]] + AIR_N_SHIFT[t["table"]]
+            out.append(ev[k:k + n].copy())
+            k += n
+        return pt, out
 
     def whir_commit(self, cfg, d_poly, actual_len):
         w = vp()

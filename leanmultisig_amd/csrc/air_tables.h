@@ -1,0 +1,328 @@
+// AIR constraint evaluators of the three leanVM tables, generic over the value type T of a column value:
+//   T = kb::u32  (base field: the first sumcheck round runs on the committed base columns)
+//   T = kb::EF   (extension field: after the first fold)
+// Each evaluator returns sum_k alpha^k * C_k(flat, shift) in EF, constraint order identical to the reference
+// (alpha power index = order of the assert_* calls):
+//   execution     crates/lean_vm/src/tables/execution/air.rs:56-129
+//   extension_op  crates/lean_vm/src/tables/extension_op/air.rs:59-163
+//   poseidon_16   crates/lean_vm/src/tables/poseidon_16/mod.rs:316-548   (sparse partial rounds, poseidon16.h tables)
+//   bus column    crates/lean_vm/src/tables/utils.rs:5-21
+#pragma once
+#include "kb.h"
+#include "poseidon16.h"
+
+namespace air {
+
+using kb::EF;
+using kb::u32;
+using kb::u64;
+
+static constexpr int T_EXECUTION = 0, T_EXTENSION_OP = 1, T_POSEIDON16 = 2;
+static constexpr int MAX_ALPHA = 101;  // max_air_constraints() + 1 (prove_execution.rs:155)
+
+KB_HD constexpr int n_columns(int t) { return t == T_EXECUTION ? 20 : t == T_EXTENSION_OP ? 29 : 109; }
+KB_HD constexpr int n_shift(int t) { return t == T_EXECUTION ? 2 : t == T_EXTENSION_OP ? 13 : 0; }
+KB_HD constexpr int degree(int t) { return t == T_EXECUTION ? 5 : t == T_EXTENSION_OP ? 6 : 10; }
+
+// ExtraDataForBuses (tables/table_trait.rs:74-95), Montgomery words
+struct Extra {
+    EF alpha_powers[MAX_ALPHA];
+    EF logup_eq[16];  // logup_alphas_eq_poly
+    EF bus_beta;
+};
+
+// ---- small algebra over T ------------------------------------------------------------------------------------------
+KB_HD u32 a_add(u32 a, u32 b) { return kb::add(a, b); }
+KB_HD u32 a_sub(u32 a, u32 b) { return kb::sub(a, b); }
+KB_HD u32 a_mul(u32 a, u32 b) { return kb::mul(a, b); }
+KB_HD u32 a_neg(u32 a) { return kb::neg(a); }
+KB_HD u32 a_mulc(u32 a, u32 c) { return kb::mul(a, c); }  // times a base constant (Montgomery)
+KB_HD u32 a_addc(u32 a, u32 c) { return kb::add(a, c); }
+KB_HD EF a_scale(const EF& e, u32 x) { return kb::ef_mul_base(e, x); }  // EF * T
+KB_HD EF a_lift(u32 x) { return kb::ef_from_base(x); }
+KB_HD u32 a_from_base(u32 c, u32) { return c; }
+
+KB_HD EF a_add(const EF& a, const EF& b) { return kb::ef_add(a, b); }
+KB_HD EF a_sub(const EF& a, const EF& b) { return kb::ef_sub(a, b); }
+KB_HD EF a_mul(const EF& a, const EF& b) { return kb::ef_mul(a, b); }
+KB_HD EF a_neg(const EF& a) { return kb::ef_neg(a); }
+KB_HD EF a_mulc(const EF& a, u32 c) { return kb::ef_mul_base(a, c); }
+KB_HD EF a_addc(const EF& a, u32 c) { return kb::ef_add_base(a, c); }
+KB_HD EF a_scale(const EF& e, const EF& x) { return kb::ef_mul(e, x); }
+KB_HD EF a_lift(const EF& x) { return x; }
+KB_HD EF a_from_base(u32 c, const EF&) { return kb::ef_from_base(c); }
+
+// small canonical integers in Montgomery form, folded at compile time by the optimiser
+KB_HD u32 mc(u32 canon) { return kb::to_monty(canon); }
+
+template <class T>
+struct Folder {
+    const Extra& x;
+    EF acc;
+    int k;
+    KB_HD explicit Folder(const Extra& e) : x(e), acc(kb::ef_zero()), k(0) {}
+    KB_HD void assert_zero(const T& v) {
+        acc = kb::ef_add(acc, a_scale(x.alpha_powers[k], v));
+        k++;
+    }
+    KB_HD void assert_zero_ef(const EF& v) {
+        acc = kb::ef_add(acc, kb::ef_mul(x.alpha_powers[k], v));
+        k++;
+    }
+};
+
+// (sum_{i<4} eq[i] * data[i] + eq[15] * DOMAINSEP) * beta + flag        (LOGUP_PRECOMPILE_DOMAINSEP = 1)
+template <class T>
+KB_HD EF bus_column(const Extra& x, const T& flag, const T& d0, const T& d1, const T& d2, const T& d3) {
+    EF s = a_scale(x.logup_eq[0], d0);
+    s = kb::ef_add(s, a_scale(x.logup_eq[1], d1));
+    s = kb::ef_add(s, a_scale(x.logup_eq[2], d2));
+    s = kb::ef_add(s, a_scale(x.logup_eq[3], d3));
+    s = kb::ef_add(s, x.logup_eq[15]);
+    return kb::ef_add(kb::ef_mul(s, x.bus_beta), a_lift(flag));
+}
+
+template <class T>
+KB_HD T bool_check(const T& v) {  // (1 - v) * v  (backend/field/src/field.rs:197-210)
+    return a_mul(a_sub(a_from_base(kb::ONE, v), v), v);
+}
+
+// ---- execution ---------------------------------------------------------------------------------------------------------
+template <class T>
+KB_HD EF eval_execution(const T* flat, const T* shift, const Extra& x) {
+    const T one = a_from_base(kb::ONE, flat[0]);
+    const T pc = flat[0], fp = flat[1], addr_a = flat[2], addr_b = flat[3], addr_c = flat[4];
+    const T value_a = flat[5], value_b = flat[6], value_c = flat[7];
+    const T operand_a = flat[8], operand_b = flat[9], operand_c = flat[10];
+    const T flag_a = flat[11], flag_b = flat[12], flag_c = flat[13], flag_c_fp = flat[14], flag_ab_fp = flat[15];
+    const T mul = flat[16], jump = flat[17], aux = flat[18], precompile_data = flat[19];
+    const T pc_shift = shift[0], fp_shift = shift[1];
+    const T omfa = a_sub(one, a_add(flag_a, flag_ab_fp));
+    const T omfb = a_sub(one, a_add(flag_b, flag_ab_fp));
+    const T omfc = a_sub(one, a_add(flag_c, flag_c_fp));
+    const T fpa = a_add(fp, operand_a), fpb = a_add(fp, operand_b), fpc = a_add(fp, operand_c);
+    const T nu_a = a_add(a_add(a_mul(flag_a, operand_a), a_mul(omfa, value_a)), a_mul(flag_ab_fp, fpa));
+    const T nu_b = a_add(a_add(a_mul(flag_b, operand_b), a_mul(omfb, value_b)), a_mul(flag_ab_fp, fpb));
+    const T nu_c = a_add(a_add(a_mul(flag_c, operand_c), a_mul(omfc, value_c)), a_mul(flag_c_fp, fpc));
+    const T add_ = a_sub(a_add(aux, aux), a_mul(aux, aux));
+    const T deref = a_mulc(a_mul(aux, a_sub(aux, one)), mc((kb::P + 1) / 2));
+    const T is_precompile = a_sub(one, a_add(a_add(a_add(add_, mul), deref), jump));
+    Folder<T> f(x);
+    f.assert_zero_ef(bus_column<T>(x, is_precompile, precompile_data, nu_a, nu_b, nu_c));
+    f.assert_zero(a_mul(omfa, a_sub(addr_a, fpa)));
+    f.assert_zero(a_mul(omfb, a_sub(addr_b, fpb)));
+    f.assert_zero(a_mul(omfc, a_sub(addr_c, fpc)));
+    f.assert_zero(a_mul(add_, a_sub(nu_b, a_add(nu_a, nu_c))));
+    f.assert_zero(a_mul(mul, a_sub(nu_b, a_mul(nu_a, nu_c))));
+    f.assert_zero(a_mul(deref, a_sub(addr_b, a_add(value_a, operand_b))));
+    f.assert_zero(a_mul(deref, a_sub(value_b, nu_c)));
+    const T jc = a_mul(jump, nu_a);
+    f.assert_zero(a_mul(jc, a_sub(nu_a, one)));
+    f.assert_zero(a_mul(jc, a_sub(pc_shift, nu_b)));
+    f.assert_zero(a_mul(jc, a_sub(fp_shift, nu_c)));
+    const T njc = a_sub(one, jc);
+    f.assert_zero(a_mul(njc, a_sub(pc_shift, a_add(pc, one))));
+    f.assert_zero(a_mul(njc, a_sub(fp_shift, fp)));
+    return f.acc;
+}
+
+// quintic product with plain dot products (extension_op/air.rs:37-42)
+template <class T>
+KB_HD void quintic_mul_air(const T a[5], const T b[5], T out[5]) {
+    const T b0m3 = a_sub(b[0], b[3]), b1m4 = a_sub(b[1], b[4]), b4m2 = a_sub(b[4], b[2]), b3m14 = a_sub(b[3], b1m4);
+    auto dot = [&](const T& r0, const T& r1, const T& r2, const T& r3, const T& r4) {
+        return a_add(a_add(a_add(a_add(a_mul(a[0], r0), a_mul(a[1], r1)), a_mul(a[2], r2)), a_mul(a[3], r3)), a_mul(a[4], r4));
+    };
+    out[0] = dot(b[0], b[4], b[3], b[2], b1m4);
+    out[1] = dot(b[1], b[0], b[4], b[3], b[2]);
+    out[2] = dot(b[2], b1m4, b0m3, b4m2, b3m14);
+    out[3] = dot(b[3], b[2], b1m4, b0m3, b4m2);
+    out[4] = dot(b[4], b[3], b[2], b1m4, b0m3);
+}
+
+// ---- extension_op ------------------------------------------------------------------------------------------------------
+template <class T>
+KB_HD EF eval_extension_op(const T* flat, const T* shift, const Extra& x) {
+    const T one = a_from_base(kb::ONE, flat[0]);
+    const T is_be = flat[0], start = flat[1], len = flat[2], flag_add = flat[3], flag_mul = flat[4], flag_poly_eq = flat[5];
+    const T idx_a = flat[6], idx_b = flat[7], idx_r = flat[13];
+    T comp[5], va[5], vb[5], vres[5], comp_shift[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        comp[k] = flat[8 + k];
+        va[k] = flat[14 + k];
+        vb[k] = flat[19 + k];
+        vres[k] = flat[24 + k];
+        comp_shift[k] = shift[8 + k];
+    }
+    const T start_shift = shift[1];
+    const T activation_flag = a_mul(start, a_add(a_add(flag_add, flag_mul), flag_poly_eq));
+    const T aux = a_add(a_add(a_add(a_add(a_mulc(is_be, mc(4)), a_mulc(flag_add, mc(8))), a_mulc(flag_mul, mc(16))),
+                              a_mulc(flag_poly_eq, mc(32))),
+                        a_mulc(len, mc(64)));
+    Folder<T> f(x);
+    f.assert_zero_ef(bus_column<T>(x, activation_flag, aux, idx_a, idx_b, idx_r));
+    const T is_ee = a_sub(one, is_be);
+    const T nss = a_sub(one, start_shift);
+    T vaf[5], comp_tail[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        vaf[k] = k == 0 ? va[0] : a_mul(va[k], is_ee);
+        comp_tail[k] = a_mul(comp_shift[k], nss);
+    }
+    f.assert_zero(bool_check(is_be));
+    f.assert_zero(bool_check(start));
+    f.assert_zero(bool_check(flag_add));
+    f.assert_zero(bool_check(flag_mul));
+    f.assert_zero(bool_check(flag_poly_eq));
+#pragma unroll
+    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(a_add(vaf[k], vb[k]), comp_tail[k])), flag_add));
+    T vavb[5];
+    quintic_mul_air<T>(vaf, vb, vavb);
+#pragma unroll
+    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(vavb[k], comp_tail[k])), flag_mul));
+    T pev[5], csoo[5], per[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const T base = a_sub(a_sub(a_add(vavb[k], vavb[k]), vaf[k]), vb[k]);
+        pev[k] = k == 0 ? a_add(base, one) : base;
+        csoo[k] = k == 0 ? a_add(comp_tail[0], start_shift) : comp_tail[k];
+    }
+    quintic_mul_air<T>(pev, csoo, per);
+#pragma unroll
+    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], per[k]), flag_poly_eq));
+#pragma unroll
+    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], vres[k]), start));
+    f.assert_zero(a_mul(nss, a_sub(a_sub(len, shift[2]), one)));
+    f.assert_zero(a_mul(nss, a_sub(is_be, shift[0])));
+    f.assert_zero(a_mul(nss, a_sub(flag_add, shift[3])));
+    f.assert_zero(a_mul(nss, a_sub(flag_mul, shift[4])));
+    f.assert_zero(a_mul(nss, a_sub(flag_poly_eq, shift[5])));
+    const T a_inc = a_add(is_be, a_mulc(is_ee, mc(5)));
+    f.assert_zero(a_mul(nss, a_sub(a_sub(shift[6], idx_a), a_inc)));
+    f.assert_zero(a_mul(nss, a_sub(a_sub(shift[7], idx_b), a_from_base(mc(5), one))));
+    f.assert_zero(a_mul(start_shift, a_sub(len, one)));
+    return f.acc;
+}
+
+// ---- poseidon_16 -------------------------------------------------------------------------------------------------------
+KB_HD void mds16(u32 s[16]) { kb::mds_circ16(s); }
+KB_HD void mds16(EF s[16]) {  // base-field matrix acts on each coefficient plane
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        u32 p[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) p[i] = s[i].v[k];
+        kb::mds_circ16(p);
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i].v[k] = p[i];
+    }
+}
+template <class T>
+KB_HD T cube(const T& a) {
+    return a_mul(a_mul(a, a), a);
+}
+
+// Column access is lazy: `col(c)` returns the value of column c at this evaluation point, so that only the 16-word state
+// and the current block of columns are live (109 columns x 5 words would not fit the register file).
+template <class T, class ColFn>
+KB_HD EF eval_poseidon16(ColFn col, const Extra& x) {
+    const kb::PoseidonConsts& K = kb::poseidon_consts();
+    const T flag_active = col(0), index_b = col(1), index_res = col(2), flag_half = col(3), flag_left = col(4);
+    const T offset_left = col(5), eff_first = col(6), eff_second = col(7), flag_permute = col(8);
+    const T one = a_from_base(kb::ONE, flag_active);
+    // precompile data: 1 + 4 half + 8 left + 16 left*offset + 2 permute (poseidon_16/mod.rs:94-98,336-343)
+    const T pdr = a_add(a_add(a_add(a_add(one, a_mulc(flag_half, mc(4))), a_mulc(flag_left, mc(8))),
+                              a_mulc(a_mul(flag_left, offset_left), mc(16))),
+                        a_mulc(flag_permute, mc(2)));
+    const T omfl = a_sub(one, flag_left);
+    const T index_a = a_sub(eff_second, a_mulc(omfl, mc(4)));
+    Folder<T> f(x);
+    f.assert_zero_ef(bus_column<T>(x, flag_active, pdr, index_a, index_b, index_res));
+    f.assert_zero(bool_check(flag_active));
+    f.assert_zero(bool_check(flag_half));
+    f.assert_zero(bool_check(flag_left));
+    f.assert_zero(bool_check(flag_permute));
+    f.assert_zero(a_mul(flag_permute, a_add(flag_half, flag_left)));
+    f.assert_zero(a_mul(flag_left, a_sub(offset_left, eff_first)));
+    f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
+
+    T s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = col(9 + i);
+    // two blocks of 2 full rounds, each re-based on the committed post-state (eval_2_full_rounds_16)
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_init[2 * blk + h][i]));
+            mds16(s);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const T post = col(25 + 16 * blk + i);
+            f.assert_zero(a_sub(s[i], post));
+            s[i] = post;
+        }
+    }
+    // partial block: s <- D (s + first_rc) = D s + dbias, then 20 sparse rounds with lane 0 re-based on partial_rounds[r]
+    {
+        T t[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t[i] = s[i];
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) {
+            T acc = a_from_base(K.dbias[i], one);
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc = a_add(acc, a_mulc(t[j], K.dmat[i][j]));
+            s[i] = acc;
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < 20; r++) {
+        const T pr = col(57 + r);
+        f.assert_zero(a_sub(cube(s[0]), pr));  // assert_eq_low(state[0]^3, partial_rounds[r])
+        T s0 = pr;
+        if (r < 19) s0 = a_addc(s0, K.pscalar[r]);
+        T n0 = a_mulc(s0, K.prow[r][0]);
+#pragma unroll
+        for (int j = 1; j < 16; j++) n0 = a_add(n0, a_mulc(s[j], K.prow[r][j]));
+#pragma unroll
+        for (int i = 1; i < 16; i++) s[i] = a_add(s[i], a_mulc(s0, K.pcol[r][i - 1]));
+        s[0] = n0;
+    }
+    // first two terminal full rounds, re-based on ending_full_rounds[0]
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_term[h][i]));
+        mds16(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const T post = col(77 + i);
+        f.assert_zero(a_sub(s[i], post));
+        s[i] = post;
+    }
+    // last two full rounds and the gated outputs (eval_last_2_full_rounds_16)
+#pragma unroll 1
+    for (int h = 2; h < 4; h++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_term[h][i]));
+        mds16(s);
+    }
+    const T not_permute = a_sub(one, flag_permute);
+    const T comp_last4 = a_sub(not_permute, flag_half);
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        const T gate = i < 4 ? not_permute : comp_last4;
+        const T ol = col(93 + i);
+        f.assert_zero(a_mul(gate, a_sub(a_add(s[i], col(9 + i)), ol)));
+        f.assert_zero(a_mul(flag_permute, a_sub(s[i], ol)));
+        f.assert_zero(a_mul(flag_permute, a_sub(s[i + 8], col(101 + i))));
+    }
+    return f.acc;
+}
+
+}  // namespace air

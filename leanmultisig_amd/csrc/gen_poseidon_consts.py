@@ -116,7 +116,7 @@ def derive(rc, M):
     D = Q
     DM = mat_mul(D, M)
     Dbias = mat_vec(D, first_rc)
-    return dict(scalar=scalar, rows=rows, cols=cols, DM=DM, Dbias=Dbias)
+    return dict(scalar=scalar, rows=rows, cols=cols, DM=DM, Dbias=Dbias, D=D)
 
 
 def sparse_eval(state, rc, M, T):
@@ -167,6 +167,8 @@ def main():
     out.append("  /* rc_term[4][16] */ { " + ",\n    ".join(fmt(rc[r]) for r in range(24, 28)) + " },")
     out.append("  /* dm[16][16] = D*MDS */ { " + ",\n    ".join(fmt(row) for row in T["DM"]) + " },")
     out.append("  /* dbias[16] */ " + fmt(T["Dbias"]) + ",")
+    out.append("  /* dmat[16][16] = D (entry map of the partial block, used by the Poseidon AIR) */ { " +
+               ",\n    ".join(fmt(row) for row in T["D"]) + " },")
     out.append("  /* prow[20][16] */ { " + ",\n    ".join(fmt(row) for row in T["rows"]) + " },")
     out.append("  /* pcol[20][16] (index 15 unused) */ { " + ",\n    ".join(fmt(c + [0]) for c in T["cols"]) + " },")
     out.append("  /* pscalar[20] (index 19 unused) */ " + fmt(T["scalar"]) + ",")

@@ -609,4 +609,126 @@ int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, c
     return LM_OK;
 }
 
+
+// prove_batched_air_sumcheck (air_sumcheck.rs:636-681) + compute_bare_round_poly / process_challenge (:225-292) host side
+int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_table* tables, uint32_t n_tables,
+                                   const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5],
+                                   const uint32_t eta[5], uint32_t* out_point, uint32_t* out_col_evals) {
+    if (!ctx || !p || !tables || !n_tables || !alpha || !logup_eq16 || !bus_beta || !eta || !out_point || !out_col_evals)
+        return LM_E_INVALID;
+    struct Session {
+        lm_air* h = nullptr;
+        u32 n_vars = 0, deg = 0;
+        std::vector<EF> eq_factor;
+        EF sum, mmf;
+    };
+    std::vector<Session> ss(n_tables);
+    auto cleanup = [&](int code) {
+        for (Session& s : ss)
+            if (s.h) lm_air_free(ctx, s.h);
+        return code;
+    };
+    u32 n_rounds = 0, max_full_degree = 1;
+    for (u32 i = 0; i < n_tables; i++) {
+        const lm_air_table& t = tables[i];
+        int rc = lm_air_new(ctx, t.table, t.d_cols, t.log_rows, t.eq_point, alpha, logup_eq16, bus_beta, &ss[i].h);
+        if (rc) return cleanup(rc);
+        ss[i].n_vars = t.log_rows;
+        ss[i].deg = lm_air_degree(ss[i].h);
+        ss[i].eq_factor.resize(t.log_rows);
+        for (u32 j = 0; j < t.log_rows; j++) ss[i].eq_factor[j] = ef_load(t.eq_point + 5 * j);
+        ss[i].sum = ef_load(t.sum);
+        ss[i].mmf = kb::ef_one();
+        n_rounds = std::max(n_rounds, t.log_rows);
+        max_full_degree = std::max(max_full_degree, ss[i].deg + 1);
+    }
+    const EF eta_e = ef_load(eta);
+    std::vector<EF> eta_p(n_tables, kb::ef_one()), k(n_tables, kb::ef_one());
+    for (u32 i = 1; i < n_tables; i++) eta_p[i] = kb::ef_mul(eta_p[i - 1], eta_e);
+    std::vector<EF> challenges;
+    for (u32 round = 0; round < n_rounds; round++) {
+        std::vector<EF> combined(max_full_degree + 1, kb::ef_zero());
+        std::vector<std::vector<EF>> bare(n_tables);
+        for (u32 i = 0; i < n_tables; i++) {
+            Session& s = ss[i];
+            const u32 join = n_rounds - s.n_vars;
+            const EF w = kb::ef_mul(eta_p[i], k[i]);
+            if (round < join) {
+                combined[1] = kb::ef_add(combined[1], kb::ef_mul(w, s.sum));
+                continue;
+            }
+            // compute_bare_round_poly: raw sums at z = 0, 2, .., deg from the device
+            std::vector<u32> raw((size_t)s.deg * 5);
+            int rc = lm_air_round(ctx, s.h, raw.data());
+            if (rc) return cleanup(rc);
+            const u32 d = s.deg;
+            std::vector<EF> ev(d + 1);
+            ev[0] = kb::ef_mul(ef_load(&raw[0]), s.mmf);
+            for (u32 z = 2; z <= d; z++) ev[z] = kb::ef_mul(ef_load(&raw[(size_t)(z - 1) * 5]), s.mmf);
+            const EF eq_alpha = s.eq_factor.back();
+            ev[1] = kb::ef_mul(kb::ef_sub(s.sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), ev[0])), kb::ef_inv(eq_alpha));
+            // DensePolynomial::lagrange_interpolation on the points 0..d
+            std::vector<EF> coeffs(d + 1, kb::ef_zero());
+            for (u32 a = 0; a <= d; a++) {
+                std::vector<u32> num{kb::ONE};  // prod_{b != a} (X - b), base coefficients
+                u32 den = kb::ONE;
+                for (u32 b = 0; b <= d; b++) {
+                    if (b == a) continue;
+                    std::vector<u32> nn(num.size() + 1, 0);
+                    const u32 mb = kb::neg(kb::to_monty(b));
+                    for (size_t c = 0; c < num.size(); c++) {
+                        nn[c + 1] = kb::add(nn[c + 1], num[c]);
+                        nn[c] = kb::add(nn[c], kb::mul(num[c], mb));
+                    }
+                    num.swap(nn);
+                    den = kb::mul(den, kb::sub(kb::to_monty(a), kb::to_monty(b)));
+                }
+                const EF scale = kb::ef_mul_base(ev[a], kb::inv(den));
+                for (size_t c = 0; c < num.size(); c++) coeffs[c] = kb::ef_add(coeffs[c], kb::ef_mul_base(scale, num[c]));
+            }
+            bare[i] = coeffs;
+            // expand_bare_to_full (fiat-shamir/src/utils.rs:30-41)
+            const EF oma = kb::ef_sub(kb::ef_one(), eq_alpha), tam = kb::ef_sub(kb::ef_dbl(eq_alpha), kb::ef_one());
+            std::vector<EF> full(d + 2);
+            full[0] = kb::ef_mul(oma, coeffs[0]);
+            for (u32 c = 1; c <= d; c++) full[c] = kb::ef_add(kb::ef_mul(oma, coeffs[c]), kb::ef_mul(tam, coeffs[c - 1]));
+            full[d + 1] = kb::ef_mul(tam, coeffs[d]);
+            for (u32 c = 0; c < d + 2; c++) combined[c] = kb::ef_add(combined[c], kb::ef_mul(w, full[c]));
+        }
+        add_sumcheck_poly(p, combined, nullptr);
+        std::vector<EF> cv;
+        if (!sample_vec(p, 1, cv)) return cleanup(LM_E_INVALID);
+        const EF ch = cv[0];
+        challenges.push_back(ch);
+        for (u32 i = 0; i < n_tables; i++) {
+            Session& s = ss[i];
+            const u32 join = n_rounds - s.n_vars;
+            if (round < join) {
+                k[i] = kb::ef_mul(k[i], ch);
+                continue;
+            }
+            // process_challenge
+            const EF a = s.eq_factor.back();
+            const EF eq_eval = kb::ef_add(kb::ef_mul(kb::ef_sub(kb::ef_one(), a), kb::ef_sub(kb::ef_one(), ch)), kb::ef_mul(a, ch));
+            EF bv = kb::ef_zero();
+            for (size_t c = bare[i].size(); c-- > 0;) bv = kb::ef_add(kb::ef_mul(bv, ch), bare[i][c]);
+            s.sum = kb::ef_mul(bv, eq_eval);
+            s.mmf = kb::ef_mul(s.mmf, eq_eval);
+            int rc = lm_air_bind(ctx, s.h, ch.v);
+            if (rc) return cleanup(rc);
+            s.eq_factor.pop_back();
+        }
+    }
+    u32* oe = out_col_evals;
+    for (u32 i = 0; i < n_tables; i++) {
+        const u32 ne = lm_air_n_evals(ss[i].h);
+        int rc = lm_air_final_evals(ctx, ss[i].h, oe);
+        if (rc) return cleanup(rc);
+        add_base(p, oe, (u64)ne * 5);  // add_extension_scalars(&col_evals)
+        oe += (size_t)ne * 5;
+    }
+    for (u32 i = 0; i < n_rounds; i++) memcpy(out_point + 5 * i, challenges[i].v, 20);
+    return cleanup(LM_OK);
+}
+
 }  // extern "C"

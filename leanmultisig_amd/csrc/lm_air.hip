@@ -1,0 +1,296 @@
+// AIR sumcheck sessions on gfx950 (reference: crates/sub_protocols/src/air_sumcheck.rs — AirSumcheckSession /
+// OuterSumcheckSession :34-292, compute_raw_poly_impl :560-634).
+//
+// A session holds the columns of one table (column-major, natural row order; base words before the first fold, SoA EF
+// afterwards) and serves one sumcheck round at a time, LSB first:
+//   lm_air_round : raw[z] = sum_pairs eq_prefix(pair) * sum_k alpha^k C_k(lo + z (hi - lo)),   z in {0, 2, .., degree}
+//   lm_air_bind  : fold every column with the challenge (fold_multilinear_at_bit :117-159, bit 0 in natural order)
+// Work decomposition: grid.y = evaluation point z, one row pair per lane; the constraint evaluators (air_tables.h) keep
+// only the live part of a row in registers.  "Shift" columns (next-row view of the first n_shift columns,
+// compute_shifted_columns :683-694) are read in place from the base columns in round 0 and materialised by the first fold.
+#include <algorithm>
+#include "air_tables.h"
+#include "lm_common.h"
+#include "lm_eqsplit.h"
+
+using namespace kb;
+
+struct lm_air {
+    int table = 0;
+    u32 log_rows = 0, round = 0;
+    u32 n_cols = 0, n_shift = 0, deg = 0;
+    const u32** d_base_cols = nullptr;  // device array of n_cols device pointers (caller's base columns)
+    u32* ef[2] = {nullptr, nullptr};    // ping-pong: (n_cols + n_shift) columns x 5 planes
+    int cur = -1;
+    air::Extra* d_extra = nullptr;
+    PrefixEqTables eqt;
+};
+
+// column value at the evaluation point z of a row pair: lo + z (hi - lo)
+__device__ __forceinline__ u32 lerp(u32 lo, u32 hi, u32 zm) { return add(lo, mul(sub(hi, lo), zm)); }
+__device__ __forceinline__ EF lerp(const EF& lo, const EF& hi, u32 zm) { return ef_add(lo, ef_mul_base(ef_sub(hi, lo), zm)); }
+
+struct BaseCols {
+    const u32* const* cols;
+    u64 n_rows;
+    u32 n_flat;
+    // column c < n_flat: flat; c >= n_flat: shift view of column c - n_flat
+    __device__ __forceinline__ u32 at(u32 c, u64 j, u32 zm) const {
+        if (c < n_flat) {
+            uint2 v = *reinterpret_cast<const uint2*>(cols[c] + 2 * j);
+            return lerp(v.x, v.y, zm);
+        }
+        const u32* p = cols[c - n_flat];
+        const u64 i1 = 2 * j + 1, i2 = (2 * j + 2 < n_rows) ? 2 * j + 2 : n_rows - 1;
+        return lerp(p[i1], p[i2], zm);
+    }
+};
+struct ExtCols {
+    const u32* buf;  // column c plane k at buf + (c * 5 + k) * n_rows
+    u64 n_rows;
+    __device__ __forceinline__ EF at(u32 c, u64 j, u32 zm) const {
+        EF lo, hi;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint2 v = *reinterpret_cast<const uint2*>(buf + ((u64)c * 5 + k) * n_rows + 2 * j);
+            lo.v[k] = v.x;
+            hi.v[k] = v.y;
+        }
+        return lerp(lo, hi, zm);
+    }
+};
+
+template <int TABLE, class T, class Cols>
+__device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, const air::Extra& x) {
+    if constexpr (TABLE == air::T_POSEIDON16) {
+        return air::eval_poseidon16<T>([&](int c) { return cols.at((u32)c, j, zm); }, x);
+    } else {
+        constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
+        T flat[NF], shift[NS];
+#pragma unroll
+        for (int c = 0; c < NF; c++) flat[c] = cols.at(c, j, zm);
+#pragma unroll
+        for (int c = 0; c < NS; c++) shift[c] = cols.at(NF + c, j, zm);
+        if constexpr (TABLE == air::T_EXECUTION)
+            return air::eval_execution<T>(flat, shift, x);
+        else
+            return air::eval_extension_op<T>(flat, shift, x);
+    }
+}
+
+// grid (blocks_x, n_z); partial[(zi * blocks_x + bx) * 5 + k]
+template <int TABLE, class T, class Cols>
+__global__ __launch_bounds__(256) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+                                                   u32* __restrict__ partial) {
+    __shared__ u32 lds[20];
+    const u32 zi = blockIdx.y;
+    const u32 z = zi == 0 ? 0 : zi + 1;  // 0, 2, 3, ..., degree
+    const u32 zm = to_monty(z);
+    EF acc = ef_zero();
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
+        const EF v = eval_table<TABLE, T, Cols>(cols, j, zm, *extra);
+        acc = ef_add(acc, ef_mul(v, eq_split_at(eq, j)));
+    }
+    u32 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = wave_sum_u32(acc.v[k]);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) lds[wave * 5 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        u32 s = 0;
+        for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
+        partial[((u64)zi * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
+    }
+}
+// one block per z: out[zi * 5 + k] = sum_b partial[(zi * n + b) * 5 + k]
+__global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n, u32* __restrict__ out) {
+    __shared__ u32 lds[20];
+    const u32 zi = blockIdx.x;
+    u32 v[5] = {0, 0, 0, 0, 0};
+    for (u32 b = threadIdx.x; b < n; b += 256)
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] = add(v[k], partial[((u64)zi * n + b) * 5 + k]);
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = wave_sum_u32(v[k]);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) lds[wave * 5 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        u32 s = 0;
+        for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
+        out[zi * 5 + threadIdx.x] = s;
+    }
+}
+
+// fold: out[c][k][j] = lo + r (hi - lo); grid (blocks_x, n_cols + n_shift)
+__global__ __launch_bounds__(256) void k_air_fold_base(BaseCols cols, u64 n_out, EF r, u32* __restrict__ out) {
+    const u32 c = blockIdx.y;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_out; j += (u64)gridDim.x * 256) {
+        u32 lo, hi;
+        if (c < cols.n_flat) {
+            uint2 v = *reinterpret_cast<const uint2*>(cols.cols[c] + 2 * j);
+            lo = v.x;
+            hi = v.y;
+        } else {
+            const u32* p = cols.cols[c - cols.n_flat];
+            lo = p[2 * j + 1];
+            hi = p[(2 * j + 2 < cols.n_rows) ? 2 * j + 2 : cols.n_rows - 1];
+        }
+        EF o = ef_mul_base(r, sub(hi, lo));
+        o.v[0] = add(o.v[0], lo);
+#pragma unroll
+        for (int k = 0; k < 5; k++) out[((u64)c * 5 + k) * n_out + j] = o.v[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, EF r, u32* __restrict__ out) {
+    const u32 c = blockIdx.y;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_out; j += (u64)gridDim.x * 256) {
+        EF lo, hi;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            uint2 v = *reinterpret_cast<const uint2*>(cols.buf + ((u64)c * 5 + k) * cols.n_rows + 2 * j);
+            lo.v[k] = v.x;
+            hi.v[k] = v.y;
+        }
+        EF o = ef_add(lo, ef_mul(r, ef_sub(hi, lo)));
+#pragma unroll
+        for (int k = 0; k < 5; k++) out[((u64)c * 5 + k) * n_out + j] = o.v[k];
+    }
+}
+
+template <int TABLE>
+static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+    const dim3 grid(blocks, a->deg), block(256);
+    if (a->cur < 0) {
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
+        LM_LAUNCH(ctx, (k_air_round<TABLE, u32, BaseCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial);
+    } else {
+        ExtCols c{a->ef[a->cur], 2 * n_pairs};
+        LM_LAUNCH(ctx, (k_air_round<TABLE, EF, ExtCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial);
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+extern "C" {
+
+void lm_air_free(lm_ctx* ctx, lm_air* a) {
+    if (!a) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (a->d_base_cols) (void)hipFree((void*)a->d_base_cols);
+    for (int i = 0; i < 2; i++)
+        if (a->ef[i]) (void)hipFree(a->ef[i]);
+    if (a->d_extra) (void)hipFree(a->d_extra);
+    if (a->eqt.d_buf) (void)hipFree(a->eqt.d_buf);
+    delete a;
+}
+
+int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint32_t log_rows, const uint32_t* eq_point,
+               const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5], lm_air** out) {
+    LM_REQUIRE(ctx && d_cols && eq_point && alpha && logup_eq16 && bus_beta && out);
+    LM_REQUIRE(table <= 2 && log_rows >= 1 && log_rows <= 30);
+    lm_air* a = new lm_air();
+    a->table = (int)table;
+    a->log_rows = log_rows;
+    a->n_cols = air::n_columns((int)table);
+    a->n_shift = air::n_shift((int)table);
+    a->deg = air::degree((int)table);
+    const u64 half = 1ull << (log_rows - 1);
+    const u64 ef_words0 = (u64)(a->n_cols + a->n_shift) * 5 * half;
+    air::Extra hx;
+    EF al, p = ef_one();
+    memcpy(al.v, alpha, 20);
+    for (int i = 0; i < air::MAX_ALPHA; i++) {  // air_alpha.powers() (prove_execution.rs:154-155)
+        hx.alpha_powers[i] = p;
+        p = ef_mul(p, al);
+    }
+    memcpy(hx.logup_eq, logup_eq16, 16 * 20);
+    memcpy(hx.bus_beta.v, bus_beta, 20);
+    bool ok = hipMalloc((void**)&a->d_base_cols, a->n_cols * sizeof(u32*)) == hipSuccess &&
+              hipMalloc(&a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
+              hipMalloc(&a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
+              hipMalloc(&a->d_extra, sizeof(air::Extra)) == hipSuccess &&
+              hipMalloc(&a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess;
+    if (!ok) {
+        lm_set_error("lm_air_new: hipMalloc failed");
+        lm_air_free(ctx, a);
+        return LM_E_NOMEM;
+    }
+    a->eqt.buf_words = PrefixEqTables::words_needed(log_rows);
+    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, d_cols, a->n_cols * sizeof(u32*), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemcpyAsync(a->d_extra, &hx, sizeof hx, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = a->eqt.build(ctx, eq_point, log_rows);
+    if (rc) {
+        lm_air_free(ctx, a);
+        return rc;
+    }
+    *out = a;
+    return LM_OK;
+}
+
+uint32_t lm_air_degree(const lm_air* a) { return a ? a->deg : 0; }
+uint32_t lm_air_n_evals(const lm_air* a) { return a ? a->n_cols + a->n_shift : 0; }
+
+// raw[zi] for z = 0, 2, 3, .., degree  (degree EF values = 5 * degree words)
+int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
+    LM_REQUIRE(ctx && a && out_raw && a->round < a->log_rows);
+    const u32 p = a->log_rows - a->round - 1;
+    const u64 n_pairs = 1ull << p;
+    const u32 blocks = (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
+    u32* s;
+    int rc = lm_scratch(ctx, (u64)blocks * a->deg * 5 + a->deg * 5 + 64, &s);
+    if (rc) return rc;
+    u32* d_out = s + (u64)blocks * a->deg * 5;
+    const EqSplit eq = a->eqt.at(p);
+    if (a->table == air::T_EXECUTION)
+        rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s);
+    else if (a->table == air::T_EXTENSION_OP)
+        rc = launch_round<air::T_EXTENSION_OP>(ctx, a, n_pairs, blocks, eq, s);
+    else
+        rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
+    if (rc) return rc;
+    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, d_out);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipMemcpyAsync(out_raw, d_out, (u64)a->deg * 20, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
+    LM_REQUIRE(ctx && a && challenge && a->round < a->log_rows);
+    EF r;
+    memcpy(r.v, challenge, 20);
+    const u64 n_out = 1ull << (a->log_rows - a->round - 1);
+    const u32 blocks = (u32)std::min<u64>((n_out + 255) / 256, 1024);
+    const dim3 grid(blocks, a->n_cols + a->n_shift);
+    if (a->cur < 0) {
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
+        LM_LAUNCH(ctx, k_air_fold_base, grid, dim3(256), 0, c, n_out, r, a->ef[0]);
+        a->cur = 0;
+    } else {
+        ExtCols c{a->ef[a->cur], 2 * n_out};
+        LM_LAUNCH(ctx, k_air_fold_ext, grid, dim3(256), 0, c, n_out, r, a->ef[1 - a->cur]);
+        a->cur = 1 - a->cur;
+    }
+    LM_HIP(hipGetLastError());
+    a->round++;
+    return LM_OK;
+}
+
+// final_column_evals (air_sumcheck.rs:294-296): (n_cols + n_shift) EF values after log_rows bindings
+int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out) {
+    LM_REQUIRE(ctx && a && out && a->round == a->log_rows && a->cur >= 0);
+    LM_HIP(hipMemcpyAsync(out, a->ef[a->cur], (u64)(a->n_cols + a->n_shift) * 20, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    return LM_OK;
+}
+
+}  // extern "C"

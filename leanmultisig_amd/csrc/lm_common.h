@@ -58,7 +58,8 @@ struct lm_ctx {
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                                  \
     do {                                                                                                 \
         lm_ctx* c__ = (ctx);                                                                             \
-        const bool p__ = !c__->prof_select.empty() && (c__->prof_select == "*" || c__->prof_select == #kernel); \
+        const bool p__ = !c__->prof_select.empty() &&                                                    \
+                         (c__->prof_select == "*" || lm_prof_match(c__->prof_select.c_str(), #kernel));  \
         hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                       \
         if (p__) {                                                                                       \
             (void)hipEventCreate(&e0__);                                                                 \
@@ -71,6 +72,12 @@ struct lm_ctx {
             c__->prof_events[#kernel].emplace_back(e0__, e1__);                                          \
         }                                                                                                \
     } while (0)
+
+static inline bool lm_prof_match(const char* want, const char* name) {
+    if (name[0] == '(') name++;  // template kernels are launched as (k<...>)
+    size_t n = strlen(want);
+    return strncmp(want, name, n) == 0 && (name[n] == 0 || name[n] == '<');
+}
 
 struct lm_tree {
     u32* d_matrix = nullptr;   // column-major: stored_cols x h words

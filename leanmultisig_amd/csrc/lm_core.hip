@@ -233,17 +233,26 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
     LM_HIP(hipStreamSynchronize(ctx->stream));
     *n_launches = 0;
     *total_ms = 0.0;
-    auto it = ctx->prof_events.find(kernel_name);
-    if (it == ctx->prof_events.end()) return LM_OK;
-    for (auto& pr : it->second) {
-        float ms = 0.f;
-        LM_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-        *total_ms += ms;
-        *n_launches += 1;
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+    // template instantiations are recorded as "name<args>": a bare name matches all of them
+    const std::string want = kernel_name;
+    for (auto it = ctx->prof_events.begin(); it != ctx->prof_events.end();) {
+        std::string key = it->first;
+        if (!key.empty() && key[0] == '(') key = key.substr(1);
+        const bool match = key == want || (key.size() > want.size() && key.compare(0, want.size(), want) == 0 && key[want.size()] == '<');
+        if (!match) {
+            ++it;
+            continue;
+        }
+        for (auto& pr : it->second) {
+            float ms = 0.f;
+            LM_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            *total_ms += ms;
+            *n_launches += 1;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        it = ctx->prof_events.erase(it);
     }
-    ctx->prof_events.erase(it);
     return LM_OK;
 }
 

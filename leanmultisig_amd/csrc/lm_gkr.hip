@@ -8,6 +8,7 @@
 // (LSB-first folding, sumcheck_utils.rs:278-357).
 #include <algorithm>
 #include "lm_common.h"
+#include "lm_eqsplit.h"
 
 using namespace kb;
 
@@ -18,15 +19,13 @@ struct lm_gkr {
     std::vector<u32*> nums, dens;  // layers n_vars-1 .. 5 (index 0 = 2^(n_vars-1) entries), SoA EF, owned
     u32* work[2] = {nullptr, nullptr};  // ping-pong: 4 arrays x 5 planes
     u64 work_words = 0;
-    u32* tables = nullptr;  // prefix eq tables of the current layer
+    PrefixEqTables eqt;  // prefix eq tables of the current layer
     // state of the layer being proven
     u32 K = 0;        // number of rounds = number of coordinates of the claim point
     u32 round = 0;
     int cur = -1;     // which work buffer holds the current arrays (-1: still in layer storage)
     u64 m = 0;        // current length of each of the 4 arrays
     EF alpha;
-    std::vector<u64> th_off, tl_off;  // table offsets (words) per prefix length
-    u32 H = 0;
 };
 
 // ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
@@ -65,51 +64,6 @@ __global__ __launch_bounds__(256) void k_gkr_layer_up(const u32* __restrict__ n_
     }
 }
 
-// ---- prefix eq tables -------------------------------------------------------------------------------------------------
-// table t (t < n_tables): eq over coordinates point[c0 .. c0 + nb), written SoA at arena + off.
-struct GkrTableDesc {
-    u64 off;
-    u32 c0, nb;
-};
-__global__ __launch_bounds__(256) void k_gkr_tables(const GkrTableDesc* __restrict__ descs, const u32* __restrict__ point,
-                                                    u32* __restrict__ arena) {
-    const GkrTableDesc d = descs[blockIdx.y];
-    const u32 len = 1u << d.nb;
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
-    EF acc = ef_one();
-    for (u32 j = 0; j < d.nb; j++) {
-        EF p;
-#pragma unroll
-        for (int k = 0; k < 5; k++) p.v[k] = point[(d.c0 + j) * 5 + k];
-        u32 bit = (i >> (d.nb - 1 - j)) & 1;
-        acc = ef_mul(acc, bit ? p : ef_sub(ef_one(), p));
-    }
-#pragma unroll
-    for (int k = 0; k < 5; k++) arena[d.off + (u64)k * len + i] = acc.v[k];
-}
-
-struct EqSplit {
-    const u32* th;  // hi table (SoA, len_hi entries)
-    const u32* tl;  // lo table (SoA, len_lo entries) or nullptr
-    u32 len_hi, log_lo;
-};
-__device__ __forceinline__ EF eq_split_at(const EqSplit& e, u64 j) {
-    EF a;
-    const u64 jh = j >> e.log_lo;
-#pragma unroll
-    for (int k = 0; k < 5; k++) a.v[k] = e.th[(u64)k * e.len_hi + jh];
-    if (e.tl) {
-        EF b;
-        const u32 len_lo = 1u << e.log_lo;
-        const u32 jl = (u32)j & (len_lo - 1);
-#pragma unroll
-        for (int k = 0; k < 5; k++) b.v[k] = e.tl[(u64)k * len_lo + jl];
-        a = ef_mul(a, b);
-    }
-    return a;
-}
-
 // pair_coeffs (sumcheck_utils.rs:65-79) accumulated with weight w into acc[0..4) = (c0_num, c2_num, c0_den, c2_den)
 __device__ __forceinline__ void pair_accumulate(const EF& nl0, const EF& nl1, const EF& nr0, const EF& nr1, const EF& dl0,
                                                 const EF& dl1, const EF& dr0, const EF& dr1, const EF& w, EF acc[4]) {
@@ -136,11 +90,6 @@ __device__ __forceinline__ void pair_accumulate_base(u32 nl0, u32 nl1, u32 nr0, 
     acc[3] = ef_add(acc[3], ef_mul(c2d, w));
 }
 
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = add(v, (u32)__shfl_down(v, off, 64));
-    return v;
-}
 // block-sum of 4 EF accumulators -> partial[block][20]
 __device__ __forceinline__ void block_store_acc(const EF acc[4], u32* lds /* 80 words */, u32* dst) {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -313,7 +262,7 @@ void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
     for (u32* p : g->dens) (void)hipFree(p);
     for (int i = 0; i < 2; i++)
         if (g->work[i]) (void)hipFree(g->work[i]);
-    if (g->tables) (void)hipFree(g->tables);
+    if (g->eqt.d_buf) (void)hipFree(g->eqt.d_buf);
     delete g;
 }
 
@@ -348,11 +297,12 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
     g->work_words = 20ull << (n_vars - 2);
     const u64 w1 = std::max<u64>(g->work_words / 2, 64);
     if (hipMalloc(&g->work[0], g->work_words * 4) != hipSuccess || hipMalloc(&g->work[1], w1 * 4) != hipSuccess ||
-        hipMalloc(&g->tables, (20ull << ((n_vars + 1) / 2 + 1)) * 4 + 4096) != hipSuccess) {
+        hipMalloc(&g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess) {
         lm_set_error("lm_gkr_build: hipMalloc failed (work)");
         lm_gkr_free(ctx, g);
         return LM_E_NOMEM;
     }
+    g->eqt.buf_words = PrefixEqTables::words_needed(n_vars);
     LM_HIP(hipGetLastError());
     *out = g;
     return LM_OK;
@@ -380,57 +330,8 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
     g->cur = -1;
     g->m = 1ull << K;  // length of each of n_l, n_r, d_l, d_r
     memcpy(g->alpha.v, alpha, 20);
-    // prefix tables: round t uses eq over point[0 .. p), p = K-1-t.  hi part: first min(p, H) coords; lo: [H, p).
-    const u32 P1 = K - 1;
-    const u32 H = (P1 + 1) / 2;
-    g->H = H;
-    std::vector<GkrTableDesc> descs;
-    g->th_off.assign(H + 1, 0);
-    g->tl_off.assign(P1 + 1, 0);
-    u64 off = 0;
-    u32 max_len = 1;
-    for (u32 q = 0; q <= H; q++) {
-        g->th_off[q] = off;
-        descs.push_back({off, 0, q});
-        off += 5ull << q;
-        max_len = std::max(max_len, 1u << q);
-    }
-    for (u32 p = H + 1; p <= P1; p++) {
-        g->tl_off[p] = off;
-        descs.push_back({off, H, p - H});
-        off += 5ull << (p - H);
-        max_len = std::max(max_len, 1u << (p - H));
-    }
-    // descriptors + point go to the tail of the table buffer
-    const u64 tail = (off + 15) & ~15ull;
-    const u64 desc_words = (descs.size() * sizeof(GkrTableDesc) + 3) / 4;
-    LM_REQUIRE(tail + desc_words + K * 5 + 16 <= (20ull << ((g->n_vars + 1) / 2 + 1)) + 1024);
-    LM_HIP(hipMemcpyAsync(g->tables + tail, descs.data(), descs.size() * sizeof(GkrTableDesc), hipMemcpyHostToDevice,
-                          ctx->stream));
-    const u64 pt_off = (tail + desc_words + 15) & ~15ull;
-    LM_HIP(hipMemcpyAsync(g->tables + pt_off, point, (u64)K * 20, hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
-    LM_LAUNCH(ctx, k_gkr_tables, dim3((max_len + 255) / 256, (u32)descs.size()), dim3(256), 0,
-              (const GkrTableDesc*)(g->tables + tail), (const u32*)(g->tables + pt_off), g->tables);
-    LM_HIP(hipGetLastError());
-    return LM_OK;
-}
-
-static EqSplit make_eq(const lm_gkr* g, u32 p) {
-    EqSplit e;
-    const u32 H = g->H;
-    if (p <= H) {
-        e.th = g->tables + g->th_off[p];
-        e.len_hi = 1u << p;
-        e.tl = nullptr;
-        e.log_lo = 0;
-    } else {
-        e.th = g->tables + g->th_off[H];
-        e.len_hi = 1u << H;
-        e.tl = g->tables + g->tl_off[p];
-        e.log_lo = p - H;
-    }
-    return e;
+    // round t uses eq over point[0 .. p), p = K-1-t
+    return g->eqt.build(ctx, point, K);
 }
 
 // One round.  prev_r = NULL on the first round of the layer; afterwards the challenge of the previous round (the
@@ -447,7 +348,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     int rc = lm_scratch(ctx, (u64)blocks * 20 + 32, &s);
     if (rc) return rc;
     u32* d_out = s + (u64)blocks * 20;
-    const EqSplit eq = make_eq(g, p);
+    const EqSplit eq = g->eqt.at(p);
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
     // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
     const bool input_layer = g->K == g->n_vars - 1;
@@ -491,7 +392,7 @@ int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[5], uint32_t 
     EF r;
     memcpy(r.v, last_r, 20);
     const int dst = 1 - g->cur;
-    EqSplit eq = make_eq(g, 0);
+    EqSplit eq = g->eqt.at(0);
     u32* s;
     int rc = lm_scratch(ctx, 64, &s);
     if (rc) return rc;

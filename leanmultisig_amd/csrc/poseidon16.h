@@ -13,6 +13,7 @@ struct PoseidonConsts {
     u32 rc_term[4][16];
     u32 dm[16][16];   // D * MDS (fused linear layer of the 4th full round and the partial-block entry)
     u32 dbias[16];    // D * first_rc
+    u32 dmat[16][16]; // D alone (Poseidon AIR: the state is re-based on committed columns before the partial block)
     u32 prow[20][16]; // sparse first row per partial round
     u32 pcol[20][16]; // sparse first column (rows 1..15) per partial round
     u32 pscalar[20];  // lane-0 constant added after the S-box of partial round r (r < 19)

@@ -289,3 +289,144 @@ int orc_gkr_verify(const uint32_t* proof_blob, uint32_t n_vars, uint32_t* out_qu
     }
 }
 }
+
+// ================================================================================================
+// AIR sumcheck (air_oracle.hpp)
+// ================================================================================================
+#include "air_oracle.hpp"
+namespace {
+// blob (u32 words): [n_sessions] [alpha x5] [bus_beta x5] [eta x5] [logup_alphas_eq_poly 16x5]
+// per session: [table, n_vars] [eq_point n_vars x5] [sum x5] [columns: n_columns x 2^n_vars base words, column major]
+struct AirProblem {
+    std::vector<AirSession> sessions;
+    EF eta;
+};
+AirProblem parse_air_problem(const uint32_t* b) {
+    AirProblem pr;
+    size_t k = 0;
+    uint32_t ns = b[k++];
+    EF alpha, beta;
+    std::memcpy(alpha.v, b + k, 20); k += 5;
+    std::memcpy(beta.v, b + k, 20); k += 5;
+    std::memcpy(pr.eta.v, b + k, 20); k += 5;
+    AirExtra ex;
+    ex.bus_beta = beta;
+    ex.logup_alphas_eq_poly.resize(16);
+    for (int i = 0; i < 16; i++) { std::memcpy(ex.logup_alphas_eq_poly[i].v, b + k, 20); k += 5; }
+    ex.alpha_powers.resize(101);
+    ex.alpha_powers[0] = ef_one();
+    for (int i = 1; i < 101; i++) ex.alpha_powers[i] = ef_mul(ex.alpha_powers[i - 1], alpha);
+    for (uint32_t s = 0; s < ns; s++) {
+        AirSession se;
+        se.table = (int)b[k++];
+        se.n_vars = b[k++];
+        se.eq_factor.resize(se.n_vars);
+        for (size_t i = 0; i < se.n_vars; i++) { std::memcpy(se.eq_factor[i].v, b + k, 20); k += 5; }
+        std::memcpy(se.sum.v, b + k, 20); k += 5;
+        se.mmf = ef_one();
+        se.extra = ex;
+        size_t n = (size_t)1 << se.n_vars, nc = air_n_columns(se.table), nsft = air_n_shift(se.table);
+        se.cols.resize(nc + nsft);
+        for (size_t c = 0; c < nc; c++) {
+            se.cols[c].resize(n);
+            for (size_t i = 0; i < n; i++) se.cols[c][i] = ef_from_base(b[k + c * n + i]);
+        }
+        for (size_t c = 0; c < nsft; c++) {
+            std::vector<uint32_t> sh = shifted_column(b + k + c * n, n);
+            se.cols[nc + c].resize(n);
+            for (size_t i = 0; i < n; i++) se.cols[nc + c][i] = ef_from_base(sh[i]);
+        }
+        k += nc * n;
+        pr.sessions.push_back(std::move(se));
+    }
+    return pr;
+}
+}  // namespace
+extern "C" {
+// Runs prove_batched_air_sumcheck then sends the final column evals (prove_execution.rs:209-214).
+// out_point: n_max x 5 challenges (sumcheck order, LSB first); out_evals: concatenated final column evals.
+uint64_t orc_air_prove(const uint32_t* blob, uint32_t* out_point, uint32_t* out_evals) {
+    AirProblem pr = parse_air_problem(blob);
+    ProverState ps;
+    std::vector<EF> ch = prove_batched_air_sumcheck(ps, pr.sessions, pr.eta);
+    std::memcpy(out_point, ch.data(), ch.size() * 20);
+    size_t k = 0;
+    for (auto& s : pr.sessions) {
+        std::vector<EF> ev = s.final_column_evals();
+        ps.add_extension_scalars(ev);
+        std::memcpy(out_evals + k, ev.data(), ev.size() * 20);
+        k += ev.size() * 5;
+    }
+    g_last_proof = serialize_proof(ps);
+    return g_last_proof.size();
+}
+// Verifier side of the same slice (verify_execution.rs:109-170): the blob carries the same public data (columns ignored).
+int orc_air_verify(const uint32_t* blob, const uint32_t* proof_blob) {
+    try {
+        AirProblem pr = parse_air_problem(blob);
+        VerifierState vs;
+        parse_proof(proof_blob, vs);
+        size_t n_max = 0, max_full_degree = 1;
+        for (auto& s : pr.sessions) { n_max = std::max(n_max, s.n_vars); max_full_degree = std::max(max_full_degree, s.degree() + 1); }
+        EF target = ef_zero(), ep = ef_one();
+        std::vector<EF> eta_p;
+        for (auto& s : pr.sessions) { target = ef_add(target, ef_mul(ep, s.sum)); eta_p.push_back(ep); ep = ef_mul(ep, pr.eta); }
+        std::vector<EF> point;
+        for (size_t r = 0; r < n_max; r++) {  // sumcheck_verify, sumcheck/src/verify.rs:5-27
+            std::vector<EF> coeffs = vs.next_sumcheck_polynomial(max_full_degree + 1, target, nullptr);
+            EF c = vs.sample();
+            point.push_back(c);
+            target = poly_eval(coeffs, c);
+        }
+        EF mine = ef_zero();
+        for (size_t i = 0; i < pr.sessions.size(); i++) {
+            AirSession& s = pr.sessions[i];
+            size_t nct = air_n_columns(s.table) + air_n_shift(s.table);
+            std::vector<EF> ev = vs.next_extension_scalars_vec(nct);
+            EF ce = air_eval(s.table, ev.data(), s.extra);
+            // back_loaded_table_contribution, verify_execution.rs:236-251
+            size_t suffix_start = n_max - s.n_vars;
+            EF eqv = ef_one();
+            for (size_t j = 0; j < s.n_vars; j++) {
+                EF nat = point[n_max - 1 - j];  // natural_ordering_point_for_session
+                EF b = s.eq_factor[j];
+                eqv = ef_mul(eqv, ef_add(ef_mul(b, nat), ef_mul(ef_sub(ef_one(), b), ef_sub(ef_one(), nat))));
+            }
+            EF kt = ef_one();
+            for (size_t j = 0; j < suffix_start; j++) kt = ef_mul(kt, point[j]);
+            mine = ef_add(mine, ef_mul(ef_mul(ef_mul(eta_p[i], kt), eqv), ce));
+        }
+        if (!ef_eq(mine, target)) throw std::runtime_error("InvalidProof (air final value)");
+        if (vs.off != vs.transcript.size()) throw std::runtime_error("trailing transcript data");
+        g_verr[0] = 0;
+        return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+// single-point AIR evaluation (EF columns): values = (n_columns + n_shift) x 5; uses the extra data of `blob` header
+void orc_air_eval(const uint32_t* blob_header, uint32_t table, const uint32_t* values, uint32_t* out5) {
+    // header = [0] [alpha][beta][eta][eqpoly]: reuse the parser with zero sessions
+    AirProblem pr;
+    std::vector<uint32_t> tmp(blob_header, blob_header + 1 + 15 + 80);
+    tmp[0] = 0;
+    parse_air_problem(tmp.data());
+    AirExtra ex;
+    size_t k = 1;
+    EF alpha;
+    std::memcpy(alpha.v, blob_header + k, 20); k += 5;
+    std::memcpy(ex.bus_beta.v, blob_header + k, 20); k += 10;
+    ex.logup_alphas_eq_poly.resize(16);
+    for (int i = 0; i < 16; i++) { std::memcpy(ex.logup_alphas_eq_poly[i].v, blob_header + k, 20); k += 5; }
+    ex.alpha_powers.resize(101);
+    ex.alpha_powers[0] = ef_one();
+    for (int i = 1; i < 101; i++) ex.alpha_powers[i] = ef_mul(ex.alpha_powers[i - 1], alpha);
+    EF r = air_eval((int)table, (const EF*)values, ex);
+    std::memcpy(out5, r.v, 20);
+}
+// fill a Poseidon table row (109 words; first 25 given) — trace_gen.rs:44-112
+void orc_poseidon16_fill_rows(uint32_t* rows, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) poseidon16_fill_row(rows + 109 * i);
+}
+}

@@ -286,3 +286,78 @@ def gkr_instance(orc, rng, log_n, active_frac=1.0):
     dens[active:] = 0
     dens[active:, 0] = 0x01FFFFFE
     return nums, dens
+
+
+# ------------------------------------------------------------------------------------------------------------
+# AIR helpers (oracle side)
+# ------------------------------------------------------------------------------------------------------------
+AIR_N_COLUMNS = {0: 20, 1: 29, 2: 109}
+AIR_N_SHIFT = {0: 2, 1: 13, 2: 0}
+
+
+def air_blob(tables, alpha, logup_eq16, bus_beta, eta):
+    """tables: list of dict(table, log_rows, cols=(n_columns, 2^log_rows) uint32, eq_point (n,5), sum ef5)"""
+    words = [np.array([len(tables)], dtype=np.uint32), np.asarray(alpha, dtype=np.uint32), np.asarray(bus_beta, dtype=np.uint32),
+             np.asarray(eta, dtype=np.uint32), np.asarray(logup_eq16, dtype=np.uint32).reshape(-1)]
+    for t in tables:
+        words += [np.array([t["table"], t["log_rows"]], dtype=np.uint32), np.asarray(t["eq_point"], dtype=np.uint32).reshape(-1),
+                  np.asarray(t["sum"], dtype=np.uint32), np.ascontiguousarray(t["cols"], dtype=np.uint32).reshape(-1)]
+    return np.concatenate(words)
+
+
+def air_prove(orc, tables, alpha, logup_eq16, bus_beta, eta):
+    blob = air_blob(tables, alpha, logup_eq16, bus_beta, eta)
+    n_max = max(t["log_rows"] for t in tables)
+    total = sum(AIR_N_COLUMNS[t["table"]] + AIR_N_SHIFT[t["table"]] for t in tables)
+    pt = np.empty((n_max, 5), dtype=np.uint32)
+    ev = np.empty((total, 5), dtype=np.uint32)
+    orc.lib.orc_air_prove.restype = C.c_uint64
+    n = orc.lib.orc_air_prove(_p(blob), _p(pt), _p(ev))
+    proof = np.empty(n, dtype=np.uint32)
+    orc.lib.orc_last_proof(_p(proof))
+    return proof, pt, ev
+
+
+def air_verify(orc, tables, alpha, logup_eq16, bus_beta, eta, proof):
+    blob = air_blob(tables, alpha, logup_eq16, bus_beta, eta)
+    proof = np.ascontiguousarray(proof, dtype=np.uint32)
+    orc.lib.orc_last_error.restype = C.c_char_p
+    ok = orc.lib.orc_air_verify(_p(blob), _p(proof))
+    return bool(ok), orc.lib.orc_last_error().decode()
+
+
+def air_eval_rows(orc, table, cols, alpha, logup_eq16, bus_beta):
+    """Constraint value sum_k alpha^k C_k at every row of a base-field table (shift = next row, last row repeated)."""
+    cols = np.asarray(cols, dtype=np.uint32)
+    nc, n = cols.shape
+    ns = AIR_N_SHIFT[table]
+    hdr = np.concatenate([np.array([0], dtype=np.uint32), np.asarray(alpha, dtype=np.uint32), np.asarray(bus_beta, dtype=np.uint32),
+                          np.zeros(5, dtype=np.uint32), np.asarray(logup_eq16, dtype=np.uint32).reshape(-1)])
+    out = np.empty((n, 5), dtype=np.uint32)
+    vals = np.zeros((nc + ns, 5), dtype=np.uint32)
+    o = np.empty(5, dtype=np.uint32)
+    for r in range(n):
+        vals[:nc, 0] = cols[:, r]
+        nr = min(r + 1, n - 1)
+        vals[nc:, 0] = cols[:ns, nr]
+        orc.lib.orc_air_eval(_p(hdr), C.c_uint32(table), _p(vals), _p(o))
+        out[r] = o
+    return out
+
+
+def poseidon_table(orc, rng, log_rows, n_active=None):
+    """A satisfiable Poseidon16 table like sub_protocols/tests/prove_poseidon_16.rs:26-37: random inputs, flag_active = 1,
+    other flags 0 on active rows; padding rows as Poseidon16Precompile::padding_row (poseidon_16/mod.rs:176-199)."""
+    n = 1 << log_rows
+    n_active = n if n_active is None else n_active
+    rows = np.zeros((n, 109), dtype=np.uint32)
+    rows[:n_active, 9:25] = rand_field(rng, (n_active, 16))
+    rows[:n_active, 0] = 0x01FFFFFE  # flag_active
+    rows[:, 1] = orc.to_monty(rng.integers(0, 1 << 20, size=n))  # index_b
+    rows[:, 2] = orc.to_monty(rng.integers(0, 1 << 20, size=n))  # index_res
+    left = rng.integers(8, 1 << 20, size=n)
+    rows[:, 6] = orc.to_monty(left)          # effective_index_left_first = index_a
+    rows[:, 7] = orc.to_monty(left + 4)      # effective_index_left_second = index_a + HALF_DIGEST_LEN
+    rows = np.ascontiguousarray(rows)
+    orc.lib.orc_poseidon16_fill_rows(_p(rows), C.c_uint64(n))
+    return np.ascontiguousarray(rows.T)  # column major (109, n)

@@ -1,0 +1,78 @@
+"""GPU parity: batched AIR sumcheck (3 leanVM tables) through the C ABI vs the CPU oracle.  The oracle evaluates the
+constraint polynomials in the literal textbook form over EF; the device uses base-field first rounds, the sparse Poseidon
+partial rounds and lazily loaded columns — transcripts must still be word-identical."""
+import numpy as np
+import pytest
+
+import leanmultisig_amd as lm
+from tests import oracle_binding as ob
+from tests.oracle_binding import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+def _challenges(rng):
+    return rand_field(rng, 5), rand_field(rng, (16, 5)), rand_field(rng, 5), rand_field(rng, 5)
+
+
+def _run(ctx, orc, tables, alpha, eq16, beta, eta):
+    ref_proof, ref_pt, ref_ev = ob.air_prove(orc, tables, alpha, eq16, beta, eta)
+    pr = lm.Prover(ctx)
+    dev_tables = []
+    keep = []
+    for t in tables:
+        bufs = [ctx.to_device(c) for c in t["cols"]]
+        keep.append(bufs)
+        dev_tables.append(dict(table=t["table"], log_rows=t["log_rows"], cols=bufs, eq_point=t["eq_point"], sum=t["sum"]))
+    pt, evs = pr.prove_batched_air_sumcheck(dev_tables, alpha, eq16, beta, eta)
+    proof = pr.proof()
+    assert np.array_equal(pt, ref_pt)
+    assert np.array_equal(np.concatenate(evs), ref_ev)
+    assert np.array_equal(proof, ref_proof)
+    return proof
+
+
+@pytest.mark.parametrize("table,log_rows", [(0, 1), (0, 5), (1, 4), (2, 3), (2, 6)])
+def test_single_table_random_columns(ctx, orc, table, log_rows):
+    """Random (unsatisfied) columns: checks the constraint POLYNOMIALS, every alpha power and the fold schedule."""
+    rng = np.random.default_rng(table * 10 + log_rows)
+    alpha, eq16, beta, eta = _challenges(rng)
+    cols = rand_field(rng, (ob.AIR_N_COLUMNS[table], 1 << log_rows))
+    t = dict(table=table, log_rows=log_rows, cols=cols, eq_point=rand_field(rng, (log_rows, 5)), sum=rand_field(rng, 5))
+    _run(ctx, orc, [t], alpha, eq16, beta, eta)
+
+
+def test_three_tables_back_loaded_and_verified(ctx, orc):
+    """Three tables of different heights (back-loaded batching, air_sumcheck.rs:636-681) with TRUE sums, so that the
+    oracle's restatement of the verifier side (verify_execution.rs:109-170) accepts the device transcript."""
+    rng = np.random.default_rng(99)
+    alpha, eq16, beta, eta = _challenges(rng)
+    specs = [(0, 6), (2, 5), (1, 3)]  # descending height
+    tables = []
+    for table, lr in specs:
+        cols = ob.poseidon_table(orc, rng, lr, n_active=(1 << lr) - 3) if table == 2 else rand_field(rng, (ob.AIR_N_COLUMNS[table], 1 << lr))
+        eqp = rand_field(rng, (lr, 5))
+        vals = ob.air_eval_rows(orc, table, cols, alpha, eq16, beta)
+        eq = orc.eq_table(eqp)
+        s = np.zeros(5, dtype=np.uint32)
+        for r in range(1 << lr):
+            s = ((s.astype(np.uint64) + orc.ef_mul(eq[r], vals[r])) % P).astype(np.uint32)
+        tables.append(dict(table=table, log_rows=lr, cols=cols, eq_point=eqp, sum=s))
+    proof = _run(ctx, orc, tables, alpha, eq16, beta, eta)
+    ok, err = ob.air_verify(orc, tables, alpha, eq16, beta, eta, proof)
+    assert ok, err
+    bad = proof.copy()
+    bad[7] ^= 1
+    assert not ob.air_verify(orc, tables, alpha, eq16, beta, eta, bad)[0]
+
+
+def test_poseidon_trace_satisfies_all_but_bus(ctx, orc):
+    """On a generated Poseidon trace every constraint except the bus column vanishes: with alpha^0 = 1 on the bus the
+    row value equals the bus expression alone (sanity of the trace generator against the AIR, trace_gen.rs:44-112)."""
+    rng = np.random.default_rng(5)
+    alpha, eq16, beta, _ = _challenges(rng)
+    cols = ob.poseidon_table(orc, rng, 3)
+    vals = ob.air_eval_rows(orc, 2, cols, alpha, eq16, beta)
+    alpha2 = rand_field(rng, 5)
+    vals2 = ob.air_eval_rows(orc, 2, cols, alpha2, eq16, beta)
+    assert np.array_equal(vals, vals2)  # independent of alpha => constraints 1..99 are all zero

@@ -94,8 +94,22 @@ def build_workload(ctx, orc, ob, rng, n_vars, log_inv_rate, gkr_log_n):
     dens[0, active:] = 0x01FFFFFE
     d_nums = ctx.to_device(nums)
     d_dens = ctx.to_device(dens)
+    # AIR tables (SURVEY.md §8 size table): execution 2^(n-6) x 20, extension_op 2^10 x 29, poseidon16 2^(n-8) x 109.
+    # The Poseidon table is a satisfiable trace (oracle trace generator, untimed setup); the other two carry random
+    # columns — same arithmetic, the sumcheck does not depend on satisfiability.
+    air_tables = []
+    for table, lr in ((0, n_vars - 6), (2, n_vars - 8), (1, 10)):
+        if table == 2:
+            cols = ob.poseidon_table(orc, rng, lr)
+        else:
+            cols = rng.integers(0, P, size=(ob.AIR_N_COLUMNS[table], 1 << lr), dtype=np.uint32)
+        bufs = [ctx.to_device(c) for c in cols]
+        air_tables.append(dict(table=table, log_rows=lr, cols=bufs, eq_point=ob.rand_field(rng, (lr, 5)),
+                               sum=ob.rand_field(rng, 5)))
+    air_ch = dict(alpha=ob.rand_field(rng, 5), eq16=ob.rand_field(rng, (16, 5)), beta=ob.rand_field(rng, 5),
+                  eta=ob.rand_field(rng, 5))
     return dict(cfg=cfg, cfgd=cfgd, builder=builder, d_poly=d_poly, actual=actual, sts=sts, d_nums=d_nums, d_dens=d_dens,
-                gkr_log_n=gkr_log_n, n_vars=n_vars, poly_host=poly)
+                gkr_log_n=gkr_log_n, n_vars=n_vars, poly_host=poly, air_tables=air_tables, air_ch=air_ch)
 
 
 def run_step(ctx, lm, w):
@@ -104,6 +118,8 @@ def run_step(ctx, lm, w):
     root = np.empty(8, dtype=np.uint32)
     ctx.lib.lmh_witness_root(wit, root.ctypes.data)
     pr.prove_gkr_quotient(w["d_nums"], w["d_dens"], w["gkr_log_n"])
+    c = w["air_ch"]
+    pr.prove_batched_air_sumcheck(w["air_tables"], c["alpha"], c["eq16"], c["beta"], c["eta"])
     pr.whir_prove(w["cfg"], w["sts"], wit, w["d_poly"])
     return pr, root
 
@@ -208,8 +224,9 @@ def main():
             "config": {
                 "workload": "xmss --n-signatures 1550 --log-inv-rate 1 (BASELINE configs[1]) — proving hot path on "
                             "synthetic trace shapes: stacked 2^26, LDE 2^20x128, logup 2^25, 252 claims, 124-bit WHIR",
-                "stages": ["whir_commit(lde+merkle+ood)", "logup_gkr", "whir_open(weights+sumcheck+pow+queries)"],
-                "missing": ["air_sumcheck (3 tables)", "logup numerator/denominator build", "witness generation (CPU VM)"],
+                "stages": ["whir_commit(lde+merkle+ood)", "logup_gkr", "batched_air_sumcheck(execution 2^20, poseidon16 2^18, extension_op 2^10)",
+                           "whir_open(weights+sumcheck+pow+queries)"],
+                "missing": ["logup numerator/denominator build + 91 column evaluations", "witness generation (CPU VM)"],
                 "per_gpu_signatures": N_SIGS,
             },
             "roofline": {
@@ -230,7 +247,8 @@ def main():
             names = ["k_ntt_pass", "k_leaf_sponge", "k_compress_layer", "k_weight_tables", "k_weights_accumulate",
                      "k_prod_round_base", "k_prod_round_ext", "k_sum10", "k_fold_base", "k_fold_ext", "k_pow_grind",
                      "k_mle_partial_base", "k_mle_partial_ext", "k_eq_table_small", "k_sum_partials", "k_tree_open",
-                     "k_gkr_layer_up", "k_gkr_tables", "k_gkr_round_storage", "k_gkr_fold_round", "k_gkr_reduce"]
+                     "k_gkr_layer_up", "k_prefix_eq_tables", "k_gkr_round_storage", "k_gkr_fold_round", "k_gkr_reduce",
+                     "k_air_round", "k_air_reduce", "k_air_fold_base", "k_air_fold_ext"]
             for k in names:
                 cnt, ms = ctx.profile_read(k)
                 if cnt:

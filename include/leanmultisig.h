@@ -134,6 +134,31 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
 int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
             uint32_t* d_out);
 
+/* ---- logup numerators / denominators -----------------------------------------------------------------------------
+ * The fill loops of prove_generic_logup (crates/sub_protocols/src/logup.rs:88-199) as a list of sections, natural order:
+ *     num[out_offset + i] = 0 | 1 | +col[i] | -col[i]
+ *     den[out_offset + i] = c  +/-  ( sum_j alpha_eq[j] * data_j(i)  +  alpha_eq[15] * domsep )     (finger_print,
+ *                                                                     crates/utils/src/multilinear.rs:76-97)
+ *     data_j(i) = d_data[j][i * stride[j]] + add[j]        or, when d_data[j] == NULL,  i + add[j]  (the row index)
+ * Everything outside the sections (bytecode padding, tail up to 2^n_vars) is the neutral pair (0, 1).
+ * d_nums: 2^n_vars base words; d_dens: SoA EF of 2^n_vars. */
+#define LM_LOGUP_MAX_DATA 13 /* max_bus_width_including_domainsep(), lean_vm/src/tables/table_enum.rs:109-111 */
+typedef struct {
+    uint64_t out_offset;
+    uint32_t log_len;
+    uint32_t num_mode;      /* 0: zero, 1: one, 2: +d_num_col, 3: -d_num_col */
+    const uint32_t* d_num_col;
+    int32_t den_sign;       /* +1: c + fingerprint (bus), -1: c - fingerprint (memory / bytecode lookups) */
+    uint32_t domsep;        /* LOGUP_{MEMORY,PRECOMPILE,BYTECODE}_DOMAINSEP = 0, 1, 2 (lean_vm/src/core/constants.rs:4-6) */
+    uint32_t n_data;
+    uint32_t reserved;
+    const uint32_t* d_data[LM_LOGUP_MAX_DATA];
+    uint32_t stride[LM_LOGUP_MAX_DATA];
+    uint32_t add[LM_LOGUP_MAX_DATA]; /* canonical small integer */
+} lm_logup_section;
+int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[LM_EF_DIM],
+                   const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens);
+
 /* ---- GKR for a sum of fractions (logup) -----------------------------------------------------------------------------
  * prove_gkr_quotient (crates/sub_protocols/src/quotient_gkr/mod.rs:31-78).  The transcript stays with the caller; the
  * device holds the layers and runs the per-round kernels.  d_nums: 2^n_vars base words, d_dens: SoA EF of 2^n_vars,

@@ -49,6 +49,7 @@ _SIGS = {
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
     "lm_fold": (C.c_int, [vp, vp, C.c_int, C.c_uint32, vp, vp]),
     "lm_pow_grind": (C.c_int, [vp, vp, C.c_uint32, u32p]),
+    "lm_logup_build": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp]),
     "lm_gkr_build": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(vp)]),
     "lm_gkr_free": (None, [vp, vp]),
     "lm_gkr_top": (C.c_int, [vp, vp, vp, vp]),
@@ -130,6 +131,17 @@ class SparseStatement(C.Structure):
     """lm_sparse_statement"""
     _fields_ = [("point_len", C.c_uint32), ("is_next", C.c_uint32), ("n_values", C.c_uint32), ("reserved", C.c_uint32),
                 ("point_offset", C.c_uint64), ("values_offset", C.c_uint64)]
+
+
+LM_LOGUP_MAX_DATA = 13
+
+
+class LogupSection(C.Structure):
+    """lm_logup_section"""
+    _fields_ = [("out_offset", C.c_uint64), ("log_len", C.c_uint32), ("num_mode", C.c_uint32), ("d_num_col", vp),
+                ("den_sign", C.c_int32), ("domsep", C.c_uint32), ("n_data", C.c_uint32), ("reserved", C.c_uint32),
+                ("d_data", vp * LM_LOGUP_MAX_DATA), ("stride", C.c_uint32 * LM_LOGUP_MAX_DATA),
+                ("add", C.c_uint32 * LM_LOGUP_MAX_DATA)]
 
 
 class AirTable(C.Structure):
@@ -335,6 +347,26 @@ class Context:
         sc = _u32(scalars).reshape(-1)
         self._check(self.lib.lm_weights_accumulate(self.h, d_W.ptr, n_vars, C.cast(arr, vp), len(items),
                                                    _ptr(pts) if pts.size else None, pts.size // 5, _ptr(sc)))
+
+    def logup_build(self, sections, c, alphas_eq16, n_vars):
+        """sections: list of dict(out_offset, log_len, num_mode, num_col (device ptr/None), den_sign, domsep,
+        data=[(device ptr or None, stride, add), ...]).  Returns (d_nums, d_dens SoA)."""
+        arr = (LogupSection * len(sections))()
+        for i, s in enumerate(sections):
+            a = arr[i]
+            a.out_offset, a.log_len, a.num_mode = s["out_offset"], s["log_len"], s["num_mode"]
+            a.d_num_col = s.get("num_col") or None
+            a.den_sign, a.domsep, a.n_data = s["den_sign"], s["domsep"], len(s["data"])
+            for j, (ptr, stride, add) in enumerate(s["data"]):
+                a.d_data[j] = ptr or None
+                a.stride[j] = stride
+                a.add[j] = add
+        d_nums = self.alloc(1 << n_vars)
+        d_dens = self.alloc(5 << n_vars)
+        cc, al = _u32(c), _u32(alphas_eq16).reshape(-1)
+        self._check(self.lib.lm_logup_build(self.h, C.cast(arr, vp), len(sections), _ptr(cc), _ptr(al), n_vars, d_nums.ptr,
+                                            d_dens.ptr))
+        return d_nums, d_dens
 
     def prod_round(self, d_f, f_is_ext, d_W, n_vars):
         out = np.empty(10, dtype=np.uint32)

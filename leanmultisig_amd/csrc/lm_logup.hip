@@ -1,0 +1,113 @@
+// logup numerators / denominators (reference: crates/sub_protocols/src/logup.rs:88-199), natural order, one launch.
+#include <algorithm>
+#include "lm_common.h"
+
+using namespace kb;
+
+struct LogupSec {
+    u64 out_offset, chunk_begin;
+    const u32* num_col;
+    const u32* data[LM_LOGUP_MAX_DATA];
+    u32 stride[LM_LOGUP_MAX_DATA];
+    u32 add_m[LM_LOGUP_MAX_DATA];  // Montgomery
+    u32 log_len, num_mode, n_data, neg_den;
+    EF contrib;  // alpha_eq[15] * domsep
+};
+
+static constexpr u32 LG_CHUNK = 1024;
+
+__global__ __launch_bounds__(256) void k_logup_fill(const LogupSec* __restrict__ secs, u32 n_secs, const EF* __restrict__ alphas,
+                                                    EF c, u64 plane, u32* __restrict__ nums, u32* __restrict__ dens, u32 r2) {
+    u32 lo = 0, hi = n_secs - 1;
+    const u64 b = blockIdx.x;
+    while (lo < hi) {
+        u32 mid = (lo + hi + 1) >> 1;
+        if (secs[mid].chunk_begin <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const LogupSec& s = secs[lo];
+    const u64 len = 1ull << s.log_len;
+    const u64 base = (b - s.chunk_begin) * LG_CHUNK;
+    for (u32 u = 0; u < LG_CHUNK / 256; u++) {
+        const u64 i = base + u * 256 + threadIdx.x;
+        if (i >= len) break;
+        u32 n;
+        if (s.num_mode == 0)
+            n = 0;
+        else if (s.num_mode == 1)
+            n = ONE;
+        else {
+            n = s.num_col[i];
+            if (s.num_mode == 3) n = neg(n);
+        }
+        EF fp = s.contrib;
+        const u32 im = mul((u32)i, r2);  // Montgomery form of the row index (i < p)
+        for (u32 j = 0; j < s.n_data; j++) {
+            u32 d = s.data[j] ? s.data[j][i * s.stride[j]] : im;
+            d = add(d, s.add_m[j]);
+            fp = ef_add(fp, ef_mul_base(alphas[j], d));
+        }
+        const EF den = s.neg_den ? ef_sub(c, fp) : ef_add(c, fp);
+        nums[s.out_offset + i] = n;
+#pragma unroll
+        for (int k = 0; k < 5; k++) dens[(u64)k * plane + s.out_offset + i] = den.v[k];
+    }
+}
+// neutral pair (0, 1) everywhere (sections overwrite their ranges afterwards)
+__global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u32* __restrict__ nums, u32* __restrict__ dens) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < plane; i += (u64)gridDim.x * 256) {
+        nums[i] = 0;
+        dens[i] = ONE;
+#pragma unroll
+        for (int k = 1; k < 5; k++) dens[(u64)k * plane + i] = 0;
+    }
+}
+
+extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
+                              const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
+    LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);
+    const u64 plane = 1ull << n_vars;
+    std::vector<LogupSec> hs(n_sections);
+    u64 chunks = 0;
+    EF a15;
+    memcpy(a15.v, alphas_eq16 + 75, 20);
+    for (u32 k = 0; k < n_sections; k++) {
+        const lm_logup_section& in = sections[k];
+        LM_REQUIRE(in.n_data <= LM_LOGUP_MAX_DATA && in.num_mode <= 3 && in.log_len <= n_vars);
+        LM_REQUIRE(in.out_offset + (1ull << in.log_len) <= plane);
+        LM_REQUIRE(in.num_mode < 2 || in.d_num_col);
+        LogupSec& s = hs[k];
+        s.out_offset = in.out_offset;
+        s.chunk_begin = chunks;
+        chunks += ((1ull << in.log_len) + LG_CHUNK - 1) / LG_CHUNK;
+        s.num_col = in.d_num_col;
+        s.log_len = in.log_len;
+        s.num_mode = in.num_mode;
+        s.n_data = in.n_data;
+        s.neg_den = in.den_sign < 0;
+        s.contrib = ef_mul_base(a15, to_monty(in.domsep));
+        for (u32 j = 0; j < LM_LOGUP_MAX_DATA; j++) {
+            s.data[j] = j < in.n_data ? in.d_data[j] : nullptr;
+            s.stride[j] = j < in.n_data ? in.stride[j] : 0;
+            s.add_m[j] = j < in.n_data ? to_monty(in.add[j]) : 0;
+        }
+    }
+    LM_REQUIRE(chunks < (1ull << 31));
+    const u64 w_secs = (sizeof(LogupSec) * n_sections + 3) / 4;
+    u32* s;
+    int rc = lm_scratch(ctx, w_secs + 16 + 80, &s);
+    if (rc) return rc;
+    u32* d_al = s + ((w_secs + 15) & ~15ull);
+    LM_HIP(hipMemcpyAsync(s, hs.data(), sizeof(LogupSec) * n_sections, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemcpyAsync(d_al, alphas_eq16, 320, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    EF cc;
+    memcpy(cc.v, c, 20);
+    LM_LAUNCH(ctx, k_logup_neutral, dim3((unsigned)std::min<u64>((plane + 255) / 256, 4096)), dim3(256), 0, plane, d_nums, d_dens);
+    LM_LAUNCH(ctx, k_logup_fill, dim3((unsigned)chunks), dim3(256), 0, (const LogupSec*)s, n_sections, (const EF*)d_al, cc,
+              plane, d_nums, d_dens, to_monty(to_monty(1)));
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}

@@ -430,3 +430,32 @@ void orc_poseidon16_fill_rows(uint32_t* rows, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) poseidon16_fill_row(rows + 109 * i);
 }
 }
+
+// ================================================================================================
+// logup fill (logup_oracle.hpp)
+// ================================================================================================
+#include "logup_oracle.hpp"
+extern "C" {
+// tables_desc: n_tables x [table, log_rows]; tables_cols: concatenated column-major traces (n_columns_total x rows each).
+// out_nums / out_dens sized for the next power of two of the active length; returns total_active_len.
+uint64_t orc_logup_fill(const uint32_t* memory, const uint32_t* memory_acc, uint32_t log_mem, const uint32_t* bytecode,
+                        const uint32_t* bytecode_acc, uint32_t log_bytecode, const uint32_t* tables_desc, uint32_t n_tables,
+                        const uint32_t* tables_cols, const uint32_t* c5, const uint32_t* alphas16, uint32_t* out_nums,
+                        uint32_t* out_dens) {
+    std::vector<VmTableTrace> tabs;
+    size_t off = 0;
+    for (uint32_t i = 0; i < n_tables; i++) {
+        VmTableTrace t{(int)tables_desc[2 * i], tables_desc[2 * i + 1], tables_cols + off};
+        off += vm_table_def(t.table).n_columns_total << t.log_rows;
+        tabs.push_back(t);
+    }
+    EF c;
+    std::memcpy(c.v, c5, 20);
+    std::vector<uint32_t> nums;
+    std::vector<EF> dens;
+    size_t total = logup_fill(memory, memory_acc, log_mem, bytecode, bytecode_acc, log_bytecode, tabs, c, (const EF*)alphas16, nums, dens);
+    if (out_nums) std::memcpy(out_nums, nums.data(), nums.size() * 4);
+    if (out_dens) std::memcpy(out_dens, dens.data(), dens.size() * 20);
+    return total;
+}
+}

@@ -361,3 +361,61 @@ def poseidon_table(orc, rng, log_rows, n_active=None):
     rows = np.ascontiguousarray(rows)
     orc.lib.orc_poseidon16_fill_rows(_p(rows), C.c_uint64(n))
     return np.ascontiguousarray(rows.T)  # column major (109, n)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# logup (oracle side) + the section list a host would hand to lm_logup_build for the three leanVM tables
+# ------------------------------------------------------------------------------------------------------------
+VM_N_TOTAL = {0: 24, 1: 31, 2: 111}
+# (index column, value columns) — lean_vm/src/tables/{execution/mod.rs:29-46, extension_op/mod.rs:90-106, poseidon_16/mod.rs:126-149}
+VM_LOOKUPS = {0: [(2, [5]), (3, [6]), (4, [7])],
+              1: [(6, list(range(14, 19))), (7, list(range(19, 24))), (13, list(range(24, 29)))],
+              2: [(6, list(range(9, 13))), (7, list(range(13, 17))), (1, list(range(17, 25))), (2, list(range(93, 109)))]}
+# (pull?, selector, data columns) — bus() of the same files
+VM_BUS = {0: (False, 20, [19, 21, 22, 23]), 1: (True, 29, [30, 6, 7, 13]), 2: (True, 0, [110, 109, 1, 2])}
+
+
+def logup_fill(orc, memory, memory_acc, bytecode, bytecode_acc, tables, c, alphas16):
+    """tables: list of (table id, cols (n_total, rows)) sorted by descending height."""
+    log_mem = int(memory.size).bit_length() - 1
+    log_bc = int(bytecode_acc.size).bit_length() - 1
+    desc = np.array([[t, int(cols.shape[1]).bit_length() - 1] for t, cols in tables], dtype=np.uint32)
+    flat = np.concatenate([np.ascontiguousarray(cols, dtype=np.uint32).reshape(-1) for _, cols in tables])
+    args = [_p(np.ascontiguousarray(memory, dtype=np.uint32)), _p(np.ascontiguousarray(memory_acc, dtype=np.uint32)),
+            C.c_uint32(log_mem), _p(np.ascontiguousarray(bytecode, dtype=np.uint32)),
+            _p(np.ascontiguousarray(bytecode_acc, dtype=np.uint32)), C.c_uint32(log_bc), _p(desc), C.c_uint32(len(tables)),
+            _p(flat), _p(np.ascontiguousarray(c, dtype=np.uint32)), _p(np.ascontiguousarray(alphas16, dtype=np.uint32))]
+    orc.lib.orc_logup_fill.restype = C.c_uint64
+    total = orc.lib.orc_logup_fill(*args, None, None)
+    p2 = 1 << (int(total) - 1).bit_length()
+    nums = np.empty(p2, dtype=np.uint32)
+    dens = np.empty((p2, 5), dtype=np.uint32)
+    orc.lib.orc_logup_fill(*args, _p(nums), _p(dens))
+    return int(total), nums, dens
+
+
+def logup_sections(d_memory, d_memory_acc, log_mem, d_bytecode, d_bytecode_acc, log_bc, d_tables):
+    """Section list of prove_generic_logup (logup.rs:88-199) for lm_logup_build.
+    d_tables: list of (table id, log_rows, [device ptr per column of the TOTAL column set])."""
+    secs, off = [], 0
+    secs.append(dict(out_offset=off, log_len=log_mem, num_mode=3, num_col=d_memory_acc, den_sign=-1, domsep=0,
+                     data=[(d_memory, 1, 0), (None, 0, 0)]))
+    off += 1 << log_mem
+    secs.append(dict(out_offset=off, log_len=log_bc, num_mode=3, num_col=d_bytecode_acc, den_sign=-1, domsep=2,
+                     data=[(d_bytecode + 4 * k, 16, 0) for k in range(12)] + [(None, 0, 0)]))
+    off += max(1 << log_bc, 1 << d_tables[0][1])
+    for t, lr, cols in d_tables:
+        if t == 0:
+            secs.append(dict(out_offset=off, log_len=lr, num_mode=1, den_sign=-1, domsep=2,
+                             data=[(cols[8 + k], 1, 0) for k in range(12)] + [(cols[0], 1, 0)]))
+            off += 1 << lr
+        pull, sel, data = VM_BUS[t]
+        secs.append(dict(out_offset=off, log_len=lr, num_mode=3 if pull else 2, num_col=cols[sel], den_sign=+1, domsep=1,
+                         data=[(cols[d], 1, 0) for d in data]))
+        off += 1 << lr
+        for idx, vals in VM_LOOKUPS[t]:
+            for i, v in enumerate(vals):
+                secs.append(dict(out_offset=off, log_len=lr, num_mode=1, den_sign=-1, domsep=0,
+                                 data=[(cols[v], 1, 0), (cols[idx], 1, i)]))
+                off += 1 << lr
+    return secs, off

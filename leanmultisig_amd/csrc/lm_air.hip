@@ -183,12 +183,10 @@ extern "C" {
 
 void lm_air_free(lm_ctx* ctx, lm_air* a) {
     if (!a) return;
-    (void)hipStreamSynchronize(ctx->stream);
-    if (a->d_base_cols) (void)hipFree((void*)a->d_base_cols);
-    for (int i = 0; i < 2; i++)
-        if (a->ef[i]) (void)hipFree(a->ef[i]);
-    if (a->d_extra) (void)hipFree(a->d_extra);
-    if (a->eqt.d_buf) (void)hipFree(a->eqt.d_buf);
+    lm_pool_free(ctx, (void*)a->d_base_cols);
+    for (int i = 0; i < 2; i++) lm_pool_free(ctx, a->ef[i]);
+    lm_pool_free(ctx, a->d_extra);
+    lm_pool_free(ctx, a->eqt.d_buf);
     delete a;
 }
 
@@ -213,13 +211,13 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     }
     memcpy(hx.logup_eq, logup_eq16, 16 * 20);
     memcpy(hx.bus_beta.v, bus_beta, 20);
-    bool ok = hipMalloc((void**)&a->d_base_cols, a->n_cols * sizeof(u32*)) == hipSuccess &&
-              hipMalloc(&a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
-              hipMalloc(&a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
-              hipMalloc(&a->d_extra, sizeof(air::Extra)) == hipSuccess &&
-              hipMalloc(&a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess;
+    bool ok = lm_pool_alloc(ctx, (void**)&a->d_base_cols, a->n_cols * sizeof(u32*)) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->d_extra, sizeof(air::Extra)) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess;
     if (!ok) {
-        lm_set_error("lm_air_new: hipMalloc failed");
+        lm_set_error("lm_air_new: device allocation failed");
         lm_air_free(ctx, a);
         return LM_E_NOMEM;
     }
@@ -257,10 +255,11 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     else
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
-    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, d_out);
+    (void)d_out;
+    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(out_raw, d_out, (u64)a->deg * 20, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);
     return LM_OK;
 }
 

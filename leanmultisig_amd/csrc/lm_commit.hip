@@ -268,11 +268,11 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
     t->eff_cols = eff_cols;
     t->stored_words = eff_cols * dim;
     t->leaf_words = n_cols * dim;
-    if (hipMalloc(&t->d_matrix, (u64)t->stored_words * h * 4) != hipSuccess ||
-        hipMalloc(&t->d_digests, (2 * h - 1) * 8 * 4) != hipSuccess) {
+    if (lm_pool_alloc_t(ctx, &t->d_matrix, (u64)t->stored_words * h * 4) != hipSuccess ||
+        lm_pool_alloc_t(ctx, &t->d_digests, (2 * h - 1) * 8 * 4) != hipSuccess) {
         lm_set_error("lm_commit: hipMalloc failed (%llu + %llu bytes)", (unsigned long long)t->stored_words * h * 4,
                      (unsigned long long)(2 * h - 1) * 32);
-        if (t->d_matrix) (void)hipFree(t->d_matrix);
+        lm_pool_free(ctx, t->d_matrix);
         delete t;
         return LM_E_NOMEM;
     }
@@ -337,10 +337,9 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
 }
 
 void lm_tree_free(lm_ctx* ctx, lm_tree* t) {
-    (void)ctx;
     if (!t) return;
-    if (t->d_matrix) (void)hipFree(t->d_matrix);
-    if (t->d_digests) (void)hipFree(t->d_digests);
+    lm_pool_free(ctx, t->d_matrix);
+    lm_pool_free(ctx, t->d_digests);
     delete t;
 }
 uint32_t lm_tree_log_height(const lm_tree* t) { return t ? t->log_h : 0; }

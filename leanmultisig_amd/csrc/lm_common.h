@@ -48,8 +48,15 @@ struct lm_ctx {
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
-    u32* h_pinned = nullptr;    // pinned host staging
-    u64 pinned_words = 0;
+    // pinned, device-visible result buffer: final reduction kernels store round results here directly, the host
+    // reads them after a stream synchronise (no D2H copy command per sumcheck round)
+    u32* h_res = nullptr;
+    static constexpr u64 RES_WORDS = 4096;
+    // caching device allocator: freed blocks are kept per size class and reused (hipMalloc/hipFree synchronise the
+    // device; a proof performs ~100 allocations).  Single stream => reuse is stream-ordered and safe.
+    std::multimap<u64, void*> pool_free;
+    std::map<void*, u64> pool_size;
+    u64 pool_bytes = 0;
     // optional per-kernel HIP-event timing (bench.py roofline leg): only launches whose kernel name is selected
     std::string prof_select;    // empty = profiling off; "*" = every kernel
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
@@ -91,4 +98,10 @@ struct lm_tree {
 };
 
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out);
-int lm_pinned(lm_ctx* ctx, u64 words, u32** out);
+// pooled device memory (see lm_ctx::pool_free); lm_pool_alloc returns hipErrorOutOfMemory on failure
+hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes);
+void lm_pool_free(lm_ctx* ctx, void* p);
+template <class T>
+static inline hipError_t lm_pool_alloc_t(lm_ctx* ctx, T** out, u64 bytes) {
+    return lm_pool_alloc(ctx, reinterpret_cast<void**>(out), bytes);
+}

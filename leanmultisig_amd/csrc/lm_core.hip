@@ -169,6 +169,50 @@ __global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ pa
     }
 }
 
+static u64 pool_class(u64 bytes) {
+    // 8 size classes per octave (<= 12.5 % slack), minimum 256 B
+    if (bytes < 256) return 256;
+    u64 hi = 1ull << (63 - __builtin_clzll(bytes));
+    u64 step = hi >> 3;
+    return (bytes + step - 1) / step * step;
+}
+hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
+    const u64 cls = pool_class(bytes);
+    auto it = ctx->pool_free.find(cls);
+    if (it != ctx->pool_free.end()) {
+        *out = it->second;
+        ctx->pool_free.erase(it);
+        return hipSuccess;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e != hipSuccess) {
+        // release cached blocks and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool_free) {
+            (void)hipFree(kv.second);
+            ctx->pool_size.erase(kv.second);
+            ctx->pool_bytes -= kv.first;
+        }
+        ctx->pool_free.clear();
+        e = hipMalloc(&p, cls);
+        if (e != hipSuccess) return e;
+    }
+    ctx->pool_size[p] = cls;
+    ctx->pool_bytes += cls;
+    *out = p;
+    return hipSuccess;
+}
+void lm_pool_free(lm_ctx* ctx, void* p) {
+    if (!p) return;
+    auto it = ctx->pool_size.find(p);
+    if (it == ctx->pool_size.end()) {  // not ours
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool_free.emplace(it->second, p);
+}
+
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {
     if (words > ctx->scratch_words) {
         LM_HIP(hipStreamSynchronize(ctx->stream));
@@ -198,6 +242,7 @@ int lm_ctx_create(int device, lm_ctx** out) {
     LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
+    LM_HIP(hipHostMalloc((void**)&c->h_res, lm_ctx::RES_WORDS * 4, hipHostMallocMapped));
     const u64 n = 1ull << (LM_TW_LOG - 1);
     LM_LAUNCH(c, k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->d_tw, c->d_tw_small,
                        to_monty(LM_G24_CANON));
@@ -212,7 +257,8 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    for (auto& kv : c->pool_size) (void)hipFree(kv.first);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -258,18 +304,15 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out) {
     LM_REQUIRE(ctx && d_out && n_words > 0);
-    if (hipMalloc(d_out, n_words * 4) != hipSuccess) {
-        lm_set_error("hipMalloc of %llu bytes failed", (unsigned long long)n_words * 4);
+    if (lm_pool_alloc_t(ctx, d_out, n_words * 4) != hipSuccess) {
+        lm_set_error("device allocation of %llu bytes failed", (unsigned long long)n_words * 4);
         return LM_E_NOMEM;
     }
     return LM_OK;
 }
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr) {
     LM_REQUIRE(ctx);
-    if (d_ptr) {
-        LM_HIP(hipStreamSynchronize(ctx->stream));
-        LM_HIP(hipFree(d_ptr));
-    }
+    lm_pool_free(ctx, d_ptr);
     return LM_OK;
 }
 int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words) {
@@ -333,10 +376,12 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     else
         LM_LAUNCH(ctx, k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words,
                            1ull << n_vars, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
-    LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, d_partial, n_hi, d_out);
+    const bool pinned = (u64)n_polys * 5 <= lm_ctx::RES_WORDS;
+    LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, d_partial, n_hi, pinned ? ctx->h_res : d_out);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
+    if (!pinned) LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
+    if (pinned) memcpy(out, ctx->h_res, (u64)n_polys * 20);
     return LM_OK;
 }
 

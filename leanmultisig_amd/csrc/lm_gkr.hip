@@ -257,12 +257,10 @@ extern "C" {
 
 void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
     if (!g) return;
-    (void)hipStreamSynchronize(ctx->stream);
-    for (u32* p : g->nums) (void)hipFree(p);
-    for (u32* p : g->dens) (void)hipFree(p);
-    for (int i = 0; i < 2; i++)
-        if (g->work[i]) (void)hipFree(g->work[i]);
-    if (g->eqt.d_buf) (void)hipFree(g->eqt.d_buf);
+    for (u32* p : g->nums) lm_pool_free(ctx, p);
+    for (u32* p : g->dens) lm_pool_free(ctx, p);
+    for (int i = 0; i < 2; i++) lm_pool_free(ctx, g->work[i]);
+    lm_pool_free(ctx, g->eqt.d_buf);
     delete g;
 }
 
@@ -277,9 +275,9 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
     for (u32 v = n_vars - 1; v >= 5; v--) {
         const u64 m = 1ull << v;
         u32 *nn = nullptr, *dd = nullptr;
-        if (hipMalloc(&nn, 5 * m * 4) != hipSuccess || hipMalloc(&dd, 5 * m * 4) != hipSuccess) {
-            lm_set_error("lm_gkr_build: hipMalloc failed");
-            if (nn) (void)hipFree(nn);
+        if (lm_pool_alloc_t(ctx, &nn, 5 * m * 4) != hipSuccess || lm_pool_alloc_t(ctx, &dd, 5 * m * 4) != hipSuccess) {
+            lm_set_error("lm_gkr_build: device allocation failed");
+            lm_pool_free(ctx, nn);
             lm_gkr_free(ctx, g);
             return LM_E_NOMEM;
         }
@@ -296,9 +294,10 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
     // work buffers: first fold of the biggest layer yields 4 arrays of 2^(n_vars-2) EF
     g->work_words = 20ull << (n_vars - 2);
     const u64 w1 = std::max<u64>(g->work_words / 2, 64);
-    if (hipMalloc(&g->work[0], g->work_words * 4) != hipSuccess || hipMalloc(&g->work[1], w1 * 4) != hipSuccess ||
-        hipMalloc(&g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess) {
-        lm_set_error("lm_gkr_build: hipMalloc failed (work)");
+    if (lm_pool_alloc_t(ctx, &g->work[0], g->work_words * 4) != hipSuccess ||
+        lm_pool_alloc_t(ctx, &g->work[1], w1 * 4) != hipSuccess ||
+        lm_pool_alloc_t(ctx, &g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess) {
+        lm_set_error("lm_gkr_build: device allocation failed (work)");
         lm_gkr_free(ctx, g);
         return LM_E_NOMEM;
     }
@@ -378,10 +377,11 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         g->cur = dst;
         g->m = m_out;
     }
-    LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, d_out);
+    (void)d_out;
+    LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, ctx->h_res);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(out_c0_c2, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_c0_c2, ctx->h_res, 40);
     g->round++;
     return LM_OK;
 }

@@ -340,10 +340,11 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
         LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
     else
         LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
-    LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, d_out);
+    (void)d_out;
+    LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(out_c0_c2, d_out, 40, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_c0_c2, ctx->h_res, 40);
     return LM_OK;
 }
 

@@ -68,6 +68,11 @@ int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64
 int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
 int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
 
+/* fill_trace_poseidon_16 / generate_trace_rows_for_perm (crates/lean_vm/src/tables/poseidon_16/trace_gen.rs:10-165):
+ * d_cols = host array of the 109 DEVICE column pointers of the Poseidon16 table (Poseidon1Cols16 order,
+ * poseidon_16/mod.rs:366-383).  Columns 0..24 (flags, indices, 16 inputs) are inputs; the 84 derived columns are written. */
+int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows);
+
 /* ---- WHIR commitment: LDE + Merkle tree -------------------------------------------------------------------------
  * lm_commit replaces reorder_and_dft (crates/whir/src/utils.rs:69-98: prepare_evals_for_fft_unpacked :128-150 +
  * EvalsDft::dft_algebra_batch_by_evals crates/whir/src/dft.rs:79-155) followed by MerkleData::build

@@ -37,6 +37,7 @@ _SIGS = {
     "lm_ef_soa_to_aos": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_poseidon16_permute": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon16_compress": (C.c_int, [vp, vp, C.c_uint64]),
+    "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_commit": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp), vp]),
     "lm_tree_free": (None, [vp, vp]),
     "lm_tree_log_height": (C.c_uint32, [vp]),
@@ -315,6 +316,11 @@ class Context:
         fn = self.lib.lm_poseidon16_compress if compress else self.lib.lm_poseidon16_permute
         self._check(fn(self.h, buf.ptr, st.shape[0]))
         return buf.download().reshape(-1, 16)
+
+    def poseidon_trace(self, col_bufs, n_rows):
+        ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
+        assert ptrs.size == 109
+        self._check(self.lib.lm_poseidon_trace(self.h, _ptr(ptrs), int(n_rows)))
 
     def commit(self, d_evals, is_ext, n_vars, folding_factor, log_inv_rate, actual_len=None):
         if actual_len is None:

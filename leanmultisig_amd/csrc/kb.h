@@ -174,16 +174,37 @@ KB_HD EF ef_pow(EF a, u64 e) {
     }
     return r;
 }
-// inverse through the norm: conj = a^(p + p^2 + p^3 + p^4), a^-1 = conj / (a * conj), a*conj in F_p.
-// (host-side use only; rare).  The value is unique, so any method matches the reference
-// (quintic_extension/extension.rs:585-607).
-KB_HD EF ef_inv(const EF& a) {
-    EF f1 = ef_pow(a, (u64)P);
-    EF f2 = ef_pow(f1, (u64)P);
-    EF f12 = ef_mul(f1, f2);             // a^(p + p^2)
-    EF f34 = ef_pow(ef_pow(f12, (u64)P), (u64)P);  // a^(p^3 + p^4)
-    EF conj = ef_mul(f12, f34);
-    EF n = ef_mul(a, conj);
+// Frobenius x -> x^p is F_p-linear: x^p = sum_i x_i (X^i)^p.  The images of the basis are derived once from the field
+// definition (the reference tabulates the same matrix, quintic_extension/mod.rs:19-48).
+struct FrobeniusTable {
+    EF img[5];
+};
+inline const FrobeniusTable& frobenius_table() {
+    static const FrobeniusTable t = [] {
+        FrobeniusTable r;
+        for (int i = 0; i < 5; i++) {
+            EF b = ef_zero();
+            b.v[i] = ONE;
+            r.img[i] = ef_pow(b, (u64)P);
+        }
+        return r;
+    }();
+    return t;
+}
+inline EF ef_frobenius(const EF& a) {
+    const FrobeniusTable& t = frobenius_table();
+    EF r = ef_zero();
+    for (int i = 0; i < 5; i++) r = ef_add(r, ef_mul_base(t.img[i], a.v[i]));
+    return r;
+}
+// inverse through the norm (host only): conj = a^(p + p^2 + p^3 + p^4), a^-1 = conj / (a * conj), a*conj in F_p.
+// The value is unique, so any method matches the reference (quintic_extension/extension.rs:585-607).
+inline EF ef_inv(const EF& a) {
+    const EF f1 = ef_frobenius(a);                      // a^p
+    const EF f12 = ef_mul(f1, ef_frobenius(f1));        // a^(p + p^2)
+    const EF f34 = ef_frobenius(ef_frobenius(f12));     // a^(p^3 + p^4)
+    const EF conj = ef_mul(f12, f34);
+    const EF n = ef_mul(a, conj);
     return ef_mul_base(conj, inv(n.v[0]));
 }
 

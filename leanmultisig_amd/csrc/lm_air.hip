@@ -80,8 +80,8 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, const 
 
 // grid (blocks_x, n_z); partial[(zi * blocks_x + bx) * 5 + k]
 template <int TABLE, class T, class Cols>
-__global__ __launch_bounds__(256) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
-                                                   u32* __restrict__ partial) {
+__global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+                                                   u32* __restrict__ partial, u32* __restrict__ final_out) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.y;
     const u32 z = zi == 0 ? 0 : zi + 1;  // 0, 2, 3, ..., degree
@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256) void k_air_round(Cols cols, u64 n_pairs, const
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        partial[((u64)zi * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
+        if (gridDim.x == 1)
+            final_out[zi * 5 + threadIdx.x] = s;  // single workgroup per point: the round is finished here
+        else
+            partial[((u64)zi * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
     }
 }
 // one block per z: out[zi * 5 + k] = sum_b partial[(zi * n + b) * 5 + k]
@@ -167,13 +170,14 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
 
 template <int TABLE>
 static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+    u32* final_out = ctx->h_res;
     const dim3 grid(blocks, a->deg), block(256);
     if (a->cur < 0) {
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
-        LM_LAUNCH(ctx, (k_air_round<TABLE, u32, BaseCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial);
+        LM_LAUNCH(ctx, (k_air_round<TABLE, u32, BaseCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial, final_out);
     } else {
         ExtCols c{a->ef[a->cur], 2 * n_pairs};
-        LM_LAUNCH(ctx, (k_air_round<TABLE, EF, ExtCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial);
+        LM_LAUNCH(ctx, (k_air_round<TABLE, EF, ExtCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial, final_out);
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -242,7 +246,7 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     LM_REQUIRE(ctx && a && out_raw && a->round < a->log_rows);
     const u32 p = a->log_rows - a->round - 1;
     const u64 n_pairs = 1ull << p;
-    const u32 blocks = (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
+    const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
     u32* s;
     int rc = lm_scratch(ctx, (u64)blocks * a->deg * 5 + a->deg * 5 + 64, &s);
     if (rc) return rc;
@@ -256,7 +260,7 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
     (void)d_out;
-    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
+    if (blocks > 1) LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
     LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);

@@ -167,8 +167,14 @@ __global__ __launch_bounds__(256) void k_leaf_sponge(const u32* __restrict__ mat
         poseidon16_compress(s);
         c = (int)a.total_chunks - 3;
     }
+    // software pipeline: the 8 words of the next chunk are requested before the current compression starts, so the
+    // HBM latency of the column-strided loads hides under ~1.2 k modular multiplications
+    u32 nxt[8];
+    if (c >= 0) load_chunk(mat, a, row, (u32)c, nxt);
     for (; c >= 0; c--) {
-        load_chunk(mat, a, row, (u32)c, s + 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[8 + i] = nxt[i];
+        if (c >= 1) load_chunk(mat, a, row, (u32)(c - 1), nxt);
         poseidon16_compress(s);
     }
     uint4* o = reinterpret_cast<uint4*>(digests + row * 8);
@@ -203,6 +209,65 @@ __global__ __launch_bounds__(256) void k_poseidon_batch(u32* __restrict__ states
     p[1] = make_uint4(s[4], s[5], s[6], s[7]);
     p[2] = make_uint4(s[8], s[9], s[10], s[11]);
     p[3] = make_uint4(s[12], s[13], s[14], s[15]);
+}
+
+// Poseidon16 table rows (reference: generate_trace_rows_for_perm, crates/lean_vm/src/tables/poseidon_16/trace_gen.rs:44-112).
+// One row per lane: reads the 16 input columns and flag_permute, writes the 84 derived columns
+// (2 x 16 post-states of the initial full-round pairs, 20 partial-round S-box outputs, 16 post-state of the first terminal
+// pair, 8 + 8 outputs).  cols: device array of 109 column pointers (Poseidon1Cols16 order, poseidon_16/mod.rs:366-383).
+__global__ __launch_bounds__(256) void k_poseidon_trace(u32* const* __restrict__ cols, u64 n_rows) {
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const PoseidonConsts& K = poseidon_consts();
+    u32 in[16], s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) in[i] = s[i] = cols[9 + i][r];
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_init[2 * blk + h][i]));
+            mds_circ16(s);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) cols[25 + 16 * blk + i][r] = s[i];
+    }
+    {
+        u32 t[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) t[i] = s[i];
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) s[i] = add(dot16(t, K.dmat[i]), K.dbias[i]);
+    }
+#pragma unroll 1
+    for (int pr = 0; pr < 20; pr++) {
+        u32 s0 = cube(s[0]);
+        cols[57 + pr][r] = s0;
+        if (pr < 19) s0 = add(s0, K.pscalar[pr]);
+        s[0] = s0;
+        const u32 n0 = dot16(s, K.prow[pr]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) s[i] = add(s[i], mul(s0, K.pcol[pr][i - 1]));
+        s[0] = n0;
+    }
+#pragma unroll 1
+    for (int h = 0; h < 4; h++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_term[h][i]));
+        mds_circ16(s);
+        if (h == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) cols[77 + i][r] = s[i];
+        }
+    }
+    const u32 fp = cols[8][r];  // flag_permute
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 cv = add(s[i], in[i]);
+        cols[93 + i][r] = add(mul(sub(ONE, fp), cv), mul(fp, s[i]));
+        cols[101 + i][r] = mul(fp, s[i + 8]);
+    }
 }
 
 // batched opening: block b serves indices[b]
@@ -241,6 +306,19 @@ int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n) {
     LM_REQUIRE(ctx && d_states);
     if (n == 0) return LM_OK;
     LM_LAUNCH(ctx, k_poseidon_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_states, n, 1);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
+int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows) {
+    LM_REQUIRE(ctx && d_cols);
+    if (n_rows == 0) return LM_OK;
+    u32* s;
+    int rc = lm_scratch(ctx, 109 * 2 + 16, &s);
+    if (rc) return rc;
+    LM_HIP(hipMemcpyAsync(s, d_cols, 109 * sizeof(u32*), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    LM_LAUNCH(ctx, k_poseidon_trace, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (u32* const*)s, n_rows);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

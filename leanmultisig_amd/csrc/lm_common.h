@@ -52,6 +52,8 @@ struct lm_ctx {
     // reads them after a stream synchronise (no D2H copy command per sumcheck round)
     u32* h_res = nullptr;
     static constexpr u64 RES_WORDS = 4096;
+    static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
+    u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
     // caching device allocator: freed blocks are kept per size class and reused (hipMalloc/hipFree synchronise the
     // device; a proof performs ~100 allocations).  Single stream => reuse is stream-ordered and safe.
     std::multimap<u64, void*> pool_free;
@@ -79,6 +81,17 @@ struct lm_ctx {
             c__->prof_events[#kernel].emplace_back(e0__, e1__);                                          \
         }                                                                                                \
     } while (0)
+
+// Publish / wait protocol for small per-round results: the last kernel of a round writes its values into the pinned
+// host-visible buffer, fences at system scope and stores the round's sequence number; the host spins on that word
+// instead of paying a stream-synchronise per sumcheck round (~300 rounds per proof).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) {
+    __threadfence_system();
+    __hip_atomic_store(h_res + lm_ctx::RES_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 
 static inline bool lm_prof_match(const char* want, const char* name) {
     if (name[0] == '(') name++;  // template kernels are launched as (k<...>)

@@ -213,6 +213,25 @@ void lm_pool_free(lm_ctx* ctx, void* p) {
     ctx->pool_free.emplace(it->second, p);
 }
 
+int lm_wait_result(lm_ctx* ctx, u32 seq) {
+    volatile u32* flag = ctx->h_res + lm_ctx::RES_FLAG;
+    for (u64 spins = 0; *flag != seq; spins++) {
+        if (spins > (1ull << 22)) {  // something is wrong or the kernel is long: fall back to the runtime
+            LM_HIP(hipStreamSynchronize(ctx->stream));
+            if (*flag != seq) {
+                lm_set_error("lm_wait_result: sequence %u never published (flag %u)", seq, *flag);
+                return LM_E_DEVICE;
+            }
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return LM_OK;
+}
+
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {
     if (words > ctx->scratch_words) {
         LM_HIP(hipStreamSynchronize(ctx->stream));
@@ -242,7 +261,8 @@ int lm_ctx_create(int device, lm_ctx** out) {
     LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
-    LM_HIP(hipHostMalloc((void**)&c->h_res, lm_ctx::RES_WORDS * 4, hipHostMallocMapped));
+    LM_HIP(hipHostMalloc((void**)&c->h_res, (lm_ctx::RES_WORDS + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    c->h_res[lm_ctx::RES_FLAG] = 0;
     const u64 n = 1ull << (LM_TW_LOG - 1);
     LM_LAUNCH(c, k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->d_tw, c->d_tw_small,
                        to_monty(LM_G24_CANON));

@@ -110,8 +110,41 @@ __device__ __forceinline__ void block_store_acc(const EF acc[4], u32* lds /* 80 
         dst[threadIdx.x] = s;
     }
 }
+// (c0_num + alpha c0_den, c2_num + alpha c2_den) from the 20 summed words
+__device__ __forceinline__ void combine_alpha(const u32* tot, const EF& alpha, u32* out) {
+    EF c0n, c2n, c0d, c2d;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        c0n.v[k] = tot[k];
+        c2n.v[k] = tot[5 + k];
+        c0d.v[k] = tot[10 + k];
+        c2d.v[k] = tot[15 + k];
+    }
+    const EF a = ef_add(c0n, ef_mul(alpha, c0d)), b = ef_add(c2n, ef_mul(alpha, c2d));
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        out[k] = a.v[k];
+        out[5 + k] = b.v[k];
+    }
+}
+// End of a round kernel: a single-block launch finishes the round itself (result straight to the host-visible buffer),
+// a multi-block launch leaves per-block partials for k_gkr_reduce.
+__device__ __forceinline__ void finish_round(const EF acc[4], u32* lds, u32* tot, u32* partial, const EF& alpha, u32* final_out,
+                                             u32 seq) {
+    block_store_acc(acc, lds, tot);
+    __syncthreads();
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) {
+            combine_alpha(tot, alpha, final_out);
+            lm_publish_flag(final_out, seq);
+        }
+    } else if (threadIdx.x < 20) {
+        partial[(u64)blockIdx.x * 20 + threadIdx.x] = tot[threadIdx.x];
+    }
+}
 // out[0..5) = c0_num + alpha c0_den ; out[5..10) = c2_num + alpha c2_den
-__global__ __launch_bounds__(256) void k_gkr_reduce(const u32* __restrict__ partial, u32 n, EF alpha, u32* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_gkr_reduce(const u32* __restrict__ partial, u32 n, EF alpha, u32* __restrict__ out,
+                                                    u32 seq) {
     __shared__ u32 lds[80];
     EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
     for (u32 i = threadIdx.x; i < n; i += 256)
@@ -123,28 +156,18 @@ __global__ __launch_bounds__(256) void k_gkr_reduce(const u32* __restrict__ part
     block_store_acc(acc, lds, tot);
     __syncthreads();
     if (threadIdx.x == 0) {
-        EF c0n, c2n, c0d, c2d;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            c0n.v[k] = tot[k];
-            c2n.v[k] = tot[5 + k];
-            c0d.v[k] = tot[10 + k];
-            c2d.v[k] = tot[15 + k];
-        }
-        EF a = ef_add(c0n, ef_mul(alpha, c0d)), b = ef_add(c2n, ef_mul(alpha, c2d));
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            out[k] = a.v[k];
-            out[5 + k] = b.v[k];
-        }
+        combine_alpha(tot, alpha, out);
+        lm_publish_flag(out, seq);
     }
 }
 
 // ---- round 0 of a layer straight from layer storage: pairs j' < n_pairs, entries 4j' .. 4j'+3 ------------------------
 template <bool BASE>
 __global__ __launch_bounds__(256) void k_gkr_round_storage(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
-                                                           u64 n_pairs, EqSplit eq, u32* __restrict__ partial) {
+                                                           u64 n_pairs, EqSplit eq, u32* __restrict__ partial, EF alpha,
+                                                           u32* __restrict__ final_out, u32 seq) {
     __shared__ u32 lds[80];
+    __shared__ u32 tot[20];
     const u64 plane = 4 * n_pairs;
     EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
     for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
@@ -174,24 +197,28 @@ __global__ __launch_bounds__(256) void k_gkr_round_storage(const u32* __restrict
             pair_accumulate(nl0, nl1, nr0, nr1, dl0, dl1, dr0, dr1, w, acc);
         }
     }
-    block_store_acc(acc, lds, partial + (u64)blockIdx.x * 20);
+    finish_round(acc, lds, tot, partial, alpha, final_out, seq);
 }
 
 // ---- fold by r then compute the next round.  MODE 0: input = layer storage with base nums, 1: layer storage with EF
 // nums, 2: four SoA arrays of length m_in.  Output: four SoA arrays of length m_out = m_in / 2 at `out`
 // (array a at out + a * 5 * m_out).  Thread j' produces outputs 2j', 2j'+1 and (if m_out >= 2) their pair coefficients.
-template <int MODE>
+template <int MODE, bool LAST>
 __global__ __launch_bounds__(256) void k_gkr_fold_round(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
                                                         const u32* __restrict__ arr_in, u64 m_out, EF r, EqSplit eq,
-                                                        u32* __restrict__ out, u32* __restrict__ partial) {
+                                                        u32* __restrict__ out, u32* __restrict__ partial, EF alpha,
+                                                        u32* __restrict__ final_out, u32 seq) {
     __shared__ u32 lds[80];
+    __shared__ u32 tot[20];
     const u64 m_in = 2 * m_out;
     EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
-    const u64 n_threads_work = m_out >= 2 ? m_out / 2 : 1;
+    // LAST: m_out == 1 (the final fold of a layer: one output per array, no pair to accumulate)
+    constexpr int N_OUT = LAST ? 1 : 2;
+    const u64 n_threads_work = LAST ? 1 : m_out / 2;
     for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_threads_work; j += (u64)gridDim.x * 256) {
-        EF o[2][4];  // [which output][array]
-        const int n_out = m_out >= 2 ? 2 : 1;
-        for (int t = 0; t < n_out; t++) {
+        EF o[N_OUT][4];  // [which output][array] — fully unrolled, stays in registers
+#pragma unroll
+        for (int t = 0; t < N_OUT; t++) {
             const u64 i = 2 * j + t;  // output index; inputs 2i, 2i+1 of each array
             EF a[4], b[4];
             if (MODE == 2) {
@@ -245,12 +272,12 @@ __global__ __launch_bounds__(256) void k_gkr_fold_round(const u32* __restrict__ 
                 for (int k = 0; k < 5; k++) out[((u64)q * 5 + k) * m_out + i] = o[t][q].v[k];
             }
         }
-        if (m_out >= 2) {
+        if constexpr (!LAST) {
             const EF w = eq_split_at(eq, j);
-            pair_accumulate(o[0][0], o[1][0], o[0][1], o[1][1], o[0][2], o[1][2], o[0][3], o[1][3], w, acc);
+            pair_accumulate(o[0][0], o[N_OUT - 1][0], o[0][1], o[N_OUT - 1][1], o[0][2], o[N_OUT - 1][2], o[0][3], o[N_OUT - 1][3], w, acc);
         }
     }
-    if (m_out >= 2) block_store_acc(acc, lds, partial + (u64)blockIdx.x * 20);
+    if constexpr (!LAST) finish_round(acc, lds, tot, partial, alpha, final_out, seq);
 }
 
 extern "C" {
@@ -342,7 +369,9 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32 t = g->round;
     const u32 p = g->K - 1 - t;  // prefix coordinates of this round's eq table
     const u64 n_pairs = 1ull << p;
-    const u32 blocks = (u32)std::min<u64>((n_pairs + 255) / 256, 1024);
+    // up to 4096 pairs: one workgroup does the whole round (no partials, no second launch)
+    const u32 blocks = n_pairs <= 512 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 1024);
+    const u32 seq = ++ctx->res_seq;
     u32* s;
     int rc = lm_scratch(ctx, (u64)blocks * 20 + 32, &s);
     if (rc) return rc;
@@ -355,9 +384,9 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32* d_st = input_layer ? g->d_dens0 : g->dens[g->n_vars - g->K - 2];
     if (t == 0) {
         if (input_layer)
-            LM_LAUNCH(ctx, k_gkr_round_storage<true>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s);
+            LM_LAUNCH(ctx, k_gkr_round_storage<true>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s, g->alpha, ctx->h_res, seq);
         else
-            LM_LAUNCH(ctx, k_gkr_round_storage<false>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s);
+            LM_LAUNCH(ctx, k_gkr_round_storage<false>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s, g->alpha, ctx->h_res, seq);
     } else {
         EF r;
         memcpy(r.v, prev_r, 20);
@@ -365,22 +394,22 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         const int dst = g->cur < 0 ? 0 : 1 - g->cur;
         if (g->cur < 0) {
             if (input_layer)
-                LM_LAUNCH(ctx, k_gkr_fold_round<0>, dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
-                          g->work[dst], s);
+                LM_LAUNCH(ctx, (k_gkr_fold_round<0, false>), dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
+                          g->work[dst], s, g->alpha, ctx->h_res, seq);
             else
-                LM_LAUNCH(ctx, k_gkr_fold_round<1>, dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
-                          g->work[dst], s);
+                LM_LAUNCH(ctx, (k_gkr_fold_round<1, false>), dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
+                          g->work[dst], s, g->alpha, ctx->h_res, seq);
         } else {
-            LM_LAUNCH(ctx, k_gkr_fold_round<2>, dim3(blocks), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
-                      (const u32*)g->work[g->cur], m_out, r, eq, g->work[dst], s);
+            LM_LAUNCH(ctx, (k_gkr_fold_round<2, false>), dim3(blocks), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
+                      (const u32*)g->work[g->cur], m_out, r, eq, g->work[dst], s, g->alpha, ctx->h_res, seq);
         }
         g->cur = dst;
         g->m = m_out;
     }
     (void)d_out;
-    LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, ctx->h_res);
+    if (blocks > 1) LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
     g->round++;
     return LM_OK;
@@ -397,8 +426,9 @@ int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[5], uint32_t 
     int rc = lm_scratch(ctx, 64, &s);
     if (rc) return rc;
     LM_REQUIRE(g->cur >= 0);  // K >= 5 rounds, so at least one fold happened
-    LM_LAUNCH(ctx, k_gkr_fold_round<2>, dim3(1), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
-              (const u32*)g->work[g->cur], (u64)1, r, eq, g->work[dst], s);
+    const u32 seq = 0;        // nothing is published by the final fold
+    LM_LAUNCH(ctx, (k_gkr_fold_round<2, true>), dim3(1), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
+              (const u32*)g->work[g->cur], (u64)1, r, eq, g->work[dst], s, g->alpha, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
     LM_HIP(hipMemcpyAsync(inner_evals, g->work[dst], 80, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));

@@ -122,7 +122,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     return v;
 }
 // sums 10 field values across the block; thread 0 writes them to dst[0..10)
-__device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, u32* dst) {
+__device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, u32* dst, u32* publish_to = nullptr, u32 seq = 0) {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 10; k++) v[k] = wave_sum(v[k]);
@@ -137,10 +137,16 @@ __device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, 
         for (u32 w = 0; w < (blockDim.x >> 6); w++) s = add(s, lds[w * 10 + threadIdx.x]);
         dst[threadIdx.x] = s;
     }
+    if (publish_to) {  // all ten writers are in wave 0: fence each, then one lane stores the sequence number
+        if (threadIdx.x < 64) {
+            __threadfence_system();
+            if (threadIdx.x == 0) lm_publish_flag(publish_to, seq);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                         u32* __restrict__ partial) {
+                                                         u32* __restrict__ partial, u32* __restrict__ final_out, u32 seq) {
     __shared__ u32 red[40];
     const u64 plane = 2 * half;
     u64 a0[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0};
@@ -160,10 +166,13 @@ __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__
         v[k] = reduce(a0[k]);
         v[5 + k] = reduce(a2[k]);
     }
-    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    if (gridDim.x == 1)
+        block_sum10(v, red, final_out, final_out, seq);
+    else
+        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
 }
 __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                        u32* __restrict__ partial) {
+                                                        u32* __restrict__ partial, u32* __restrict__ final_out, u32 seq) {
     __shared__ u32 red[40];
     const u64 plane = 2 * half;
     EF c0 = ef_zero(), c2 = ef_zero();
@@ -185,15 +194,18 @@ __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ 
         v[k] = c0.v[k];
         v[5 + k] = c2.v[k];
     }
-    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    if (gridDim.x == 1)
+        block_sum10(v, red, final_out, final_out, seq);
+    else
+        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
 }
-__global__ __launch_bounds__(256) void k_sum10(const u32* __restrict__ partial, u32 n, u32* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_sum10(const u32* __restrict__ partial, u32 n, u32* __restrict__ out, u32 seq) {
     __shared__ u32 red[40];
     u32 v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 i = threadIdx.x; i < n; i += 256)
 #pragma unroll
         for (int k = 0; k < 10; k++) v[k] = add(v[k], partial[(u64)i * 10 + k]);
-    block_sum10(v, red, out);
+    block_sum10(v, red, out, out, seq);
 }
 
 __global__ __launch_bounds__(256) void k_fold_base(const u32* __restrict__ in, u64 half, EF r, u32* __restrict__ out) {
@@ -331,19 +343,20 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
                   uint32_t out_c0_c2[10]) {
     LM_REQUIRE(ctx && d_f && d_W && out_c0_c2 && n_vars >= 1 && n_vars <= 40);
     const u64 half = 1ull << (n_vars - 1);
-    u32 blocks = (u32)std::min<u64>((half + 255) / 256, 2048);
+    u32 blocks = half <= 512 ? 1 : (u32)std::min<u64>((half + 255) / 256, 2048);
+    const u32 seq = ++ctx->res_seq;
     u32* s;
     int rc = lm_scratch(ctx, (u64)blocks * 10 + 16, &s);
     if (rc) return rc;
     u32* d_out = s + (u64)blocks * 10;
     if (f_is_ext)
-        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
+        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s);
+        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->h_res, seq);
     (void)d_out;
-    LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
+    if (blocks > 1) LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
     return LM_OK;
 }

@@ -76,3 +76,20 @@ def test_poseidon_trace_satisfies_all_but_bus(ctx, orc):
     alpha2 = rand_field(rng, 5)
     vals2 = ob.air_eval_rows(orc, 2, cols, alpha2, eq16, beta)
     assert np.array_equal(vals, vals2)  # independent of alpha => constraints 1..99 are all zero
+
+
+def test_poseidon_trace_rows_match_oracle(ctx, orc):
+    """a21: device trace generation == oracle generate_trace_rows_for_perm, including permute-mode rows."""
+    rng = np.random.default_rng(21)
+    n = 1000
+    ref = ob.poseidon_table(orc, rng, 10, n_active=n)  # (109, 1024) column major, padding rows included
+    # make some rows permute-mode (flag_permute = 1): regenerate those rows with the oracle
+    rows = np.ascontiguousarray(ref.T)
+    rows[5:50, 8] = 0x01FFFFFE
+    import ctypes
+    orc.lib.orc_poseidon16_fill_rows(rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(rows.shape[0]))
+    ref = np.ascontiguousarray(rows.T)
+    bufs = [ctx.to_device(ref[c] if c < 25 else np.zeros(1024, dtype=np.uint32)) for c in range(109)]
+    ctx.poseidon_trace(bufs, 1024)
+    got = np.stack([b.download() for b in bufs])
+    assert np.array_equal(got, ref)

@@ -109,6 +109,12 @@ int lm_tree_download_digests(lm_ctx* ctx, const lm_tree* tree, uint32_t* digests
  * out: n_polys x 5 host words. */
 int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
                 uint64_t stride_words, const uint32_t* point, uint32_t* out);
+/* Same for n_cols base columns given by a host array of DEVICE pointers (the 91 column evaluations that follow the GKR,
+ * crates/sub_protocols/src/logup.rs:224-308, are batches of this form). */
+int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t n_vars, const uint32_t* point,
+                     uint32_t* out);
+/* device-to-device copy of n_words (stack_polynomials_and_commit, crates/sub_protocols/src/stacked_pcs.rs:118-136) */
+int lm_copy_d2d(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint64_t n_words);
 
 /* ---- weight polynomial of the WHIR sumcheck -----------------------------------------------------------------------
  * combine_statement (crates/whir/src/open.rs:518-584), SumcheckSingle::add_new_equality / add_new_base_equality

@@ -101,6 +101,31 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
                                    const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5],
                                    const uint32_t eta[5], uint32_t* out_point, uint32_t* out_col_evals);
 
+/* ---- prove_execution after witness generation --------------------------------------------------------------------
+ * crates/lean_prover/src/prove_execution.rs:47-274: Fiat–Shamir preamble, stack_polynomials_and_commit, prove_generic_logup
+ * (fill + GKR + column evaluations), batched AIR sumcheck, statement assembly (stacked_pcs_global_statements) and
+ * WhirConfig::prove.  Inputs are what get_execution_trace (lean_prover/src/trace_gen.rs) hands to the prover, resident in
+ * HBM: memory, the access counters, the bytecode multilinear (2^log_bytecode rows x 16 words) and per table the TOTAL
+ * column set (committed columns first, then the virtual bus columns: execution 24, extension_op 31, poseidon16 111).
+ * cfg must be the WhirConfig integers for lmh_stacked_n_vars(trace) variables. */
+typedef struct {
+    uint32_t log_rows;
+    const uint32_t* const* d_cols; /* host array of device column pointers (n_columns_total of the table) */
+} lm_vm_table;
+typedef struct {
+    uint32_t log_inv_rate, log_memory, log_bytecode, ending_pc, public_memory_size, n_public_input;
+    const uint32_t* public_input;  /* host */
+    const uint32_t* bytecode_hash; /* host, 8 words */
+    const uint32_t* d_bytecode;    /* device */
+    const uint32_t* d_bytecode_acc;
+    const uint32_t* d_memory;
+    const uint32_t* d_memory_acc;
+    lm_vm_table tables[3]; /* indexed by table id: execution, extension_op, poseidon16 */
+} lm_execution_trace;
+uint32_t lmh_stacked_n_vars(const lm_execution_trace* trace); /* compute_stacked_n_vars, stacked_pcs.rs:183-196 */
+/* returns LM_E_INVALID with lm_last_error "logup sum != 0" when the witness is inconsistent (prove_generic_logup asserts) */
+int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* trace, const lm_whir_config* cfg);
+
 #ifdef __cplusplus
 }
 #endif

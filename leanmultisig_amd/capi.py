@@ -45,6 +45,8 @@ _SIGS = {
     "lm_tree_open": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
     "lm_tree_download_matrix": (C.c_int, [vp, vp, vp]),
     "lm_tree_download_digests": (C.c_int, [vp, vp, vp]),
+    "lm_mle_eval_cols": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
+    "lm_copy_d2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
     "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
@@ -86,6 +88,8 @@ _HOST_SIGS = {
     "lmh_witness_root": (None, [vp, vp]),
     "lmh_prove_gkr_quotient": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "lmh_prove_batched_air_sumcheck": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
+    "lmh_stacked_n_vars": (C.c_uint32, [vp]),
+    "lmh_prove_execution": (C.c_int, [vp, vp, vp, vp]),
     "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
 }
 
@@ -153,6 +157,18 @@ class AirTable(C.Structure):
 AIR_N_COLUMNS = {0: 20, 1: 29, 2: 109}
 AIR_N_SHIFT = {0: 2, 1: 13, 2: 0}
 AIR_DEGREE = {0: 5, 1: 6, 2: 10}
+
+
+class VmTable(C.Structure):
+    """lm_vm_table"""
+    _fields_ = [("log_rows", C.c_uint32), ("d_cols", vp)]
+
+
+class ExecutionTrace(C.Structure):
+    """lm_execution_trace"""
+    _fields_ = [("log_inv_rate", C.c_uint32), ("log_memory", C.c_uint32), ("log_bytecode", C.c_uint32), ("ending_pc", C.c_uint32),
+                ("public_memory_size", C.c_uint32), ("n_public_input", C.c_uint32), ("public_input", vp), ("bytecode_hash", vp),
+                ("d_bytecode", vp), ("d_bytecode_acc", vp), ("d_memory", vp), ("d_memory_acc", vp), ("tables", VmTable * 3)]
 
 
 class WeightItem(C.Structure):
@@ -392,6 +408,29 @@ class Context:
         return w.value
 
 
+def make_execution_trace(ctx, w):
+    """Upload a witness dict (tests/synth_witness.py layout) and build the lm_execution_trace; returns (trace, keepalive)."""
+    keep = []
+    tr = ExecutionTrace()
+    tr.log_inv_rate, tr.log_memory, tr.log_bytecode = w["log_inv_rate"], w["log_memory"], w["log_bytecode"]
+    tr.ending_pc, tr.public_memory_size = w["ending_pc"], w["public_memory_size"]
+    pi = _u32(w["public_input"])
+    bh = _u32(w["bytecode_hash"])
+    keep += [pi, bh]
+    tr.n_public_input, tr.public_input, tr.bytecode_hash = pi.size, pi.ctypes.data, bh.ctypes.data
+    for name, key in (("d_bytecode", "bytecode"), ("d_bytecode_acc", "bytecode_acc"), ("d_memory", "memory"), ("d_memory_acc", "memory_acc")):
+        b = ctx.to_device(w[key])
+        keep.append(b)
+        setattr(tr, name, b.ptr)
+    for t in range(3):
+        bufs = [ctx.to_device(c) for c in w["tables"][t]]
+        ptrs = np.array([b.ptr for b in bufs], dtype=np.uint64)
+        keep += [bufs, ptrs]
+        tr.tables[t].log_rows = w["log_rows"][t]
+        tr.tables[t].d_cols = ptrs.ctypes.data
+    return tr, keep
+
+
 class Prover:
     """lmh_prover: ProverState of the reference (transcript + challenger) driving the device."""
 
@@ -465,6 +504,9 @@ class Prover:
             out.append(ev[k:k + n].copy())
             k += n
         return pt, out
+
+    def prove_execution(self, trace, cfg):
+        self.ctx._check(self.lib.lmh_prove_execution(self.ctx.h, self.h, C.byref(trace), C.byref(cfg)))
 
     def whir_commit(self, cfg, d_poly, actual_len):
         w = vp()

@@ -731,4 +731,330 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     return cleanup(LM_OK);
 }
 
+
+}  // extern "C" (helpers below have C++ linkage)
+
+namespace {
+// ---- leanVM table metadata the prover needs (bus and memory lookups) ------------------------------------------------
+// lean_vm/src/tables/execution/mod.rs:29-60, extension_op/mod.rs:90-123, poseidon_16/mod.rs:126-174
+struct VmLookup {
+    u32 index, first_value, n_values;
+};
+struct VmTableDef {
+    u32 n_columns, n_shift, n_total;
+    u32 n_lookups;
+    VmLookup lookups[4];
+    bool pull;
+    u32 selector, bus_data[4];
+};
+const VmTableDef kVmTables[3] = {
+    {20, 2, 24, 3, {{2, 5, 1}, {3, 6, 1}, {4, 7, 1}, {0, 0, 0}}, false, 20, {19, 21, 22, 23}},
+    {29, 13, 31, 3, {{6, 14, 5}, {7, 19, 5}, {13, 24, 5}, {0, 0, 0}}, true, 29, {30, 6, 7, 13}},
+    {109, 0, 111, 4, {{6, 9, 4}, {7, 13, 4}, {1, 17, 8}, {2, 93, 16}}, true, 0, {110, 109, 1, 2}},
+};
+const u32 kSnarkDomainSep[8] = {130704175, 1303721200, 493664240, 1035493700,
+                                2063844858, 1410214009, 1938905908, 1696767928};  // lean_prover/src/lib.rs:30-32
+u32 log2_ceil_u64(u64 x) {
+    u32 l = 0;
+    while ((1ull << l) < x) l++;
+    return l;
+}
+void sorted_tables(const lm_execution_trace* t, int order[3]) {  // sort_tables_by_height (stable, descending)
+    order[0] = 0;
+    order[1] = 1;
+    order[2] = 2;
+    std::stable_sort(order, order + 3, [&](int a, int b) { return t->tables[a].log_rows > t->tables[b].log_rows; });
+}
+struct DevBuf {  // RAII device allocation
+    lm_ctx* ctx;
+    u32* p = nullptr;
+    DevBuf(lm_ctx* c) : ctx(c) {}
+    ~DevBuf() {
+        if (p) lm_free(ctx, p);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+uint32_t lmh_stacked_n_vars(const lm_execution_trace* t) {
+    u32 mx = std::max(t->tables[0].log_rows, std::max(t->tables[1].log_rows, t->tables[2].log_rows));
+    u64 total = (2ull << t->log_memory) + (1ull << std::max(t->log_bytecode, mx));
+    for (int k = 0; k < 3; k++) total += (u64)kVmTables[k].n_columns << t->tables[k].log_rows;
+    return log2_ceil_u64(total);
+}
+
+int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr, const lm_whir_config* cfg) {
+    if (!ctx || !p || !tr || !cfg) return LM_E_INVALID;
+    int rc;
+    int order[3];
+    sorted_tables(tr, order);
+    const u32 log_mem = tr->log_memory, log_bc = tr->log_bytecode;
+    // assertions of stack_polynomials_and_commit (stacked_pcs.rs:108-112)
+    if (log_mem < tr->tables[0].log_rows || tr->tables[0].log_rows < tr->tables[order[0]].log_rows) return LM_E_INVALID;
+    const u32 stacked_n_vars = lmh_stacked_n_vars(tr);
+    if (cfg->num_variables != stacked_n_vars || cfg->starting_log_inv_rate != tr->log_inv_rate) return LM_E_INVALID;
+    // ---- Fiat-Shamir preamble (prove_execution.rs:47-63) ----
+    p->ch.observe_many(tr->public_input, tr->n_public_input);
+    {
+        u32 st[16];
+        memcpy(st, tr->bytecode_hash, 32);
+        for (int i = 0; i < 8; i++) st[8 + i] = kb::to_monty(kSnarkDomainSep[i]);
+        kb::poseidon16_compress(st);  // poseidon16_compress_pair(bytecode.hash, SNARK_DOMAIN_SEP)
+        p->ch.observe_many(st, 8);
+        u32 dims[6] = {kb::to_monty(tr->log_inv_rate), kb::to_monty(log_mem), kb::to_monty(tr->n_public_input),
+                       kb::to_monty(tr->tables[0].log_rows), kb::to_monty(tr->tables[1].log_rows), kb::to_monty(tr->tables[2].log_rows)};
+        add_base(p, dims, 6);
+    }
+    // ---- stack_polynomials_and_commit (stacked_pcs.rs:99-157) ----
+    const u64 mem = 1ull << log_mem;
+    DevBuf poly(ctx);
+    if ((rc = lm_malloc(ctx, 1ull << stacked_n_vars, &poly.p))) return rc;
+    if ((rc = lm_memset_zero(ctx, poly.p, 1ull << stacked_n_vars))) return rc;
+    lm_copy_d2d(ctx, poly.p, tr->d_memory, mem);
+    lm_copy_d2d(ctx, poly.p + mem, tr->d_memory_acc, mem);
+    u64 off = 2 * mem;
+    lm_copy_d2d(ctx, poly.p + off, tr->d_bytecode_acc, 1ull << log_bc);
+    off += std::max(1ull << tr->tables[order[0]].log_rows, 1ull << log_bc);
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        for (u32 c = 0; c < kVmTables[t].n_columns; c++) {
+            lm_copy_d2d(ctx, poly.p + off, tr->tables[t].d_cols[c], 1ull << tr->tables[t].log_rows);
+            off += 1ull << tr->tables[t].log_rows;
+        }
+    }
+    lmh_witness* wit = nullptr;
+    if ((rc = lmh_whir_commit(ctx, p, cfg, poly.p, off, &wit))) return rc;
+    auto fail = [&](int code) {
+        if (wit) lmh_witness_free(ctx, wit);
+        return code;
+    };
+    // ---- logup (prove_execution.rs:123-137, logup.rs:27-308) ----
+    std::vector<EF> cv, alphas;
+    if (!sample_vec(p, 1, cv)) return fail(LM_E_INVALID);
+    const EF logup_c = cv[0];
+    p->ch.duplex();
+    if (!sample_vec(p, 4, alphas)) return fail(LM_E_INVALID);
+    EF aeq[16];  // eval_eq(&logup_alphas): index bits MSB first
+    for (u32 i = 0; i < 16; i++) {
+        EF a = kb::ef_one();
+        for (u32 j = 0; j < 4; j++) a = kb::ef_mul(a, ((i >> (3 - j)) & 1) ? alphas[j] : kb::ef_sub(kb::ef_one(), alphas[j]));
+        aeq[i] = a;
+    }
+    std::vector<lm_logup_section> secs;
+    auto new_sec = [&](u64 offset, u32 log_len, u32 num_mode, const u32* num_col, int den_sign, u32 domsep) {
+        lm_logup_section s;
+        memset(&s, 0, sizeof s);
+        s.out_offset = offset;
+        s.log_len = log_len;
+        s.num_mode = num_mode;
+        s.d_num_col = num_col;
+        s.den_sign = den_sign;
+        s.domsep = domsep;
+        secs.push_back(s);
+        return &secs.back();
+    };
+    auto add_data = [&](lm_logup_section* s, const u32* col, u32 stride, u32 add) {
+        s->d_data[s->n_data] = col;
+        s->stride[s->n_data] = stride;
+        s->add[s->n_data] = add;
+        s->n_data++;
+    };
+    u64 loff = 0;
+    {
+        lm_logup_section* s = new_sec(loff, log_mem, 3, tr->d_memory_acc, -1, 0);  // logup.rs:94-109
+        add_data(s, tr->d_memory, 1, 0);
+        add_data(s, nullptr, 0, 0);
+        loff += mem;
+        s = new_sec(loff, log_bc, 3, tr->d_bytecode_acc, -1, 2);  // :111-125
+        for (u32 k = 0; k < 12; k++) add_data(s, tr->d_bytecode + k, 16, 0);
+        add_data(s, nullptr, 0, 0);
+        loff += std::max(1ull << log_bc, 1ull << tr->tables[order[0]].log_rows);
+    }
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        const VmTableDef& def = kVmTables[t];
+        const u32 lr = tr->tables[t].log_rows;
+        const u32* const* cols = tr->tables[t].d_cols;
+        if (t == 0) {  // :141-156
+            lm_logup_section* s = new_sec(loff, lr, 1, nullptr, -1, 2);
+            for (u32 c = 0; c < 12; c++) add_data(s, cols[8 + c], 1, 0);
+            add_data(s, cols[0], 1, 0);
+            loff += 1ull << lr;
+        }
+        {  // bus, :158-176
+            lm_logup_section* s = new_sec(loff, lr, def.pull ? 3 : 2, cols[def.selector], +1, 1);
+            for (u32 c = 0; c < 4; c++) add_data(s, cols[def.bus_data[c]], 1, 0);
+            loff += 1ull << lr;
+        }
+        for (u32 l = 0; l < def.n_lookups; l++)  // :178-199
+            for (u32 i = 0; i < def.lookups[l].n_values; i++) {
+                lm_logup_section* s = new_sec(loff, lr, 1, nullptr, -1, 0);
+                add_data(s, cols[def.lookups[l].first_value + i], 1, 0);
+                add_data(s, cols[def.lookups[l].index], 1, i);
+                loff += 1ull << lr;
+            }
+    }
+    const u32 gkr_n_vars = log2_ceil_u64(loff);
+    DevBuf nums(ctx), dens(ctx);
+    if ((rc = lm_malloc(ctx, 1ull << gkr_n_vars, &nums.p))) return fail(rc);
+    if ((rc = lm_malloc(ctx, 5ull << gkr_n_vars, &dens.p))) return fail(rc);
+    if ((rc = lm_logup_build(ctx, secs.data(), (u32)secs.size(), logup_c.v, aeq[0].v, gkr_n_vars, nums.p, dens.p))) return fail(rc);
+    u32 quotient[5], claims[10];
+    std::vector<u32> gkr_pt((size_t)gkr_n_vars * 5);
+    if ((rc = lmh_prove_gkr_quotient(ctx, p, nums.p, dens.p, gkr_n_vars, quotient, gkr_pt.data(), claims))) return fail(rc);
+    if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) return fail(LM_E_INVALID);  // assert_eq!(sum, ZERO)
+    auto from_end = [&](u32 n) { return gkr_pt.data() + (size_t)(gkr_n_vars - n) * 5; };
+    // column evaluations (logup.rs:224-308)
+    EF value_memory_acc, value_memory, value_bytecode_acc;
+    if ((rc = lm_mle_eval(ctx, tr->d_memory_acc, 0, log_mem, 1, 0, from_end(log_mem), value_memory_acc.v))) return fail(rc);
+    add_base(p, value_memory_acc.v, 5);
+    if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, log_mem, 1, 0, from_end(log_mem), value_memory.v))) return fail(rc);
+    add_base(p, value_memory.v, 5);
+    if ((rc = lm_mle_eval(ctx, tr->d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail(rc);
+    add_base(p, value_bytecode_acc.v, 5);
+    struct ColVal {
+        u32 col;
+        EF v;
+    };
+    std::vector<ColVal> columns_values[3];
+    EF bus_num[3], bus_den[3];
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        const VmTableDef& def = kVmTables[t];
+        const u32 lr = tr->tables[t].log_rows;
+        const u32* const* cols = tr->tables[t].d_cols;
+        // gather the column list in transcript order, evaluate them in one batch
+        std::vector<u32> want;
+        if (t == 0) {
+            want.push_back(0);
+            for (u32 c = 0; c < 12; c++) want.push_back(8 + c);
+        }
+        const size_t i_sel = want.size();
+        want.push_back(def.selector);
+        for (u32 c = 0; c < 4; c++) want.push_back(def.bus_data[c]);
+        const size_t i_lk = want.size();
+        for (u32 l = 0; l < def.n_lookups; l++) {
+            want.push_back(def.lookups[l].index);
+            for (u32 i = 0; i < def.lookups[l].n_values; i++) want.push_back(def.lookups[l].first_value + i);
+        }
+        std::vector<const u32*> ptrs;
+        for (u32 c : want) ptrs.push_back(cols[c]);
+        std::vector<u32> ev(want.size() * 5);
+        if ((rc = lm_mle_eval_cols(ctx, ptrs.data(), (u32)ptrs.size(), lr, from_end(lr), ev.data()))) return fail(rc);
+        auto E = [&](size_t i) { return ef_load(&ev[5 * i]); };
+        if (t == 0) {
+            add_base(p, &ev[0], 5);       // eval_on_pc
+            add_base(p, &ev[5], 12 * 5);  // instr_evals
+            for (size_t i = 0; i < 13; i++) columns_values[t].push_back({want[i], E(i)});
+        }
+        EF esel = E(i_sel);
+        if (def.pull) esel = kb::ef_neg(esel);  // * direction.to_field_flag()
+        add_base(p, esel.v, 5);
+        EF fp = aeq[15];  // finger_print(LOGUP_PRECOMPILE_DOMAINSEP = 1, bus data evals)
+        for (u32 c = 0; c < 4; c++) fp = kb::ef_add(fp, kb::ef_mul(aeq[c], E(i_sel + 1 + c)));
+        const EF edata = kb::ef_add(logup_c, fp);
+        add_base(p, edata.v, 5);
+        bus_num[t] = esel;
+        bus_den[t] = edata;
+        for (size_t i = i_lk; i < want.size(); i++) {
+            add_base(p, &ev[5 * i], 5);
+            columns_values[t].push_back({want[i], E(i)});
+        }
+    }
+    // ---- AIR (prove_execution.rs:152-223) ----
+    std::vector<EF> tmp;
+    if (!sample_vec(p, 1, tmp)) return fail(LM_E_INVALID);
+    const EF bus_beta = tmp[0];
+    p->ch.duplex();
+    if (!sample_vec(p, 1, tmp)) return fail(LM_E_INVALID);
+    const EF air_alpha = tmp[0];
+    p->ch.duplex();
+    if (!sample_vec(p, 1, tmp)) return fail(LM_E_INVALID);
+    const EF air_eta = tmp[0];
+    lm_air_table at[3];
+    u32 n_evals_total = 0;
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        at[k].table = (u32)t;
+        at[k].log_rows = tr->tables[t].log_rows;
+        at[k].d_cols = tr->tables[t].d_cols;
+        at[k].eq_point = from_end(tr->tables[t].log_rows);
+        const EF dir = kVmTables[t].pull ? kb::ef_neg(kb::ef_one()) : kb::ef_one();
+        const EF bfv = kb::ef_add(kb::ef_mul(bus_num[t], dir), kb::ef_mul(bus_beta, kb::ef_sub(bus_den[t], logup_c)));
+        memcpy(at[k].sum, bfv.v, 20);
+        n_evals_total += kVmTables[t].n_columns + kVmTables[t].n_shift;
+    }
+    const u32 n_max = tr->tables[order[0]].log_rows;
+    std::vector<u32> air_point((size_t)n_max * 5), col_evals((size_t)n_evals_total * 5);
+    if ((rc = lmh_prove_batched_air_sumcheck(ctx, p, at, 3, air_alpha.v, aeq[0].v, bus_beta.v, air_eta.v, air_point.data(), col_evals.data())))
+        return fail(rc);
+    // ---- public memory, statements (:225-260; stacked_pcs.rs:40-97) ----
+    const u32 lpm = log2_ceil_u64(tr->public_memory_size);
+    std::vector<EF> pm_pt;
+    if (!sample_vec(p, lpm, pm_pt)) return fail(LM_E_INVALID);
+    EF pm_eval;
+    if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, lpm, 1, 0, lpm ? pm_pt[0].v : nullptr, pm_eval.v))) return fail(rc);
+    std::vector<lm_sparse_statement> sts;
+    std::vector<u32> pts, vals;
+    std::vector<u64> sels;
+    auto begin_statement = [&](const u32* point, u32 point_len, u32 is_next) {
+        lm_sparse_statement s;
+        memset(&s, 0, sizeof s);
+        s.point_len = point_len;
+        s.is_next = is_next;
+        s.point_offset = pts.size() / 5;
+        s.values_offset = sels.size();
+        pts.insert(pts.end(), point, point + (size_t)point_len * 5);
+        sts.push_back(s);
+    };
+    auto add_value = [&](u64 selector, const EF& v) {
+        sels.push_back(selector);
+        vals.insert(vals.end(), v.v, v.v + 5);
+        sts.back().n_values++;
+    };
+    begin_statement(from_end(log_mem), log_mem, 0);
+    add_value(0, value_memory);
+    add_value(1, value_memory_acc);
+    begin_statement(lpm ? pm_pt[0].v : nullptr, lpm, 0);
+    add_value(0, pm_eval);
+    begin_statement(from_end(log_bc), log_bc, 0);
+    add_value((2 * mem) >> log_bc, value_bytecode_acc);
+    u64 soff = 2 * mem + (1ull << std::max(log_bc, tr->tables[order[0]].log_rows));
+    const u32* ce = col_evals.data();
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        const VmTableDef& def = kVmTables[t];
+        const u32 nv = tr->tables[t].log_rows;
+        if (t == 0) {
+            begin_statement(nullptr, 0, 0);  // unique_value(STARTING_PC = 0)
+            add_value(soff + (0ull << nv), kb::ef_zero());
+            begin_statement(nullptr, 0, 0);
+            add_value(soff + (1ull << nv) - 1, kb::ef_from_base(kb::to_monty(tr->ending_pc)));
+        }
+        // first committed statement: logup column values at from_end(gkr_point, nv), ascending column index (BTreeMap)
+        std::vector<ColVal> cvs = columns_values[t];
+        std::sort(cvs.begin(), cvs.end(), [](const ColVal& a, const ColVal& b) { return a.col < b.col; });
+        begin_statement(from_end(nv), nv, 0);
+        for (const ColVal& c : cvs) add_value((soff >> nv) + c.col, c.v);
+        // second: AIR point (natural_ordering_point_for_session: last nv challenges reversed), next values then eq values
+        std::vector<u32> nat((size_t)nv * 5);
+        for (u32 j = 0; j < nv; j++) memcpy(&nat[5 * j], &air_point[(size_t)(n_max - 1 - j) * 5], 20);
+        if (def.n_shift) {
+            begin_statement(nat.data(), nv, 1);
+            for (u32 c = 0; c < def.n_shift; c++) add_value((soff >> nv) + c, ef_load(ce + (size_t)(def.n_columns + c) * 5));
+        }
+        begin_statement(nat.data(), nv, 0);
+        for (u32 c = 0; c < def.n_columns; c++) add_value((soff >> nv) + c, ef_load(ce + (size_t)c * 5));
+        ce += (size_t)(def.n_columns + def.n_shift) * 5;
+        soff += (u64)def.n_columns << nv;
+    }
+    std::vector<u32> out_point((size_t)stacked_n_vars * 5);
+    lmh_witness* w = wit;
+    wit = nullptr;  // consumed by lmh_whir_prove
+    rc = lmh_whir_prove(ctx, p, cfg, sts.data(), (u32)sts.size(), pts.data(), pts.size() / 5, sels.data(), vals.data(), sels.size(), w,
+                        poly.p, out_point.data());
+    return rc;
+}
+
 }  // extern "C"

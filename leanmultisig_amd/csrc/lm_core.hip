@@ -123,6 +123,37 @@ __global__ __launch_bounds__(256) void k_mle_partial_base(const u32* __restrict_
         for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
     }
 }
+// same with one device pointer per polynomial
+__global__ __launch_bounds__(256) void k_mle_partial_cols(const u32* const* __restrict__ cols, u32 k_lo,
+                                                          const u32* __restrict__ eq_lo, const u32* __restrict__ eq_hi,
+                                                          u32 n_hi, u32* __restrict__ partial) {
+    __shared__ u32 red[32];
+    const u32 hi = blockIdx.x, poly = blockIdx.y;
+    const u32 len_lo = 1u << k_lo;
+    const u32* v = cols[poly] + (u64)hi * len_lo;
+    u64 acc[5] = {0, 0, 0, 0, 0};
+    for (u32 i = threadIdx.x; i < len_lo; i += 256) {
+        u32 x = v[i];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            u64 t = acc[k] + (u64)x * eq_lo[(u64)k * len_lo + i];
+            u64 y = t - P_SHL32;
+            acc[k] = t >= P_SHL32 ? y : t;
+        }
+    }
+    EF s;
+#pragma unroll
+    for (int k = 0; k < 5; k++) s.v[k] = reduce(acc[k]);
+    EF r = block_reduce_ef(s, red);
+    if (threadIdx.x == 0) {
+        EF e;
+#pragma unroll
+        for (int k = 0; k < 5; k++) e.v[k] = eq_hi[(u64)k * n_hi + hi];
+        r = ef_mul(r, e);
+#pragma unroll
+        for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
+    }
+}
 __global__ __launch_bounds__(256) void k_mle_partial_ext(const u32* __restrict__ evals, u64 stride_words, u64 plane,
                                                          u32 k_lo, const u32* __restrict__ eq_lo,
                                                          const u32* __restrict__ eq_hi, u32 n_hi,
@@ -402,6 +433,42 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     if (!pinned) LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
     if (pinned) memcpy(out, ctx->h_res, (u64)n_polys * 20);
+    return LM_OK;
+}
+
+
+int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t n_vars, const uint32_t* point,
+                     uint32_t* out) {
+    LM_REQUIRE(ctx && d_cols && out && n_cols >= 1 && n_vars <= 32 && (u64)n_cols * 5 <= lm_ctx::RES_WORDS);
+    LM_REQUIRE(n_vars == 0 || point);
+    const u32 k_lo = n_vars < 12 ? n_vars : 12;
+    const u32 k_hi = n_vars - k_lo;
+    const u32 n_hi = 1u << k_hi, len_lo = 1u << k_lo;
+    const u64 need = 2ull * n_cols + (u64)n_vars * 5 + 5ull * len_lo + 5ull * n_hi + (u64)n_cols * n_hi * 5 + 64;
+    u32* s;
+    int rc = lm_scratch(ctx, need, &s);
+    if (rc) return rc;
+    const u32** d_ptrs = reinterpret_cast<const u32**>(s);
+    u32* d_point = s + 2ull * n_cols;
+    u32* d_eq_lo = d_point + ((n_vars * 5 + 15) & ~15u);
+    u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
+    u32* d_partial = d_eq_hi + 5ull * n_hi;
+    LM_HIP(hipMemcpyAsync((void*)d_ptrs, d_cols, (u64)n_cols * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_vars) LM_HIP(hipMemcpyAsync(d_point, point, (u64)n_vars * 20, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, d_point, k_hi, d_eq_hi);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, d_point + k_hi * 5, k_lo, d_eq_lo);
+    LM_LAUNCH(ctx, k_mle_partial_cols, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, k_lo, d_eq_lo, d_eq_hi, n_hi,
+              d_partial);
+    LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, d_partial, n_hi, ctx->h_res);
+    LM_HIP(hipGetLastError());
+    LM_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->h_res, (u64)n_cols * 20);
+    return LM_OK;
+}
+int lm_copy_d2d(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint64_t n_words) {
+    LM_REQUIRE(ctx && d_dst && d_src);
+    if (n_words) LM_HIP(hipMemcpyAsync(d_dst, d_src, n_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return LM_OK;
 }
 

@@ -459,3 +459,58 @@ uint64_t orc_logup_fill(const uint32_t* memory, const uint32_t* memory_acc, uint
     return total;
 }
 }
+
+// ================================================================================================
+// prove_execution / verify_execution after witness generation (execution_oracle.hpp)
+// ================================================================================================
+#include "execution_oracle.hpp"
+extern "C" {
+// hdr = [log_inv_rate, log_memory, log_bytecode, ending_pc, public_memory_size, n_public_input, log_rows x3]
+// builder: 8 words as in make_builder, or NULL for default_whir_config(log_inv_rate)
+// tables[t]: n_columns_total x 2^log_rows[t] words, column major.  Returns proof words (orc_last_proof), 0 on failure.
+uint64_t orc_prove_execution(const uint32_t* hdr, const uint32_t* builder, const uint32_t* bytecode_hash, const uint32_t* public_input,
+                             const uint32_t* bytecode, const uint32_t* bytecode_acc, const uint32_t* memory, const uint32_t* memory_acc,
+                             const uint32_t* t_exec, const uint32_t* t_ext, const uint32_t* t_pos) {
+    try {
+        ExecutionInput in;
+        in.log_inv_rate = hdr[0];
+        in.log_memory = hdr[1];
+        in.log_bytecode = hdr[2];
+        in.ending_pc = hdr[3];
+        in.public_memory_size = hdr[4];
+        in.public_input.assign(public_input, public_input + hdr[5]);
+        std::memcpy(in.bytecode_hash, bytecode_hash, 32);
+        in.bytecode = bytecode;
+        in.bytecode_acc = bytecode_acc;
+        in.memory = memory;
+        in.memory_acc = memory_acc;
+        const uint32_t* tp[3] = {t_exec, t_ext, t_pos};
+        for (int t = 0; t < 3; t++) in.tables[t] = VmTableTrace{t, hdr[6 + t], tp[t]};
+        WhirConfigBuilder b = builder ? make_builder(builder) : default_whir_config(in.log_inv_rate);
+        ProverState ps;
+        prove_execution(ps, in, b);
+        g_last_proof = serialize_proof(ps);
+        g_verr[0] = 0;
+        return g_last_proof.size();
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+int orc_verify_execution(const uint32_t* proof_blob, const uint32_t* builder, const uint32_t* bytecode_hash, const uint32_t* public_input,
+                         uint32_t n_public_input, const uint32_t* bytecode, uint32_t log_bytecode, uint32_t ending_pc) {
+    try {
+        VerifierState vs;
+        parse_proof(proof_blob, vs);
+        std::vector<uint32_t> pi(public_input, public_input + n_public_input);
+        WhirConfigBuilder b;
+        if (builder) b = make_builder(builder);
+        verify_execution(vs, pi, bytecode_hash, bytecode, log_bytecode, ending_pc, builder ? &b : nullptr);
+        g_verr[0] = 0;
+        return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+}

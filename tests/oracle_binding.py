@@ -419,3 +419,29 @@ def logup_sections(d_memory, d_memory_acc, log_mem, d_bytecode, d_bytecode_acc, 
                                  data=[(cols[v], 1, 0), (cols[idx], 1, i)]))
                 off += 1 << lr
     return secs, off
+
+
+# ------------------------------------------------------------------------------------------------------------
+# prove_execution / verify_execution slice (oracle side)
+# ------------------------------------------------------------------------------------------------------------
+def prove_execution(orc, w, hdr, builder=None):
+    orc.lib.orc_prove_execution.restype = C.c_uint64
+    orc.lib.orc_last_error.restype = C.c_char_p
+    c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint32))  # noqa: E731
+    n = orc.lib.orc_prove_execution(c(hdr), c(builder) if builder is not None else None, c(w["bytecode_hash"]), c(w["public_input"]),
+                                    c(w["bytecode"]), c(w["bytecode_acc"]), c(w["memory"]), c(w["memory_acc"]),
+                                    c(w["tables"][0]), c(w["tables"][1]), c(w["tables"][2]))
+    if n == 0:
+        raise RuntimeError("oracle prove_execution failed: " + orc.lib.orc_last_error().decode())
+    proof = np.empty(n, dtype=np.uint32)
+    orc.lib.orc_last_proof(_p(proof))
+    return proof
+
+
+def verify_execution(orc, w, proof, builder=None, public_input=None):
+    orc.lib.orc_last_error.restype = C.c_char_p
+    c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint32))  # noqa: E731
+    pi = w["public_input"] if public_input is None else public_input
+    ok = orc.lib.orc_verify_execution(c(proof), c(builder) if builder is not None else None, c(w["bytecode_hash"]), c(pi),
+                                      C.c_uint32(pi.size), c(w["bytecode"]), C.c_uint32(w["log_bytecode"]), C.c_uint32(w["ending_pc"]))
+    return bool(ok), orc.lib.orc_last_error().decode()

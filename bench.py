@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — XMSS signatures aggregated per second on the proving hot path, 1550 signatures, WHIR rate 1/2.
 
-One "step" = one pass of the proving hot path over one batch of synthetic input of the config-2 shape
-(BASELINE.json configs[1]: `xmss --n-signatures 1550 --log-inv-rate 1`):
-    stacked polynomial 2^26 words (51*2^20 non-zero)  -> WHIR commit (LDE 2^20 x 128 + Poseidon1-16 Merkle tree)
-    logup vector of 2^25 (num, den) pairs              -> GKR sum-of-fractions proof
-    252 sparse claims on the stacked polynomial        -> WHIR open (weights, 26 sumcheck rounds, 3 folded commitments,
-                                                          PoW grinding, 370 Merkle openings), 124-bit parameters
-Inputs are resident in HBM before the timed region.  Stages not yet on the device are listed in config["missing"]:
-the metric is only the reference's whole-node number once that list is empty.
+One "step" = one `lmh_prove_execution` (the reference's prove_execution from the execution trace to the proof,
+crates/lean_prover/src/prove_execution.rs:47-274) on a consistent synthetic leanVM trace of the config-2 shape
+(BASELINE.json configs[1]: `xmss --n-signatures 1550 --log-inv-rate 1`): stack + WHIR commit (LDE 2^20 x 128, Merkle),
+logup fill + GKR over 2^24 pairs + 91 column evaluations, batched AIR sumcheck (3 tables), 252-claim WHIR open with
+124-bit parameters.  The trace is resident in HBM before the timed region; the proof verifies (--verify).
+What is NOT in the step: the VM interpreter and trace builder (CPU side of the reference's whole-node number) — listed in
+config["missing"].
 
 Multi-GPU (north_star / SURVEY.md §8(e)): independent 1550-signature leaves, one per GPU, no data-path collective; the
 only exchange is an RCCL all-gather of the 8-word commitment roots at the end of each step.  scaling = "weak".
@@ -56,72 +55,43 @@ def signer_ranges(n_total, world):
     return out
 
 
-def build_workload(ctx, orc, ob, rng, n_vars, log_inv_rate, gkr_log_n):
-    """Synthetic inputs of the config-2 shape (SURVEY.md §8 size table), uploaded once."""
+def build_workload(ctx, orc, ob, rng, scale_log=0):
+    """A consistent synthetic leanVM execution trace of the config-2 shape (SURVEY.md §8 size table), uploaded once:
+    1550 signatures x 167 Poseidon calls = 258 850 active Poseidon rows (table 2^18 x 109), execution table 2^20 x 20,
+    extension_op 2^8 x 29, memory 2^20, bytecode 2^19  ->  stacked polynomial 2^26, logup vector 2^24.
+    tests/synth_witness.py builds it (straight-line program of precompile calls + the VM's own padding rows); every AIR
+    constraint, lookup and bus relation holds, so the proof verifies (bench.py --verify)."""
     import leanmultisig_amd as lm
-    n = 1 << n_vars
-    actual = 51 << (n_vars - 6)
-    poly = rng.integers(0, P, size=n, dtype=np.uint32)
-    poly[actual:] = 0
-    d_poly = ctx.to_device(poly)
-    builder = ob.whir_builder(log_inv_rate=log_inv_rate)
+    from tests import synth_witness
+    sh = scale_log  # --scale-log k shrinks every table by 2^k (smoke / CI)
+    n_calls = (N_SIGS * 167) >> sh
+
+    def fill_rows(rows):  # Poseidon trace rows on the device (lm_poseidon_trace), columns 25.. are overwritten
+        cols = [ctx.to_device(np.ascontiguousarray(rows[:, c])) for c in range(109)]
+        ctx.poseidon_trace(cols, rows.shape[0])
+        for c in range(25, 109):
+            rows[:, c] = cols[c].download()
+
+    w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,
+                            log_ext=8, log_memory=max(20 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows)
+    tr, keep = lm.make_execution_trace(ctx, w)
+    n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
+    builder = ob.whir_builder(log_inv_rate=1)  # default_whir_config(1): 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50)
     cfgd = ob.whir_config(orc, builder, n_vars)
     cfg = lm.WhirConfig.from_dict(cfgd)
-    # 252 claims (stacked_pcs.rs:206-221: 6 + 28 + 60 + 145 + 13), as (log block size, count, #values per point)
-    groups = [(n_vars - 5, 6, 1), (n_vars - 6, 14, 2), (n_vars - 14, 60, 1), (n_vars - 8, 145, 1), (n_vars - 7, 13, 1)]
-    sts = []
-    for k, count, per in groups:
-        done = 0
-        while done < count:
-            pt = ob.rand_field(rng, (k, 5))
-            vals = []
-            used = set()
-            for _ in range(min(per, count - done)):
-                sel = int(rng.integers(0, max(1, actual >> k)))
-                while sel in used:
-                    sel = (sel + 1) % max(1, actual >> k)
-                used.add(sel)
-                vals.append((sel, ctx.mle_eval(d_poly.ptr + 4 * (sel << k), False, k, pt)[0]))
-            sts.append(dict(point=pt, is_next=False, values=vals))
-            done += len(vals)
-    # logup vector: L = 16.5M active pairs padded to 2^25 (logup.rs:495-518), natural order, (0,1) padding
-    L = 1 << gkr_log_n
-    active = int(L * 16.5 / 32)
-    nums = rng.integers(0, P, size=L, dtype=np.uint32)
-    nums[active:] = 0
-    dens = rng.integers(0, P, size=(5, L), dtype=np.uint32)  # SoA planes
-    dens[:, active:] = 0
-    dens[0, active:] = 0x01FFFFFE
-    d_nums = ctx.to_device(nums)
-    d_dens = ctx.to_device(dens)
-    # AIR tables (SURVEY.md §8 size table): execution 2^(n-6) x 20, extension_op 2^10 x 29, poseidon16 2^(n-8) x 109.
-    # The Poseidon table is a satisfiable trace (oracle trace generator, untimed setup); the other two carry random
-    # columns — same arithmetic, the sumcheck does not depend on satisfiability.
-    air_tables = []
-    for table, lr in ((0, n_vars - 6), (2, n_vars - 8), (1, 10)):
-        if table == 2:
-            cols = ob.poseidon_table(orc, rng, lr)
-        else:
-            cols = rng.integers(0, P, size=(ob.AIR_N_COLUMNS[table], 1 << lr), dtype=np.uint32)
-        bufs = [ctx.to_device(c) for c in cols]
-        air_tables.append(dict(table=table, log_rows=lr, cols=bufs, eq_point=ob.rand_field(rng, (lr, 5)),
-                               sum=ob.rand_field(rng, 5)))
-    air_ch = dict(alpha=ob.rand_field(rng, 5), eq16=ob.rand_field(rng, (16, 5)), beta=ob.rand_field(rng, 5),
-                  eta=ob.rand_field(rng, 5))
-    return dict(cfg=cfg, cfgd=cfgd, builder=builder, d_poly=d_poly, actual=actual, sts=sts, d_nums=d_nums, d_dens=d_dens,
-                gkr_log_n=gkr_log_n, n_vars=n_vars, poly_host=poly, air_tables=air_tables, air_ch=air_ch)
+    return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfgd, n_vars=n_vars, builder=builder)
 
 
 def run_step(ctx, lm, w):
     pr = lm.Prover(ctx)
-    wit = pr.whir_commit(w["cfg"], w["d_poly"], w["actual"])
-    root = np.empty(8, dtype=np.uint32)
-    ctx.lib.lmh_witness_root(wit, root.ctypes.data)
-    pr.prove_gkr_quotient(w["d_nums"], w["d_dens"], w["gkr_log_n"])
-    c = w["air_ch"]
-    pr.prove_batched_air_sumcheck(w["air_tables"], c["alpha"], c["eq16"], c["beta"], c["eta"])
-    pr.whir_prove(w["cfg"], w["sts"], wit, w["d_poly"])
-    return pr, root
+    pr.prove_execution(w["tr"], w["cfg"])
+    return pr
+
+
+def step_root(pr):
+    """commitment root = transcript words 6..14 (after the 6 dimension words, prove_execution.rs:50-63, commit.rs:87)"""
+    blob = pr.proof()
+    return blob[1 + 6:1 + 14]
 
 
 def cpu_baseline(orc, ob, log_scale=6):
@@ -151,7 +121,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--n-vars", type=int, default=26)
+    ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
+    ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
     args = ap.parse_args()
 
@@ -172,12 +143,11 @@ def main():
     orc = ob.load()  # only for WhirConfig integers (f64 derivation stays on the caller side) and the cpu_baseline leg
     ctx = lm.Context(local_rank)
     rng = np.random.default_rng(1000 + rank)
-    gkr_log_n = args.n_vars - 1
-    w = build_workload(ctx, orc, ob, rng, args.n_vars, 1, gkr_log_n)
+    w = build_workload(ctx, orc, ob, rng, args.scale_log)
 
     for _ in range(args.warmup):
         run_step(ctx, lm, w)
-    dominant = "k_leaf_sponge"
+    dominant = "k_air_round"
     ctx.profile_select(dominant)
     ctx.sync()
     torch.cuda.synchronize()
@@ -185,9 +155,10 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     roots = None
+    pr = None
     for _ in range(args.steps):
-        pr, root = run_step(ctx, lm, w)
-        roots = exchange_roots(root, device)
+        pr = run_step(ctx, lm, w)
+        roots = exchange_roots(step_root(pr), device)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -204,39 +175,54 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = N_SIGS * world / (dt / args.steps)
-        # dominant kernel: leaf sponge.  Algorithmic bytes per step: read every stored LDE word
-        # once, write one 32-byte digest per row, for the 4 trees of a proof.
-        cfgd = w["cfgd"]
-        trees = [(args.n_vars + 1 - 7, 102)]  # base tree: 2^20 rows x 102 stored columns
-        lir = 1
-        nv = args.n_vars - 7
-        for r in range(cfgd["n_rounds"]):
-            lir = lir + (7 if r == 0 else 5) - (5 if r == 0 else 1)
-            trees.append((nv + lir - 5, 160))
-            nv -= 5
-        alg_bytes = sum((1 << lh) * (4 * cols + 32) for lh, cols in trees)
+        # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
+        # Algorithmic bytes per step: every column value of every sumcheck round is read once:
+        # round 0 on base words (4 B), round r >= 1 on EF (20 B) over 2^(log_rows - r) rows, (n_columns + n_shift) columns.
+        alg_bytes = 0
+        for t, ncols in ((0, 22), (1, 42), (2, 109)):
+            lr = w["w"]["log_rows"][t]
+            alg_bytes += ncols * 4 * (1 << lr)
+            for r in range(1, lr):
+                alg_bytes += ncols * 20 * (1 << (lr - r))
         achieved = alg_bytes * args.steps / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_commit_fetch_write.json")
+        leaf = None
+        if os.path.exists(pmc_path):
+            j = json.load(open(pmc_path))["k_leaf_sponge_base_tree"]
+            leaf = {"kernel": "k_leaf_sponge (base tree, 2^20 rows x 102 columns)", "bound": "hbm",
+                    "algorithmic_bytes": j["algorithmic_bytes_per_launch"], "traffic": j["hbm_bytes_per_launch"],
+                    "source": "profiles/r01_pmc_commit_fetch_write.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         out = {
             "metric": "xmss_sigs_aggregated_per_sec", "value": value, "unit": "xmss_sigs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
             "data": "synthetic",
             "config": {
-                "workload": "xmss --n-signatures 1550 --log-inv-rate 1 (BASELINE configs[1]) — proving hot path on "
-                            "synthetic trace shapes: stacked 2^26, LDE 2^20x128, logup 2^25, 252 claims, 124-bit WHIR",
-                "stages": ["whir_commit(lde+merkle+ood)", "logup_gkr", "batched_air_sumcheck(execution 2^20, poseidon16 2^18, extension_op 2^10)",
-                           "whir_open(weights+sumcheck+pow+queries)"],
-                "missing": ["logup numerator/denominator build + 91 column evaluations", "witness generation (CPU VM)"],
+                "workload": "xmss --n-signatures 1550 --log-inv-rate 1 (BASELINE configs[1]): prove_execution from the "
+                            "execution trace to the proof on a consistent synthetic leanVM trace — 258850 Poseidon rows, "
+                            "tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
+                            + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
+                "stages": ["fiat_shamir_preamble", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
+                           "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)"],
+                "missing": ["witness generation: VM interpreter + trace builder (CPU, SURVEY §8(f) rank 1/4) — the reference's "
+                            "whole-node number includes it"],
                 "per_gpu_signatures": N_SIGS,
             },
             "roofline": {
                 "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
-                "note": "Poseidon1-16 sponge is int-ALU bound (~1.6k modmul per 32 B hashed); HBM fraction is small by "
-                        "construction — see DESIGN.md",
+                "note": "constraint evaluation is int-ALU bound (one Poseidon-AIR evaluation ~ 4k-25k modmul per row pair and "
+                        "point); HBM fraction is small by construction — see DESIGN.md §3",
+                "secondary": leaf,
             },
         }
+        if args.verify:
+            ok, err = ob.verify_execution(orc, w["w"], pr.proof(), None)
+            out["config"]["proof_verified_by_oracle"] = bool(ok)
+            if not ok:
+                print("VERIFY FAILED:", err, file=sys.stderr)
+        out["config"]["proof_KiB"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)  # un-pruned hints (benchmark.rs:447 formula)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(orc, ob)
         print(json.dumps(out), flush=True)
@@ -248,6 +234,7 @@ def main():
                      "k_prod_round_base", "k_prod_round_ext", "k_sum10", "k_fold_base", "k_fold_ext", "k_pow_grind",
                      "k_mle_partial_base", "k_mle_partial_ext", "k_eq_table_small", "k_sum_partials", "k_tree_open",
                      "k_gkr_layer_up", "k_prefix_eq_tables", "k_gkr_round_storage", "k_gkr_fold_round", "k_gkr_reduce",
+                     "k_logup_fill", "k_logup_neutral", "k_mle_partial_cols",
                      "k_air_round", "k_air_reduce", "k_air_fold_base", "k_air_fold_ext"]
             for k in names:
                 cnt, ms = ctx.profile_read(k)

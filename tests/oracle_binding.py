@@ -38,6 +38,14 @@ class Oracle:
         x = np.asarray(x, dtype=np.uint32)
         return np.array([self.lib.orc_from_monty(int(v)) for v in x.reshape(-1)], dtype=np.uint32).reshape(x.shape)
 
+    def from_monty_fast(self, x):
+        """vectorised from_monty: x * R^-1 mod p"""
+        rinv = pow(1 << 32, P - 2, P)
+        x = np.asarray(x, dtype=np.uint64)
+        # (x * rinv) may exceed 64 bits: split rinv
+        hi, lo = rinv >> 16, rinv & 0xFFFF
+        return (((x * np.uint64(hi)) % np.uint64(P) * np.uint64(1 << 16) + x * np.uint64(lo)) % np.uint64(P)).astype(np.uint32)
+
     def mul(self, a, b):
         return self.lib.orc_mul(int(a), int(b))
 

@@ -19,7 +19,8 @@ from tests.oracle_binding import P
 ONE = 0x01FFFFFE
 
 
-def build(orc, rng, n_calls, n_blocks=8, log_exec=8, log_pos=8, log_ext=8, log_memory=16, log_bytecode=8):
+def build(orc, rng, n_calls, n_blocks=8, log_exec=8, log_pos=8, log_ext=8, log_memory=16, log_bytecode=8, fill_rows=None):
+    """fill_rows(rows) may replace the oracle's Poseidon trace generator for big tables (rows: (n, 109) uint32, in place)."""
     M = lambda x: orc.to_monty(np.asarray(x, dtype=np.uint64))  # noqa: E731
     n_exec, n_pos, n_ext = 1 << log_exec, 1 << log_pos, 1 << log_ext
     assert n_calls < n_exec and n_calls <= n_pos and n_calls < (1 << log_bytecode)
@@ -33,49 +34,48 @@ def build(orc, rng, n_calls, n_blocks=8, log_exec=8, log_pos=8, log_ext=8, log_m
     NULL = 96         # null hash: compress(0^16)[0..8] followed by 8 zeros
     memory[NULL:NULL + 8] = orc.poseidon16_compress(np.zeros(16, dtype=np.uint32))[0][:8]
     base = 128
-    blocks = []
-    for b in range(n_blocks):
-        a0 = base + 32 * b
-        inp = ob.rand_field(rng, 16)
-        memory[a0:a0 + 16] = inp
-        out = orc.poseidon16_compress(inp)[0][:8]
-        memory[a0 + 16:a0 + 24] = out      # res: outputs_left; res+8..16 stay 0 (outputs_right = 0 in compress mode)
-        blocks.append((a0, a0 + 8, a0 + 16))
+    assert base + 32 * n_blocks <= mem_len
+    inputs = ob.rand_field(rng, (n_blocks, 16))
+    outs = orc.poseidon16_compress(inputs)[:, :8]
+    blk = memory[base:base + 32 * n_blocks].reshape(n_blocks, 32)
+    blk[:, :16] = inputs
+    blk[:, 16:24] = outs     # res: outputs_left; res+8..16 stay 0 (outputs_right = 0 in compress mode)
+    call_blk = np.arange(n_calls) % n_blocks
+    addr_a = base + 32 * call_blk
+    addr_b, addr_r = addr_a + 8, addr_a + 16
     ending_pc = n_calls
     # ---- bytecode (row-major, stride 16; columns = the 12 instruction columns of the execution table) ----------
+    # operand_a, operand_b, operand_c, flag_a, flag_b, flag_c, flag_c_fp, flag_ab_fp, mul, jump, aux, precompile_data
     bytecode = np.zeros((1 << log_bytecode, 16), dtype=np.uint32)
-    calls = [blocks[i % n_blocks] for i in range(n_calls)]
-    for pc, (a, b, r) in enumerate(calls):
-        # operand_a, operand_b, operand_c, flag_a, flag_b, flag_c, flag_c_fp, flag_ab_fp, mul, jump, aux, precompile_data
-        bytecode[pc, :12] = [int(M(a)), int(M(b)), int(M(r)), ONE, ONE, ONE, 0, 0, 0, 0, 0, ONE]
+    bytecode[:n_calls, 0], bytecode[:n_calls, 1], bytecode[:n_calls, 2] = M(addr_a), M(addr_b), M(addr_r)
+    bytecode[:n_calls, 3:6] = ONE
+    bytecode[:n_calls, 11] = ONE
     bytecode[ending_pc, :12] = [ONE, int(M(ending_pc)), 0, ONE, ONE, 0, ONE, 0, 0, ONE, 0, 0]
     # ---- execution table (24 columns: 20 committed + is_precompile, nu_a, nu_b, nu_c) -----------------------------
     ex = np.zeros((24, n_exec), dtype=np.uint32)
-    for row in range(n_exec):
-        pc = min(row, ending_pc)
-        ex[0, row] = int(M(pc))
-        ex[8:20, row] = bytecode[pc, :12]
-        ex[2:5, row] = int(M(Z))                 # addr_a/b/c -> zero vector, values 0
-        if pc < n_calls:
-            a, b, r = calls[pc]
-            ex[20, row] = ONE                     # is_precompile
-            ex[21, row], ex[22, row], ex[23, row] = int(M(a)), int(M(b)), int(M(r))
-        else:
-            ex[21, row] = ONE                     # nu_a = 1 (jump condition)
-            ex[22, row] = int(M(ending_pc))       # nu_b = jump destination
+    pcs = np.minimum(np.arange(n_exec), ending_pc)
+    ex[0] = M(pcs)
+    ex[8:20] = bytecode[pcs, :12].T
+    ex[2:5] = int(M(Z))                       # addr_a/b/c -> zero vector, values 0
+    ex[20, :n_calls] = ONE                    # is_precompile
+    ex[21, :n_calls], ex[22, :n_calls], ex[23, :n_calls] = M(addr_a), M(addr_b), M(addr_r)
+    ex[21, n_calls:] = ONE                    # nu_a = 1 (jump condition)
+    ex[22, n_calls:] = int(M(ending_pc))      # nu_b = jump destination
     # ---- poseidon table (111 columns: 109 committed + index_input_left, precompile_data) -------------------------
     rows = np.zeros((n_pos, 109), dtype=np.uint32)
-    left = np.array([c[0] for c in calls] + [Z] * (n_pos - n_calls))
+    left = np.concatenate([addr_a, np.full(n_pos - n_calls, Z)])
     rows[:, 6] = M(left)
     rows[:, 7] = M(left + 4)
     rows[:n_calls, 0] = ONE
-    rows[:, 1] = M([c[1] for c in calls] + [Z] * (n_pos - n_calls))
-    rows[:, 2] = M([c[2] for c in calls] + [NULL] * (n_pos - n_calls))
-    for i, (a, b, r) in enumerate(calls):
-        rows[i, 9:25] = memory[a:a + 16]
+    rows[:, 1] = M(np.concatenate([addr_b, np.full(n_pos - n_calls, Z)]))
+    rows[:, 2] = M(np.concatenate([addr_r, np.full(n_pos - n_calls, NULL)]))
+    rows[:n_calls, 9:25] = inputs[call_blk]
     rows = np.ascontiguousarray(rows)
-    import ctypes
-    orc.lib.orc_poseidon16_fill_rows(rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n_pos))
+    if fill_rows is None:
+        import ctypes
+        orc.lib.orc_poseidon16_fill_rows(rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n_pos))
+    else:
+        fill_rows(rows)
     pos = np.zeros((111, n_pos), dtype=np.uint32)
     pos[:109] = rows.T
     pos[109] = M(left)
@@ -89,14 +89,13 @@ def build(orc, rng, n_calls, n_blocks=8, log_exec=8, log_pos=8, log_ext=8, log_m
     # ---- access counters (prove_execution.rs:91-110) -----------------------------------------------------------------
     tables = {0: ex, 1: ext, 2: pos}
     memory_acc = np.zeros(mem_len, dtype=np.int64)
-    canon = lambda col: orc.from_monty(col).astype(np.int64)  # noqa: E731
+    canon = lambda col: orc.from_monty_fast(col).astype(np.int64)  # noqa: E731
     for t, cols in tables.items():
         for idx, vals in ob.VM_LOOKUPS[t]:
             addr = canon(cols[idx])
             for j in range(len(vals)):
-                np.add.at(memory_acc, addr + j, 1)
-    bytecode_acc = np.zeros(1 << log_bytecode, dtype=np.int64)
-    np.add.at(bytecode_acc, canon(ex[0]), 1)
+                memory_acc += np.bincount(addr + j, minlength=mem_len)
+    bytecode_acc = np.bincount(canon(ex[0]), minlength=1 << log_bytecode).astype(np.int64)
     return dict(log_inv_rate=1, log_memory=log_memory, log_bytecode=log_bytecode, ending_pc=ending_pc, public_memory_size=n_pub,
                 public_input=public_input, bytecode_hash=ob.rand_field(rng, 8), bytecode=np.ascontiguousarray(bytecode),
                 bytecode_acc=M(bytecode_acc), memory=memory, memory_acc=M(memory_acc), tables=tables,

@@ -55,6 +55,38 @@ KB_HD EF a_from_base(u32 c, const EF&) { return kb::ef_from_base(c); }
 // small canonical integers in Montgomery form, folded at compile time by the optimiser
 KB_HD u32 mc(u32 canon) { return kb::to_monty(canon); }
 
+// keeps the scheduler from hoisting every plane's column loads above the first plane's arithmetic (register pressure)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AIR_SCHED_FENCE() ((void)0)
+#else
+#define AIR_SCHED_FENCE() ((void)0)
+#endif
+
+// plane access: an EF value is 5 base-field planes, a base value is 1
+template <class T>
+struct Planes;
+template <>
+struct Planes<u32> {
+    static constexpr int N = 1;
+    static KB_HD u32& at(u32& v, int) { return v; }
+};
+template <>
+struct Planes<EF> {
+    static constexpr int N = 5;
+    static KB_HD u32& at(EF& v, int k) { return v.v[k]; }
+};
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+template <int I, int N, class F>
+KB_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <class T>
 struct Folder {
     const Extra& x;
@@ -225,102 +257,145 @@ KB_HD T cube(const T& a) {
 
 // Column access is lazy: `col(c)` returns the value of column c at this evaluation point, so that only the 16-word state
 // and the current block of columns are live (109 columns x 5 words would not fit the register file).
-template <class T, class ColFn>
-KB_HD EF eval_poseidon16(ColFn col, const Extra& x) {
-    const kb::PoseidonConsts& K = kb::poseidon_consts();
-    const T flag_active = col(0), index_b = col(1), index_res = col(2), flag_half = col(3), flag_left = col(4);
-    const T offset_left = col(5), eff_first = col(6), eff_second = col(7), flag_permute = col(8);
-    const T one = a_from_base(kb::ONE, flag_active);
-    // precompile data: 1 + 4 half + 8 left + 16 left*offset + 2 permute (poseidon_16/mod.rs:94-98,336-343)
-    const T pdr = a_add(a_add(a_add(a_add(one, a_mulc(flag_half, mc(4))), a_mulc(flag_left, mc(8))),
-                              a_mulc(a_mul(flag_left, offset_left), mc(16))),
-                        a_mulc(flag_permute, mc(2)));
-    const T omfl = a_sub(one, flag_left);
-    const T index_a = a_sub(eff_second, a_mulc(omfl, mc(4)));
-    Folder<T> f(x);
-    f.assert_zero_ef(bus_column<T>(x, flag_active, pdr, index_a, index_b, index_res));
-    f.assert_zero(bool_check(flag_active));
-    f.assert_zero(bool_check(flag_half));
-    f.assert_zero(bool_check(flag_left));
-    f.assert_zero(bool_check(flag_permute));
-    f.assert_zero(a_mul(flag_permute, a_add(flag_half, flag_left)));
-    f.assert_zero(a_mul(flag_left, a_sub(offset_left, eff_first)));
-    f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
+//
+// The AIR re-bases its state on committed columns after every pair of full rounds, so it splits into four independent
+// SEGMENTS, each starting from columns only; a (row pair, evaluation point) is evaluated by 5 lanes, one per segment, and
+// the alpha-weighted partial sums are added afterwards (the constraint sum is linear in the segments):
+//   segment 0: bus + 7 flag constraints (alpha^0..7), inputs -> beginning_full_rounds[0]        (alpha^8..23)
+//   segment 1: beginning_full_rounds[0] -> beginning_full_rounds[1]                               (alpha^24..39)
+//   segment 2: the 20 partial-round constraints through the affine forms y_r                       (alpha^40..59)
+//   segment 3: affine exit state of the partial block -> ending_full_rounds[0]                     (alpha^60..75)
+//   segment 4: ending_full_rounds[0] -> gated outputs                                              (alpha^76..99)
+// This cuts the dependent-instruction chain of one evaluation ~5x (the late, small sumcheck rounds are latency bound).
+static constexpr int POSEIDON_SEGMENTS = 5;
 
+// Affine forms of the partial block (gen_poseidon_consts.py::linearise): lanes 1..15 see no S-box inside the block and lane 0
+// is re-based on the committed partial_rounds[r] column every round, so over u = (t_0..t_15, q_0..q_19, 1) with
+// t = beginning_full_rounds[1] columns and q = partial_rounds columns, the value cubed in round r and the state leaving the
+// block are affine.  Same constraint polynomials as the round-by-round substitution of poseidon_16/mod.rs:430-470, but every
+// constraint becomes one dot product with delayed reduction and the 20 rounds no longer form a dependent chain.
+// The tables are constexpr so that, with every index a compile-time constant, each coefficient becomes an instruction
+// literal (s_mov) next to its use.  As a __constant__ table the ~1500 scalar loads are hoisted to the top of the kernel and
+// spilled to VGPR lanes (thousands of v_readlane).
+struct PoseidonLinear {
+    u32 y[20][37];    // y_r = y[r][0..16+r) . u + y[r][36]
+    u32 fin[16][37];  // state entering ending_full_rounds
+};
+static constexpr PoseidonLinear kPoseidonLinear =
+#include "poseidon16_linear.inc"
+    ;
+
+// (static_for, not "#pragma unroll": the pragma gives up on the EF body size, and a rolled loop indexes s[] dynamically,
+// which sends the whole state to scratch)
+template <class T>
+KB_HD void two_full_rounds(T s[16], const u32 rc0[16], const u32 rc1[16]) {
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        s[i] = cube(a_addc(s[i], rc0[i]));
+    });
+    mds16(s);
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        s[i] = cube(a_addc(s[i], rc1[i]));
+    });
+    mds16(s);
+}
+
+// col(c) = column c at the evaluation point; colp(c, k) = its plane k only
+template <class T, int SEG, class ColFn, class ColPlaneFn>
+KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
+    const kb::PoseidonConsts& K = kb::poseidon_consts();
+    Folder<T> f(x);
     T s[16];
+    if constexpr (SEG == 0) {
+        const T flag_active = col(0), index_b = col(1), index_res = col(2), flag_half = col(3), flag_left = col(4);
+        const T offset_left = col(5), eff_first = col(6), eff_second = col(7), flag_permute = col(8);
+        const T one = a_from_base(kb::ONE, flag_active);
+        // precompile data: 1 + 4 half + 8 left + 16 left*offset + 2 permute (poseidon_16/mod.rs:94-98,336-343)
+        const T pdr = a_add(a_add(a_add(a_add(one, a_mulc(flag_half, mc(4))), a_mulc(flag_left, mc(8))),
+                                  a_mulc(a_mul(flag_left, offset_left), mc(16))),
+                            a_mulc(flag_permute, mc(2)));
+        const T omfl = a_sub(one, flag_left);
+        const T index_a = a_sub(eff_second, a_mulc(omfl, mc(4)));
+        f.assert_zero_ef(bus_column<T>(x, flag_active, pdr, index_a, index_b, index_res));
+        f.assert_zero(bool_check(flag_active));
+        f.assert_zero(bool_check(flag_half));
+        f.assert_zero(bool_check(flag_left));
+        f.assert_zero(bool_check(flag_permute));
+        f.assert_zero(a_mul(flag_permute, a_add(flag_half, flag_left)));
+        f.assert_zero(a_mul(flag_left, a_sub(offset_left, eff_first)));
+        f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = col(9 + i);
-    // two blocks of 2 full rounds, each re-based on the committed post-state (eval_2_full_rounds_16)
-#pragma unroll 1
-    for (int blk = 0; blk < 2; blk++) {
-#pragma unroll 1
-        for (int h = 0; h < 2; h++) {
+        for (int i = 0; i < 16; i++) s[i] = col(9 + i);
+        two_full_rounds<T>(s, K.rc_init[0], K.rc_init[1]);
 #pragma unroll
-            for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_init[2 * blk + h][i]));
-            mds16(s);
-        }
+        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(25 + i)));
+    } else if constexpr (SEG == 1) {
+        f.k = 24;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const T post = col(25 + 16 * blk + i);
-            f.assert_zero(a_sub(s[i], post));
-            s[i] = post;
-        }
-    }
-    // partial block: s <- D (s + first_rc) = D s + dbias, then 20 sparse rounds with lane 0 re-based on partial_rounds[r]
-    {
-        T t[16];
+        for (int i = 0; i < 16; i++) s[i] = col(25 + i);
+        two_full_rounds<T>(s, K.rc_init[2], K.rc_init[3]);
 #pragma unroll
-        for (int i = 0; i < 16; i++) t[i] = s[i];
-#pragma unroll 1
-        for (int i = 0; i < 16; i++) {
-            T acc = a_from_base(K.dbias[i], one);
+        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(41 + i)));
+    } else if constexpr (SEG == 2) {
+        f.k = 40;
+        T y[20];
+        static_for<0, Planes<T>::N>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            u32 u[35];
 #pragma unroll
-            for (int j = 0; j < 16; j++) acc = a_add(acc, a_mulc(t[j], K.dmat[i][j]));
-            s[i] = acc;
-        }
-    }
-#pragma unroll 1
-    for (int r = 0; r < 20; r++) {
-        const T pr = col(57 + r);
-        f.assert_zero(a_sub(cube(s[0]), pr));  // assert_eq_low(state[0]^3, partial_rounds[r])
-        T s0 = pr;
-        if (r < 19) s0 = a_addc(s0, K.pscalar[r]);
-        T n0 = a_mulc(s0, K.prow[r][0]);
+            for (int j = 0; j < 35; j++) u[j] = colp(41 + j, k);  // t_0..t_15, q_0..q_18
+            static_for<0, 20>([&](auto RR) {
+                constexpr int r = decltype(RR)::value;
+                u32 v = kb::dot_n<16 + r>(u, kPoseidonLinear.y[r]);
+                if (k == 0) v = kb::add(v, kPoseidonLinear.y[r][36]);
+                Planes<T>::at(y[r], k) = v;
+            });
+            AIR_SCHED_FENCE();
+        });
+        static_for<0, 20>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            f.assert_zero(a_sub(cube(y[r]), col(57 + r)));  // assert_eq_low(state[0]^3, partial_rounds[r])
+        });
+    } else if constexpr (SEG == 3) {
+        f.k = 60;
+        static_for<0, Planes<T>::N>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            u32 u[36];
 #pragma unroll
-        for (int j = 1; j < 16; j++) n0 = a_add(n0, a_mulc(s[j], K.prow[r][j]));
+            for (int j = 0; j < 36; j++) u[j] = colp(41 + j, k);  // t_0..t_15, q_0..q_19
+            static_for<0, 16>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                u32 v = kb::dot_n<36>(u, kPoseidonLinear.fin[i]);
+                if (k == 0) v = kb::add(v, kPoseidonLinear.fin[i][36]);
+                Planes<T>::at(s[i], k) = v;
+            });
+            AIR_SCHED_FENCE();
+        });
+        two_full_rounds<T>(s, K.rc_term[0], K.rc_term[1]);
 #pragma unroll
-        for (int i = 1; i < 16; i++) s[i] = a_add(s[i], a_mulc(s0, K.pcol[r][i - 1]));
-        s[0] = n0;
-    }
-    // first two terminal full rounds, re-based on ending_full_rounds[0]
-#pragma unroll 1
-    for (int h = 0; h < 2; h++) {
+        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(77 + i)));
+    } else {
+        f.k = 76;
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_term[h][i]));
-        mds16(s);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const T post = col(77 + i);
-        f.assert_zero(a_sub(s[i], post));
-        s[i] = post;
-    }
-    // last two full rounds and the gated outputs (eval_last_2_full_rounds_16)
-#pragma unroll 1
-    for (int h = 2; h < 4; h++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(a_addc(s[i], K.rc_term[h][i]));
-        mds16(s);
-    }
-    const T not_permute = a_sub(one, flag_permute);
-    const T comp_last4 = a_sub(not_permute, flag_half);
-#pragma unroll 1
-    for (int i = 0; i < 8; i++) {
-        const T gate = i < 4 ? not_permute : comp_last4;
-        const T ol = col(93 + i);
-        f.assert_zero(a_mul(gate, a_sub(a_add(s[i], col(9 + i)), ol)));
-        f.assert_zero(a_mul(flag_permute, a_sub(s[i], ol)));
-        f.assert_zero(a_mul(flag_permute, a_sub(s[i + 8], col(101 + i))));
+        for (int i = 0; i < 16; i++) s[i] = col(77 + i);
+        two_full_rounds<T>(s, K.rc_term[2], K.rc_term[3]);
+        const T flag_half = col(3), flag_permute = col(8);
+        const T one = a_from_base(kb::ONE, flag_half);
+        const T not_permute = a_sub(one, flag_permute);
+        const T comp_last4 = a_sub(not_permute, flag_half);
+        // unrolled by hand: the pragma gives up on this body size, and a rolled loop would index s[] dynamically, which
+        // pushes the whole state to scratch
+        auto out_row = [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const T gate = i < 4 ? not_permute : comp_last4;
+            const T ol = col(93 + i);
+            f.assert_zero(a_mul(gate, a_sub(a_add(s[i], col(9 + i)), ol)));
+            f.assert_zero(a_mul(flag_permute, a_sub(s[i], ol)));
+            f.assert_zero(a_mul(flag_permute, a_sub(s[i + 8], col(101 + i))));
+        };
+        out_row(IntC<0>{}), out_row(IntC<1>{}), out_row(IntC<2>{}), out_row(IntC<3>{});
+        out_row(IntC<4>{}), out_row(IntC<5>{}), out_row(IntC<6>{}), out_row(IntC<7>{});
     }
     return f.acc;
 }

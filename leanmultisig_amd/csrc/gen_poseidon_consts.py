@@ -138,6 +138,62 @@ def sparse_eval(state, rc, M, T):
     return s
 
 
+def linearise(T):
+    """Affine forms of the partial block over u = (t_0..t_15, q_0..q_19, 1): t = state entering the block (the AIR's
+    beginning_full_rounds[1] columns), q_r = committed post-S-box lane-0 value of partial round r (partial_rounds[r]).
+    Lanes 1..15 never see an S-box inside the block and lane 0 is re-based on q_r each round, so the value cubed in
+    round r (y_r) and the state leaving the block (fin) are affine in u.  Returns (Y[20][37], F[16][37])."""
+    NU = W + RP + 1
+
+    def unit(j):
+        v = [0] * NU
+        v[j] = 1
+        return v
+
+    def axpy(a, x, y):  # a*x + y
+        return [(a * xi + yi) % P for xi, yi in zip(x, y)]
+
+    s = []
+    for i in range(W):
+        v = [0] * NU
+        for j in range(W):
+            v[j] = T["D"][i][j]
+        v[NU - 1] = T["Dbias"][i]
+        s.append(v)
+    Y = []
+    for r in range(RP):
+        Y.append(s[0][:])
+        s0 = unit(W + r)
+        if r < RP - 1:
+            s0[NU - 1] = T["scalar"][r]
+        n0 = [T["rows"][r][0] * x % P for x in s0]
+        for j in range(1, W):
+            n0 = axpy(T["rows"][r][j], s[j], n0)
+        for i in range(1, W):
+            s[i] = axpy(T["cols"][r][i - 1], s0, s[i])
+        s[0] = n0
+    for r in range(RP):
+        assert all(Y[r][W + k] == 0 for k in range(r, RP)), "y_r must only depend on q_0..q_{r-1}"
+    return Y, s
+
+
+def linear_eval(state, rc, M, T, Y, F):
+    """Full permutation through the affine forms: q_r = y_r^3 (honest trace), cross-check against the textbook."""
+    s = state[:]
+    for r in range(RF_HALF):
+        s = [pow((x + c) % P, 3, P) for x, c in zip(s, rc[r])]
+        s = mat_vec(M, s)
+    u = s + [0] * RP + [1]
+    for r in range(RP):
+        y = sum(a * b for a, b in zip(Y[r], u)) % P
+        u[W + r] = pow(y, 3, P)
+    s = [sum(a * b for a, b in zip(row, u)) % P for row in F]
+    for r in range(RF_HALF + RP, 2 * RF_HALF + RP):
+        s = [pow((x + c) % P, 3, P) for x, c in zip(s, rc[r])]
+        s = mat_vec(M, s)
+    return s
+
+
 def monty(x):
     return (x % P) * R % P
 
@@ -159,6 +215,16 @@ def main():
     for _ in range(20):
         st = [rng.randrange(P) for _ in range(16)]
         assert textbook(st, rc, M) == sparse_eval(st, rc, M, T)
+    Y, F = linearise(T)
+    assert linear_eval(kat_in, rc, M, T, Y, F) == kat_out, "linearised partial block does not reproduce the KAT"
+    for _ in range(5):
+        st = [rng.randrange(P) for _ in range(16)]
+        assert textbook(st, rc, M) == linear_eval(st, rc, M, T, Y, F)
+    lin = ["// GENERATED by gen_poseidon_consts.py — do not edit.  Montgomery form.  Affine forms of the 20 partial rounds over",
+           "// u = (t_0..t_15, q_0..q_19, 1); layout must match struct PoseidonLinear in air_tables.h", "{",
+           "  /* y[20][37] */ { " + ",\n    ".join(fmt(row) for row in Y) + " },",
+           "  /* fin[16][37] */ { " + ",\n    ".join(fmt(row) for row in F) + " },", "}"]
+    open(os.path.join(HERE, "poseidon16_linear.inc"), "w").write("\n".join(lin) + "\n")
     out = []
     out.append("// GENERATED by gen_poseidon_consts.py — do not edit.  All values Montgomery form (R = 2^32).")
     out.append("// layout must match struct PoseidonConsts in poseidon16.h")

@@ -140,14 +140,36 @@ KB_HD EF ef_add_base(const EF& a, u32 b) {
     return r;
 }
 
-// 5-term dot product with delayed reduction: 4 products (< 4p^2 < 2^64) then fold, then the 5th.
+// Delayed reduction.  Products of reduced values are < p^2 < 2^62, so four of them fit a u64.  fold32 brings any u64 back
+// below 2^57 + 2^32 without changing it mod p (2^32 = ONE mod p, a 25-bit constant): one v_mad_u64_u32 instead of the
+// compare/subtract/select of a conditional subtraction.  After a fold there is room for three more products (< 2^64), or
+// for one more product before `reduce` (which needs < 2^32 p).
+KB_HD u64 fold32(u64 x) { return (u64)(u32)(x >> 32) * ONE + (u32)x; }
+
+// sum_i a[i*SA] * b[i*SB] mod p (Montgomery product form), N >= 1, inputs in [0,p)
+template <int N, int SA = 1, int SB = 1>
+KB_HD u32 dot_n(const u32* a, const u32* b) {
+    u64 x = 0;
+    int room = 4;  // products that may still be added to x without overflow
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (room == 0) {
+            x = fold32(x);
+            room = 3;
+        }
+        x += (u64)a[i * SA] * b[i * SB];
+        room--;
+    }
+    // x < 2^32 p holds after at most 1 product on a folded value or 2 products from zero
+    const bool small = N <= 2 || (N > 4 && (N - 4) % 3 == 1);
+    if (!small) x = fold32(x);
+    return reduce(x);
+}
+
+// 5-term dot product: 4 products (< 4p^2 < 2^64), fold, the 5th, reduce.
 KB_HD u32 dot5(const u32* a, u32 b0, u32 b1, u32 b2, u32 b3, u32 b4) {
     u64 x = (u64)a[0] * b0 + (u64)a[1] * b1 + (u64)a[2] * b2 + (u64)a[3] * b3;
-    u64 y = x - P_SHL32;
-    x = x >= P_SHL32 ? y : x;  // < 2^32 p <= 2^63 - ...
-    x += (u64)a[4] * b4;       // < 2^32 p + p^2 < 2^64
-    y = x - P_SHL32;
-    x = x >= P_SHL32 ? y : x;
+    x = fold32(x) + (u64)a[4] * b4;  // < 2^57 + 2^32 + p^2 < 2^32 p
     return reduce(x);
 }
 // Product as 5 dot products of length 5: rows of the multiplication-by-b matrix in the basis above.

@@ -44,6 +44,7 @@ struct BaseCols {
         const u64 i1 = 2 * j + 1, i2 = (2 * j + 2 < n_rows) ? 2 * j + 2 : n_rows - 1;
         return lerp(p[i1], p[i2], zm);
     }
+    __device__ __forceinline__ u32 at_plane(u32 c, u64 j, u32 zm, int) const { return at(c, j, zm); }
 };
 struct ExtCols {
     const u32* buf;  // column c plane k at buf + (c * 5 + k) * n_rows
@@ -58,13 +59,28 @@ struct ExtCols {
         }
         return lerp(lo, hi, zm);
     }
+    __device__ __forceinline__ u32 at_plane(u32 c, u64 j, u32 zm, int k) const {
+        uint2 v = *reinterpret_cast<const uint2*>(buf + ((u64)c * 5 + k) * n_rows + 2 * j);
+        return lerp(v.x, v.y, zm);
+    }
 };
 
-template <int TABLE, class T, class Cols>
-__device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, const air::Extra& x) {
+static constexpr u64 AIR_SPLIT_LAUNCH_PAIRS = 1ull << 13;
+
+template <int TABLE, class T, class Cols, int SEG>
+__device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
     if constexpr (TABLE == air::T_POSEIDON16) {
-        return air::eval_poseidon16<T>([&](int c) { return cols.at((u32)c, j, zm); }, x);
+        auto col = [&](int c) { return cols.at((u32)c, j, zm); };
+        auto colp = [&](int c, int k) { return cols.at_plane((u32)c, j, zm, k); };
+        if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, colp, x);
+        // segment is uniform per workgroup (blockIdx.y), so this switch does not diverge
+        if (seg == 0) return air::eval_poseidon16_segment<T, 0>(col, colp, x);
+        if (seg == 1) return air::eval_poseidon16_segment<T, 1>(col, colp, x);
+        if (seg == 2) return air::eval_poseidon16_segment<T, 2>(col, colp, x);
+        if (seg == 3) return air::eval_poseidon16_segment<T, 3>(col, colp, x);
+        return air::eval_poseidon16_segment<T, 4>(col, colp, x);
     } else {
+        (void)seg;
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
         T flat[NF], shift[NS];
 #pragma unroll
@@ -78,17 +94,20 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, const 
     }
 }
 
-// grid (blocks_x, n_z); partial[(zi * blocks_x + bx) * 5 + k]
-template <int TABLE, class T, class Cols>
+// grid (blocks_x, n_z * n_seg); partial[((zi * n_seg + seg) * blocks_x + bx) * 5 + k].
+// SEG < 0: all segments in one launch, blockIdx.y = zi * n_seg + seg (small rounds: one launch, 4x shorter chains);
+// SEG >= 0: one launch per segment with blockIdx.y = zi (large rounds: each segment gets its own register budget).
+template <int TABLE, class T, class Cols, int SEG>
 __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32* __restrict__ final_out) {
     __shared__ u32 lds[20];
-    const u32 zi = blockIdx.y;
+    constexpr u32 N_SEG = TABLE == air::T_POSEIDON16 ? air::POSEIDON_SEGMENTS : 1;
+    const u32 zi = SEG >= 0 ? blockIdx.y : blockIdx.y / N_SEG, seg = SEG >= 0 ? (u32)SEG : blockIdx.y % N_SEG;
     const u32 z = zi == 0 ? 0 : zi + 1;  // 0, 2, 3, ..., degree
     const u32 zm = to_monty(z);
     EF acc = ef_zero();
     for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
-        const EF v = eval_table<TABLE, T, Cols>(cols, j, zm, *extra);
+        const EF v = eval_table<TABLE, T, Cols, SEG>(cols, j, zm, seg, *extra);
         acc = ef_add(acc, ef_mul(v, eq_split_at(eq, j)));
     }
     u32 v[5];
@@ -103,13 +122,13 @@ __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, co
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        if (gridDim.x == 1)
+        if (gridDim.x == 1 && N_SEG == 1)
             final_out[zi * 5 + threadIdx.x] = s;  // single workgroup per point: the round is finished here
         else
-            partial[((u64)zi * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
+            partial[((u64)(zi * N_SEG + seg) * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
     }
 }
-// one block per z: out[zi * 5 + k] = sum_b partial[(zi * n + b) * 5 + k]
+// one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
 __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n, u32* __restrict__ out) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.x;
@@ -168,19 +187,42 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
     }
 }
 
-template <int TABLE>
-static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
-    u32* final_out = ctx->h_res;
-    const dim3 grid(blocks, a->deg), block(256);
-    if (a->cur < 0) {
-        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
-        LM_LAUNCH(ctx, (k_air_round<TABLE, u32, BaseCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial, final_out);
+template <int TABLE, class T, class Cols, int SEG>
+static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
+                          u32* partial) {
+    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), grid, dim3(256), 0, c, n_pairs, extra, eq, partial, ctx->h_res);
+    return LM_OK;
+}
+template <int TABLE, class T, class Cols>
+static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+    const air::Extra* extra = a->d_extra;
+    if constexpr (TABLE == air::T_POSEIDON16) {
+        // Large rounds: one launch per segment (own register budget, full-chip grids).  Small rounds are latency bound:
+        // one launch with the segment in blockIdx.y so that the four chains run side by side.
+        if (n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
+            const dim3 grid(blocks, a->deg);
+            launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, 2>(ctx, c, grid, n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, 3>(ctx, c, grid, n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, 4>(ctx, c, grid, n_pairs, extra, eq, partial);
+        } else {
+            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg * air::POSEIDON_SEGMENTS), n_pairs, extra, eq, partial);
+        }
     } else {
-        ExtCols c{a->ef[a->cur], 2 * n_pairs};
-        LM_LAUNCH(ctx, (k_air_round<TABLE, EF, ExtCols>), grid, block, 0, c, n_pairs, (const air::Extra*)a->d_extra, eq, partial, final_out);
+        launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial);
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+template <int TABLE>
+static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+    if (a->cur < 0) {
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
+        return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial);
+    }
+    ExtCols c{a->ef[a->cur], 2 * n_pairs};
+    return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial);
 }
 
 extern "C" {
@@ -246,11 +288,12 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     LM_REQUIRE(ctx && a && out_raw && a->round < a->log_rows);
     const u32 p = a->log_rows - a->round - 1;
     const u64 n_pairs = 1ull << p;
+    const u32 n_seg = a->table == air::T_POSEIDON16 ? air::POSEIDON_SEGMENTS : 1;
     const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
     u32* s;
-    int rc = lm_scratch(ctx, (u64)blocks * a->deg * 5 + a->deg * 5 + 64, &s);
+    int rc = lm_scratch(ctx, (u64)blocks * a->deg * n_seg * 5 + a->deg * 5 + 64, &s);
     if (rc) return rc;
-    u32* d_out = s + (u64)blocks * a->deg * 5;
+    u32* d_out = s + (u64)blocks * a->deg * n_seg * 5;
     const EqSplit eq = a->eqt.at(p);
     if (a->table == air::T_EXECUTION)
         rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s);
@@ -260,7 +303,7 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
     (void)d_out;
-    if (blocks > 1) LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks, ctx->h_res);
+    if (blocks * n_seg > 1) LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks * n_seg, ctx->h_res);
     LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);

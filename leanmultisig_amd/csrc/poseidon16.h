@@ -37,21 +37,35 @@ KB_HD const PoseidonConsts& poseidon_consts() {
 #endif
 }
 
-// x < 2^40  ->  [0, p).   2^31 = 2^24 - 1 (mod p), applied twice.
+// On the device small compile-time multipliers are hidden from the optimiser (an empty asm on an SGPR): otherwise x*1,
+// x*2 and x*(2^24-1) in 64 bits are strength-reduced to v_lshl_add_u64 / shift-subtract chains, and v_lshl_add_u64 issues
+// at about a third of the v_mad_u64_u32 rate on gfx950 (tools/ubench/int_rates.hip, mds_variants.hip: +12% on the MDS).
+KB_HD u32 opaque_const(u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(c));
+#endif
+    return c;
+}
+
+// x < 2^43  ->  [0, p).   2^31 = 2^24 - 1 (mod p), applied twice.
 KB_HD u32 reduce40(u64 s) {
-    u32 a = (u32)(s >> 31);
+    const u32 m24 = opaque_const(0x00ffffffu);
+    u32 a = (u32)(s >> 31);             // < 2^12
     u32 b = (u32)s & 0x7fffffffu;
-    u64 r1 = (u64)a * 0x00ffffffu + b;  // < 2^34
-    u32 a2 = (u32)(r1 >> 31);           // < 8
+    u64 r1 = (u64)a * m24 + b;          // < 2^36 + 2^31
+    u32 a2 = (u32)(r1 >> 31);           // < 2^6
     u32 b2 = (u32)r1 & 0x7fffffffu;
-    u32 r2 = b2 + a2 * 0x00ffffffu;     // < 2^31 + 2^27 < 2p
+    u32 r2 = b2 + a2 * 0x00ffffffu;     // < 2^31 + 2^30 < 2p
     return umin(r2, r2 - P);
 }
 
 // s <- C * s with C[i][j] = col[(i - j) mod 16], col = {1,3,13,22,67,2,15,63,101,1,2,17,11,1,51,1}
 // (poseidon1_koalabear_16.rs:22,580-581).  Plain small integers act directly on Montgomery-form values.
 KB_HD void mds_circ16(u32 s[16]) {
-    constexpr u32 C[16] = {1, 3, 13, 22, 67, 2, 15, 63, 101, 1, 2, 17, 11, 1, 51, 1};
+    const u32 c1 = opaque_const(1), c2 = opaque_const(2), c3 = opaque_const(3), c13 = opaque_const(13);
+    const u32 c22 = opaque_const(22), c67 = opaque_const(67), c15 = opaque_const(15), c63 = opaque_const(63);
+    const u32 c101 = opaque_const(101), c17 = opaque_const(17), c11 = opaque_const(11), c51 = opaque_const(51);
+    const u32 C[16] = {c1, c3, c13, c22, c67, c2, c15, c63, c101, c1, c2, c17, c11, c1, c51, c1};
     u32 o[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -65,20 +79,7 @@ KB_HD void mds_circ16(u32 s[16]) {
 }
 
 // 16-term dot product with delayed reduction (4 products per fold).
-KB_HD u32 dot16(const u32 s[16], const u32 c[16]) {
-    u64 acc = 0;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        u64 x = (u64)s[4 * g] * c[4 * g] + (u64)s[4 * g + 1] * c[4 * g + 1] + (u64)s[4 * g + 2] * c[4 * g + 2] +
-                (u64)s[4 * g + 3] * c[4 * g + 3];  // < 4p^2 < 2^64
-        u64 y = x - P_SHL32;
-        x = x >= P_SHL32 ? y : x;                 // < 2^32 p
-        acc += x;                                 // acc < 2^32 p before this add -> < 2^33 p < 2^64
-        y = acc - P_SHL32;
-        acc = acc >= P_SHL32 ? y : acc;
-    }
-    return reduce(acc);
-}
+KB_HD u32 dot16(const u32 s[16], const u32 c[16]) { return dot_n<16>(s, c); }
 
 KB_HD void poseidon16_permute(u32 s[16]) {
     const PoseidonConsts& K = poseidon_consts();

@@ -75,17 +75,8 @@ struct Planes<EF> {
     static constexpr int N = 5;
     static KB_HD u32& at(EF& v, int k) { return v.v[k]; }
 };
-template <int I>
-struct IntC {
-    static constexpr int value = I;
-};
-template <int I, int N, class F>
-KB_HD void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(IntC<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
+using kb::IntC;
+using kb::static_for;
 
 template <class T>
 struct Folder {
@@ -287,24 +278,23 @@ static constexpr PoseidonLinear kPoseidonLinear =
 
 // (static_for, not "#pragma unroll": the pragma gives up on the EF body size, and a rolled loop indexes s[] dynamically,
 // which sends the whole state to scratch)
-template <class T>
-KB_HD void two_full_rounds(T s[16], const u32 rc0[16], const u32 rc1[16]) {
-    static_for<0, 16>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        s[i] = cube(a_addc(s[i], rc0[i]));
+// full rounds R0 and R0 + 1 of the 8 (0..3 initial, 4..7 terminal); round constants are instruction literals
+template <class T, int R0>
+KB_HD void two_full_rounds(T s[16]) {
+    static_for<0, 2>([&](auto RR) {
+        constexpr int r = R0 + decltype(RR)::value;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr u32 rc = r < 4 ? kb::kPoseidonHost.rc_init[r & 3][i] : kb::kPoseidonHost.rc_term[r & 3][i];
+            s[i] = cube(a_addc(s[i], rc));
+        });
+        mds16(s);
     });
-    mds16(s);
-    static_for<0, 16>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        s[i] = cube(a_addc(s[i], rc1[i]));
-    });
-    mds16(s);
 }
 
 // col(c) = column c at the evaluation point; colp(c, k) = its plane k only
 template <class T, int SEG, class ColFn, class ColPlaneFn>
 KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
-    const kb::PoseidonConsts& K = kb::poseidon_consts();
     Folder<T> f(x);
     T s[16];
     if constexpr (SEG == 0) {
@@ -327,14 +317,14 @@ KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
         f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = col(9 + i);
-        two_full_rounds<T>(s, K.rc_init[0], K.rc_init[1]);
+        two_full_rounds<T, 0>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(25 + i)));
     } else if constexpr (SEG == 1) {
         f.k = 24;
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = col(25 + i);
-        two_full_rounds<T>(s, K.rc_init[2], K.rc_init[3]);
+        two_full_rounds<T, 2>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(41 + i)));
     } else if constexpr (SEG == 2) {
@@ -372,14 +362,14 @@ KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
             });
             AIR_SCHED_FENCE();
         });
-        two_full_rounds<T>(s, K.rc_term[0], K.rc_term[1]);
+        two_full_rounds<T, 4>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(77 + i)));
     } else {
         f.k = 76;
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = col(77 + i);
-        two_full_rounds<T>(s, K.rc_term[2], K.rc_term[3]);
+        two_full_rounds<T, 6>(s);
         const T flag_half = col(3), flag_permute = col(8);
         const T one = a_from_base(kb::ONE, flag_half);
         const T not_permute = a_sub(one, flag_permute);

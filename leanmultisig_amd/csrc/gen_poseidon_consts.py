@@ -225,6 +225,27 @@ def main():
            "  /* y[20][37] */ { " + ",\n    ".join(fmt(row) for row in Y) + " },",
            "  /* fin[16][37] */ { " + ",\n    ".join(fmt(row) for row in F) + " },", "}"]
     open(os.path.join(HERE, "poseidon16_linear.inc"), "w").write("\n".join(lin) + "\n")
+    # hashing variant: t = M c with c = the S-box outputs of the 4th full round, so the MDS of that round is folded in
+    def fuse(rows):
+        return [[sum(row[i] * M[i][j] for i in range(W)) % P for j in range(W)] + row[W:] for row in rows]
+    YM, FM = fuse(Y), fuse(F)
+    for _ in range(5):
+        st = [rng.randrange(P) for _ in range(16)]
+        s4 = st[:]
+        for r in range(RF_HALF - 1):
+            s4 = mat_vec(M, [pow((x + c) % P, 3, P) for x, c in zip(s4, rc[r])])
+        u = [pow((x + c) % P, 3, P) for x, c in zip(s4, rc[RF_HALF - 1])] + [0] * RP + [1]
+        for r in range(RP):
+            u[W + r] = pow(sum(a * b for a, b in zip(YM[r], u)) % P, 3, P)
+        s4 = [sum(a * b for a, b in zip(row, u)) % P for row in FM]
+        for r in range(RF_HALF + RP, 2 * RF_HALF + RP):
+            s4 = mat_vec(M, [pow((x + c) % P, 3, P) for x, c in zip(s4, rc[r])])
+        assert s4 == textbook(st, rc, M), "fused linearised partial block is wrong"
+    linh = ["// GENERATED by gen_poseidon_consts.py — do not edit.  Montgomery form.  Partial block as affine forms over",
+            "// u = (c_0..c_15, q_0..q_19, 1), c = S-box outputs of the 4th full round (its MDS is folded in).", "{",
+            "  /* y[20][37] */ { " + ",\n    ".join(fmt(row) for row in YM) + " },",
+            "  /* fin[16][37] */ { " + ",\n    ".join(fmt(row) for row in FM) + " },", "}"]
+    open(os.path.join(HERE, "poseidon16_linear_hash.inc"), "w").write("\n".join(linh) + "\n")
     out = []
     out.append("// GENERATED by gen_poseidon_consts.py — do not edit.  All values Montgomery form (R = 2^32).")
     out.append("// layout must match struct PoseidonConsts in poseidon16.h")

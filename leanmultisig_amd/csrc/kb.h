@@ -140,6 +140,20 @@ KB_HD EF ef_add_base(const EF& a, u32 b) {
     return r;
 }
 
+// compile-time loop: f(IntC<I>{}) for I in [I0, N).  Unlike "#pragma unroll" it cannot be refused for body size, so arrays
+// indexed by the loop variable always stay in registers and table entries indexed by it become instruction literals.
+template <int I>
+struct IntC {
+    static constexpr int value = I;
+};
+template <int I, int N, class F>
+KB_HD void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 // Delayed reduction.  Products of reduced values are < p^2 < 2^62, so four of them fit a u64.  fold32 brings any u64 back
 // below 2^57 + 2^32 without changing it mod p (2^32 = ONE mod p, a 25-bit constant): one v_mad_u64_u32 instead of the
 // compare/subtract/select of a conditional subtraction.  After a fold there is room for three more products (< 2^64), or

@@ -1,8 +1,9 @@
 // Poseidon1-16 over KoalaBear (x^3, 4 + 20 + 4 rounds, circulant MDS) for gfx950 lanes and for the host transcript.
-// Same permutation as the reference (crates/backend/koala-bear/src/poseidon1_koalabear_16.rs:873-912): the partial
-// rounds run in the sparse form derived by gen_poseidon_consts.py; the full rounds use the small-integer circulant
-// directly (entries <= 101, row sum 371), accumulated in 64 bits and folded with 2^31 = 2^24 - 1 (mod p).
-// One permutation = one lane; the 16-word state lives in VGPRs, every constant is wave-uniform (scalar loads).
+// Same permutation as the reference (crates/backend/koala-bear/src/poseidon1_koalabear_16.rs:873-912).  The partial block
+// is evaluated through affine forms derived by gen_poseidon_consts.py (the sparse-matrix form of the reference, :399-480,
+// is kept for the trace generator, which must emit the per-round lane-0 values); the full rounds use the small-integer
+// circulant directly (entries <= 101, row sum 371), accumulated in 64 bits and folded with 2^31 = 2^24 - 1 (mod p).
+// One permutation = one lane; the 16-word state lives in VGPRs, every constant is an instruction literal.
 #pragma once
 #include "kb.h"
 
@@ -19,8 +20,23 @@ struct PoseidonConsts {
     u32 pscalar[20];  // lane-0 constant added after the S-box of partial round r (r < 19)
 };
 
-static const PoseidonConsts kPoseidonHost =
+// constexpr copy: with compile-time indices every entry becomes an instruction literal on the device (no scalar loads to
+// hoist and spill); the __constant__ copy below serves dynamically indexed uses (rolled loops).
+static constexpr PoseidonConsts kPoseidonHost =
 #include "poseidon16_consts.inc"
+    ;
+
+// Partial block as affine forms (gen_poseidon_consts.py::linearise, hashing variant).  Lanes 1..15 see no S-box inside the
+// block, so with c = S-box outputs of the 4th full round and q_r = lane-0 S-box output of partial round r, the value cubed in
+// round r and the state leaving the block are affine in u = (c_0..c_15, q_0..q_19, 1); the MDS of the 4th full round is
+// folded in.  20 + 16 dot products with delayed reduction replace the MDS, the dense entry map and 20 sparse rounds of a
+// mul+reduce per term: 4.9 vs 3.7 G perm/s on MI355X (tools/ubench/perm_variants.hip).
+struct PoseidonLinearHash {
+    u32 y[20][37];    // y_r = y[r][0..16+r) . u + y[r][36],  q_r = y_r^3
+    u32 fin[16][37];  // state entering the terminal full rounds
+};
+static constexpr PoseidonLinearHash kPoseidonLinearHash =
+#include "poseidon16_linear_hash.inc"
     ;
 
 #if defined(__HIPCC__)
@@ -82,40 +98,38 @@ KB_HD void mds_circ16(u32 s[16]) {
 KB_HD u32 dot16(const u32 s[16], const u32 c[16]) { return dot_n<16>(s, c); }
 
 KB_HD void poseidon16_permute(u32 s[16]) {
-    const PoseidonConsts& K = poseidon_consts();
     // 3 plain initial full rounds
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_init[r][i]));
+    static_for<0, 3>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            s[i] = cube(add(s[i], kPoseidonHost.rc_init[r][i]));
+        });
         mds_circ16(s);
-    }
-    // 4th full round: S-box, then fused (D * MDS) and bias
-    {
-        u32 t[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) t[i] = cube(add(s[i], K.rc_init[3][i]));
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = add(dot16(t, K.dm[i]), K.dbias[i]);
-    }
-    // 20 partial rounds, sparse form
-#pragma unroll 1
-    for (int r = 0; r < 20; r++) {
-        u32 s0 = cube(s[0]);
-        if (r < 19) s0 = add(s0, K.pscalar[r]);
-        s[0] = s0;
-        u32 n0 = dot16(s, K.prow[r]);
-#pragma unroll
-        for (int i = 1; i < 16; i++) s[i] = add(s[i], mul(s0, K.pcol[r][i - 1]));
-        s[0] = n0;
-    }
+    });
+    // S-boxes of the 4th full round, then the partial block through its affine forms
+    u32 u[36];
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        u[i] = cube(add(s[i], kPoseidonHost.rc_init[3][i]));
+    });
+    static_for<0, 20>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        u[16 + r] = cube(add(dot_n<16 + r>(u, kPoseidonLinearHash.y[r]), kPoseidonLinearHash.y[r][36]));
+    });
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        s[i] = add(dot_n<36>(u, kPoseidonLinearHash.fin[i]), kPoseidonLinearHash.fin[i][36]);
+    });
     // 4 terminal full rounds
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = cube(add(s[i], K.rc_term[r][i]));
+    static_for<0, 4>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        static_for<0, 16>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            s[i] = cube(add(s[i], kPoseidonHost.rc_term[r][i]));
+        });
         mds_circ16(s);
-    }
+    });
 }
 
 // compression mode: perm(x) + x (poseidon1_koalabear_16.rs:1018-1030)

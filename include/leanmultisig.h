@@ -114,6 +114,11 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
 int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t n_vars, const uint32_t* point,
                      uint32_t* out);
 /* device-to-device copy of n_words (stack_polynomials_and_commit, crates/sub_protocols/src/stacked_pcs.rs:118-136) */
+/* stack_polynomials (crates/sub_protocols/src/stacked_pcs.rs:99-157): d_dst[0..total_words) = zero everywhere except
+ * d_dst[dst_offset[i] .. +n_words[i]) = d_src[i][0..n_words[i]).  d_src is a HOST array of device pointers; jobs must be
+ * sorted by dst_offset and disjoint.  One pass over the destination (no separate zero-fill). */
+int lm_stack_columns(lm_ctx* ctx, uint32_t* d_dst, uint64_t total_words, uint32_t n_jobs, const uint32_t* const* d_src,
+                     const uint64_t* dst_offset, const uint64_t* n_words);
 int lm_copy_d2d(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint64_t n_words);
 
 /* ---- weight polynomial of the WHIR sumcheck -----------------------------------------------------------------------
@@ -132,6 +137,10 @@ typedef struct {
 } lm_weight_item;
 int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
                           const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars);
+/* Same, but W is write-only: on exit W = sum of the items (uninitialised memory on entry is fine).  combine_statement's
+ * first use (open.rs:518-584 starts from a zeroed weight polynomial); saves the zero-fill and one read of W. */
+int lm_weights_init(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                    const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars);
 
 /* ---- product sumcheck (WHIR) --------------------------------------------------------------------------------------
  * One round of run_product_sumcheck / sumcheck_prove_many_rounds with ProductComputation

@@ -49,6 +49,8 @@ _SIGS = {
     "lm_copy_d2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
     "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
+    "lm_stack_columns": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "lm_weights_init": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
     "lm_fold": (C.c_int, [vp, vp, C.c_int, C.c_uint32, vp, vp]),
     "lm_pow_grind": (C.c_int, [vp, vp, C.c_uint32, u32p]),
@@ -360,15 +362,27 @@ class Context:
         return out
 
 
-    def weights_accumulate(self, d_W, n_vars, items, points, scalars):
-        """items: list of (offset, inner_n, is_next, point_offset); points (k,5); scalars (n_items,5)"""
+    def stack_columns(self, total_words, jobs):
+        """jobs: list of (DeviceBuffer src, src_word_offset, dst_offset, n_words) sorted by dst_offset -> DeviceBuffer"""
+        out = self.alloc(total_words)
+        n = len(jobs)
+        srcs = (C.c_void_p * max(n, 1))(*[b.ptr + 4 * so for b, so, _, _ in jobs])
+        offs = (C.c_uint64 * max(n, 1))(*[d for _, _, d, _ in jobs])
+        lens = (C.c_uint64 * max(n, 1))(*[w for _, _, _, w in jobs])
+        self._check(self.lib.lm_stack_columns(self.h, out.ptr, total_words, n, srcs, offs, lens))
+        return out
+
+    def weights_accumulate(self, d_W, n_vars, items, points, scalars, init=False):
+        """items: list of (offset, inner_n, is_next, point_offset); points (k,5); scalars (n_items,5).
+        init=True: lm_weights_init (W is write-only)"""
         arr = (WeightItem * len(items))()
         for i, (off, inner, nxt, poff) in enumerate(items):
             arr[i].offset, arr[i].inner_n, arr[i].is_next, arr[i].point_offset = off, inner, int(nxt), poff
         pts = _u32(points).reshape(-1)
         sc = _u32(scalars).reshape(-1)
-        self._check(self.lib.lm_weights_accumulate(self.h, d_W.ptr, n_vars, C.cast(arr, vp), len(items),
-                                                   _ptr(pts) if pts.size else None, pts.size // 5, _ptr(sc)))
+        fn = self.lib.lm_weights_init if init else self.lib.lm_weights_accumulate
+        self._check(fn(self.h, d_W.ptr, n_vars, C.cast(arr, vp), len(items), _ptr(pts) if pts.size else None, pts.size // 5,
+                       _ptr(sc)))
 
     def logup_build(self, sections, c, alphas_eq16, n_vars):
         """sections: list of dict(out_offset, log_len, num_mode, num_col (device ptr/None), den_sign, domsep,

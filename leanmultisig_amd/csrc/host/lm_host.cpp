@@ -1,8 +1,11 @@
 // Host-side mirror of the reference's transcript and WHIR driver (see include/leanmultisig_host.h).
 // Everything heavy goes through the device ABI (include/leanmultisig.h); this file only sequences the protocol:
 // Fiat–Shamir state, round polynomials, query sampling, tiny leaf evaluations.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include "../../../include/leanmultisig_host.h"
 #include "../kb.h"
@@ -392,9 +395,8 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
     if ((rc = lm_malloc(ctx, 5 * (len / 2) + 8, &sc.w_buf[1]))) return rc;
     if ((rc = lm_malloc(ctx, 5 * (len / 2) + 8, &sc.f_buf[0]))) return rc;
     if ((rc = lm_malloc(ctx, 5 * (len / 4) + 8, &sc.f_buf[1]))) return rc;
-    if ((rc = lm_memset_zero(ctx, sc.w_buf[0], 5 * len))) return rc;
     // combine_statement, open.rs:518-584
-    rc = lm_weights_accumulate(ctx, sc.w_buf[0], n, items.data(), (u32)items.size(), pts.data(), pts.size() / 5, scalars.data());
+    rc = lm_weights_init(ctx, sc.w_buf[0], n, items.data(), (u32)items.size(), pts.data(), pts.size() / 5, scalars.data());
     if (rc) return rc;
     sc.f = d_poly;
     sc.f_is_ext = false;
@@ -543,6 +545,14 @@ int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, c
         lm_gkr_free(ctx, g);
         return code;
     };
+    // LM_STAGE_TIMES: where the wall clock of the layer loop goes (device round trips vs host transcript work)
+    const bool clk_on = getenv("LM_STAGE_TIMES") != nullptr;
+    double t_round = 0, t_host = 0, t_begin = 0, t_end = 0;
+    u32 n_rounds_total = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
     u32 tn[160], td[160];
     if ((rc = lm_gkr_top(ctx, g, tn, td))) return fail(rc);
     add_base(p, tn, 160);
@@ -566,12 +576,16 @@ int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, c
         const EF alpha = av[0];
         EF sum = kb::ef_add(claim_num, kb::ef_mul(alpha, claim_den));
         EF mmf = kb::ef_one();
+        auto tb0 = now();
         if ((rc = lm_gkr_layer_begin(ctx, g, K, point[0].v, alpha.v))) return fail(rc);
+        if (clk_on) t_begin += ms(tb0, now());
         std::vector<EF> q;
         EF r_prev;
         for (u32 t = 0; t < K; t++) {
             u32 c[10];
+            auto tr0 = now();
             if ((rc = lm_gkr_round(ctx, g, t == 0 ? nullptr : r_prev.v, c))) return fail(rc);
+            auto tr1 = now();
             const EF eq_alpha = point[K - 1 - t];
             // build_bare_from_coeffs, sumcheck_utils.rs:491-503
             const EF c0 = kb::ef_mul(ef_load(c), mmf), c2 = kb::ef_mul(ef_load(c + 5), mmf);
@@ -588,9 +602,16 @@ int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, c
             mmf = kb::ef_mul(mmf, eq_eval);
             q.push_back(r);
             r_prev = r;
+            if (clk_on) {
+                t_round += ms(tr0, tr1);
+                t_host += ms(tr1, now());
+                n_rounds_total++;
+            }
         }
         u32 ie[20];
+        auto te0 = now();
         if ((rc = lm_gkr_layer_end(ctx, g, r_prev.v, ie))) return fail(rc);
+        if (clk_on) t_end += ms(te0, now());
         add_base(p, ie, 20);
         std::vector<EF> bv;
         if (!sample_vec(p, 1, bv)) return fail(LM_E_INVALID);
@@ -601,6 +622,9 @@ int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, c
         np.push_back(beta);
         point = np;
     }
+    if (clk_on)
+        fprintf(stderr, "#   gkr: %u rounds: device round trips %.3f ms, host transcript %.3f ms, layer_begin %.3f ms, layer_end %.3f ms\n",
+                n_rounds_total, t_round, t_host, t_begin, t_end);
     lm_gkr_free(ctx, g);
     memcpy(out_quotient, quotient.v, 20);
     for (u32 i = 0; i < n_vars; i++) memcpy(out_point + 5 * i, point[i].v, 20);
@@ -784,9 +808,30 @@ uint32_t lmh_stacked_n_vars(const lm_execution_trace* t) {
     return log2_ceil_u64(total);
 }
 
+// LM_STAGE_TIMES=1: wall clock per stage on stderr (each mark synchronises the stream, so the total is slightly pessimistic)
+struct StageClock {
+    lm_ctx* ctx;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageClock(lm_ctx* c) : ctx(c), on(getenv("LM_STAGE_TIMES") != nullptr) {
+        if (on) {
+            lm_sync(ctx);
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+    void mark(const char* name) {
+        if (!on) return;
+        lm_sync(ctx);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "# stage %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr, const lm_whir_config* cfg) {
     if (!ctx || !p || !tr || !cfg) return LM_E_INVALID;
     int rc;
+    StageClock clk(ctx);
     int order[3];
     sorted_tables(tr, order);
     const u32 log_mem = tr->log_memory, log_bc = tr->log_bytecode;
@@ -810,21 +855,30 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     const u64 mem = 1ull << log_mem;
     DevBuf poly(ctx);
     if ((rc = lm_malloc(ctx, 1ull << stacked_n_vars, &poly.p))) return rc;
-    if ((rc = lm_memset_zero(ctx, poly.p, 1ull << stacked_n_vars))) return rc;
-    lm_copy_d2d(ctx, poly.p, tr->d_memory, mem);
-    lm_copy_d2d(ctx, poly.p + mem, tr->d_memory_acc, mem);
+    std::vector<const u32*> srcs;
+    std::vector<u64> offs, lens;
+    auto place = [&](const u32* src, u64 at, u64 n) {
+        srcs.push_back(src);
+        offs.push_back(at);
+        lens.push_back(n);
+    };
+    place(tr->d_memory, 0, mem);
+    place(tr->d_memory_acc, mem, mem);
     u64 off = 2 * mem;
-    lm_copy_d2d(ctx, poly.p + off, tr->d_bytecode_acc, 1ull << log_bc);
+    place(tr->d_bytecode_acc, off, 1ull << log_bc);
     off += std::max(1ull << tr->tables[order[0]].log_rows, 1ull << log_bc);
     for (int k = 0; k < 3; k++) {
         const int t = order[k];
         for (u32 c = 0; c < kVmTables[t].n_columns; c++) {
-            lm_copy_d2d(ctx, poly.p + off, tr->tables[t].d_cols[c], 1ull << tr->tables[t].log_rows);
+            place(tr->tables[t].d_cols[c], off, 1ull << tr->tables[t].log_rows);
             off += 1ull << tr->tables[t].log_rows;
         }
     }
+    if ((rc = lm_stack_columns(ctx, poly.p, 1ull << stacked_n_vars, (u32)srcs.size(), srcs.data(), offs.data(), lens.data()))) return rc;
     lmh_witness* wit = nullptr;
+    clk.mark("stack");
     if ((rc = lmh_whir_commit(ctx, p, cfg, poly.p, off, &wit))) return rc;
+    clk.mark("whir_commit");
     auto fail = [&](int code) {
         if (wit) lmh_witness_free(ctx, wit);
         return code;
@@ -900,9 +954,11 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     if ((rc = lm_malloc(ctx, 1ull << gkr_n_vars, &nums.p))) return fail(rc);
     if ((rc = lm_malloc(ctx, 5ull << gkr_n_vars, &dens.p))) return fail(rc);
     if ((rc = lm_logup_build(ctx, secs.data(), (u32)secs.size(), logup_c.v, aeq[0].v, gkr_n_vars, nums.p, dens.p))) return fail(rc);
+    clk.mark("logup_fill");
     u32 quotient[5], claims[10];
     std::vector<u32> gkr_pt((size_t)gkr_n_vars * 5);
     if ((rc = lmh_prove_gkr_quotient(ctx, p, nums.p, dens.p, gkr_n_vars, quotient, gkr_pt.data(), claims))) return fail(rc);
+    clk.mark("logup_gkr");
     if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) return fail(LM_E_INVALID);  // assert_eq!(sum, ZERO)
     auto from_end = [&](u32 n) { return gkr_pt.data() + (size_t)(gkr_n_vars - n) * 5; };
     // column evaluations (logup.rs:224-308)
@@ -962,6 +1018,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
             columns_values[t].push_back({want[i], E(i)});
         }
     }
+    clk.mark("column_evaluations");
     // ---- AIR (prove_execution.rs:152-223) ----
     std::vector<EF> tmp;
     if (!sample_vec(p, 1, tmp)) return fail(LM_E_INVALID);
@@ -989,6 +1046,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     std::vector<u32> air_point((size_t)n_max * 5), col_evals((size_t)n_evals_total * 5);
     if ((rc = lmh_prove_batched_air_sumcheck(ctx, p, at, 3, air_alpha.v, aeq[0].v, bus_beta.v, air_eta.v, air_point.data(), col_evals.data())))
         return fail(rc);
+    clk.mark("batched_air_sumcheck");
     // ---- public memory, statements (:225-260; stacked_pcs.rs:40-97) ----
     const u32 lpm = log2_ceil_u64(tr->public_memory_size);
     std::vector<EF> pm_pt;
@@ -1049,11 +1107,13 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
         ce += (size_t)(def.n_columns + def.n_shift) * 5;
         soff += (u64)def.n_columns << nv;
     }
+    clk.mark("statement_assembly");
     std::vector<u32> out_point((size_t)stacked_n_vars * 5);
     lmh_witness* w = wit;
     wit = nullptr;  // consumed by lmh_whir_prove
     rc = lmh_whir_prove(ctx, p, cfg, sts.data(), (u32)sts.size(), pts.data(), pts.size() / 5, sels.data(), vals.data(), sels.size(), w,
                         poly.p, out_point.data());
+    clk.mark("whir_open");
     return rc;
 }
 

@@ -23,6 +23,8 @@ struct NttArgs {
     u32 first;      // 1: read (replicated) input, 0: in place
     u32 log_rate;   // replicate factor of the first pass
     u64 in_col_len; // input words per column (first pass)
+    u32 cols_per_plane;   // input column c lives at (c / cols_per_plane) * in_plane_stride + (c % cols_per_plane) * in_col_len
+    u64 in_plane_stride;  // (EF polynomials: 5 SoA planes of 2^n_vars words; the output matrix is plane-major contiguous)
 };
 
 __global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u32* __restrict__ out,
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u3
         }
     }
     if (a.first) {
-        const u32* src = in + col * a.in_col_len;
+        const u32* src = in + (col / a.cols_per_plane) * a.in_plane_stride + (col % a.cols_per_plane) * a.in_col_len;
         for (u32 x = tid; x < tile; x += 256) {
             u32 hi = x >> m, lo_l = x & ((1u << m) - 1);
             u64 e = base + ((u64)hi << S) + lo_l;
@@ -91,17 +93,22 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u3
     }
 }
 
-// columns: n_cols contiguous inputs of in_col_len = h >> log_rate words at d_in; output column-major n_cols x h.
-static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 n_cols, u32 log_h, u32 log_rate) {
+// columns: n_planes x cols_per_plane inputs of in_col_len = h >> log_rate words (planes in_plane_stride apart) at d_in;
+// output column-major (n_planes * cols_per_plane) x h.  All planes go through the same launches.
+static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 cols_per_plane, u32 n_planes, u64 in_plane_stride, u32 log_h,
+                       u32 log_rate) {
+    const u32 n_cols = cols_per_plane * n_planes;
     LM_REQUIRE(log_h <= LM_TW_LOG);
     if (log_h == 0) {
-        LM_HIP(hipMemcpyAsync(d_out, d_in, (u64)n_cols * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        for (u32 k = 0; k < n_planes; k++)
+            LM_HIP(hipMemcpyAsync(d_out + (u64)k * cols_per_plane, d_in + k * in_plane_stride, (u64)cols_per_plane * 4,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
         return LM_OK;
     }
     const u32 K1 = log_h < 12 ? log_h : 12;
     u32 done = 0;
     {
-        NttArgs a{log_h, 0, K1, 0, 1, log_rate, (1ull << log_h) >> log_rate};
+        NttArgs a{log_h, 0, K1, 0, 1, log_rate, (1ull << log_h) >> log_rate, cols_per_plane, in_plane_stride};
         dim3 grid(1u << (log_h - K1), n_cols);
         size_t sh = ((1u << K1) * 2) * 4;
         LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
@@ -113,7 +120,7 @@ static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 n_cols, u32
         u32 K = (rem + (n_pass - p) - 1) / (n_pass - p);
         u32 m = 13 - K;
         if (m > done) m = done;
-        NttArgs a{log_h, done, K, m, 0, 0, 0};
+        NttArgs a{log_h, done, K, m, 0, 0, 0, cols_per_plane, in_plane_stride};
         dim3 grid(1u << (log_h - K - m), n_cols);
         size_t sh = ((1u << (K + m)) + (1u << K) + (K << m)) * 4;
         LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
@@ -355,15 +362,8 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
         return LM_E_NOMEM;
     }
     int rc;
-    if (!is_ext) {
-        rc = lde_columns(ctx, d_evals, t->d_matrix, eff_cols, log_h, log_inv_rate);
-    } else {
-        // SoA planes: plane k holds 2^n_vars words; its first eff_cols column slices are stored at k*eff_cols + c
-        rc = LM_OK;
-        for (u32 k = 0; k < 5 && rc == LM_OK; k++)
-            rc = lde_columns(ctx, d_evals + (u64)k * len, t->d_matrix + (u64)k * eff_cols * h, eff_cols, log_h,
-                             log_inv_rate);
-    }
+    // EF: SoA planes, plane k holds 2^n_vars words; its first eff_cols column slices are stored at k*eff_cols + c
+    rc = lde_columns(ctx, d_evals, t->d_matrix, eff_cols, is_ext ? 5 : 1, len, log_h, log_inv_rate);
     if (rc != LM_OK) {
         lm_tree_free(ctx, t);
         return rc;

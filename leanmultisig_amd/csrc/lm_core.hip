@@ -280,6 +280,32 @@ int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {
     return LM_OK;
 }
 
+// stack_polynomials (crates/sub_protocols/src/stacked_pcs.rs:99-157): dst = zero-padded concatenation of column slices.
+// One pass over the destination: every uint4 finds the job that covers it (jobs sorted by destination), or is zero.
+struct StackJob {
+    const u32* src;
+    u64 begin, end;  // destination range in uint4 units
+};
+__global__ __launch_bounds__(256) void k_stack_columns(uint4* __restrict__ dst, u64 n_vec, const StackJob* __restrict__ jobs,
+                                                       u32 n_jobs) {
+    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < n_vec; e += (u64)gridDim.x * 256) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (n_jobs) {
+            u32 lo = 0, hi = n_jobs - 1;  // last job with begin <= e
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (jobs[mid].begin <= e)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            const StackJob j = jobs[lo];
+            if (j.begin <= e && e < j.end) v = reinterpret_cast<const uint4*>(j.src)[e - j.begin];
+        }
+        dst[e] = v;
+    }
+}
+
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
@@ -466,6 +492,42 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     memcpy(out, ctx->h_res, (u64)n_cols * 20);
     return LM_OK;
 }
+int lm_stack_columns(lm_ctx* ctx, uint32_t* d_dst, uint64_t total_words, uint32_t n_jobs, const uint32_t* const* d_src,
+                     const uint64_t* dst_offset, const uint64_t* n_words) {
+    LM_REQUIRE(ctx && d_dst && (total_words & 3) == 0 && ((uintptr_t)d_dst & 15) == 0);
+    LM_REQUIRE(n_jobs == 0 || (d_src && dst_offset && n_words));
+    if (total_words == 0) return LM_OK;
+    bool vec_ok = true;
+    u64 prev_end = 0;
+    for (u32 i = 0; i < n_jobs; i++) {
+        LM_REQUIRE(d_src[i] && dst_offset[i] >= prev_end && dst_offset[i] + n_words[i] <= total_words);
+        prev_end = dst_offset[i] + n_words[i];
+        if ((dst_offset[i] & 3) || (n_words[i] & 3) || ((uintptr_t)d_src[i] & 15)) vec_ok = false;
+    }
+    if (!vec_ok) {  // unaligned pieces: plain copies
+        LM_HIP(hipMemsetAsync(d_dst, 0, total_words * 4, ctx->stream));
+        for (u32 i = 0; i < n_jobs; i++)
+            if (n_words[i]) LM_HIP(hipMemcpyAsync(d_dst + dst_offset[i], d_src[i], n_words[i] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return LM_OK;
+    }
+    std::vector<StackJob> jobs;
+    for (u32 i = 0; i < n_jobs; i++)
+        if (n_words[i]) jobs.push_back({d_src[i], dst_offset[i] / 4, (dst_offset[i] + n_words[i]) / 4});
+    u32* s;
+    int rc = lm_scratch(ctx, (jobs.size() * sizeof(StackJob) + 3) / 4 + 16, &s);
+    if (rc) return rc;
+    if (!jobs.empty()) {
+        LM_HIP(hipMemcpyAsync(s, jobs.data(), jobs.size() * sizeof(StackJob), hipMemcpyHostToDevice, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` must outlive the copy
+    }
+    const u64 n_vec = total_words / 4;
+    const u32 blocks = (u32)std::min<u64>((n_vec + 255) / 256, 16384);
+    LM_LAUNCH(ctx, k_stack_columns, dim3(blocks), dim3(256), 0, reinterpret_cast<uint4*>(d_dst), n_vec, (const StackJob*)s,
+              (u32)jobs.size());
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 int lm_copy_d2d(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* d_src, uint64_t n_words) {
     LM_REQUIRE(ctx && d_dst && d_src);
     if (n_words) LM_HIP(hipMemcpyAsync(d_dst, d_src, n_words * 4, hipMemcpyDeviceToDevice, ctx->stream));

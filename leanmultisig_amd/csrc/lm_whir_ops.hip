@@ -1,4 +1,5 @@
 // Device side of WhirConfig::prove: weight-polynomial construction, product-sumcheck rounds, folds, PoW grinding.
+#include <stdlib.h>
 #include <algorithm>
 #include "lm_common.h"
 
@@ -13,16 +14,19 @@ using namespace kb;
 // =====================================================================================================
 static constexpr u32 W_KLO = 10;
 static constexpr u32 W_CHUNK = 1u << W_KLO;
+static constexpr u32 W_FAST_TILE = 256;  // fast items staged in LDS per pass
 
 struct WItem {
     u64 thi_off, tlo_off;  // word offsets into the table arena (SoA tables)
     u32 inner_n, is_next;
     u64 point_off;         // EF index into the points array
+    u32 lo_base, pad;      // 1: the last k_lo coordinates are base-field elements, T_lo has only plane 0 (STIR query points)
 };
 struct WGroup {
     u64 offset;
     u64 chunk_begin;
-    u32 inner_n, item_begin, item_end, pad;
+    u32 inner_n, item_begin, item_end;
+    u32 fast_end;  // items [item_begin, fast_end) take the base-point path
 };
 
 // grid: (ceil(max_table/256), n_items, 2).  z = 0: T_hi over the first inner-k_lo coordinates, times the scalar;
@@ -71,9 +75,95 @@ __device__ __forceinline__ EF weight_eq_at(const u32* __restrict__ arena, const 
     return ef_mul(a, b);
 }
 
+// Contribution of one group to the U elements of this lane: element u is group-relative index i_base + u*256 + tid.
+// acc[u] += sum_items scalar * w(i).  Block-uniform control flow (contains __syncthreads).
+static constexpr u32 W_U = W_CHUNK / 256;  // elements per lane
+__device__ __forceinline__ void group_contrib(const WGroup& g, u64 i_base, const WItem* __restrict__ items,
+                                              const u32* __restrict__ arena, u32* a_lds, EF acc[W_U]) {
+    const u64 len = 1ull << g.inner_n;
+    const u32 k_lo = g.inner_n < W_KLO ? g.inner_n : W_KLO;
+    const u64 hi_len = 1ull << (g.inner_n - k_lo);
+    const u32 lo_len = 1u << k_lo;
+    const u64 jh = i_base >> k_lo;  // uniform: a chunk never straddles a T_hi entry (W_CHUNK = 2^W_KLO)
+    // ---- fast items [item_begin, fast_end): eq weights whose T_lo is a base-field table (STIR query points; the later
+    // rounds add hundreds of them to one region).  The group's T_hi entries for this chunk are staged in LDS once, then
+    // each item costs one LDS broadcast, U coalesced loads and 5 U multiply-adds into 64-bit accumulators.
+    const u32 n_fast = g.fast_end - g.item_begin;
+    if (n_fast) {
+        u64 a64[W_U][5];
+#pragma unroll
+        for (u32 u = 0; u < W_U; u++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) a64[u][k] = 0;
+        const WItem first = items[g.item_begin];
+        const u64 stride = 5 * hi_len + 5 * (u64)lo_len;  // arena layout of consecutive items of one group
+        bool live[W_U];
+        u32 jl[W_U];
+#pragma unroll
+        for (u32 u = 0; u < W_U; u++) {
+            const u64 i = i_base + u * 256 + threadIdx.x;
+            live[u] = i < len;
+            jl[u] = (u32)i & (lo_len - 1);
+        }
+        u32 pending = 0;
+        for (u32 t0 = 0; t0 < n_fast; t0 += W_FAST_TILE) {
+            const u32 nt = n_fast - t0 < W_FAST_TILE ? n_fast - t0 : W_FAST_TILE;
+            __syncthreads();
+            for (u32 x = threadIdx.x; x < nt * 5; x += 256) {
+                const u32 t = x / 5, k = x - t * 5;
+                a_lds[x] = arena[first.thi_off + (u64)(t0 + t) * stride + (u64)k * hi_len + jh];
+            }
+            __syncthreads();
+            const u32* lo_tab = arena + first.tlo_off + (u64)t0 * stride;
+#pragma unroll 2
+            for (u32 t = 0; t < nt; t++) {
+                u32 bl[W_U];
+#pragma unroll
+                for (u32 u = 0; u < W_U; u++) bl[u] = live[u] ? lo_tab[(u64)t * stride + jl[u]] : 0u;
+                u32 av[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) av[k] = a_lds[t * 5 + k];
+#pragma unroll
+                for (u32 u = 0; u < W_U; u++)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) a64[u][k] += (u64)av[k] * bl[u];
+                if (++pending == 3) {
+                    pending = 0;
+#pragma unroll
+                    for (u32 u = 0; u < W_U; u++)
+#pragma unroll
+                        for (int k = 0; k < 5; k++) a64[u][k] = fold32(a64[u][k]);
+                }
+            }
+        }
+#pragma unroll
+        for (u32 u = 0; u < W_U; u++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[u].v[k] = add(acc[u].v[k], reduce(fold32(a64[u][k])));
+    }
+    // ---- remaining items (EF points, `next` weights)
+    if (g.fast_end == g.item_end) return;
+#pragma unroll
+    for (u32 u = 0; u < W_U; u++) {
+        const u64 i = i_base + u * 256 + threadIdx.x;
+        if (i >= len) continue;
+        for (u32 j = g.fast_end; j < g.item_end; j++) {
+            const WItem it = items[j];
+            if (!it.is_next) {
+                acc[u] = ef_add(acc[u], weight_eq_at(arena, it, k_lo, i));
+            } else {
+                if (i >= 1) acc[u] = ef_add(acc[u], weight_eq_at(arena, it, k_lo, i - 1));
+                if (i == len - 1) acc[u] = ef_add(acc[u], weight_eq_at(arena, it, k_lo, i));
+            }
+        }
+    }
+}
+
+// W[g.offset + i] += contributions of g, one launch for all groups of one inner_n (disjoint regions).
 __global__ __launch_bounds__(256) void k_weights_accumulate(u32* __restrict__ W, u64 plane, const WGroup* __restrict__ groups,
                                                             u32 n_groups, const WItem* __restrict__ items,
                                                             const u32* __restrict__ arena) {
+    __shared__ u32 a_lds[W_FAST_TILE * 5];
     // find the group of this block
     u32 lo = 0, hi = n_groups - 1;
     const u64 b = blockIdx.x;
@@ -85,26 +175,51 @@ __global__ __launch_bounds__(256) void k_weights_accumulate(u32* __restrict__ W,
             hi = mid - 1;
     }
     const WGroup g = groups[lo];
-    const u64 len = 1ull << g.inner_n;
     const u64 i_base = (b - g.chunk_begin) * W_CHUNK;
-    const u32 k_lo = g.inner_n < W_KLO ? g.inner_n : W_KLO;
-#pragma unroll 1
-    for (u32 u = 0; u < W_CHUNK / 256; u++) {
+    EF acc[W_U];
+#pragma unroll
+    for (u32 u = 0; u < W_U; u++) acc[u] = ef_zero();
+    group_contrib(g, i_base, items, arena, a_lds, acc);
+#pragma unroll
+    for (u32 u = 0; u < W_U; u++) {
         const u64 i = i_base + u * 256 + threadIdx.x;
-        if (i >= len) break;
-        EF acc = ef_zero();
-        for (u32 j = g.item_begin; j < g.item_end; j++) {
-            const WItem it = items[j];
-            if (!it.is_next) {
-                acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i));
-            } else {
-                if (i >= 1) acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i - 1));
-                if (i == len - 1) acc = ef_add(acc, weight_eq_at(arena, it, k_lo, i));
-            }
-        }
+        if (i >= (1ull << g.inner_n)) continue;
         u32* w = W + g.offset + i;
 #pragma unroll
-        for (int k = 0; k < 5; k++) w[(u64)k * plane] = add(w[(u64)k * plane], acc.v[k]);
+        for (int k = 0; k < 5; k++) w[(u64)k * plane] = add(w[(u64)k * plane], acc[u].v[k]);
+    }
+}
+
+// W <- (whole-domain group) + (the one top-level region that contains the chunk, if any): plain stores, W is written once.
+// groups[0] = the whole-domain group (possibly without items), groups[1..n_groups) = disjoint regions of >= W_CHUNK
+// elements sorted by offset.  One block per chunk of the domain.
+__global__ __launch_bounds__(256) void k_weights_init(u32* __restrict__ W, u64 plane, const WGroup* __restrict__ groups,
+                                                      u32 n_groups, const WItem* __restrict__ items,
+                                                      const u32* __restrict__ arena) {
+    __shared__ u32 a_lds[W_FAST_TILE * 5];
+    const u64 i_base = (u64)blockIdx.x * W_CHUNK;
+    EF acc[W_U];
+#pragma unroll
+    for (u32 u = 0; u < W_U; u++) acc[u] = ef_zero();
+    group_contrib(groups[0], i_base, items, arena, a_lds, acc);
+    if (n_groups > 1) {  // last region with offset <= i_base
+        u32 lo = 1, hi = n_groups - 1;
+        while (lo < hi) {
+            u32 mid = (lo + hi + 1) >> 1;
+            if (groups[mid].offset <= i_base)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const WGroup g = groups[lo];
+        if (g.offset <= i_base && i_base < g.offset + (1ull << g.inner_n)) group_contrib(g, i_base - g.offset, items, arena, a_lds, acc);
+    }
+#pragma unroll
+    for (u32 u = 0; u < W_U; u++) {
+        const u64 i = i_base + u * 256 + threadIdx.x;
+        if (i >= plane) continue;
+#pragma unroll
+        for (int k = 0; k < 5; k++) W[(u64)k * plane + i] = acc[u].v[k];
     }
 }
 
@@ -255,38 +370,55 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ 
     if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
 }
 
-extern "C" {
-
-int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
-                          const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars) {
+// init: W holds garbage on entry and must equal the sum on exit
+static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                        const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars, bool init) {
     LM_REQUIRE(ctx && d_W && n_vars <= 40);
-    if (n_items == 0) return LM_OK;
-    LM_REQUIRE(items && scalars && (points || n_point_coords == 0));
     const u64 plane = 1ull << n_vars;
-    // order items by (inner_n, offset): groups (same region) are contiguous, and all groups of one inner_n — which are
-    // pairwise disjoint aligned blocks — form one launch.  Regions of different sizes may nest, so they must not be
-    // updated by the same launch (read-modify-write of W).
+    if (n_items == 0) {
+        if (init) LM_HIP(hipMemsetAsync(d_W, 0, 5 * plane * 4, ctx->stream));
+        return LM_OK;
+    }
+    LM_REQUIRE(n_vars <= 36);
+    LM_REQUIRE(items && scalars && (points || n_point_coords == 0));
+    // order items by (inner_n descending, offset): groups (same region) are contiguous, and all groups of one inner_n —
+    // which are pairwise disjoint aligned blocks — form one launch.  Regions of different sizes may nest, so they must not
+    // be updated by the same launch (read-modify-write of W).  Largest first: a whole-domain group (the OOD constraints of
+    // combine_statement) then initialises W with plain stores instead of a memset plus a read-modify-write.
     std::vector<u32> order(n_items);
-    for (u32 i = 0; i < n_items; i++) order[i] = i;
+    std::vector<uint8_t> fast(n_items);
+    for (u32 i = 0; i < n_items; i++) {
+        order[i] = i;
+        const lm_weight_item& s = items[i];
+        LM_REQUIRE(s.inner_n <= n_vars && s.inner_n <= 36 && s.point_offset + s.inner_n <= n_point_coords);
+        const u32 k_lo = s.inner_n < W_KLO ? s.inner_n : W_KLO;
+        bool f = !s.is_next;  // fast: eq weight whose last k_lo coordinates are base-field elements
+        for (u32 c = s.inner_n - k_lo; c < s.inner_n && f; c++) {
+            const u32* e = points + (s.point_offset + c) * 5;
+            if (e[1] | e[2] | e[3] | e[4]) f = false;
+        }
+        fast[i] = f;
+    }
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) {
-        if (items[a].inner_n != items[b].inner_n) return items[a].inner_n < items[b].inner_n;
-        return items[a].offset < items[b].offset;
+        if (items[a].inner_n != items[b].inner_n) return items[a].inner_n > items[b].inner_n;
+        if (items[a].offset != items[b].offset) return items[a].offset < items[b].offset;
+        return fast[a] > fast[b];  // fast items first within a group
     });
     std::vector<WItem> hit(n_items);
     std::vector<WGroup> hgr;
     std::vector<u32> hsc((u64)n_items * 5);
-    u64 arena_words = 0, chunks = 0;
+    u64 arena_words = 0;
     u32 max_table = 1;
     for (u32 k = 0; k < n_items; k++) {
         const lm_weight_item& s = items[order[k]];
-        LM_REQUIRE(s.inner_n <= n_vars && s.inner_n <= 36);
         LM_REQUIRE(s.offset + (1ull << s.inner_n) <= plane && (s.offset & ((1ull << s.inner_n) - 1)) == 0);
-        LM_REQUIRE(s.point_offset + s.inner_n <= n_point_coords);
         const u32 k_lo = s.inner_n < W_KLO ? s.inner_n : W_KLO;
         WItem& w = hit[k];
         w.inner_n = s.inner_n;
         w.is_next = s.is_next ? 1 : 0;
         w.point_off = s.point_offset;
+        w.lo_base = fast[order[k]];
+        w.pad = 0;
         w.thi_off = arena_words;
         arena_words += 5ull << (s.inner_n - k_lo);
         w.tlo_off = arena_words;
@@ -299,44 +431,97 @@ int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_
             g.inner_n = s.inner_n;
             g.item_begin = k;
             g.item_end = k + 1;
-            if (!hgr.empty() && hgr.back().inner_n != s.inner_n) chunks = 0;  // chunk numbering restarts per launch
-            g.chunk_begin = chunks;
-            g.pad = 0;
-            chunks += ((1ull << s.inner_n) + W_CHUNK - 1) / W_CHUNK;
-            LM_REQUIRE(chunks < (1ull << 31));
+            g.fast_end = k;
+            g.chunk_begin = 0;
             hgr.push_back(g);
         } else {
             hgr.back().item_end = k + 1;
         }
+        if (w.lo_base) hgr.back().fast_end = k + 1;
     }
-    // scratch layout (words): items | groups | scalars | points | arena
-    const u64 w_items = (sizeof(WItem) * n_items + 3) / 4, w_groups = (sizeof(WGroup) * hgr.size() + 3) / 4;
+    // init: one launch over the whole domain stores (whole-domain group) + (top-level region of the chunk); only regions
+    // nested inside those, or smaller than a chunk, still need read-modify-write launches afterwards.
+    std::vector<WGroup> merged, rest;
+    if (init) {
+        WGroup whole;
+        whole.offset = 0;
+        whole.inner_n = n_vars;
+        whole.chunk_begin = 0;
+        whole.item_begin = whole.item_end = whole.fast_end = 0;
+        size_t first = 0;
+        if (hgr[0].inner_n == n_vars) whole = hgr[first++];
+        merged.push_back(whole);
+        for (size_t i = first; i < hgr.size(); i++) {
+            const WGroup& g = hgr[i];
+            bool top = g.inner_n >= W_KLO;
+            for (size_t m = 1; m < merged.size() && top; m++)  // hgr is sorted largest first: only earlier ones can contain g
+                if (merged[m].offset <= g.offset && g.offset < merged[m].offset + (1ull << merged[m].inner_n)) top = false;
+            (top ? merged : rest).push_back(g);
+        }
+        std::sort(merged.begin() + 1, merged.end(), [](const WGroup& a, const WGroup& b) { return a.offset < b.offset; });
+    } else {
+        rest = hgr;
+    }
+    u64 chunks = 0;
+    for (size_t i = 0; i < rest.size(); i++) {  // chunk numbering restarts per launch (= per inner_n)
+        if (i && rest[i - 1].inner_n != rest[i].inner_n) chunks = 0;
+        rest[i].chunk_begin = chunks;
+        chunks += ((1ull << rest[i].inner_n) + W_CHUNK - 1) / W_CHUNK;
+        LM_REQUIRE(chunks < (1ull << 31));
+    }
+    LM_REQUIRE(((plane + W_CHUNK - 1) / W_CHUNK) < (1ull << 31));
+    // scratch layout (words): items | merged groups | rest groups | scalars | points | arena
+    const u64 w_items = (sizeof(WItem) * n_items + 3) / 4, w_merged = (sizeof(WGroup) * merged.size() + 3) / 4,
+              w_rest = (sizeof(WGroup) * rest.size() + 3) / 4;
     const u64 w_sc = (u64)n_items * 5, w_pts = n_point_coords * 5;
     auto al = [](u64 x) { return (x + 15) & ~15ull; };
-    const u64 o_items = 0, o_groups = al(o_items + w_items), o_sc = al(o_groups + w_groups), o_pts = al(o_sc + w_sc),
-              o_arena = al(o_pts + w_pts);
+    const u64 o_items = 0, o_merged = al(o_items + w_items), o_rest = al(o_merged + w_merged), o_sc = al(o_rest + w_rest),
+              o_pts = al(o_sc + w_sc), o_arena = al(o_pts + w_pts);
     u32* s;
     int rc = lm_scratch(ctx, o_arena + arena_words, &s);
     if (rc) return rc;
     LM_HIP(hipMemcpyAsync(s + o_items, hit.data(), sizeof(WItem) * n_items, hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipMemcpyAsync(s + o_groups, hgr.data(), sizeof(WGroup) * hgr.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!merged.empty())
+        LM_HIP(hipMemcpyAsync(s + o_merged, merged.data(), sizeof(WGroup) * merged.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!rest.empty())
+        LM_HIP(hipMemcpyAsync(s + o_rest, rest.data(), sizeof(WGroup) * rest.size(), hipMemcpyHostToDevice, ctx->stream));
     LM_HIP(hipMemcpyAsync(s + o_sc, hsc.data(), w_sc * 4, hipMemcpyHostToDevice, ctx->stream));
     if (w_pts) LM_HIP(hipMemcpyAsync(s + o_pts, points, w_pts * 4, hipMemcpyHostToDevice, ctx->stream));
     // the host vectors must outlive the async copies
     LM_HIP(hipStreamSynchronize(ctx->stream));
     LM_LAUNCH(ctx, k_weight_tables, dim3((max_table + 255) / 256, n_items, 2), dim3(256), 0, (const WItem*)(s + o_items),
               s + o_pts, s + o_sc, s + o_arena);
-    for (size_t g0 = 0; g0 < hgr.size();) {
+    const bool dbg = getenv("LM_DEBUG_WEIGHTS") != nullptr;
+    if (init) {
+        if (dbg) fprintf(stderr, "# weights init launch: whole-domain items=%u, top-level regions=%zu\n",
+                         merged[0].item_end - merged[0].item_begin, merged.size() - 1);
+        LM_LAUNCH(ctx, k_weights_init, dim3((unsigned)((plane + W_CHUNK - 1) / W_CHUNK)), dim3(256), 0, d_W, plane,
+                  (const WGroup*)(s + o_merged), (u32)merged.size(), (const WItem*)(s + o_items), s + o_arena);
+    }
+    for (size_t g0 = 0; g0 < rest.size();) {
         size_t g1 = g0;
-        while (g1 < hgr.size() && hgr[g1].inner_n == hgr[g0].inner_n) g1++;
-        const WGroup& last = hgr[g1 - 1];
+        while (g1 < rest.size() && rest[g1].inner_n == rest[g0].inner_n) g1++;
+        const WGroup& last = rest[g1 - 1];
         const u64 n_chunks = last.chunk_begin + ((1ull << last.inner_n) + W_CHUNK - 1) / W_CHUNK;
+        if (dbg) fprintf(stderr, "# weights rmw launch inner_n=%u groups=%zu chunks=%llu\n", last.inner_n, g1 - g0,
+                         (unsigned long long)n_chunks);
         LM_LAUNCH(ctx, k_weights_accumulate, dim3((unsigned)n_chunks), dim3(256), 0, d_W, plane,
-                  (const WGroup*)(s + o_groups) + g0, (u32)(g1 - g0), (const WItem*)(s + o_items), s + o_arena);
+                  (const WGroup*)(s + o_rest) + g0, (u32)(g1 - g0), (const WItem*)(s + o_items), s + o_arena);
         g0 = g1;
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
+}
+
+extern "C" {
+
+int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                          const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars) {
+    return weights_impl(ctx, d_W, n_vars, items, n_items, points, n_point_coords, scalars, false);
+}
+int lm_weights_init(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
+                    const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars) {
+    return weights_impl(ctx, d_W, n_vars, items, n_items, points, n_point_coords, scalars, true);
 }
 
 int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars,

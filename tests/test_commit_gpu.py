@@ -112,3 +112,22 @@ def test_ood_point_is_dft_consistent(ctx, orc):
         for c in (0, 77, 127):
             got = ctx.mle_eval(d.ptr + 4 * c * col_len, False, n_vars - fold, pt_col)
             assert got[0][0] == leaves[k][c] and not got[0][1:].any()
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_stack_columns(ctx, aligned):
+    """stack_polynomials (stacked_pcs.rs:99-157): zero-padded concatenation in one pass; unaligned pieces take the copy path."""
+    rng = np.random.default_rng(3)
+    total = 1 << 14
+    src = rng.integers(0, 0x7F000001, size=1 << 13, dtype=np.uint32)
+    d_src = ctx.to_device(src)
+    if aligned:
+        jobs = [(0, 0, 1024), (1024, 1024, 256), (1280, 2048, 4), (4096, 4096, 4096), (100 * 4, 12288, 1000)]
+    else:
+        jobs = [(0, 0, 1023), (1024, 1025, 256), (4096, 4096, 4095), (3, 9000, 7)]
+    out = ctx.stack_columns(total, [(d_src, so, do, n) for so, do, n in jobs]).download()
+    want = np.zeros(total, dtype=np.uint32)
+    for so, do, n in jobs:
+        want[do:do + n] = src[so:so + n]
+    assert np.array_equal(out, want)
+    assert np.array_equal(ctx.stack_columns(64, []).download(), np.zeros(64, dtype=np.uint32))

@@ -127,6 +127,63 @@ def test_weights_accumulate_matches_oracle(ctx, orc):
     assert np.array_equal(got, want)
 
 
+def _weights_reference(orc, W0, items, pts, scalars):
+    want = W0.copy()
+    for (off, inner, nxt, po), sc in zip(items, scalars):
+        pt = pts[po:po + inner]
+        eq = orc.eq_table(pt, sc) if inner else sc.reshape(1, 5)
+        if nxt:
+            w = np.zeros_like(eq)
+            w[1:] = eq[:-1]
+            w[-1] = ef_add(w[-1], eq[-1])
+        else:
+            w = eq
+        want[off:off + (1 << inner)] = ef_add(want[off:off + (1 << inner)], w)
+    return want
+
+
+@pytest.mark.parametrize("n_vars,n_base,with_full_domain", [(12, 37, True), (12, 5, False), (7, 20, True), (3, 4, True)])
+def test_weights_base_points_and_init(ctx, orc, n_vars, n_base, with_full_domain):
+    """STIR-round shape (open.rs:337-382): a few EF (OOD) points and many base-field points on the whole domain, mixed
+    with a `next` item; base points take the delayed-reduction path.  lm_weights_init must ignore the prior contents of W
+    (plain stores when a whole-domain group exists, zero-fill otherwise)."""
+    rng = np.random.default_rng(n_vars * 100 + n_base)
+    n = 1 << n_vars
+    items, pts_list, off = [], [], 0
+    if with_full_domain:
+        for _ in range(2):  # OOD: EF points
+            items.append((0, n_vars, 0, off))
+            pts_list.append(rand_field(rng, (n_vars, 5)))
+            off += n_vars
+        for q in range(n_base):  # query points: expand_from_univariate of a base element
+            z = int(rng.integers(1, P))
+            pt = np.zeros((n_vars, 5), dtype=np.uint32)
+            pw = [pow(z, 1 << (n_vars - 1 - j), P) for j in range(n_vars)]
+            pt[:, 0] = orc.to_monty(np.array(pw, dtype=np.uint32))
+            items.append((0, n_vars, 0, off))
+            pts_list.append(pt)
+            off += n_vars
+        items.append((0, n_vars, 1, off))
+        pts_list.append(rand_field(rng, (n_vars, 5)))
+        off += n_vars
+    inner = max(n_vars - 2, 0)
+    for q in range(n_base if not with_full_domain else 2):  # a nested region with base points
+        pt = np.zeros((inner, 5), dtype=np.uint32)
+        pt[:, 0] = rand_field(rng, inner)
+        items.append((1 << inner, inner, 0, off))
+        pts_list.append(pt)
+        off += inner
+    pts = np.concatenate(pts_list) if off else np.zeros((0, 5), dtype=np.uint32)
+    scalars = rand_field(rng, (len(items), 5))
+    W0 = rand_field(rng, (n, 5))
+    dW = ctx.ef_to_device_soa(W0)
+    ctx.weights_accumulate(dW, n_vars, items, pts, scalars)
+    assert np.array_equal(dW.download().reshape(5, n).T, _weights_reference(orc, W0, items, pts, scalars))
+    dW = ctx.ef_to_device_soa(W0)  # garbage on entry
+    ctx.weights_accumulate(dW, n_vars, items, pts, scalars, init=True)
+    assert np.array_equal(dW.download().reshape(5, n).T, _weights_reference(orc, np.zeros_like(W0), items, pts, scalars))
+
+
 def test_next_weights_match_reference_definition(orc):
     """CPU-side pin of the identity used on the device: matrix_next_mle_folded(p)[i] == eq(p, i-1) (+ wrap)."""
     # the oracle's combine_statement builds `next` tables with the literal reference loop (next_mle.rs:35-53);

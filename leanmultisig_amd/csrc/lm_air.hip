@@ -94,19 +94,33 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
     }
 }
 
-// grid (blocks_x, n_z * n_seg); partial[((zi * n_seg + seg) * blocks_x + bx) * 5 + k].
-// SEG < 0: all segments in one launch, blockIdx.y = zi * n_seg + seg (small rounds: one launch, 4x shorter chains);
-// SEG >= 0: one launch per segment with blockIdx.y = zi (large rounds: each segment gets its own register budget).
+// 1-D grid of blocks_x * ny workgroups, ny = n_z * n_seg (SEG < 0) or n_z (SEG >= 0);
+// partial[((zi * n_seg + seg) * blocks_x + tile) * 5 + k].
+// Workgroup -> (tile, y) is XCD-aware: the ny workgroups that evaluate the same row pairs (at different points / segments)
+// read the same column words, so they get ids that are equal mod 8 (same XCD, same L2 — workgroups are dealt round-robin
+// over the 8 XCDs) and adjacent in dispatch order.  With y as the slow grid dimension every point re-read the columns
+// from HBM (rocprofv3 FETCH_SIZE: 10x the algorithmic bytes).
+// SEG < 0: all segments in one launch (small rounds: one launch, 5x shorter dependent chains);
+// SEG >= 0: one launch per segment (large rounds: each segment gets its own register budget).
 template <int TABLE, class T, class Cols, int SEG>
 __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
-                                                   u32* __restrict__ partial, u32* __restrict__ final_out) {
+                                                   u32* __restrict__ partial, u32* __restrict__ final_out, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
     constexpr u32 N_SEG = TABLE == air::T_POSEIDON16 ? air::POSEIDON_SEGMENTS : 1;
-    const u32 zi = SEG >= 0 ? blockIdx.y : blockIdx.y / N_SEG, seg = SEG >= 0 ? (u32)SEG : blockIdx.y % N_SEG;
+    u32 tile, y;
+    if ((blocks_x & 7) == 0) {
+        const u32 group = blockIdx.x / (8 * ny), rem = blockIdx.x % (8 * ny);
+        y = rem >> 3;
+        tile = group * 8 + (rem & 7);
+    } else {
+        y = blockIdx.x / blocks_x;
+        tile = blockIdx.x % blocks_x;
+    }
+    const u32 zi = SEG >= 0 ? y : y / N_SEG, seg = SEG >= 0 ? (u32)SEG : y % N_SEG;
     const u32 z = zi == 0 ? 0 : zi + 1;  // 0, 2, 3, ..., degree
     const u32 zm = to_monty(z);
     EF acc = ef_zero();
-    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
+    for (u64 j = (u64)tile * 256 + threadIdx.x; j < n_pairs; j += (u64)blocks_x * 256) {
         const EF v = eval_table<TABLE, T, Cols, SEG>(cols, j, zm, seg, *extra);
         acc = ef_add(acc, ef_mul(v, eq_split_at(eq, j)));
     }
@@ -122,10 +136,10 @@ __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, co
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        if (gridDim.x == 1 && N_SEG == 1)
+        if (blocks_x == 1 && N_SEG == 1)
             final_out[zi * 5 + threadIdx.x] = s;  // single workgroup per point: the round is finished here
         else
-            partial[((u64)(zi * N_SEG + seg) * gridDim.x + blockIdx.x) * 5 + threadIdx.x] = s;
+            partial[((u64)(zi * N_SEG + seg) * blocks_x + tile) * 5 + threadIdx.x] = s;
     }
 }
 // one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
@@ -190,7 +204,8 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
 template <int TABLE, class T, class Cols, int SEG>
 static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
                           u32* partial) {
-    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), grid, dim3(256), 0, c, n_pairs, extra, eq, partial, ctx->h_res);
+    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, ctx->h_res,
+              grid.x, grid.y);
     return LM_OK;
 }
 template <int TABLE, class T, class Cols>

@@ -153,6 +153,11 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
  * EF of 2^(n_vars-1) (d_out may not alias d_in). */
 int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
             uint32_t* d_out);
+/* lm_fold of f and W by r fused with lm_prod_round of the folded tables (the next round of run_product_sumcheck,
+ * product_computation.rs:37-125): d_f_out / d_W_out receive the folded SoA EF tables of n_vars - 1 variables and
+ * out_c0_c2 the next round's (c0, c2).  One pass over the data instead of three.  n_vars >= 2. */
+int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars,
+                  const uint32_t r[LM_EF_DIM], uint32_t* d_f_out, uint32_t* d_W_out, uint32_t out_c0_c2[10]);
 
 /* ---- logup numerators / denominators -----------------------------------------------------------------------------
  * The fill loops of prove_generic_logup (crates/sub_protocols/src/logup.rs:88-199) as a list of sections, natural order:

@@ -49,6 +49,7 @@ _SIGS = {
     "lm_copy_d2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
     "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
+    "lm_fold_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]),
     "lm_stack_columns": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lm_weights_init": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
@@ -414,6 +415,15 @@ class Context:
         r = _u32(r)
         self._check(self.lib.lm_fold(self.h, d_in.ptr, int(bool(in_is_ext)), n_vars, _ptr(r), out.ptr))
         return out
+
+    def fold_round(self, d_f, f_is_ext, d_W, n_vars, r):
+        """-> (f' SoA EF, W' SoA EF, c0, c2 of the next round)"""
+        half = 1 << (n_vars - 1)
+        fo, wo = self.alloc(5 * half), self.alloc(5 * half)
+        out = np.zeros(10, dtype=np.uint32)
+        rr = _u32(r)
+        self._check(self.lib.lm_fold_round(self.h, d_f.ptr, int(f_is_ext), d_W.ptr, n_vars, _ptr(rr), fo.ptr, wo.ptr, _ptr(out)))
+        return fo, wo, out[:5].copy(), out[5:].copy()
 
     def pow_grind(self, capacity, bits):
         cap = _u32(capacity)

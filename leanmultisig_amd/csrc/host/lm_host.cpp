@@ -56,6 +56,27 @@ struct Challenger {
     }
 };
 
+// LM_STAGE_TIMES=1: wall clock per stage on stderr (each mark synchronises the stream, so the total is slightly pessimistic)
+struct StageClock {
+    const char* prefix = "";
+    lm_ctx* ctx;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageClock(lm_ctx* c) : ctx(c), on(getenv("LM_STAGE_TIMES") != nullptr) {
+        if (on) {
+            lm_sync(ctx);
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+    void mark(const char* name) {
+        if (!on) return;
+        lm_sync(ctx);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "# stage %s%-28s %8.3f ms\n", prefix, name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 struct Opening {
     u64 index;
     std::vector<u32> leaf, path;
@@ -183,10 +204,11 @@ struct Sumcheck {  // SumcheckSingle, open.rs:322-330 — device resident
 
 // run_product_sumcheck / run_sumcheck_many_rounds (product_computation.rs:37-125, open.rs:384-409)
 int sumcheck_rounds(lm_ctx* ctx, lmh_prover* p, Sumcheck& sc, u32 n_rounds, u32 pow_bits, std::vector<EF>& challenges) {
+    u32 c[10];
+    bool have_c = false;  // (c0, c2) of this round already produced by the previous round's fused fold
     for (u32 r = 0; r < n_rounds; r++) {
-        u32 c[10];
-        int rc = lm_prod_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, c);
-        if (rc) return rc;
+        int rc;
+        if (!have_c && (rc = lm_prod_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, c))) return rc;
         EF c0 = ef_load(c), c2 = ef_load(c + 5);
         EF c1 = kb::ef_sub(kb::ef_sub(sc.sum, kb::ef_dbl(c0)), c2);
         add_sumcheck_poly(p, {c0, c1, c2}, nullptr);
@@ -198,10 +220,17 @@ int sumcheck_rounds(lm_ctx* ctx, lmh_prover* p, Sumcheck& sc, u32 n_rounds, u32 
         challenges.push_back(ch);
         sc.sum = kb::ef_add(c0, kb::ef_mul(ch, kb::ef_add(c1, kb::ef_mul(ch, c2))));
         int fn = sc.f_cur < 0 ? 0 : 1 - sc.f_cur, wn = 1 - sc.w_cur;
-        rc = lm_fold(ctx, sc.f, sc.f_is_ext, sc.n_vars, ch.v, sc.f_buf[fn]);
-        if (rc) return rc;
-        rc = lm_fold(ctx, sc.W, 1, sc.n_vars, ch.v, sc.w_buf[wn]);
-        if (rc) return rc;
+        // the weights change between calls (add_new_equality), so the fused look-ahead is only valid inside this loop
+        have_c = r + 1 < n_rounds && sc.n_vars >= 2;
+        if (have_c) {
+            rc = lm_fold_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, ch.v, sc.f_buf[fn], sc.w_buf[wn], c);
+            if (rc) return rc;
+        } else {
+            rc = lm_fold(ctx, sc.f, sc.f_is_ext, sc.n_vars, ch.v, sc.f_buf[fn]);
+            if (rc) return rc;
+            rc = lm_fold(ctx, sc.W, 1, sc.n_vars, ch.v, sc.w_buf[wn]);
+            if (rc) return rc;
+        }
         sc.f = sc.f_buf[fn];
         sc.f_is_ext = true;
         sc.f_cur = fn;
@@ -388,6 +417,8 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         }
     }
 
+    StageClock wclk(ctx);
+    wclk.prefix = "  whir.";
     Sumcheck sc;
     sc.ctx = ctx;
     const u64 len = 1ull << n;
@@ -406,8 +437,10 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
     sc.sum = sum;
     // f_buf[1] must hold the second fold (len/4) and later ones; f_buf[0] the first (len/2): ping-pong sizes shrink.
 
+    wclk.mark("weights_init");
     std::vector<EF> randomness;
     if ((rc = sumcheck_rounds(ctx, p, sc, fold_at(c, 0), c->starting_folding_pow_bits, randomness))) return rc;
+    wclk.mark("sumcheck_0");
 
     u64 domain_size = 1ull << (n + c->starting_log_inv_rate);
     u32 next_domain_gen_log = ilog2(domain_size) - fold_at(c, 0);  // two_adic_generator(bits)
@@ -447,14 +480,17 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
                 if (i < j) std::swap(coeffs[i], coeffs[j]);
             }
             add_ext(p, coeffs);
+            wclk.mark("final.coeffs");
             if ((rc = pow_grinding(ctx, p, c->final_query_pow_bits))) return fail(rc);
             std::vector<u64> idx;
             if (!sample_in_range(p, ilog2(domain_size >> fold_at(c, round)), c->final_queries, idx)) return fail(LM_E_INVALID);
             std::vector<u32> leaves;
             u32 lw;
             if ((rc = open_and_hint(ctx, p, tree, idx, leaves, lw))) return fail(rc);
+            wclk.mark("final.pow+queries");
             if (c->final_sumcheck_rounds > 0)
                 if ((rc = sumcheck_rounds(ctx, p, sc, c->final_sumcheck_rounds, 0, randomness))) return fail(rc);
+            wclk.mark("final.sumcheck");
             break;
         }
         const u32 fnext = fold_at(c, round + 1);
@@ -466,10 +502,13 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         u32 root[8];
         rc = lm_commit(ctx, sc.f, 1, num_variables, fnext, ilog2(inv_rate), 1ull << num_variables, &new_tree, root);
         if (rc) return fail(rc);
+        wclk.mark("round.commit");
         add_base(p, root, 8);
         std::vector<EF> ood_points, ood_answers;
         rc = sample_ood(ctx, p, c->rounds[round].ood_samples, num_variables, sc.f, true, ood_points, ood_answers);
+        wclk.mark("round.ood");
         if (!rc) rc = pow_grinding(ctx, p, c->rounds[round].query_pow_bits);
+        wclk.mark("round.pow");
         std::vector<u64> idx;
         if (!rc && !sample_in_range(p, ilog2(domain_size >> fold_at(c, round)), c->rounds[round].num_queries, idx)) rc = LM_E_INVALID;
         std::vector<u32> leaves;
@@ -479,10 +518,35 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
             lm_tree_free(ctx, new_tree);
             return fail(rc);
         }
+        wclk.mark("round.open_queries");
         const u32 ff = fold_at(c, round);
         const EF* folding_randomness = randomness.data() + (randomness.size() - ff);
+        // leaf value at the folding randomness = <leaf, eq(randomness, .)>: the eq table is shared by all queries (a base
+        // leaf then costs 5 multiplications per word instead of a chain of EF folds; same field element either way)
         std::vector<EF> stir_evals(idx.size());
-        for (size_t q = 0; q < idx.size(); q++) stir_evals[q] = eval_leaf(&leaves[q * lw], tree_is_ext, ff, folding_randomness);
+        {
+            const u64 m = 1ull << ff;
+            std::vector<EF> eq(m);
+            eq[0] = kb::ef_one();
+            for (u32 j = 0; j < ff; j++) {  // after step j: eq over the first j+1 coordinates, coordinate 0 <-> MSB
+                const u64 cur = 1ull << j;
+                for (u64 i = cur; i-- > 0;) {
+                    const EF hi = kb::ef_mul(eq[i], folding_randomness[j]);
+                    eq[2 * i + 1] = hi;
+                    eq[2 * i] = kb::ef_sub(eq[i], hi);
+                }
+            }
+            for (size_t q = 0; q < idx.size(); q++) {
+                const u32* leaf = &leaves[q * lw];
+                EF acc = kb::ef_zero();
+                if (tree_is_ext)
+                    for (u64 i = 0; i < m; i++) acc = kb::ef_add(acc, kb::ef_mul(eq[i], ef_load(leaf + 5 * i)));
+                else
+                    for (u64 i = 0; i < m; i++) acc = kb::ef_add(acc, kb::ef_mul_base(eq[i], leaf[i]));
+                stir_evals[q] = acc;
+            }
+        }
+        wclk.mark("round.stir_evals(host)");
         p->ch.duplex();
         std::vector<EF> g1;
         if (!sample_vec(p, 1, g1)) {
@@ -515,7 +579,9 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         }
         rc = lm_weights_accumulate(ctx, sc.W, num_variables, items.data(), (u32)items.size(), pts.data(), pts.size() / 5,
                                    scalars.data());
+        wclk.mark("round.weights");
         if (!rc) rc = sumcheck_rounds(ctx, p, sc, fnext, c->rounds[round].folding_pow_bits, randomness);
+        wclk.mark("round.sumcheck");
         if (rc) {
             lm_tree_free(ctx, new_tree);
             return fail(rc);
@@ -807,26 +873,6 @@ uint32_t lmh_stacked_n_vars(const lm_execution_trace* t) {
     for (int k = 0; k < 3; k++) total += (u64)kVmTables[k].n_columns << t->tables[k].log_rows;
     return log2_ceil_u64(total);
 }
-
-// LM_STAGE_TIMES=1: wall clock per stage on stderr (each mark synchronises the stream, so the total is slightly pessimistic)
-struct StageClock {
-    lm_ctx* ctx;
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    explicit StageClock(lm_ctx* c) : ctx(c), on(getenv("LM_STAGE_TIMES") != nullptr) {
-        if (on) {
-            lm_sync(ctx);
-            t0 = std::chrono::steady_clock::now();
-        }
-    }
-    void mark(const char* name) {
-        if (!on) return;
-        lm_sync(ctx);
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "# stage %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr, const lm_whir_config* cfg) {
     if (!ctx || !p || !tr || !cfg) return LM_E_INVALID;

@@ -23,6 +23,8 @@ struct lm_air {
     u32* ef[2] = {nullptr, nullptr};    // ping-pong: (n_cols + n_shift) columns x 5 planes
     int cur = -1;
     air::Extra* d_extra = nullptr;
+    air::Extra h_extra;                  // host copies outlive the asynchronous uploads (no synchronisation in lm_air_new)
+    std::vector<const u32*> h_cols;
     PrefixEqTables eqt;
 };
 
@@ -136,14 +138,13 @@ __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, co
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        if (blocks_x == 1 && N_SEG == 1)
-            final_out[zi * 5 + threadIdx.x] = s;  // single workgroup per point: the round is finished here
-        else
-            partial[((u64)(zi * N_SEG + seg) * blocks_x + tile) * 5 + threadIdx.x] = s;
+        partial[((u64)(zi * N_SEG + seg) * blocks_x + tile) * 5 + threadIdx.x] = s;
     }
 }
 // one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
-__global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n, u32* __restrict__ out) {
+// out = pinned result buffer; the block that finishes last publishes the sequence number
+__global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n, u32* __restrict__ out,
+                                                    u32* __restrict__ done_counter, u32 seq) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.x;
     u32 v[5] = {0, 0, 0, 0, 0};
@@ -162,6 +163,13 @@ __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ part
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
         out[zi * 5 + threadIdx.x] = s;
+    }
+    if (threadIdx.x < 64) {  // the five writers are in wave 0
+        __threadfence_system();
+        if (threadIdx.x == 0 && atomicAdd(done_counter, 1u) == gridDim.x - 1) {
+            *done_counter = 0;
+            lm_publish_flag(out, seq);
+        }
     }
 }
 
@@ -244,6 +252,7 @@ extern "C" {
 
 void lm_air_free(lm_ctx* ctx, lm_air* a) {
     if (!a) return;
+    (void)hipStreamSynchronize(ctx->stream);  // the uploads of lm_air_new read from *a
     lm_pool_free(ctx, (void*)a->d_base_cols);
     for (int i = 0; i < 2; i++) lm_pool_free(ctx, a->ef[i]);
     lm_pool_free(ctx, a->d_extra);
@@ -263,7 +272,7 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->deg = air::degree((int)table);
     const u64 half = 1ull << (log_rows - 1);
     const u64 ef_words0 = (u64)(a->n_cols + a->n_shift) * 5 * half;
-    air::Extra hx;
+    air::Extra& hx = a->h_extra;
     EF al, p = ef_one();
     memcpy(al.v, alpha, 20);
     for (int i = 0; i < air::MAX_ALPHA; i++) {  // air_alpha.powers() (prove_execution.rs:154-155)
@@ -283,9 +292,9 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
         return LM_E_NOMEM;
     }
     a->eqt.buf_words = PrefixEqTables::words_needed(log_rows);
-    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, d_cols, a->n_cols * sizeof(u32*), hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipMemcpyAsync(a->d_extra, &hx, sizeof hx, hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    a->h_cols.assign(d_cols, d_cols + a->n_cols);
+    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, a->h_cols.data(), a->n_cols * sizeof(u32*), hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemcpyAsync(a->d_extra, &a->h_extra, sizeof(air::Extra), hipMemcpyHostToDevice, ctx->stream));
     int rc = a->eqt.build(ctx, eq_point, log_rows);
     if (rc) {
         lm_air_free(ctx, a);
@@ -318,9 +327,10 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
     (void)d_out;
-    if (blocks * n_seg > 1) LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks * n_seg, ctx->h_res);
+    const u32 seq = ++ctx->res_seq;
+    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks * n_seg, ctx->h_res, ctx->d_sync + 1, seq);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);
     return LM_OK;
 }

@@ -46,6 +46,8 @@ struct lm_ctx {
     hipStream_t stream = nullptr;
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
+    u32* d_sync = nullptr;      // [0] PoW result (0xffffffff when idle), [1] "writers done" counter of multi-block publishers
+    u32* d_coop = nullptr;      // COOP_TAB_WORDS: per-lane coefficient table of the 16-lane Poseidon (poseidon16_coop.h)
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
     // pinned, device-visible result buffer: final reduction kernels store round results here directly, the host

@@ -1,6 +1,7 @@
 // Context, memory helpers, twiddle tables, multilinear evaluation.
 #include <stdarg.h>
 #include "lm_common.h"
+#include "poseidon16_coop.h"
 
 using namespace kb;
 
@@ -306,6 +307,9 @@ __global__ __launch_bounds__(256) void k_stack_columns(uint4* __restrict__ dst, 
     }
 }
 
+// which lane's value does lane 0 receive from a DPP row rotation by one? (defines the table of poseidon16_coop.h)
+__global__ void k_coop_probe(u32* out) { out[threadIdx.x] = coop_rot<1>(threadIdx.x); }
+
 extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
@@ -325,6 +329,28 @@ int lm_ctx_create(int device, lm_ctx** out) {
                        to_monty(LM_G24_CANON));
     LM_HIP(hipGetLastError());
     LM_HIP(hipStreamSynchronize(c->stream));
+    {
+        const u32 init[4] = {0xffffffffu, 0, 0, 0};
+        LM_HIP(hipMalloc(&c->d_sync, sizeof init));
+        LM_HIP(hipMemcpy(c->d_sync, init, sizeof init, hipMemcpyHostToDevice));
+    }
+    {  // 16-lane Poseidon: probe the DPP rotation direction, build the coefficient table for it
+        LM_HIP(hipMalloc(&c->d_coop, COOP_TAB_WORDS * 4));
+        LM_LAUNCH(c, k_coop_probe, dim3(1), dim3(64), 0, c->d_coop);
+        u32 probe[64];
+        LM_HIP(hipMemcpyAsync(probe, c->d_coop, sizeof probe, hipMemcpyDeviceToHost, c->stream));
+        LM_HIP(hipStreamSynchronize(c->stream));
+        std::vector<u32> tab(COOP_TAB_WORDS);
+        bool ok = lm_coop_table_build(probe[0], tab.data());
+        for (u32 l = 0; l < 64 && ok; l++)  // the rotation must stay inside each 16-lane row
+            ok = probe[l] == (l & ~15u) + ((probe[0] == 15 ? (l & 15) + 15 : (l & 15) + 1) & 15);
+        if (!ok) {
+            lm_set_error("lm_ctx_create: unexpected DPP row rotation (lane 0 reads lane %u)", probe[0]);
+            return LM_E_DEVICE;
+        }
+        LM_HIP(hipMemcpyAsync(c->d_coop, tab.data(), COOP_TAB_WORDS * 4, hipMemcpyHostToDevice, c->stream));
+        LM_HIP(hipStreamSynchronize(c->stream));
+    }
     *out = c;
     return LM_OK;
 }
@@ -333,6 +359,8 @@ void lm_ctx_destroy(lm_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
+    if (c->d_coop) (void)hipFree(c->d_coop);
+    if (c->d_sync) (void)hipFree(c->d_sync);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);

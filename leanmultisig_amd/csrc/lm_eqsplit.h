@@ -9,28 +9,36 @@
 //   p <= H : one table over the first p coordinates
 //   p >  H : T_hi over the first H coordinates  x  T_lo over coordinates [H, p)
 // with H = ceil(P1 / 2).  All tables of a point are built by one launch.
-struct EqTableDesc {
-    kb::u64 off;
-    kb::u32 c0, nb;
+// The point and the table layout travel as kernel arguments (no host-to-device copy, no synchronisation per sumcheck):
+// table d <= H: coordinates [0, d), offset 5 (2^d - 1); table d > H: coordinates [H, d), after the hi tables.
+static constexpr kb::u32 EQ_MAX_COORDS = 32;
+struct EqPointArg {
+    kb::u32 v[EQ_MAX_COORDS * 5];
+    kb::u32 H, P1;
 };
+__host__ __device__ inline kb::u64 eq_table_offset(kb::u32 d, kb::u32 H) {
+    if (d <= H) return 5ull * ((1ull << d) - 1);
+    return 5ull * ((1ull << (H + 1)) - 1) + 5ull * ((1ull << (d - H)) - 2);  // + sum_{p=H+1}^{d-1} 2^(p-H)
+}
 template <int UNUSED>
-__global__ __launch_bounds__(256) void k_prefix_eq_tables(const EqTableDesc* __restrict__ descs, const kb::u32* __restrict__ point,
-                                                          kb::u32* __restrict__ arena) {
+__global__ __launch_bounds__(256) void k_prefix_eq_tables(EqPointArg pt, kb::u32* __restrict__ arena) {
     using namespace kb;
-    const EqTableDesc d = descs[blockIdx.y];
-    const u32 len = 1u << d.nb;
+    const u32 d = blockIdx.y;  // 0 .. P1
+    const u32 c0 = d <= pt.H ? 0 : pt.H, nb = d <= pt.H ? d : d - pt.H;
+    const u64 off = eq_table_offset(d, pt.H);
+    const u32 len = 1u << nb;
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;
     EF acc = ef_one();
-    for (u32 j = 0; j < d.nb; j++) {
+    for (u32 j = 0; j < nb; j++) {
         EF p;
 #pragma unroll
-        for (int k = 0; k < 5; k++) p.v[k] = point[(d.c0 + j) * 5 + k];
-        u32 bit = (i >> (d.nb - 1 - j)) & 1;
+        for (int k = 0; k < 5; k++) p.v[k] = pt.v[(c0 + j) * 5 + k];
+        u32 bit = (i >> (nb - 1 - j)) & 1;
         acc = ef_mul(acc, bit ? p : ef_sub(ef_one(), p));
     }
 #pragma unroll
-    for (int k = 0; k < 5; k++) arena[d.off + (u64)k * len + i] = acc.v[k];
+    for (int k = 0; k < 5; k++) arena[off + (u64)k * len + i] = acc.v[k];
 }
 
 struct EqSplit {
@@ -67,35 +75,26 @@ struct PrefixEqTables {
     // point: host, n_coords x 5 words; tables for prefixes of the first P1 = n_coords - 1 coordinates
     int build(lm_ctx* ctx, const kb::u32* point, kb::u32 n_coords) {
         using namespace kb;
-        LM_REQUIRE(d_buf && n_coords >= 1);
+        LM_REQUIRE(d_buf && n_coords >= 1 && n_coords <= EQ_MAX_COORDS);
         const u32 P1 = n_coords - 1;
         H = (P1 + 1) / 2;
-        std::vector<EqTableDesc> descs;
         th_off.assign(H + 1, 0);
         tl_off.assign(P1 + 1, 0);
-        u64 off = 0;
         u32 max_len = 1;
         for (u32 q = 0; q <= H; q++) {
-            th_off[q] = off;
-            descs.push_back({off, 0, q});
-            off += 5ull << q;
+            th_off[q] = eq_table_offset(q, H);
             max_len = std::max(max_len, 1u << q);
         }
         for (u32 p = H + 1; p <= P1; p++) {
-            tl_off[p] = off;
-            descs.push_back({off, H, p - H});
-            off += 5ull << (p - H);
+            tl_off[p] = eq_table_offset(p, H);
             max_len = std::max(max_len, 1u << (p - H));
         }
-        const u64 tail = (off + 15) & ~15ull;
-        const u64 desc_words = (descs.size() * sizeof(EqTableDesc) + 3) / 4;
-        const u64 pt_off = (tail + desc_words + 15) & ~15ull;
-        LM_REQUIRE(pt_off + (u64)n_coords * 5 <= buf_words);
-        LM_HIP(hipMemcpyAsync(d_buf + tail, descs.data(), descs.size() * sizeof(EqTableDesc), hipMemcpyHostToDevice, ctx->stream));
-        LM_HIP(hipMemcpyAsync(d_buf + pt_off, point, (u64)n_coords * 20, hipMemcpyHostToDevice, ctx->stream));
-        LM_HIP(hipStreamSynchronize(ctx->stream));  // descs is a local
-        LM_LAUNCH(ctx, k_prefix_eq_tables<0>, dim3((max_len + 255) / 256, (u32)descs.size()), dim3(256), 0,
-                  (const EqTableDesc*)(d_buf + tail), (const u32*)(d_buf + pt_off), d_buf);
+        LM_REQUIRE(eq_table_offset(P1 + 1, H) <= buf_words || P1 + 1 <= H);
+        EqPointArg a;
+        memcpy(a.v, point, (size_t)n_coords * 20);
+        a.H = H;
+        a.P1 = P1;
+        LM_LAUNCH(ctx, k_prefix_eq_tables<0>, dim3((max_len + 255) / 256, P1 + 1), dim3(256), 0, a, d_buf);
         LM_HIP(hipGetLastError());
         return LM_OK;
     }

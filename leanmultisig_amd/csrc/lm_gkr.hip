@@ -277,7 +277,18 @@ __global__ __launch_bounds__(256) void k_gkr_fold_round(const u32* __restrict__ 
             pair_accumulate(o[0][0], o[N_OUT - 1][0], o[0][1], o[N_OUT - 1][1], o[0][2], o[N_OUT - 1][2], o[0][3], o[N_OUT - 1][3], w, acc);
         }
     }
-    if constexpr (!LAST) finish_round(acc, lds, tot, partial, alpha, final_out, seq);
+    if constexpr (!LAST) {
+        finish_round(acc, lds, tot, partial, alpha, final_out, seq);
+    } else {
+        // layer end: the four folded values go straight to the pinned result buffer (one lane wrote them)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) final_out[q * 5 + k] = out[((u64)q * 5 + k) * m_out];
+            lm_publish_flag(final_out, seq);
+        }
+    }
 }
 
 extern "C" {
@@ -426,12 +437,12 @@ int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[5], uint32_t 
     int rc = lm_scratch(ctx, 64, &s);
     if (rc) return rc;
     LM_REQUIRE(g->cur >= 0);  // K >= 5 rounds, so at least one fold happened
-    const u32 seq = 0;        // nothing is published by the final fold
+    const u32 seq = ++ctx->res_seq;
     LM_LAUNCH(ctx, (k_gkr_fold_round<2, true>), dim3(1), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
               (const u32*)g->work[g->cur], (u64)1, r, eq, g->work[dst], s, g->alpha, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(inner_evals, g->work[dst], 80, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
+    memcpy(inner_evals, ctx->h_res, 80);
     g->cur = dst;
     g->m = 1;
     return LM_OK;

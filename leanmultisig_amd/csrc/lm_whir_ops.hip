@@ -348,6 +348,61 @@ __global__ __launch_bounds__(256) void k_fold_ext(const u32* __restrict__ in, u6
     }
 }
 
+// Fold both tables by r and accumulate the NEXT round's (c0, c2) on the folded values while they are in registers:
+// one pass instead of fold(f), fold(W), prod_round (which would read f', W' again).  quarter = half / 2 >= 1.
+// Lane i < quarter produces outputs i and i + quarter (the next round's pair) from inputs i, i+quarter, i+half, i+half+quarter.
+template <bool F_BASE>
+__global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, const u32* __restrict__ W, u64 half, EF r,
+                                                    u32* __restrict__ f_out, u32* __restrict__ W_out, u32* __restrict__ partial,
+                                                    u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[40];
+    const u64 plane = 2 * half, quarter = half >> 1;
+    EF c0 = ef_zero(), c2 = ef_zero();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
+        EF fo[2], wo[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const u64 j = i + t * quarter;
+            EF a, b;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                a.v[k] = W[(u64)k * plane + j];
+                b.v[k] = W[(u64)k * plane + j + half];
+            }
+            wo[t] = ef_add(a, ef_mul(r, ef_sub(b, a)));
+            if (F_BASE) {
+                const u32 fa = f[j], d = sub(f[j + half], fa);
+                fo[t] = ef_mul_base(r, d);
+                fo[t].v[0] = add(fo[t].v[0], fa);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    a.v[k] = f[(u64)k * plane + j];
+                    b.v[k] = f[(u64)k * plane + j + half];
+                }
+                fo[t] = ef_add(a, ef_mul(r, ef_sub(b, a)));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                f_out[(u64)k * half + j] = fo[t].v[k];
+                W_out[(u64)k * half + j] = wo[t].v[k];
+            }
+        }
+        c0 = ef_add(c0, ef_mul(fo[0], wo[0]));
+        c2 = ef_add(c2, ef_mul(ef_sub(fo[1], fo[0]), ef_sub(wo[1], wo[0])));
+    }
+    u32 v[10];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        v[k] = c0.v[k];
+        v[5 + k] = c2.v[k];
+    }
+    if (gridDim.x == 1)
+        block_sum10(v, red, final_out, final_out, seq);
+    else
+        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+}
+
 // =====================================================================================================
 // PoW: candidates base .. base + n; result = min hit (or 0xffffffff)
 // =====================================================================================================
@@ -513,6 +568,15 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
     return LM_OK;
 }
 
+// result -> pinned host buffer, device word re-armed for the next grind, sequence flag (no copy command, no stream sync)
+__global__ void k_pow_publish(u32* __restrict__ result, u32* __restrict__ h_res, u32 seq) {
+    if (threadIdx.x == 0) {
+        h_res[0] = *result;
+        *result = 0xffffffffu;
+        lm_publish_flag(h_res, seq);
+    }
+}
+
 extern "C" {
 
 int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
@@ -561,15 +625,34 @@ int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, c
     return LM_OK;
 }
 
+int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, const uint32_t r[LM_EF_DIM],
+                  uint32_t* d_f_out, uint32_t* d_W_out, uint32_t out_c0_c2[10]) {
+    LM_REQUIRE(ctx && d_f && d_W && d_f_out && d_W_out && r && out_c0_c2 && n_vars >= 2 && n_vars <= 40);
+    const u64 half = 1ull << (n_vars - 1), quarter = half >> 1;
+    const u32 blocks = quarter <= 512 ? 1 : (u32)std::min<u64>((quarter + 255) / 256, 4096);
+    const u32 seq = ++ctx->res_seq;
+    u32* s;
+    int rc = lm_scratch(ctx, (u64)blocks * 10 + 16, &s);
+    if (rc) return rc;
+    EF rr;
+    memcpy(rr.v, r, 20);
+    if (f_is_ext)
+        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->h_res, seq);
+    else
+        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->h_res, seq);
+    if (blocks > 1) LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res, seq);
+    LM_HIP(hipGetLastError());
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
+    memcpy(out_c0_c2, ctx->h_res, 40);
+    return LM_OK;
+}
+
 int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_t* witness) {
     LM_REQUIRE(ctx && capacity && witness && bits < 31);
     if (bits == 0) {
         *witness = 0;
         return LM_OK;
     }
-    u32* s;
-    int rc = lm_scratch(ctx, 16, &s);
-    if (rc) return rc;
     PowArgs a;
     memcpy(a.cap, capacity, 32);
     a.mask = (1u << bits) - 1;
@@ -577,14 +660,15 @@ int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_
     // batch sized to the expected work (2^bits candidates), at least one full wave of the chip
     u64 batch = std::max<u64>(1ull << 16, std::min<u64>(1ull << bits, 1ull << 22));
     for (u64 base = 0; base < P; base += batch) {
-        LM_HIP(hipMemsetAsync(s, 0xff, 4, ctx->stream));
         a.base = (u32)base;
         a.n = (u32)std::min<u64>(batch, (u64)P - base);
-        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, s);
+        const u32 seq = ++ctx->res_seq;
+        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, ctx->d_sync);
+        LM_LAUNCH(ctx, k_pow_publish, dim3(1), dim3(64), 0, ctx->d_sync, ctx->h_res, seq);
         LM_HIP(hipGetLastError());
-        u32 res;
-        LM_HIP(hipMemcpyAsync(&res, s, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LM_HIP(hipStreamSynchronize(ctx->stream));
+        int rc = lm_wait_result(ctx, seq);
+        if (rc) return rc;
+        const u32 res = ctx->h_res[0];
         if (res != 0xffffffffu) {
             *witness = to_monty(res);
             return LM_OK;

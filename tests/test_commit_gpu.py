@@ -131,3 +131,18 @@ def test_stack_columns(ctx, aligned):
         want[do:do + n] = src[so:so + n]
     assert np.array_equal(out, want)
     assert np.array_equal(ctx.stack_columns(64, []).download(), np.zeros(64, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 4096, 16384, 16385, 40000])
+def test_poseidon_batch_both_kernels(ctx, orc, n):
+    """lm_poseidon16_permute / compress switch to the 16-lane cooperative kernel at small n (poseidon16_coop.h): same
+    permutation on both sides of the threshold, checked against the textbook oracle."""
+    rng = np.random.default_rng(n)
+    st = rand_field(rng, (n, 16))
+    got_p = ctx.poseidon16(st)
+    got_c = ctx.poseidon16(st, compress=True)
+    idx = np.unique(np.concatenate([[0, n - 1], rng.integers(0, n, size=min(n, 40))]))
+    for i in idx:
+        want = orc.poseidon16_permute(st[i:i + 1])[0]
+        assert np.array_equal(got_p[i], want), i
+        assert np.array_equal(got_c[i], (want.astype(np.uint64) + st[i]) % P), i

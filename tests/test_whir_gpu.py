@@ -127,6 +127,22 @@ def test_weights_accumulate_matches_oracle(ctx, orc):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n_vars", [2, 3, 9, 13])
+def test_fold_round_equals_fold_then_prod_round(ctx, n_vars):
+    """lm_fold_round = lm_fold(f), lm_fold(W), lm_prod_round on the results, bit for bit, for base and EF f."""
+    rng = np.random.default_rng(40 + n_vars)
+    n = 1 << n_vars
+    r = rand_field(rng, 5)
+    dW = ctx.ef_to_device_soa(rand_field(rng, (n, 5)))
+    for f_is_ext in (False, True):
+        df = ctx.ef_to_device_soa(rand_field(rng, (n, 5))) if f_is_ext else ctx.to_device(rand_field(rng, n))
+        f2, W2 = ctx.fold(df, f_is_ext, n_vars, r), ctx.fold(dW, True, n_vars, r)
+        c0, c2 = ctx.prod_round(f2, True, W2, n_vars - 1)
+        g2, V2, d0, d2 = ctx.fold_round(df, f_is_ext, dW, n_vars, r)
+        assert np.array_equal(g2.download(), f2.download()) and np.array_equal(V2.download(), W2.download())
+        assert list(d0) == list(c0) and list(d2) == list(c2)
+
+
 def _weights_reference(orc, W0, items, pts, scalars):
     want = W0.copy()
     for (off, inner, nxt, po), sc in zip(items, scalars):

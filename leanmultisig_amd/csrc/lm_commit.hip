@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void k_compress_layer_coop(const u32* __restri
 }
 // the last levels of a tree in ONE workgroup of 256 lanes (16 nodes per pass): level sizes n0 >= n0/2 >= .. >= 1 nodes,
 // level k read at lvl and written right behind it (digest layers are contiguous, bottom-up)
-__global__ __launch_bounds__(256) void k_merkle_top_coop(u32* __restrict__ lvl, u64 n_in, const u32* __restrict__ tab) {
+// The root is published through the pinned result buffer (sequence flag), so lm_commit needs no copy command.
+__global__ __launch_bounds__(256) void k_merkle_top_coop(u32* __restrict__ lvl, u64 n_in, const u32* __restrict__ tab,
+                                                         u32* __restrict__ h_res, u32 seq) {
     CoopRegs R;
     coop_load(R, tab);
     const u32 l = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -258,6 +260,11 @@ __global__ __launch_bounds__(256) void k_merkle_top_coop(u32* __restrict__ lvl, 
         __threadfence_block();
         __syncthreads();
         cur = nxt;
+    }
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < 8) h_res[threadIdx.x] = cur[threadIdx.x];
+        __threadfence_system();
+        if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
     }
 }
 // leaf sponge with one row per 16 lanes: lanes 0..7 carry the chaining value, lanes 8..15 fetch the next chunk
@@ -478,10 +485,12 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
     // levels: one permutation per lane while the level fills the chip, 16 lanes per node below that, and the last levels
     // (<= 64 nodes) in a single workgroup
     u64 off = 0;
+    u32 root_seq = 0;
     for (u64 n = h; n > 1; n >>= 1) {
         u64 next_n = n >> 1;
         if (next_n <= 64) {
-            LM_LAUNCH(ctx, k_merkle_top_coop, dim3(1), dim3(256), 0, t->d_digests + off * 8, n, coop);
+            root_seq = ++ctx->res_seq;
+            LM_LAUNCH(ctx, k_merkle_top_coop, dim3(1), dim3(256), 0, t->d_digests + off * 8, n, coop, ctx->h_res, root_seq);
             break;
         }
         if (next_n <= COOP_MAX_PERMS)
@@ -492,9 +501,15 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
                       t->d_digests + off * 8, t->d_digests + (off + n) * 8, next_n);
         off += n;
     }
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(root, t->d_digests + (2 * h - 2) * 8, 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    bool ok = hipGetLastError() == hipSuccess;
+    if (ok && root_seq) {
+        ok = lm_wait_result(ctx, root_seq) == LM_OK;
+        if (ok) memcpy(root, ctx->h_res, 32);
+    } else if (ok) {  // single-row tree: the leaf digest is the root
+        ok = hipMemcpyAsync(root, t->d_digests + (2 * h - 2) * 8, 32, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (!ok) {
         lm_set_error("lm_commit: kernel launch / sync failed: %s", hipGetErrorString(hipGetLastError()));
         lm_tree_free(ctx, t);
         return LM_E_DEVICE;

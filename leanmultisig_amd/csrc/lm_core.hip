@@ -43,7 +43,11 @@ __global__ void k_soa_to_aos(const u32* __restrict__ soa, u32* __restrict__ aos,
 // One entry per thread: n EF multiplications.  Only used for small tables (<= 2^16).
 // point: device, n x 5 words AoS.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_eq_table_small(const u32* __restrict__ point, u32 n, u32* __restrict__ out) {
+// the coordinates travel as a kernel argument (no host-to-device copy per evaluation)
+struct EqSmallArg {
+    u32 v[20 * 5];
+};
+__global__ void k_eq_table_small(EqSmallArg point, u32 n, u32* __restrict__ out) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u32 len = 1u << n;
     if (i >= len) return;
@@ -51,7 +55,7 @@ __global__ void k_eq_table_small(const u32* __restrict__ point, u32 n, u32* __re
     for (u32 j = 0; j < n; j++) {
         EF p;
 #pragma unroll
-        for (int k = 0; k < 5; k++) p.v[k] = point[j * 5 + k];
+        for (int k = 0; k < 5; k++) p.v[k] = point.v[j * 5 + k];
         u32 bit = (i >> (n - 1 - j)) & 1;
         EF f = bit ? p : ef_sub(ef_one(), p);
         acc = ef_mul(acc, f);
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(256) void k_mle_partial_ext(const u32* __restrict__
     }
 }
 // out[poly] = sum_hi partial[poly][hi]   (AoS EF)
-__global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ partial, u32 n_hi, u32* __restrict__ out) {
+// publish_to != NULL: out is the pinned result buffer; the last block to finish stores the sequence number
+__global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ partial, u32 n_hi, u32* __restrict__ out,
+                                                      u32* __restrict__ done_counter, u32* publish_to, u32 seq) {
     __shared__ u32 red[32];
     const u32 poly = blockIdx.x;
     EF s = ef_zero();
@@ -198,6 +204,13 @@ __global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ pa
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 5; k++) out[poly * 5 + k] = r.v[k];
+        if (publish_to) {
+            __threadfence_system();
+            if (atomicAdd(done_counter, 1u) == gridDim.x - 1) {
+                *done_counter = 0;
+                lm_publish_flag(publish_to, seq);
+            }
+        }
     }
 }
 
@@ -465,16 +478,16 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     u32* s;
     int rc = lm_scratch(ctx, need, &s);
     if (rc) return rc;
-    u32* d_point = s;
-    u32* d_eq_lo = d_point + ((n_vars * 5 + 15) & ~15u);
+    u32* d_eq_lo = s;
     u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
     u32* d_partial = d_eq_hi + 5ull * n_hi;
     u32* d_out = d_partial + (u64)n_polys * n_hi * 5;
-    if (n_vars) LM_HIP(hipMemcpyAsync(d_point, point, (u64)n_vars * 20, hipMemcpyHostToDevice, ctx->stream));
     // point = (hi part: first k_hi coordinates) ++ (lo part: last k_lo coordinates)
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, d_point, k_hi, d_eq_hi);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, d_point + k_hi * 5, k_lo,
-                       d_eq_lo);
+    EqSmallArg p_hi, p_lo;
+    if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
+    if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
     if (!is_ext)
         LM_LAUNCH(ctx, k_mle_partial_base, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words, k_lo,
                            d_eq_lo, d_eq_hi, n_hi, d_partial);
@@ -482,11 +495,19 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
         LM_LAUNCH(ctx, k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words,
                            1ull << n_vars, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
     const bool pinned = (u64)n_polys * 5 <= lm_ctx::RES_WORDS;
-    LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, d_partial, n_hi, pinned ? ctx->h_res : d_out);
-    LM_HIP(hipGetLastError());
-    if (!pinned) LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
-    if (pinned) memcpy(out, ctx->h_res, (u64)n_polys * 20);
+    if (pinned) {
+        const u32 seq = ++ctx->res_seq;
+        LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res,
+                  seq);
+        LM_HIP(hipGetLastError());
+        if ((rc = lm_wait_result(ctx, seq))) return rc;
+        memcpy(out, ctx->h_res, (u64)n_polys * 20);
+    } else {
+        LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, (const u32*)d_partial, n_hi, d_out, ctx->d_sync + 1, (u32*)nullptr, 0u);
+        LM_HIP(hipGetLastError());
+        LM_HIP(hipMemcpyAsync(out, d_out, (u64)n_polys * 20, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return LM_OK;
 }
 
@@ -498,25 +519,28 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     const u32 k_lo = n_vars < 12 ? n_vars : 12;
     const u32 k_hi = n_vars - k_lo;
     const u32 n_hi = 1u << k_hi, len_lo = 1u << k_lo;
-    const u64 need = 2ull * n_cols + (u64)n_vars * 5 + 5ull * len_lo + 5ull * n_hi + (u64)n_cols * n_hi * 5 + 64;
+    LM_REQUIRE(k_hi <= 20);
+    const u64 need = 2ull * n_cols + 5ull * len_lo + 5ull * n_hi + (u64)n_cols * n_hi * 5 + 96;
     u32* s;
     int rc = lm_scratch(ctx, need, &s);
     if (rc) return rc;
     const u32** d_ptrs = reinterpret_cast<const u32**>(s);
-    u32* d_point = s + 2ull * n_cols;
-    u32* d_eq_lo = d_point + ((n_vars * 5 + 15) & ~15u);
+    u32* d_eq_lo = s + ((2ull * n_cols + 15) & ~15ull);
     u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
     u32* d_partial = d_eq_hi + 5ull * n_hi;
     LM_HIP(hipMemcpyAsync((void*)d_ptrs, d_cols, (u64)n_cols * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (n_vars) LM_HIP(hipMemcpyAsync(d_point, point, (u64)n_vars * 20, hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, d_point, k_hi, d_eq_hi);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, d_point + k_hi * 5, k_lo, d_eq_lo);
+    LM_HIP(hipStreamSynchronize(ctx->stream));  // d_cols is the caller's
+    EqSmallArg p_hi, p_lo;
+    if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
+    if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
+    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
     LM_LAUNCH(ctx, k_mle_partial_cols, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, k_lo, d_eq_lo, d_eq_hi, n_hi,
               d_partial);
-    LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, d_partial, n_hi, ctx->h_res);
+    const u32 seq = ++ctx->res_seq;
+    LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out, ctx->h_res, (u64)n_cols * 20);
     return LM_OK;
 }

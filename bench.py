@@ -221,7 +221,7 @@ def main():
                             "execution trace to the proof on a consistent synthetic leanVM trace — 258850 Poseidon rows, "
                             "tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
-                "stages": ["fiat_shamir_preamble", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
+                "stages": ["fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
                            "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)"],
                 "missing": ["witness generation: VM interpreter + trace builder (CPU, SURVEY §8(f) rank 1/4) — the reference's "
                             "whole-node number includes it"],

@@ -114,6 +114,13 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
 int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t n_vars, const uint32_t* point,
                      uint32_t* out);
 /* device-to-device copy of n_words (stack_polynomials_and_commit, crates/sub_protocols/src/stacked_pcs.rs:118-136) */
+/* Access counters of prove_execution (crates/lean_prover/src/prove_execution.rs:90-110): d_acc[0..len) = number of times
+ * each address is read, as field elements: for every job (an index column of a table lookup, canonical value = address)
+ * and every row, d_acc[address + j] += 1 for j < n_values.  Rows whose address range falls outside [0, len) are ignored
+ * (the reference would panic).  Used for memory_acc (all table lookups) and bytecode_acc (the pc column, n_values = 1). */
+int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint32_t n_jobs, const uint32_t* const* d_index_cols,
+                     const uint64_t* n_rows, const uint32_t* n_values);
+
 /* stack_polynomials (crates/sub_protocols/src/stacked_pcs.rs:99-157): d_dst[0..total_words) = zero everywhere except
  * d_dst[dst_offset[i] .. +n_words[i]) = d_src[i][0..n_words[i]).  d_src is a HOST array of device pointers; jobs must be
  * sorted by dst_offset and disjoint.  One pass over the destination (no separate zero-fill). */

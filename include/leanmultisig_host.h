@@ -117,9 +117,9 @@ typedef struct {
     const uint32_t* public_input;  /* host */
     const uint32_t* bytecode_hash; /* host, 8 words */
     const uint32_t* d_bytecode;    /* device */
-    const uint32_t* d_bytecode_acc;
+    const uint32_t* d_bytecode_acc; /* access counters: NULL = computed on the device (prove_execution.rs:90-110) */
     const uint32_t* d_memory;
-    const uint32_t* d_memory_acc;
+    const uint32_t* d_memory_acc;   /* NULL = computed on the device */
     lm_vm_table tables[3]; /* indexed by table id: execution, extension_op, poseidon16 */
 } lm_execution_trace;
 uint32_t lmh_stacked_n_vars(const lm_execution_trace* trace); /* compute_stacked_n_vars, stacked_pcs.rs:183-196 */

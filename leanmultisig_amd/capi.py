@@ -50,6 +50,7 @@ _SIGS = {
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
     "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_fold_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]),
+    "lm_access_counts": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lm_stack_columns": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lm_weights_init": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
@@ -363,6 +364,16 @@ class Context:
         return out
 
 
+    def access_counts(self, length, jobs):
+        """jobs: list of (DeviceBuffer index column, n_rows, n_values) -> DeviceBuffer of `length` field elements"""
+        out = self.alloc(length)
+        n = len(jobs)
+        cols = (C.c_void_p * max(n, 1))(*[b.ptr for b, _, _ in jobs])
+        rows = (C.c_uint64 * max(n, 1))(*[r for _, r, _ in jobs])
+        nv = (C.c_uint32 * max(n, 1))(*[v for _, _, v in jobs])
+        self._check(self.lib.lm_access_counts(self.h, out.ptr, length, n, cols, rows, nv))
+        return out
+
     def stack_columns(self, total_words, jobs):
         """jobs: list of (DeviceBuffer src, src_word_offset, dst_offset, n_words) sorted by dst_offset -> DeviceBuffer"""
         out = self.alloc(total_words)
@@ -432,8 +443,10 @@ class Context:
         return w.value
 
 
-def make_execution_trace(ctx, w):
-    """Upload a witness dict (tests/synth_witness.py layout) and build the lm_execution_trace; returns (trace, keepalive)."""
+def make_execution_trace(ctx, w, device_counters=True):
+    """Upload a witness dict (tests/synth_witness.py layout) and build the lm_execution_trace; returns (trace, keepalive).
+    device_counters: leave memory_acc / bytecode_acc to the library (prove_execution.rs:90-110 on the device) instead of
+    uploading the witness's own."""
     keep = []
     tr = ExecutionTrace()
     tr.log_inv_rate, tr.log_memory, tr.log_bytecode = w["log_inv_rate"], w["log_memory"], w["log_bytecode"]
@@ -443,6 +456,9 @@ def make_execution_trace(ctx, w):
     keep += [pi, bh]
     tr.n_public_input, tr.public_input, tr.bytecode_hash = pi.size, pi.ctypes.data, bh.ctypes.data
     for name, key in (("d_bytecode", "bytecode"), ("d_bytecode_acc", "bytecode_acc"), ("d_memory", "memory"), ("d_memory_acc", "memory_acc")):
+        if device_counters and key.endswith("_acc"):
+            setattr(tr, name, None)
+            continue
         b = ctx.to_device(w[key])
         keep.append(b)
         setattr(tr, name, b.ptr)

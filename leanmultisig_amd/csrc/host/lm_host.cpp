@@ -908,10 +908,36 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
         offs.push_back(at);
         lens.push_back(n);
     };
+    // access counters (prove_execution.rs:90-110) unless the caller already has them
+    DevBuf mem_acc(ctx), bc_acc(ctx);
+    const u32* d_memory_acc = tr->d_memory_acc;
+    const u32* d_bytecode_acc = tr->d_bytecode_acc;
+    if (!d_memory_acc) {
+        std::vector<const u32*> idx;
+        std::vector<u64> rows;
+        std::vector<u32> nv;
+        for (int t = 0; t < 3; t++)
+            for (u32 l = 0; l < kVmTables[t].n_lookups; l++) {
+                idx.push_back(tr->tables[t].d_cols[kVmTables[t].lookups[l].index]);
+                rows.push_back(1ull << tr->tables[t].log_rows);
+                nv.push_back(kVmTables[t].lookups[l].n_values);
+            }
+        if ((rc = lm_malloc(ctx, mem, &mem_acc.p))) return rc;
+        if ((rc = lm_access_counts(ctx, mem_acc.p, mem, (u32)idx.size(), idx.data(), rows.data(), nv.data()))) return rc;
+        d_memory_acc = mem_acc.p;
+    }
+    if (!d_bytecode_acc) {
+        const u32* pc = tr->tables[0].d_cols[0];  // COL_PC
+        const u64 rows = 1ull << tr->tables[0].log_rows;
+        const u32 one = 1;
+        if ((rc = lm_malloc(ctx, 1ull << log_bc, &bc_acc.p))) return rc;
+        if ((rc = lm_access_counts(ctx, bc_acc.p, 1ull << log_bc, 1, &pc, &rows, &one))) return rc;
+        d_bytecode_acc = bc_acc.p;
+    }
     place(tr->d_memory, 0, mem);
-    place(tr->d_memory_acc, mem, mem);
+    place(d_memory_acc, mem, mem);
     u64 off = 2 * mem;
-    place(tr->d_bytecode_acc, off, 1ull << log_bc);
+    place(d_bytecode_acc, off, 1ull << log_bc);
     off += std::max(1ull << tr->tables[order[0]].log_rows, 1ull << log_bc);
     for (int k = 0; k < 3; k++) {
         const int t = order[k];
@@ -962,11 +988,11 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     };
     u64 loff = 0;
     {
-        lm_logup_section* s = new_sec(loff, log_mem, 3, tr->d_memory_acc, -1, 0);  // logup.rs:94-109
+        lm_logup_section* s = new_sec(loff, log_mem, 3, d_memory_acc, -1, 0);  // logup.rs:94-109
         add_data(s, tr->d_memory, 1, 0);
         add_data(s, nullptr, 0, 0);
         loff += mem;
-        s = new_sec(loff, log_bc, 3, tr->d_bytecode_acc, -1, 2);  // :111-125
+        s = new_sec(loff, log_bc, 3, d_bytecode_acc, -1, 2);  // :111-125
         for (u32 k = 0; k < 12; k++) add_data(s, tr->d_bytecode + k, 16, 0);
         add_data(s, nullptr, 0, 0);
         loff += std::max(1ull << log_bc, 1ull << tr->tables[order[0]].log_rows);
@@ -1009,11 +1035,11 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     auto from_end = [&](u32 n) { return gkr_pt.data() + (size_t)(gkr_n_vars - n) * 5; };
     // column evaluations (logup.rs:224-308)
     EF value_memory_acc, value_memory, value_bytecode_acc;
-    if ((rc = lm_mle_eval(ctx, tr->d_memory_acc, 0, log_mem, 1, 0, from_end(log_mem), value_memory_acc.v))) return fail(rc);
+    if ((rc = lm_mle_eval(ctx, d_memory_acc, 0, log_mem, 1, 0, from_end(log_mem), value_memory_acc.v))) return fail(rc);
     add_base(p, value_memory_acc.v, 5);
     if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, log_mem, 1, 0, from_end(log_mem), value_memory.v))) return fail(rc);
     add_base(p, value_memory.v, 5);
-    if ((rc = lm_mle_eval(ctx, tr->d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail(rc);
+    if ((rc = lm_mle_eval(ctx, d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail(rc);
     add_base(p, value_bytecode_acc.v, 5);
     struct ColVal {
         u32 col;

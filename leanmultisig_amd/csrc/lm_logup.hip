@@ -65,6 +65,62 @@ __global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u32* __restric
     }
 }
 
+// ---- access counters (crates/lean_prover/src/prove_execution.rs:90-110) ---------------------------------------------
+// acc[index(row) + j] += 1 for every row of an index column and j < n_values: a histogram.  The reference loops
+// sequentially ("TODO parallelize"); here: integer atomics, with the whole-wave-same-address case (padding rows, which all
+// point at one address) collapsed into one atomic, then one pass converts counts to field elements in place.
+struct AccessJob {
+    const u32* index_col;  // Montgomery words, canonical value = address
+    u64 n_rows;
+    u32 n_values, pad;
+};
+// (A difference-array variant — +1 at the address, -1 after the last word, prefix sum — was measured SLOWER on MI355X:
+// device-scope atomics are executed memory-side, and n_values atomics on one cache line cost less than two on distant lines.)
+__global__ __launch_bounds__(256) void k_access_count(const AccessJob* __restrict__ jobs, u32* __restrict__ cnt, u64 len) {
+    const AccessJob jb = jobs[blockIdx.y];
+    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < jb.n_rows; r += (u64)gridDim.x * 256) {
+        const u32 a = from_monty(jb.index_col[r]);
+        const bool ok = (u64)a + jb.n_values <= len;
+        const u32 first = __builtin_amdgcn_readfirstlane(a);
+        const u64 same = __ballot(a == first);
+        if (same == __ballot(1)) {  // every active lane hits the same address: one lane adds for the wave
+            if (ok && (threadIdx.x & 63) == (u32)__builtin_ctzll(same))
+                for (u32 j = 0; j < jb.n_values; j++) atomicAdd(&cnt[a + j], (u32)__popcll(same));
+        } else if (ok) {
+            for (u32 j = 0; j < jb.n_values; j++) atomicAdd(&cnt[a + j], 1u);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_counts_to_field(u32* __restrict__ v, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) v[i] = to_monty(v[i]);
+}
+
+extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint32_t n_jobs, const uint32_t* const* d_index_cols,
+                                const uint64_t* n_rows, const uint32_t* n_values) {
+    LM_REQUIRE(ctx && d_acc && len > 0 && len < (1ull << 31));
+    LM_REQUIRE(n_jobs == 0 || (d_index_cols && n_rows && n_values));
+    LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
+    if (n_jobs) {
+        std::vector<AccessJob> jobs(n_jobs);
+        u64 max_rows = 1;
+        for (u32 i = 0; i < n_jobs; i++) {
+            LM_REQUIRE(d_index_cols[i] && n_values[i] >= 1 && n_values[i] <= len);
+            jobs[i] = {d_index_cols[i], n_rows[i], n_values[i], 0};
+            max_rows = std::max(max_rows, n_rows[i]);
+        }
+        u32* s;
+        int rc = lm_scratch(ctx, (sizeof(AccessJob) * n_jobs + 3) / 4 + 16, &s);
+        if (rc) return rc;
+        LM_HIP(hipMemcpyAsync(s, jobs.data(), sizeof(AccessJob) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` is a local
+        const u32 blocks = (u32)std::min<u64>((max_rows + 255) / 256, 4096);
+        LM_LAUNCH(ctx, k_access_count, dim3(blocks, n_jobs), dim3(256), 0, (const AccessJob*)s, d_acc, len);
+    }
+    LM_LAUNCH(ctx, k_counts_to_field, dim3((unsigned)std::min<u64>((len + 255) / 256, 4096)), dim3(256), 0, d_acc, len);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
                               const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
     LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);

@@ -10,8 +10,8 @@ from tests import synth_witness
 pytestmark = pytest.mark.gpu
 
 
-def _device_proof(ctx, orc, w, builder):
-    tr, keep = lm.make_execution_trace(ctx, w)
+def _device_proof(ctx, orc, w, builder, device_counters=True):
+    tr, keep = lm.make_execution_trace(ctx, w, device_counters=device_counters)
     n = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
     cfg = lm.WhirConfig.from_dict(ob.whir_config(orc, builder, n))
     pr = lm.Prover(ctx)
@@ -28,6 +28,29 @@ def test_prove_execution_matches_oracle_and_verifies(ctx, orc):
     ok, err = ob.verify_execution(orc, w, proof, b)
     assert ok, err
     assert proof.size == ref.size and np.array_equal(proof, ref)
+    # the access counters computed on the device (prove_execution.rs:90-110) equal the witness generator's
+    assert np.array_equal(_device_proof(ctx, orc, w, b, device_counters=False), ref)
+
+
+def test_access_counts_match_histogram(ctx):
+    """lm_access_counts vs numpy: uniform addresses, heavily repeated addresses (whole waves on one address, as padding rows
+    are), multi-word lookups, and out-of-range rows that must be ignored."""
+    rng = np.random.default_rng(4)
+    P = 0x7F000001
+    length = 1 << 12
+    to_m = lambda a: ((a.astype(np.uint64) << np.uint64(32)) % np.uint64(P)).astype(np.uint32)  # noqa: E731
+    a1 = rng.integers(0, length - 16, size=5000)
+    a2 = np.concatenate([np.full(3000, 7), rng.integers(0, 64, size=1000), np.full(777, length - 4)])
+    a3 = np.concatenate([rng.integers(0, length, size=300), [length - 1, length - 2, length + 5]])  # last rows overflow with n_values 4
+    jobs, want = [], np.zeros(length, dtype=np.int64)
+    for addr, nv in ((a1, 1), (a2, 4), (a3, 4), (a1, 16)):
+        jobs.append((ctx.to_device(to_m(addr)), addr.size, nv))
+        ok = addr + nv <= length
+        for j in range(nv):
+            want += np.bincount(addr[ok] + j, minlength=length)
+    got = ctx.access_counts(length, jobs).download()
+    assert np.array_equal(got, to_m(want))
+    assert np.array_equal(ctx.access_counts(64, []).download(), np.zeros(64, dtype=np.uint32))
 
 
 def test_prove_execution_production_parameters_verifies(ctx, orc):
@@ -45,5 +68,14 @@ def test_inconsistent_witness_is_rejected(ctx, orc):
     w = synth_witness.build(orc, rng, n_calls=40)
     w["memory_acc"] = w["memory_acc"].copy()
     w["memory_acc"][200] = int(orc.to_monty(77))  # wrong access count -> logup sum != 0
+    b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
     with pytest.raises(lm.LmError):
-        _device_proof(ctx, orc, w, ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60))
+        _device_proof(ctx, orc, w, b, device_counters=False)
+    # with the counters recomputed on the device the same witness is fine again ...
+    _device_proof(ctx, orc, w, b, device_counters=True)
+    # ... but a memory word that no longer matches what a table looked up is not (logup sum != 0)
+    w["memory"] = w["memory"].copy()
+    hot = int(np.argmax(orc.from_monty_fast(w["memory_acc"]) > 0))
+    w["memory"][hot] = (int(w["memory"][hot]) + 1) % 0x7F000001
+    with pytest.raises(lm.LmError):
+        _device_proof(ctx, orc, w, b, device_counters=True)

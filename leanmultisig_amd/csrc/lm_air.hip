@@ -68,6 +68,8 @@ struct ExtCols {
 };
 
 static constexpr u64 AIR_SPLIT_LAUNCH_PAIRS = 1ull << 13;
+static constexpr u32 AIR_POS_POINTS = 10;                      // evaluation points of the Poseidon table (degree 10)
+static constexpr u32 AIR_POS_SLOTS = 4 * AIR_POS_POINTS + 4;   // rows of its partial-sum matrix, see k_air_round
 
 template <int TABLE, class T, class Cols, int SEG>
 __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
@@ -96,8 +98,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
     }
 }
 
-// 1-D grid of blocks_x * ny workgroups, ny = n_z * n_seg (SEG < 0) or n_z (SEG >= 0);
-// partial[((zi * n_seg + seg) * blocks_x + tile) * 5 + k].
+// 1-D grid of blocks_x * ny workgroups; ny = slots of this launch; partial[(slot * blocks_x + tile) * 5 + k].
 // Workgroup -> (tile, y) is XCD-aware: the ny workgroups that evaluate the same row pairs (at different points / segments)
 // read the same column words, so they get ids that are equal mod 8 (same XCD, same L2 — workgroups are dealt round-robin
 // over the 8 XCDs) and adjacent in dispatch order.  With y as the slow grid dimension every point re-read the columns
@@ -108,7 +109,6 @@ template <int TABLE, class T, class Cols, int SEG>
 __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32* __restrict__ final_out, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
-    constexpr u32 N_SEG = TABLE == air::T_POSEIDON16 ? air::POSEIDON_SEGMENTS : 1;
     u32 tile, y;
     if ((blocks_x & 7) == 0) {
         const u32 group = blockIdx.x / (8 * ny), rem = blockIdx.x % (8 * ny);
@@ -118,8 +118,35 @@ __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, co
         y = blockIdx.x / blocks_x;
         tile = blockIdx.x % blocks_x;
     }
-    const u32 zi = SEG >= 0 ? y : y / N_SEG, seg = SEG >= 0 ? (u32)SEG : y % N_SEG;
-    const u32 z = zi == 0 ? 0 : zi + 1;  // 0, 2, 3, ..., degree
+    // slot = row of the partial-sum matrix.  Poseidon: slots 0..39 = (point zi, segment in {0,1,3,4}), slots 40..43 = the
+    // partial-round segment 2 at z = 0,1,2,3 — its constraints have degree 3 in the row variable, so four points determine
+    // it and k_air_reduce extrapolates the SUMS to the other points (4 evaluations instead of 10).
+    u32 seg, z, slot;
+    if constexpr (TABLE == air::T_POSEIDON16) {
+        if constexpr (SEG < 0) {
+            slot = y;
+            if (y < 4 * AIR_POS_POINTS) {
+                const u32 s4 = y & 3, zi = y >> 2;
+                seg = s4 < 2 ? s4 : s4 + 1;
+                z = zi == 0 ? 0 : zi + 1;
+            } else {
+                seg = 2;
+                z = y - 4 * AIR_POS_POINTS;
+            }
+        } else if constexpr (SEG == 2) {
+            seg = 2;
+            z = y;
+            slot = 4 * AIR_POS_POINTS + y;
+        } else {
+            seg = SEG;
+            z = y == 0 ? 0 : y + 1;
+            slot = y * 4 + (SEG < 2 ? SEG : SEG - 1);
+        }
+    } else {
+        seg = 0;
+        z = y == 0 ? 0 : y + 1;  // 0, 2, 3, ..., degree
+        slot = y;
+    }
     const u32 zm = to_monty(z);
     EF acc = ef_zero();
     for (u64 j = (u64)tile * 256 + threadIdx.x; j < n_pairs; j += (u64)blocks_x * 256) {
@@ -138,19 +165,36 @@ __global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, co
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        partial[((u64)(zi * N_SEG + seg) * blocks_x + tile) * 5 + threadIdx.x] = s;
+        partial[((u64)slot * blocks_x + tile) * 5 + threadIdx.x] = s;
     }
 }
 // one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
-// out = pinned result buffer; the block that finishes last publishes the sequence number
-__global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n, u32* __restrict__ out,
-                                                    u32* __restrict__ done_counter, u32 seq) {
+// out = pinned result buffer; the block that finishes last publishes the sequence number.
+// Block zi sums the n_main consecutive partials of point zi and, for the Poseidon table, adds the degree-3 segment:
+// sum_t lag[zi][t] * (sum of the n_low partials of its slot t), lag = Lagrange basis of the nodes 0..3 at the point.
+struct AirLagrange {
+    u32 c[AIR_POS_POINTS][4];
+};
+__global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n_main, u32* __restrict__ out,
+                                                    u32* __restrict__ done_counter, u32 seq, u32 n_low, u64 low_offset,
+                                                    AirLagrange lag) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.x;
     u32 v[5] = {0, 0, 0, 0, 0};
-    for (u32 b = threadIdx.x; b < n; b += 256)
+    for (u32 b = threadIdx.x; b < n_main; b += 256)
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = add(v[k], partial[((u64)zi * n + b) * 5 + k]);
+        for (int k = 0; k < 5; k++) v[k] = add(v[k], partial[((u64)zi * n_main + b) * 5 + k]);
+    if (n_low) {
+        for (u32 t = 0; t < 4; t++) {
+            u32 w[5] = {0, 0, 0, 0, 0};
+            for (u32 b = threadIdx.x; b < n_low; b += 256)
+#pragma unroll
+                for (int k = 0; k < 5; k++) w[k] = add(w[k], partial[(low_offset + (u64)t * n_low + b) * 5 + k]);
+            const u32 c = lag.c[zi][t];
+#pragma unroll
+            for (int k = 0; k < 5; k++) v[k] = add(v[k], mul(w[k], c));
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 5; k++) v[k] = wave_sum_u32(v[k]);
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,14 +267,14 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
         // Large rounds: one launch per segment (own register budget, full-chip grids).  Small rounds are latency bound:
         // one launch with the segment in blockIdx.y so that the four chains run side by side.
         if (n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
-            const dim3 grid(blocks, a->deg);
+            const dim3 grid(blocks, AIR_POS_POINTS);
             launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial);
             launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial);
-            launch_segment<TABLE, T, Cols, 2>(ctx, c, grid, n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, 2>(ctx, c, dim3(blocks, 4), n_pairs, extra, eq, partial);
             launch_segment<TABLE, T, Cols, 3>(ctx, c, grid, n_pairs, extra, eq, partial);
             launch_segment<TABLE, T, Cols, 4>(ctx, c, grid, n_pairs, extra, eq, partial);
         } else {
-            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg * air::POSEIDON_SEGMENTS), n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial);
         }
     } else {
         launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial);
@@ -312,12 +356,12 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     LM_REQUIRE(ctx && a && out_raw && a->round < a->log_rows);
     const u32 p = a->log_rows - a->round - 1;
     const u64 n_pairs = 1ull << p;
-    const u32 n_seg = a->table == air::T_POSEIDON16 ? air::POSEIDON_SEGMENTS : 1;
+    const bool pos = a->table == air::T_POSEIDON16;
     const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
+    const u32 slots = pos ? AIR_POS_SLOTS : a->deg;
     u32* s;
-    int rc = lm_scratch(ctx, (u64)blocks * a->deg * n_seg * 5 + a->deg * 5 + 64, &s);
+    int rc = lm_scratch(ctx, (u64)blocks * slots * 5 + 64, &s);
     if (rc) return rc;
-    u32* d_out = s + (u64)blocks * a->deg * n_seg * 5;
     const EqSplit eq = a->eqt.at(p);
     if (a->table == air::T_EXECUTION)
         rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s);
@@ -326,9 +370,25 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     else
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
-    (void)d_out;
     const u32 seq = ++ctx->res_seq;
-    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, blocks * n_seg, ctx->h_res, ctx->d_sync + 1, seq);
+    AirLagrange lag;
+    memset(&lag, 0, sizeof lag);
+    if (pos) {  // Lagrange basis of the nodes 0,1,2,3 at z = 0,2,3,..,10 (exact field constants)
+        for (u32 zi = 0; zi < AIR_POS_POINTS; zi++) {
+            const u32 z = zi == 0 ? 0 : zi + 1;
+            for (u32 t = 0; t < 4; t++) {
+                u32 num = ONE, den = ONE;
+                for (u32 m = 0; m < 4; m++) {
+                    if (m == t) continue;
+                    num = mul(num, sub(to_monty(z), to_monty(m)));
+                    den = mul(den, sub(to_monty(t), to_monty(m)));
+                }
+                lag.c[zi][t] = mul(num, inv(den));
+            }
+        }
+    }
+    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, pos ? 4 * blocks : blocks, ctx->h_res, ctx->d_sync + 1, seq,
+              pos ? blocks : 0u, (u64)4 * AIR_POS_POINTS * blocks, lag);
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);

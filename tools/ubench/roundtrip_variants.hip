@@ -1,0 +1,92 @@
+// micro-benchmark: pieces of one Fiat-Shamir round trip (host launch -> small kernel -> host sees 10 result words)
+//   A  payload stores, __threadfence_system, release flag                (product protocol)
+//   B  payload stores, checksum + flag as plain stores (no fence)         (host validates the checksum)
+//   C  as B, kernel launched in advance and waiting for the host's "go" word in pinned memory (launch latency hidden)
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+__device__ __forceinline__ unsigned work(const unsigned* data) {
+    __shared__ unsigned l[256];
+    unsigned v = data[threadIdx.x];
+    for (int i = 0; i < 200; i++) v = v * 1664525u + 1013904223u;
+    l[threadIdx.x] = v;
+    __syncthreads();
+    unsigned s = 0;
+    if (threadIdx.x == 0) for (int i = 0; i < 256; i++) s += l[i];
+    return s;
+}
+__global__ void k_a(volatile unsigned* h, unsigned seq, const unsigned* data) {
+    unsigned s = work(data);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 10; i++) h[i] = s + i + seq;
+        __threadfence_system();
+        __hip_atomic_store((unsigned*)h + 16, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void k_b(volatile unsigned* h, unsigned seq, const unsigned* data) {
+    unsigned s = work(data);
+    if (threadIdx.x == 0) {
+        unsigned chk = seq * 0x9E3779B1u;
+        for (int i = 0; i < 10; i++) { unsigned v = s + i + seq; h[i] = v; chk += v * (2 * i + 1); }
+        h[15] = chk;
+        h[16] = seq;
+    }
+}
+__global__ void k_c(volatile unsigned* h, volatile unsigned* go, unsigned seq, const unsigned* data) {
+    __shared__ unsigned ok;
+    if (threadIdx.x == 0) {
+        long long t0 = wall_clock64();
+        unsigned g;
+        while ((g = *go) != seq && wall_clock64() - t0 < 100000000ll) __builtin_amdgcn_s_sleep(1);
+        ok = g == seq;
+    }
+    __syncthreads();
+    if (!ok) return;
+    unsigned s = work(data);
+    if (threadIdx.x == 0) {
+        unsigned chk = seq * 0x9E3779B1u;
+        for (int i = 0; i < 10; i++) { unsigned v = s + i + seq; h[i] = v; chk += v * (2 * i + 1); }
+        h[15] = chk;
+        h[16] = seq;
+    }
+}
+static bool valid(volatile unsigned* h, unsigned seq) {
+    if (h[16] != seq) return false;
+    unsigned chk = seq * 0x9E3779B1u;
+    for (int i = 0; i < 10; i++) chk += h[i] * (2 * i + 1);
+    return chk == h[15];
+}
+int main() {
+    hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    unsigned *h, *go;
+    hipHostMalloc((void**)&h, 256, hipHostMallocMapped | hipHostMallocCoherent);
+    hipHostMalloc((void**)&go, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    for (int i = 0; i < 64; i++) h[i] = 0;
+    go[0] = 0;
+    unsigned* d; hipMalloc(&d, 4096); hipMemset(d, 1, 4096);
+    const int N = 3000;
+    for (int mode = 0; mode < 3; mode++) {
+        unsigned base = (mode + 1) * 100000;
+        if (mode == 2) hipLaunchKernelGGL(k_c, dim3(1), dim3(256), 0, st, h, go, base + 1, d);
+        auto t0 = std::chrono::steady_clock::now();
+        unsigned retries = 0;
+        for (int i = 1; i <= N; i++) {
+            unsigned seq = base + i;
+            volatile unsigned* f = h;
+            if (mode == 0) { hipLaunchKernelGGL(k_a, dim3(1), dim3(256), 0, st, h, seq, d); while (f[16] != seq) {} }
+            if (mode == 1) { hipLaunchKernelGGL(k_b, dim3(1), dim3(256), 0, st, h, seq, d); while (!valid(f, seq)) retries++; }
+            if (mode == 2) {
+                if (i < N) hipLaunchKernelGGL(k_c, dim3(1), dim3(256), 0, st, h, go, seq + 1, d);  // next round, early
+                *(volatile unsigned*)go = seq;                                                     // "challenge" of this round
+                while (!valid(f, seq)) retries++;
+            }
+            // ~3 us of host work between rounds (transcript)
+            auto w0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count() < 3.0) {}
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        hipStreamSynchronize(st);
+        printf("mode %c: %.2f us per round (incl. 3 us host work)\n", 'A' + mode,
+               std::chrono::duration<double, std::micro>(t1 - t0).count() / N);
+    }
+}

@@ -43,6 +43,10 @@ typedef struct lm_tree lm_tree;
 int lm_ctx_create(int device, lm_ctx** out);
 void lm_ctx_destroy(lm_ctx* ctx);
 const char* lm_last_error(void);
+/* The HIP "current device" is a property of the host thread: a thread that did not create the context calls this once
+ * before using it (the lmh_* drivers do it themselves).  One context = one stream = one prover; several contexts on the
+ * same GPU may be driven concurrently from different threads (independent proofs in flight). */
+int lm_bind_thread(lm_ctx* ctx);
 int lm_sync(lm_ctx* ctx);
 /* the HIP stream every kernel of this context is launched on (hipStream_t), for event timing by the caller */
 void* lm_ctx_stream(lm_ctx* ctx);

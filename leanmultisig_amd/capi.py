@@ -25,6 +25,7 @@ _SIGS = {
     "lm_ctx_destroy": (None, [vp]),
     "lm_last_error": (C.c_char_p, []),
     "lm_sync": (C.c_int, [vp]),
+    "lm_bind_thread": (C.c_int, [vp]),
     "lm_ctx_stream": (vp, [vp]),
     "lm_profile_select": (C.c_int, [vp, C.c_char_p]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),

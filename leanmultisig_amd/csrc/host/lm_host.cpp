@@ -877,6 +877,7 @@ uint32_t lmh_stacked_n_vars(const lm_execution_trace* t) {
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr, const lm_whir_config* cfg) {
     if (!ctx || !p || !tr || !cfg) return LM_E_INVALID;
     int rc;
+    if ((rc = lm_bind_thread(ctx))) return rc;
     StageClock clk(ctx);
     int order[3];
     sorted_tables(tr, order);

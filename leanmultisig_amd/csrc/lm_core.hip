@@ -380,6 +380,11 @@ void lm_ctx_destroy(lm_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
+int lm_bind_thread(lm_ctx* ctx) {
+    LM_REQUIRE(ctx);
+    LM_HIP(hipSetDevice(ctx->device));
+    return LM_OK;
+}
 int lm_sync(lm_ctx* ctx) {
     LM_REQUIRE(ctx);
     LM_HIP(hipStreamSynchronize(ctx->stream));

@@ -79,3 +79,38 @@ def test_inconsistent_witness_is_rejected(ctx, orc):
     w["memory"][hot] = (int(w["memory"][hot]) + 1) % 0x7F000001
     with pytest.raises(lm.LmError):
         _device_proof(ctx, orc, w, b, device_counters=True)
+
+
+def test_concurrent_provers_are_independent(orc):
+    """Three lm_ctx (one stream each) driven from three host threads on the same GPU — the bench's proofs-in-flight mode.
+    Every proof must equal the one the same prover produces alone."""
+    import threading
+    b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    ctxs, traces, cfgs, alone = [], [], [], []
+    for c in range(3):
+        ctx = lm.Context(0)
+        w = synth_witness.build(orc, np.random.default_rng(50 + c), n_calls=30 + 7 * c)
+        tr, keep = lm.make_execution_trace(ctx, w)
+        cfg = lm.WhirConfig.from_dict(ob.whir_config(orc, b, ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))))
+        pr = lm.Prover(ctx)
+        pr.prove_execution(tr, cfg)
+        ctxs.append(ctx), traces.append((tr, keep)), cfgs.append(cfg), alone.append(pr.proof())
+    got = [[] for _ in range(3)]
+    start = threading.Barrier(3)
+
+    def worker(c):
+        start.wait()
+        for _ in range(4):
+            pr = lm.Prover(ctxs[c])
+            pr.prove_execution(traces[c][0], cfgs[c])
+            got[c].append(pr.proof())
+
+    th = [threading.Thread(target=worker, args=(c,)) for c in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c in range(3):
+        assert len(got[c]) == 4
+        for pf in got[c]:
+            assert np.array_equal(pf, alone[c])

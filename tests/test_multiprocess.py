@@ -20,6 +20,12 @@ allr = bench.exchange_roots(root, torch.device("cpu"))
 assert allr.shape == (world, 8)
 for r in range(world):
     assert list(allr[r]) == list(np.arange(8) + 100 * r + 0x7E000000), allr
+# the bench's timed region gathers the roots of all leaves of a rank at once (C streams x K steps x 8 words)
+blk = np.arange(3 * 2 * 8, dtype=np.int64) + 1000 * rank + 0x7E000000
+allb = bench.exchange_roots_block(blk, torch.device("cpu"))
+assert allb.shape == (world, 48)
+for r in range(world):
+    assert list(allb[r]) == list(np.arange(48) + 1000 * r + 0x7E000000)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -234,9 +234,9 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:  # (a closed context has already released every pooled block)
             self.ctx.lib.lm_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -270,9 +270,9 @@ class Tree:
         return out
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             self.ctx.lib.lm_tree_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

@@ -303,6 +303,12 @@ KB_HD T cube(const T& a) {
 //   segment 4: ending_full_rounds[0] -> gated outputs                                              (alpha^76..99)
 // This cuts the dependent-instruction chain of one evaluation ~5x (the late, small sumcheck rounds are latency bound).
 static constexpr int POSEIDON_SEGMENTS = 5;
+// Virtual columns of the Poseidon table: the affine forms of the partial block (below) evaluated row by row.  They are
+// linear in committed columns, so they fold like columns; the constraint kernels then read 36 values instead of
+// recomputing 16 x 36 + 20 x ~26 multiply-adds per plane at every evaluation point of every round.
+static constexpr int POS_VIRT_Y = 109;       // 20 columns: value cubed in partial round r
+static constexpr int POS_VIRT_E = 109 + 20;  // 16 columns: state entering ending_full_rounds
+static constexpr int POS_N_VIRT = 36;
 
 // Affine forms of the partial block (gen_poseidon_consts.py::linearise): lanes 1..15 see no S-box inside the block and lane 0
 // is re-based on the committed partial_rounds[r] column every round, so over u = (t_0..t_15, q_0..q_19, 1) with
@@ -339,6 +345,7 @@ KB_HD void two_full_rounds(T s[16]) {
 // col(c) = column c at the evaluation point; colp(c, k) = its plane k only
 template <class T, int SEG, class ColFn, class ColPlaneFn>
 KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
+    (void)colp;
     Folder<T> f(x);
     T s[16];
     if constexpr (SEG == 0) {
@@ -373,39 +380,16 @@ KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(41 + i)));
     } else if constexpr (SEG == 2) {
         f.k = 40;
-        T y[20];
-        static_for<0, Planes<T>::N>([&](auto KK) {
-            constexpr int k = decltype(KK)::value;
-            u32 u[35];
-#pragma unroll
-            for (int j = 0; j < 35; j++) u[j] = colp(41 + j, k);  // t_0..t_15, q_0..q_18
-            static_for<0, 20>([&](auto RR) {
-                constexpr int r = decltype(RR)::value;
-                u32 v = kb::dot_n<16 + r>(u, kPoseidonLinear.y[r]);
-                if (k == 0) v = kb::add(v, kPoseidonLinear.y[r][36]);
-                Planes<T>::at(y[r], k) = v;
-            });
-            AIR_SCHED_FENCE();
-        });
+        // y_r (the value cubed in partial round r) is an affine form of committed columns: it is read as virtual column
+        // POS_VIRT_Y + r, computed once per table and folded with the others (lm_air.hip: k_air_virtual_columns)
         static_for<0, 20>([&](auto RR) {
             constexpr int r = decltype(RR)::value;
-            f.assert_zero(a_sub(cube(y[r]), col(57 + r)));  // assert_eq_low(state[0]^3, partial_rounds[r])
+            f.assert_zero(a_sub(cube(col(POS_VIRT_Y + r)), col(57 + r)));  // assert_eq_low(state[0]^3, partial_rounds[r])
         });
     } else if constexpr (SEG == 3) {
         f.k = 60;
-        static_for<0, Planes<T>::N>([&](auto KK) {
-            constexpr int k = decltype(KK)::value;
-            u32 u[36];
 #pragma unroll
-            for (int j = 0; j < 36; j++) u[j] = colp(41 + j, k);  // t_0..t_15, q_0..q_19
-            static_for<0, 16>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                u32 v = kb::dot_n<36>(u, kPoseidonLinear.fin[i]);
-                if (k == 0) v = kb::add(v, kPoseidonLinear.fin[i][36]);
-                Planes<T>::at(s[i], k) = v;
-            });
-            AIR_SCHED_FENCE();
-        });
+        for (int i = 0; i < 16; i++) s[i] = col(POS_VIRT_E + i);  // exit state of the partial block (affine, virtual column)
         two_full_rounds<T, 4>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(77 + i)));

@@ -19,8 +19,10 @@ struct lm_air {
     int table = 0;
     u32 log_rows = 0, round = 0;
     u32 n_cols = 0, n_shift = 0, deg = 0;
-    const u32** d_base_cols = nullptr;  // device array of n_cols device pointers (caller's base columns)
-    u32* ef[2] = {nullptr, nullptr};    // ping-pong: (n_cols + n_shift) columns x 5 planes
+    u32 n_virt = 0;                     // virtual columns appended after the committed ones (Poseidon: air::POS_N_VIRT)
+    u32* d_virt = nullptr;              // their base-field values, n_virt x 2^log_rows
+    const u32** d_base_cols = nullptr;  // device array of n_cols + n_virt device pointers (caller's base columns, then virtual)
+    u32* ef[2] = {nullptr, nullptr};    // ping-pong: (n_cols + n_virt + n_shift) columns x 5 planes
     int cur = -1;
     air::Extra* d_extra = nullptr;
     air::Extra h_extra;                  // host copies outlive the asynchronous uploads (no synchronisation in lm_air_new)
@@ -253,6 +255,24 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
     }
 }
 
+// Virtual columns of the Poseidon table (air_tables.h: POS_VIRT_Y / POS_VIRT_E): per row the 20 + 16 affine forms of the
+// partial block over u = (beginning_full_rounds[1] (16), partial_rounds (20)).  Base-field in, base-field out.
+__global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* __restrict__ cols, u64 n_rows, u32* __restrict__ virt) {
+    const u64 r0 = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r0 >= n_rows) return;
+    u32 u[36];
+#pragma unroll
+    for (int j = 0; j < 36; j++) u[j] = cols[41 + j][r0];
+    static_for<0, 20>([&](auto RR) {
+        constexpr int r = decltype(RR)::value;
+        virt[(u64)r * n_rows + r0] = add(dot_n<16 + r>(u, air::kPoseidonLinear.y[r]), air::kPoseidonLinear.y[r][36]);
+    });
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        virt[(u64)(20 + i) * n_rows + r0] = add(dot_n<36>(u, air::kPoseidonLinear.fin[i]), air::kPoseidonLinear.fin[i][36]);
+    });
+}
+
 template <int TABLE, class T, class Cols, int SEG>
 static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
                           u32* partial) {
@@ -285,7 +305,7 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
 template <int TABLE>
 static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
     if (a->cur < 0) {
-        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial);
     }
     ExtCols c{a->ef[a->cur], 2 * n_pairs};
@@ -298,6 +318,7 @@ void lm_air_free(lm_ctx* ctx, lm_air* a) {
     if (!a) return;
     (void)hipStreamSynchronize(ctx->stream);  // the uploads of lm_air_new read from *a
     lm_pool_free(ctx, (void*)a->d_base_cols);
+    lm_pool_free(ctx, a->d_virt);
     for (int i = 0; i < 2; i++) lm_pool_free(ctx, a->ef[i]);
     lm_pool_free(ctx, a->d_extra);
     lm_pool_free(ctx, a->eqt.d_buf);
@@ -313,9 +334,10 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->log_rows = log_rows;
     a->n_cols = air::n_columns((int)table);
     a->n_shift = air::n_shift((int)table);
+    a->n_virt = table == air::T_POSEIDON16 ? air::POS_N_VIRT : 0;  // (that table has no shift columns)
     a->deg = air::degree((int)table);
     const u64 half = 1ull << (log_rows - 1);
-    const u64 ef_words0 = (u64)(a->n_cols + a->n_shift) * 5 * half;
+    const u64 ef_words0 = (u64)(a->n_cols + a->n_virt + a->n_shift) * 5 * half;
     air::Extra& hx = a->h_extra;
     EF al, p = ef_one();
     memcpy(al.v, alpha, 20);
@@ -325,7 +347,8 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     }
     memcpy(hx.logup_eq, logup_eq16, 16 * 20);
     memcpy(hx.bus_beta.v, bus_beta, 20);
-    bool ok = lm_pool_alloc(ctx, (void**)&a->d_base_cols, a->n_cols * sizeof(u32*)) == hipSuccess &&
+    bool ok = lm_pool_alloc(ctx, (void**)&a->d_base_cols, (a->n_cols + a->n_virt) * sizeof(u32*)) == hipSuccess &&
+              (a->n_virt == 0 || lm_pool_alloc_t(ctx, &a->d_virt, ((u64)a->n_virt << log_rows) * 4) == hipSuccess) &&
               lm_pool_alloc_t(ctx, &a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->d_extra, sizeof(air::Extra)) == hipSuccess &&
@@ -337,7 +360,12 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     }
     a->eqt.buf_words = PrefixEqTables::words_needed(log_rows);
     a->h_cols.assign(d_cols, d_cols + a->n_cols);
-    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, a->h_cols.data(), a->n_cols * sizeof(u32*), hipMemcpyHostToDevice, ctx->stream));
+    for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
+    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*), hipMemcpyHostToDevice,
+                          ctx->stream));
+    if (a->n_virt)
+        LM_LAUNCH(ctx, k_air_virtual_columns, dim3((unsigned)(((1ull << log_rows) + 255) / 256)), dim3(256), 0,
+                  (const u32* const*)a->d_base_cols, 1ull << log_rows, a->d_virt);
     LM_HIP(hipMemcpyAsync(a->d_extra, &a->h_extra, sizeof(air::Extra), hipMemcpyHostToDevice, ctx->stream));
     int rc = a->eqt.build(ctx, eq_point, log_rows);
     if (rc) {
@@ -401,9 +429,9 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
     memcpy(r.v, challenge, 20);
     const u64 n_out = 1ull << (a->log_rows - a->round - 1);
     const u32 blocks = (u32)std::min<u64>((n_out + 255) / 256, 1024);
-    const dim3 grid(blocks, a->n_cols + a->n_shift);
+    const dim3 grid(blocks, a->n_cols + a->n_virt + a->n_shift);
     if (a->cur < 0) {
-        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols};
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         LM_LAUNCH(ctx, k_air_fold_base, grid, dim3(256), 0, c, n_out, r, a->ef[0]);
         a->cur = 0;
     } else {

@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
@@ -316,12 +316,13 @@ def main():
             ctx.profile_select("*")
             run_step(ctx, lm, w)
             ctx.sync()
-            names = ["k_ntt_pass", "k_leaf_sponge", "k_compress_layer", "k_weight_tables", "k_weights_accumulate",
-                     "k_prod_round_base", "k_prod_round_ext", "k_sum10", "k_fold_base", "k_fold_ext", "k_pow_grind",
-                     "k_mle_partial_base", "k_mle_partial_ext", "k_eq_table_small", "k_sum_partials", "k_tree_open",
-                     "k_gkr_layer_up", "k_prefix_eq_tables", "k_gkr_round_storage", "k_gkr_fold_round", "k_gkr_reduce",
-                     "k_logup_fill", "k_logup_neutral", "k_mle_partial_cols",
-                     "k_air_round", "k_air_reduce", "k_air_fold_base", "k_air_fold_ext"]
+            names = ["k_access_count", "k_counts_to_field", "k_stack_columns", "k_ntt_pass", "k_leaf_sponge", "k_leaf_sponge_coop",
+                     "k_compress_layer", "k_compress_layer_coop", "k_merkle_top_coop", "k_weight_tables", "k_weights_init",
+                     "k_weights_accumulate", "k_prod_round_base", "k_prod_round_ext", "k_fold_round", "k_sum10", "k_fold_base",
+                     "k_fold_ext", "k_pow_grind", "k_pow_publish", "k_mle_partial_base", "k_mle_partial_ext", "k_eq_table_small",
+                     "k_sum_partials", "k_tree_open", "k_gkr_layer_up", "k_prefix_eq_tables", "k_gkr_round_storage",
+                     "k_gkr_fold_round", "k_gkr_reduce", "k_logup_fill", "k_logup_neutral", "k_mle_partial_cols",
+                     "k_air_virtual_columns", "k_air_round", "k_air_reduce", "k_air_fold_base", "k_air_fold_ext"]
             for k in names:
                 cnt, ms = ctx.profile_read(k)
                 if cnt:

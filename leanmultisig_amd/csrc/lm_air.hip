@@ -284,9 +284,11 @@ template <int TABLE, class T, class Cols>
 static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
     const air::Extra* extra = a->d_extra;
     if constexpr (TABLE == air::T_POSEIDON16) {
-        // Large rounds: one launch per segment (own register budget, full-chip grids).  Small rounds are latency bound:
-        // one launch with the segment in blockIdx.y so that the four chains run side by side.
-        if (n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
+        // Base-field rounds, large: one launch per segment (the combined kernel needs 256 VGPRs there, the per-segment ones
+        // 165-240).  Extension-field rounds and small rounds: ONE launch with the segment in the workgroup id — the
+        // combined extension-field kernel compiles to 148 VGPRs (3 waves per SIMD) where the specialised ones take
+        // 256 + AGPRs (1 wave), and small rounds are latency bound anyway (the five chains run side by side).
+        if (sizeof(T) == sizeof(u32) && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
             const dim3 grid(blocks, AIR_POS_POINTS);
             launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial);
             launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial);

@@ -225,7 +225,8 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        value = N_SIGS * C * world / (dt / args.steps)
+        sigs = ((N_SIGS * 167) >> args.scale_log) // 167  # signatures per proof (--scale-log shrinks the leaf)
+        value = sigs * C * world / (dt / args.steps)
         # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
         # Algorithmic bytes per step: every column value of every sumcheck round is read once:
         # round 0 on base words (4 B), round r >= 1 on EF (20 B) over 2^(log_rows - r) rows, (n_columns + n_shift) columns.
@@ -282,7 +283,7 @@ def main():
                            "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)"],
                 "missing": ["witness generation: VM interpreter + trace builder (CPU, SURVEY §8(f) rank 1/4) — the reference's "
                             "whole-node number includes it"],
-                "per_gpu_signatures": N_SIGS * C,
+                "per_gpu_signatures": sigs * C,
                 "proofs_in_flight_per_gpu": C,
                 "single_proof_latency_ms": single_ms,
             },

@@ -77,7 +77,10 @@ KB_HD u32 reduce40(u64 s) {
 
 // s <- C * s with C[i][j] = col[(i - j) mod 16], col = {1,3,13,22,67,2,15,63,101,1,2,17,11,1,51,1}
 // (poseidon1_koalabear_16.rs:22,580-581).  Plain small integers act directly on Montgomery-form values.
-KB_HD void mds_circ16(u32 s[16]) {
+// bias: optional per-lane constants added before the reduction (the round constants of the NEXT round ride along for
+// free in the 64-bit accumulator instead of costing a modular addition each)
+template <bool WITH_BIAS>
+KB_HD void mds_circ16_impl(u32 s[16], const u32* bias) {
     const u32 c1 = opaque_const(1), c2 = opaque_const(2), c3 = opaque_const(3), c13 = opaque_const(13);
     const u32 c22 = opaque_const(22), c67 = opaque_const(67), c15 = opaque_const(15), c63 = opaque_const(63);
     const u32 c101 = opaque_const(101), c17 = opaque_const(17), c11 = opaque_const(11), c51 = opaque_const(51);
@@ -85,7 +88,7 @@ KB_HD void mds_circ16(u32 s[16]) {
     u32 o[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        u64 acc = 0;
+        u64 acc = WITH_BIAS ? (u64)bias[i] : 0;
 #pragma unroll
         for (int j = 0; j < 16; j++) acc += (u64)s[j] * C[(16 + i - j) & 15];
         o[i] = reduce40(acc);
@@ -93,25 +96,31 @@ KB_HD void mds_circ16(u32 s[16]) {
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = o[i];
 }
+KB_HD void mds_circ16(u32 s[16]) { mds_circ16_impl<false>(s, nullptr); }
+KB_HD void mds_circ16_bias(u32 s[16], const u32 bias[16]) { mds_circ16_impl<true>(s, bias); }
 
 // 16-term dot product with delayed reduction (4 products per fold).
 KB_HD u32 dot16(const u32 s[16], const u32 c[16]) { return dot_n<16>(s, c); }
 
 KB_HD void poseidon16_permute(u32 s[16]) {
-    // 3 plain initial full rounds
+    // 3 plain initial full rounds; the round constants of round r + 1 are added inside the MDS of round r
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        s[i] = add(s[i], kPoseidonHost.rc_init[0][i]);
+    });
     static_for<0, 3>([&](auto R) {
         constexpr int r = decltype(R)::value;
         static_for<0, 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            s[i] = cube(add(s[i], kPoseidonHost.rc_init[r][i]));
+            s[i] = cube(s[i]);
         });
-        mds_circ16(s);
+        mds_circ16_bias(s, kPoseidonHost.rc_init[r + 1]);
     });
     // S-boxes of the 4th full round, then the partial block through its affine forms
     u32 u[36];
     static_for<0, 16>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        u[i] = cube(add(s[i], kPoseidonHost.rc_init[3][i]));
+        u[i] = cube(s[i]);
     });
     static_for<0, 20>([&](auto R) {
         constexpr int r = decltype(R)::value;
@@ -119,16 +128,20 @@ KB_HD void poseidon16_permute(u32 s[16]) {
     });
     static_for<0, 16>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        s[i] = add(dot_n<36>(u, kPoseidonLinearHash.fin[i]), kPoseidonLinearHash.fin[i][36]);
+        constexpr u32 c = (u32)(((u64)kPoseidonLinearHash.fin[i][36] + kPoseidonHost.rc_term[0][i]) % P);  // + first terminal constant
+        s[i] = add(dot_n<36>(u, kPoseidonLinearHash.fin[i]), c);
     });
     // 4 terminal full rounds
     static_for<0, 4>([&](auto R) {
         constexpr int r = decltype(R)::value;
         static_for<0, 16>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            s[i] = cube(add(s[i], kPoseidonHost.rc_term[r][i]));
+            s[i] = cube(s[i]);
         });
-        mds_circ16(s);
+        if constexpr (r < 3)
+            mds_circ16_bias(s, kPoseidonHost.rc_term[r + 1]);
+        else
+            mds_circ16(s);
     });
 }
 

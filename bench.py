@@ -309,7 +309,9 @@ def main():
             out["config"]["proof_verified_by_oracle"] = bool(ok)
             if not ok:
                 print("VERIFY FAILED:", err, file=sys.stderr)
-        out["config"]["proof_KiB"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)  # un-pruned hints (benchmark.rs:447 formula)
+        # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
+        out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
+        out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(orc, ob)
         print(json.dumps(out), flush=True)

@@ -65,6 +65,20 @@ void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]);
 uint64_t lmh_proof_words(const lmh_prover* p);
 void lmh_proof_copy(const lmh_prover* p, uint32_t* out);
 
+/* Merkle-path pruning, the first step of the reference's proof wire format (MerklePaths::prune,
+ * crates/backend/fiat-shamir/src/merkle_pruning.rs:18-86; `Proof { transcript, merkle_paths }`, transcript.rs:33-36).  One
+ * batch = one hint_merkle_paths call (the query set of one commitment).  Blob of u32 words:
+ *   [T][transcript x T][B]  B x { height, n_trailing_zeros, n_orig, original_order x n_orig, n_paths,
+ *                                 n_paths x { index_lo, index_hi, leaf_len, leaf x leaf_len, n_sib, sibling x 8 n_sib } }
+ * lmh_proof_size_fe = Proof::proof_size_fe (transcript.rs:39-53); the reference quotes proof sizes as
+ * size_fe * 31 / 8192 KiB (rec_aggregation/src/benchmark.rs:447).  postcard + lz4 framing is not produced here.
+ * lmh_proof_batch_sizes: the openings per batch of the un-pruned blob (what a verifier-side restore needs to re-batch). */
+uint64_t lmh_proof_pruned_words(const lmh_prover* p);
+void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out);
+uint64_t lmh_proof_size_fe(const lmh_prover* p);
+uint32_t lmh_proof_n_batches(const lmh_prover* p);
+void lmh_proof_batch_sizes(const lmh_prover* p, uint32_t* out);
+
 /* ---- WHIR ------------------------------------------------------------------------------------------------------- */
 typedef struct lmh_witness lmh_witness; /* Witness, commit.rs:49-57: device-resident tree + OOD points/answers */
 /* WhirConfig::commit (commit.rs:64-99): d_poly = 2^num_variables base words in HBM. */

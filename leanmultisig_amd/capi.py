@@ -87,6 +87,11 @@ _HOST_SIGS = {
     "lmh_pow_grinding": (C.c_int, [vp, vp, C.c_uint32]),
     "lmh_challenger_state": (None, [vp, vp]),
     "lmh_proof_words": (C.c_uint64, [vp]),
+    "lmh_proof_pruned_words": (C.c_uint64, [vp]),
+    "lmh_proof_pruned_copy": (None, [vp, vp]),
+    "lmh_proof_size_fe": (C.c_uint64, [vp]),
+    "lmh_proof_n_batches": (C.c_uint32, [vp]),
+    "lmh_proof_batch_sizes": (None, [vp, vp]),
     "lmh_proof_copy": (None, [vp, vp]),
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
@@ -499,6 +504,22 @@ class Prover:
         n = self.lib.lmh_proof_words(self.h)
         out = np.empty(n, dtype=np.uint32)
         self.lib.lmh_proof_copy(self.h, _ptr(out))
+        return out
+
+    def proof_pruned(self):
+        """Pruned proof blob (MerklePaths::prune per query set; layout in include/leanmultisig_host.h)."""
+        out = np.empty(self.lib.lmh_proof_pruned_words(self.h), dtype=np.uint32)
+        self.lib.lmh_proof_pruned_copy(self.h, _ptr(out))
+        return out
+
+    def proof_size_fe(self):
+        """Proof::proof_size_fe of the reference (field elements of the pruned proof)."""
+        return int(self.lib.lmh_proof_size_fe(self.h))
+
+    def batch_sizes(self):
+        out = np.empty(self.lib.lmh_proof_n_batches(self.h), dtype=np.uint32)
+        if out.size:
+            self.lib.lmh_proof_batch_sizes(self.h, _ptr(out))
         return out
 
     def state(self):

@@ -122,6 +122,7 @@ struct lmh_prover {
     Challenger ch;
     std::vector<u32> transcript;
     std::vector<Opening> openings;
+    std::vector<u32> batch_sizes;  // openings per hint_merkle_paths call (one query set of one commitment), in order
 };
 struct lmh_witness {
     lm_tree* tree = nullptr;
@@ -249,6 +250,7 @@ int open_and_hint(lm_ctx* ctx, lmh_prover* p, const lm_tree* tree, const std::ve
     std::vector<u32> sib((u64)idx.size() * log_h * 8 + 1);
     int rc = lm_tree_open(ctx, tree, idx.data(), (u32)idx.size(), leaves.data(), sib.data());
     if (rc) return rc;
+    p->batch_sizes.push_back((u32)idx.size());
     for (size_t q = 0; q < idx.size(); q++) {
         Opening o;
         o.index = idx[q];
@@ -314,6 +316,103 @@ void lmh_add_sumcheck_polynomial(lmh_prover* p, const uint32_t* coeffs, uint32_t
 }
 int lmh_pow_grinding(lm_ctx* ctx, lmh_prover* p, uint32_t bits) { return pow_grinding(ctx, p, bits); }
 void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]) { memcpy(out16, p->ch.state, 64); }
+
+// ---- Merkle-path pruning (crates/backend/fiat-shamir/src/merkle_pruning.rs:18-86) ---------------------------------------
+// Per batch: sort by leaf index, drop repeated leaves, cut the all-zero tail shared by every leaf, and keep for path i only
+// the siblings below its divergence from path i-1, except the one level where path i+1 joins it (that hash is recomputed
+// by the verifier from path i+1).  Blob layout: include/leanmultisig_host.h.
+namespace {
+unsigned diverge_level(u64 a, u64 b) {  // lca_level: number of low bits to drop until a == b
+    unsigned l = 0;
+    for (u64 x = a ^ b; x; x >>= 1) l++;
+    return l;
+}
+std::vector<u32> pruned_blob(const lmh_prover* p) {
+    std::vector<u32> o;
+    o.push_back((u32)p->transcript.size());
+    o.insert(o.end(), p->transcript.begin(), p->transcript.end());
+    o.push_back((u32)p->batch_sizes.size());
+    size_t first = 0;
+    for (u32 bs : p->batch_sizes) {
+        const Opening* ops = p->openings.data() + first;
+        first += bs;
+        std::vector<u32> by_index(bs);
+        for (u32 i = 0; i < bs; i++) by_index[i] = i;
+        std::stable_sort(by_index.begin(), by_index.end(), [&](u32 a, u32 b) { return ops[a].index < ops[b].index; });
+        std::vector<u32> kept, original_order(bs);  // kept: distinct leaves in index order
+        for (u32 i : by_index) {
+            if (kept.empty() || ops[kept.back()].index != ops[i].index) kept.push_back(i);
+            original_order[i] = (u32)kept.size() - 1;
+        }
+        const size_t leaf_len = ops[kept[0]].leaf.size();
+        size_t live = leaf_len;  // length after cutting the common zero tail
+        while (live > 0) {
+            bool zero = true;
+            for (u32 i : kept) zero = zero && ops[i].leaf[live - 1] == 0;
+            if (!zero) break;
+            live--;
+        }
+        const u32 height = (u32)(ops[kept[0]].path.size() / 8);
+        o.push_back(height);
+        o.push_back((u32)(leaf_len - live));
+        o.push_back(bs);
+        o.insert(o.end(), original_order.begin(), original_order.end());
+        o.push_back((u32)kept.size());
+        for (size_t k = 0; k < kept.size(); k++) {
+            const Opening& me = ops[kept[k]];
+            const unsigned top = k == 0 ? height : diverge_level(ops[kept[k - 1]].index, me.index);
+            const int hole = k + 1 < kept.size() ? (int)diverge_level(me.index, ops[kept[k + 1]].index) - 1 : -1;
+            o.push_back((u32)me.index);
+            o.push_back((u32)(me.index >> 32));
+            o.push_back((u32)live);
+            o.insert(o.end(), me.leaf.begin(), me.leaf.begin() + live);
+            const size_t n_sib_at = o.size();
+            o.push_back(0);
+            u32 n_sib = 0;
+            for (unsigned lvl = 0; lvl < top; lvl++) {
+                if ((int)lvl == hole) continue;
+                o.insert(o.end(), me.path.begin() + 8 * lvl, me.path.begin() + 8 * lvl + 8);
+                n_sib++;
+            }
+            o[n_sib_at] = n_sib;
+        }
+    }
+    return o;
+}
+}  // namespace
+
+uint64_t lmh_proof_pruned_words(const lmh_prover* p) { return p ? pruned_blob(p).size() : 0; }
+void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out) {
+    const std::vector<u32> b = pruned_blob(p);
+    memcpy(out, b.data(), b.size() * 4);
+}
+// Proof::proof_size_fe (fiat-shamir/src/transcript.rs:39-53): transcript + pruned leaf data + 8 words per kept sibling
+uint64_t lmh_proof_size_fe(const lmh_prover* p) {
+    if (!p) return 0;
+    const std::vector<u32> b = pruned_blob(p);
+    size_t k = 1 + b[0];
+    u64 fe = b[0];
+    const u32 B = b[k++];
+    for (u32 bi = 0; bi < B; bi++) {
+        k += 2;
+        const u32 n_orig = b[k++];
+        k += n_orig;
+        const u32 n_paths = b[k++];
+        for (u32 i = 0; i < n_paths; i++) {
+            k += 2;
+            const u32 ll = b[k++];
+            k += ll;
+            const u32 ns = b[k++];
+            k += 8ull * ns;
+            fe += ll + 8ull * ns;
+        }
+    }
+    return fe;
+}
+uint32_t lmh_proof_n_batches(const lmh_prover* p) { return p ? (uint32_t)p->batch_sizes.size() : 0; }
+void lmh_proof_batch_sizes(const lmh_prover* p, uint32_t* out) {
+    if (p && !p->batch_sizes.empty()) memcpy(out, p->batch_sizes.data(), p->batch_sizes.size() * 4);
+}
 
 uint64_t lmh_proof_words(const lmh_prover* p) {
     u64 n = 2 + p->transcript.size();

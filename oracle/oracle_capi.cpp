@@ -464,6 +464,7 @@ uint64_t orc_logup_fill(const uint32_t* memory, const uint32_t* memory_acc, uint
 // prove_execution / verify_execution after witness generation (execution_oracle.hpp)
 // ================================================================================================
 #include "execution_oracle.hpp"
+#include "pruning_oracle.hpp"
 extern "C" {
 // hdr = [log_inv_rate, log_memory, log_bytecode, ending_pc, public_memory_size, n_public_input, log_rows x3]
 // builder: 8 words as in make_builder, or NULL for default_whir_config(log_inv_rate)
@@ -508,6 +509,37 @@ int orc_verify_execution(const uint32_t* proof_blob, const uint32_t* builder, co
         verify_execution(vs, pi, bytecode_hash, bytecode, log_bytecode, ending_pc, builder ? &b : nullptr);
         g_verr[0] = 0;
         return 1;
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+
+// ---- Merkle-path pruning (pruning_oracle.hpp); results through orc_last_proof ------------------------------------------
+uint64_t orc_prune_proof(const uint32_t* blob, const uint32_t* batch_sizes, uint32_t n_batches) {
+    try {
+        g_last_proof = prune_blob(blob, batch_sizes, n_batches);
+        g_verr[0] = 0;
+        return g_last_proof.size();
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+uint64_t orc_restore_proof(const uint32_t* pruned, uint64_t n_words) {
+    try {
+        g_last_proof = restore_blob(pruned, n_words);
+        g_verr[0] = 0;
+        return g_last_proof.size();
+    } catch (const std::exception& e) {
+        snprintf(g_verr, sizeof g_verr, "%s", e.what());
+        return 0;
+    }
+}
+uint64_t orc_pruned_size_fe(const uint32_t* pruned, uint64_t n_words) {
+    try {
+        g_verr[0] = 0;
+        return pruned_size_fe(pruned, n_words);
     } catch (const std::exception& e) {
         snprintf(g_verr, sizeof g_verr, "%s", e.what());
         return 0;

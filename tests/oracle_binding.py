@@ -453,3 +453,39 @@ def verify_execution(orc, w, proof, builder=None, public_input=None):
     ok = orc.lib.orc_verify_execution(c(proof), c(builder) if builder is not None else None, c(w["bytecode_hash"]), c(pi),
                                       C.c_uint32(pi.size), c(w["bytecode"]), C.c_uint32(w["log_bytecode"]), C.c_uint32(w["ending_pc"]))
     return bool(ok), orc.lib.orc_last_error().decode()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Merkle-path pruning (oracle/pruning_oracle.hpp)
+# ------------------------------------------------------------------------------------------------------------
+def _last_proof(orc, n):
+    out = np.empty(n, dtype=np.uint32)
+    orc.lib.orc_last_proof(_p(out))
+    return out
+
+
+def prune_proof(orc, blob, batch_sizes):
+    orc.lib.orc_prune_proof.restype = C.c_uint64
+    orc.lib.orc_last_error.restype = C.c_char_p
+    b = np.ascontiguousarray(blob, dtype=np.uint32)
+    bs = np.ascontiguousarray(batch_sizes, dtype=np.uint32)
+    n = orc.lib.orc_prune_proof(_p(b), _p(bs), C.c_uint32(bs.size))
+    if n == 0:
+        raise RuntimeError("oracle prune failed: " + orc.lib.orc_last_error().decode())
+    return _last_proof(orc, n)
+
+
+def restore_proof(orc, pruned):
+    orc.lib.orc_restore_proof.restype = C.c_uint64
+    orc.lib.orc_last_error.restype = C.c_char_p
+    b = np.ascontiguousarray(pruned, dtype=np.uint32)
+    n = orc.lib.orc_restore_proof(_p(b), C.c_uint64(b.size))
+    if n == 0:
+        raise RuntimeError("oracle restore failed: " + orc.lib.orc_last_error().decode())
+    return _last_proof(orc, n)
+
+
+def pruned_size_fe(orc, pruned):
+    orc.lib.orc_pruned_size_fe.restype = C.c_uint64
+    b = np.ascontiguousarray(pruned, dtype=np.uint32)
+    return int(orc.lib.orc_pruned_size_fe(_p(b), C.c_uint64(b.size)))

@@ -114,3 +114,24 @@ def test_concurrent_provers_are_independent(orc):
         assert len(got[c]) == 4
         for pf in got[c]:
             assert np.array_equal(pf, alone[c])
+
+
+def test_pruned_proof_matches_oracle_and_restores(ctx, orc):
+    """Merkle-path pruning of the device proof (lmh_proof_pruned_*, merkle_pruning.rs:18-86): word-identical to the oracle's
+    restatement, restores to the un-pruned proof, which the oracle verifier accepts; Proof::proof_size_fe agrees."""
+    rng = np.random.default_rng(3)
+    w = synth_witness.build(orc, rng, n_calls=120, n_blocks=16, log_exec=9, log_pos=8)
+    b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    tr, keep = lm.make_execution_trace(ctx, w)
+    cfg = lm.WhirConfig.from_dict(ob.whir_config(orc, b, ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))))
+    pr = lm.Prover(ctx)
+    pr.prove_execution(tr, cfg)
+    full, pruned, sizes = pr.proof(), pr.proof_pruned(), pr.batch_sizes()
+    assert sizes.sum() == full[1 + full[0]] and len(sizes) >= 2  # one batch per queried commitment
+    assert np.array_equal(pruned, ob.prune_proof(orc, full, sizes))
+    restored = ob.restore_proof(orc, pruned)
+    assert np.array_equal(restored, full)
+    ok, err = ob.verify_execution(orc, w, restored, b)
+    assert ok, err
+    fe = pr.proof_size_fe()
+    assert fe == ob.pruned_size_fe(orc, pruned) and fe < full.size

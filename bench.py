@@ -312,7 +312,7 @@ def main():
         # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
         out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
         out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc, ob)
         print(json.dumps(out), flush=True)
         if args.profile_all:

@@ -76,6 +76,18 @@ struct AccessJob {
 };
 // (A difference-array variant — +1 at the address, -1 after the last word, prefix sum — was measured SLOWER on MI355X:
 // device-scope atomics are executed memory-side, and n_values atomics on one cache line cost less than two on distant lines.)
+// n consecutive counters += v each: 64-bit atomics cover two adjacent 32-bit counters at once (a counter never carries
+// into its neighbour: counts stay far below 2^32)
+__device__ __forceinline__ void add_run(u32* __restrict__ cnt, u32 a, u32 n, u32 v) {
+    u32 j = 0;
+    if ((a & 1) && n) {
+        atomicAdd(&cnt[a], v);
+        j = 1;
+    }
+    const unsigned long long vv = ((unsigned long long)v << 32) | v;
+    for (; j + 2 <= n; j += 2) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[a + j]), vv);
+    if (j < n) atomicAdd(&cnt[a + j], v);
+}
 __global__ __launch_bounds__(256) void k_access_count(const AccessJob* __restrict__ jobs, u32* __restrict__ cnt, u64 len) {
     const AccessJob jb = jobs[blockIdx.y];
     for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < jb.n_rows; r += (u64)gridDim.x * 256) {
@@ -84,10 +96,9 @@ __global__ __launch_bounds__(256) void k_access_count(const AccessJob* __restric
         const u32 first = __builtin_amdgcn_readfirstlane(a);
         const u64 same = __ballot(a == first);
         if (same == __ballot(1)) {  // every active lane hits the same address: one lane adds for the wave
-            if (ok && (threadIdx.x & 63) == (u32)__builtin_ctzll(same))
-                for (u32 j = 0; j < jb.n_values; j++) atomicAdd(&cnt[a + j], (u32)__popcll(same));
+            if (ok && (threadIdx.x & 63) == (u32)__builtin_ctzll(same)) add_run(cnt, a, jb.n_values, (u32)__popcll(same));
         } else if (ok) {
-            for (u32 j = 0; j < jb.n_values; j++) atomicAdd(&cnt[a + j], 1u);
+            add_run(cnt, a, jb.n_values, 1u);
         }
     }
 }

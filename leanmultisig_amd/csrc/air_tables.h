@@ -329,25 +329,34 @@ static constexpr PoseidonLinear kPoseidonLinear =
 // (static_for, not "#pragma unroll": the pragma gives up on the EF body size, and a rolled loop indexes s[] dynamically,
 // which sends the whole state to scratch)
 // full rounds R0 and R0 + 1 of the 8 (0..3 initial, 4..7 terminal); round constants are instruction literals
-template <class T, int R0>
-KB_HD void two_full_rounds(T s[16]) {
-    static_for<0, 2>([&](auto RR) {
-        constexpr int r = R0 + decltype(RR)::value;
-        static_for<0, 16>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            constexpr u32 rc = r < 4 ? kb::kPoseidonHost.rc_init[r & 3][i] : kb::kPoseidonHost.rc_term[r & 3][i];
-            s[i] = cube(a_addc(s[i], rc));
-        });
-        mds16(s);
+template <class T, int R>
+KB_HD void full_round(T s[16]) {
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr u32 rc = R < 4 ? kb::kPoseidonHost.rc_init[R & 3][i] : kb::kPoseidonHost.rc_term[R & 3][i];
+        s[i] = cube(a_addc(s[i], rc));
     });
+    mds16(s);
 }
 
-// col(c) = column c at the evaluation point; colp(c, k) = its plane k only
-template <class T, int SEG, class ColFn, class ColPlaneFn>
-KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
-    (void)colp;
+// A segment of the Poseidon AIR (see above) in two halves, so that the first S-box layer — which has degree 3 in the row
+// variable — can be evaluated at 4 points only and extrapolated (lm_air.hip: k_air_round_pos_ef2):
+//   seg_first  : the 16 input columns of the segment through full round R0 (S-box + MDS)
+//   seg_finish : [segment 0: bus + flag constraints] full round R0 + 1, then the segment's constraints
+template <int SEG>
+struct SegInfo {
+    static constexpr int input_col = SEG == 0 ? 9 : SEG == 1 ? 25 : SEG == 3 ? POS_VIRT_E : 77;
+    static constexpr int round0 = SEG == 0 ? 0 : SEG == 1 ? 2 : SEG == 3 ? 4 : 6;
+};
+template <class T, int SEG, class ColFn>
+KB_HD void seg_first(ColFn col, T s[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = col(SegInfo<SEG>::input_col + i);
+    full_round<T, SegInfo<SEG>::round0>(s);
+}
+template <class T, int SEG, class ColFn>
+KB_HD EF seg_finish(T s[16], ColFn col, const Extra& x) {
     Folder<T> f(x);
-    T s[16];
     if constexpr (SEG == 0) {
         const T flag_active = col(0), index_b = col(1), index_res = col(2), flag_half = col(3), flag_left = col(4);
         const T offset_left = col(5), eff_first = col(6), eff_second = col(7), flag_permute = col(8);
@@ -366,38 +375,23 @@ KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
         f.assert_zero(a_mul(flag_permute, a_add(flag_half, flag_left)));
         f.assert_zero(a_mul(flag_left, a_sub(offset_left, eff_first)));
         f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = col(9 + i);
-        two_full_rounds<T, 0>(s);
+        full_round<T, 1>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(25 + i)));
     } else if constexpr (SEG == 1) {
         f.k = 24;
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = col(25 + i);
-        two_full_rounds<T, 2>(s);
+        full_round<T, 3>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(41 + i)));
-    } else if constexpr (SEG == 2) {
-        f.k = 40;
-        // y_r (the value cubed in partial round r) is an affine form of committed columns: it is read as virtual column
-        // POS_VIRT_Y + r, computed once per table and folded with the others (lm_air.hip: k_air_virtual_columns)
-        static_for<0, 20>([&](auto RR) {
-            constexpr int r = decltype(RR)::value;
-            f.assert_zero(a_sub(cube(col(POS_VIRT_Y + r)), col(57 + r)));  // assert_eq_low(state[0]^3, partial_rounds[r])
-        });
     } else if constexpr (SEG == 3) {
         f.k = 60;
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = col(POS_VIRT_E + i);  // exit state of the partial block (affine, virtual column)
-        two_full_rounds<T, 4>(s);
+        full_round<T, 5>(s);
 #pragma unroll
         for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(77 + i)));
     } else {
+        static_assert(SEG == 4, "segment 2 has no full rounds");
         f.k = 76;
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = col(77 + i);
-        two_full_rounds<T, 6>(s);
+        full_round<T, 7>(s);
         const T flag_half = col(3), flag_permute = col(8);
         const T one = a_from_base(kb::ONE, flag_half);
         const T not_permute = a_sub(one, flag_permute);
@@ -416,6 +410,27 @@ KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
         out_row(IntC<4>{}), out_row(IntC<5>{}), out_row(IntC<6>{}), out_row(IntC<7>{});
     }
     return f.result();
+}
+
+// col(c) = column c at the evaluation point
+template <class T, int SEG, class ColFn, class ColPlaneFn>
+KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
+    (void)colp;
+    if constexpr (SEG == 2) {
+        Folder<T> f(x);
+        f.k = 40;
+        // y_r (the value cubed in partial round r) is an affine form of committed columns: it is read as virtual column
+        // POS_VIRT_Y + r, computed once per table and folded with the others (lm_air.hip: k_air_virtual_columns)
+        static_for<0, 20>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            f.assert_zero(a_sub(cube(col(POS_VIRT_Y + r)), col(57 + r)));  // assert_eq_low(state[0]^3, partial_rounds[r])
+        });
+        return f.result();
+    } else {
+        T s[16];
+        seg_first<T, SEG>(col, s);
+        return seg_finish<T, SEG>(s, col, x);
+    }
 }
 
 }  // namespace air

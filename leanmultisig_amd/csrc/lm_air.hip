@@ -107,8 +107,9 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // from HBM (rocprofv3 FETCH_SIZE: 10x the algorithmic bytes).
 // SEG < 0: all segments in one launch (small rounds: one launch, 5x shorter dependent chains);
 // SEG >= 0: one launch per segment (large rounds: each segment gets its own register budget).
+// (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
-__global__ __launch_bounds__(256, 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32* __restrict__ final_out, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
     u32 tile, y;

@@ -94,7 +94,27 @@ def build_workload(ctx, orc, ob, rng, scale_log=0):
     return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfgd, n_vars=n_vars, builder=builder)
 
 
+def pin_witness(w):
+    """--host-resident: pinned host copies of every committed column / memory image, re-uploaded at the start of each step
+    (what a node pays when the trace builder leaves the witness in host memory): (device ptr, pinned tensor) pairs."""
+    import torch
+    pairs = []
+
+    def walk(x):
+        if hasattr(x, "ptr") and hasattr(x, "n_words"):
+            t = torch.from_numpy(x.download().view(np.int32)).pin_memory()
+            pairs.append((x.ptr, t))
+        elif isinstance(x, (list, tuple)):
+            for y in x:
+                walk(y)
+
+    walk(w["keep"])
+    return pairs
+
+
 def run_step(ctx, lm, w):
+    for dptr, t in w.get("pinned", ()):  # PCIe-inclusive mode: host -> HBM copies are part of the step
+        ctx._check(ctx.lib.lm_upload_async(ctx.h, dptr, t.data_ptr(), t.numel()))
     pr = lm.Prover(ctx)
     pr.prove_execution(w["tr"], w["cfg"])
     return pr
@@ -134,6 +154,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
                     help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs")
+    ap.add_argument("--host-resident", action="store_true",
+                    help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
@@ -162,6 +184,9 @@ def main():
     C = max(1, args.inflight)
     ctxs = [lm.Context(local_rank) for _ in range(C)]
     ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log) for c in range(C)]
+    if args.host_resident:
+        for w_ in ws:
+            w_["pinned"] = pin_witness(w_)
     ctx, w = ctxs[0], ws[0]
 
     # warmup: every stream once; then W single-stream steps, which also give the latency of one proof alone on the GPU
@@ -285,6 +310,8 @@ def main():
                             "whole-node number includes it"],
                 "per_gpu_signatures": sigs * C,
                 "proofs_in_flight_per_gpu": C,
+                "witness": "re-uploaded from pinned host memory every step (PCIe inclusive)" if args.host_resident
+                           else "resident in HBM before the timed region",
                 "single_proof_latency_ms": single_ms,
             },
             "roofline": {

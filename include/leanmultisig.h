@@ -60,6 +60,9 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr);
 int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words);
+/* lm_upload without the synchronisation: stream-ordered with the kernels that follow; `src` must stay valid (and should be
+ * pinned host memory for full PCIe rate) until the stream has passed the copy. */
+int lm_upload_async(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words);
 int lm_download(lm_ctx* ctx, uint32_t* dst, const uint32_t* d_src, uint64_t n_words);
 int lm_memset_zero(lm_ctx* ctx, uint32_t* d_dst, uint64_t n_words);
 int lm_ef_aos_to_soa(lm_ctx* ctx, const uint32_t* d_aos, uint32_t* d_soa, uint64_t n);

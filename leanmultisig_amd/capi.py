@@ -32,6 +32,7 @@ _SIGS = {
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lm_free": (C.c_int, [vp, vp]),
     "lm_upload": (C.c_int, [vp, vp, vp, C.c_uint64]),
+    "lm_upload_async": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_download": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_memset_zero": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_ef_aos_to_soa": (C.c_int, [vp, vp, vp, C.c_uint64]),

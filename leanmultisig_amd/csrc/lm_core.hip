@@ -444,6 +444,11 @@ int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_word
     LM_HIP(hipStreamSynchronize(ctx->stream));
     return LM_OK;
 }
+int lm_upload_async(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words) {
+    LM_REQUIRE(ctx && d_dst && src);
+    LM_HIP(hipMemcpyAsync(d_dst, src, n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    return LM_OK;
+}
 int lm_download(lm_ctx* ctx, uint32_t* dst, const uint32_t* d_src, uint64_t n_words) {
     LM_REQUIRE(ctx && dst && d_src);
     LM_HIP(hipMemcpyAsync(dst, d_src, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -135,3 +135,19 @@ def test_pruned_proof_matches_oracle_and_restores(ctx, orc):
     assert ok, err
     fe = pr.proof_size_fe()
     assert fe == ob.pruned_size_fe(orc, pruned) and fe < full.size
+
+
+@pytest.mark.parametrize("log_inv_rate", [2, 3])
+def test_prove_execution_other_rates_verify(ctx, orc, log_inv_rate):
+    """BASELINE config 3 (rate 1/4) and rate 1/8: the WHIR schedule (queries, folding, PoW) changes with the rate; the device
+    proof equals the oracle's at reduced security and is accepted at the production parameters."""
+    rng = np.random.default_rng(20 + log_inv_rate)
+    w = synth_witness.build(orc, rng, n_calls=60)
+    w["log_inv_rate"] = log_inv_rate
+    small = ob.whir_builder(log_inv_rate=log_inv_rate, pow_bits=6, security=60)
+    ref = ob.prove_execution(orc, w, synth_witness.header(w), small)
+    proof = _device_proof(ctx, orc, w, small)
+    assert np.array_equal(proof, ref)
+    prod = _device_proof(ctx, orc, w, ob.whir_builder(log_inv_rate=log_inv_rate))
+    ok, err = ob.verify_execution(orc, w, prod, None)
+    assert ok, err

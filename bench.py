@@ -67,7 +67,7 @@ def signer_ranges(n_total, world):
     return out
 
 
-def build_workload(ctx, orc, ob, rng, scale_log=0):
+def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1):
     """A consistent synthetic leanVM execution trace of the config-2 shape (SURVEY.md §8 size table), uploaded once:
     1550 signatures x 167 Poseidon calls = 258 850 active Poseidon rows (table 2^18 x 109), execution table 2^20 x 20,
     extension_op 2^8 x 29, memory 2^20, bytecode 2^19  ->  stacked polynomial 2^26, logup vector 2^24.
@@ -86,9 +86,10 @@ def build_workload(ctx, orc, ob, rng, scale_log=0):
 
     w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,
                             log_ext=8, log_memory=max(20 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows)
+    w["log_inv_rate"] = log_inv_rate
     tr, keep = lm.make_execution_trace(ctx, w)
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
-    builder = ob.whir_builder(log_inv_rate=1)  # default_whir_config(1): 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50)
+    builder = ob.whir_builder(log_inv_rate=log_inv_rate)  # default_whir_config(1): 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50)
     cfgd = ob.whir_config(orc, builder, n_vars)
     cfg = lm.WhirConfig.from_dict(cfgd)
     return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfgd, n_vars=n_vars, builder=builder)
@@ -156,6 +157,7 @@ def main():
                     help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs")
     ap.add_argument("--host-resident", action="store_true",
                     help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
+    ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
@@ -183,7 +185,7 @@ def main():
     import threading
     C = max(1, args.inflight)
     ctxs = [lm.Context(local_rank) for _ in range(C)]
-    ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log) for c in range(C)]
+    ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log, args.log_inv_rate) for c in range(C)]
     if args.host_resident:
         for w_ in ws:
             w_["pinned"] = pin_witness(w_)
@@ -300,7 +302,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
             "data": "synthetic",
             "config": {
-                "workload": "xmss --n-signatures 1550 --log-inv-rate 1 (BASELINE configs[1]): prove_execution from the "
+                "workload": f"xmss --n-signatures 1550 --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): prove_execution from the "
                             "execution trace to the proof on a consistent synthetic leanVM trace — 258850 Poseidon rows, "
                             "tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),

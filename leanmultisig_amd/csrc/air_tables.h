@@ -413,9 +413,8 @@ KB_HD EF seg_finish(T s[16], ColFn col, const Extra& x) {
 }
 
 // col(c) = column c at the evaluation point
-template <class T, int SEG, class ColFn, class ColPlaneFn>
-KB_HD EF eval_poseidon16_segment(ColFn col, ColPlaneFn colp, const Extra& x) {
-    (void)colp;
+template <class T, int SEG, class ColFn>
+KB_HD EF eval_poseidon16_segment(ColFn col, const Extra& x) {
     if constexpr (SEG == 2) {
         Folder<T> f(x);
         f.k = 40;

@@ -48,7 +48,6 @@ struct BaseCols {
         const u64 i1 = 2 * j + 1, i2 = (2 * j + 2 < n_rows) ? 2 * j + 2 : n_rows - 1;
         return lerp(p[i1], p[i2], zm);
     }
-    __device__ __forceinline__ u32 at_plane(u32 c, u64 j, u32 zm, int) const { return at(c, j, zm); }
 };
 struct ExtCols {
     const u32* buf;  // column c plane k at buf + (c * 5 + k) * n_rows
@@ -63,10 +62,6 @@ struct ExtCols {
         }
         return lerp(lo, hi, zm);
     }
-    __device__ __forceinline__ u32 at_plane(u32 c, u64 j, u32 zm, int k) const {
-        uint2 v = *reinterpret_cast<const uint2*>(buf + ((u64)c * 5 + k) * n_rows + 2 * j);
-        return lerp(v.x, v.y, zm);
-    }
 };
 
 static constexpr u64 AIR_SPLIT_LAUNCH_PAIRS = 1ull << 13;
@@ -77,14 +72,13 @@ template <int TABLE, class T, class Cols, int SEG>
 __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
     if constexpr (TABLE == air::T_POSEIDON16) {
         auto col = [&](int c) { return cols.at((u32)c, j, zm); };
-        auto colp = [&](int c, int k) { return cols.at_plane((u32)c, j, zm, k); };
-        if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, colp, x);
+        if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, x);
         // segment is uniform per workgroup (blockIdx.y), so this switch does not diverge
-        if (seg == 0) return air::eval_poseidon16_segment<T, 0>(col, colp, x);
-        if (seg == 1) return air::eval_poseidon16_segment<T, 1>(col, colp, x);
-        if (seg == 2) return air::eval_poseidon16_segment<T, 2>(col, colp, x);
-        if (seg == 3) return air::eval_poseidon16_segment<T, 3>(col, colp, x);
-        return air::eval_poseidon16_segment<T, 4>(col, colp, x);
+        if (seg == 0) return air::eval_poseidon16_segment<T, 0>(col, x);
+        if (seg == 1) return air::eval_poseidon16_segment<T, 1>(col, x);
+        if (seg == 2) return air::eval_poseidon16_segment<T, 2>(col, x);
+        if (seg == 3) return air::eval_poseidon16_segment<T, 3>(col, x);
+        return air::eval_poseidon16_segment<T, 4>(col, x);
     } else {
         (void)seg;
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
@@ -110,7 +104,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
 __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
-                                                   u32* __restrict__ partial, u32* __restrict__ final_out, u32 blocks_x, u32 ny) {
+                                                   u32* __restrict__ partial, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
     u32 tile, y;
     if ((blocks_x & 7) == 0) {
@@ -277,8 +271,7 @@ __global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* _
 template <int TABLE, class T, class Cols, int SEG>
 static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
                           u32* partial) {
-    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, ctx->h_res,
-              grid.x, grid.y);
+    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, grid.x, grid.y);
     return LM_OK;
 }
 template <int TABLE, class T, class Cols>

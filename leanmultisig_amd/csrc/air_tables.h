@@ -181,16 +181,23 @@ KB_HD EF eval_execution(const T* flat, const T* shift, const Extra& x) {
     f.assert_zero(a_mul(omfc, a_sub(addr_c, fpc)));
     f.assert_zero(a_mul(add_, a_sub(nu_b, a_add(nu_a, nu_c))));
     f.assert_zero(a_mul(mul, a_sub(nu_b, a_mul(nu_a, nu_c))));
-    f.assert_zero(a_mul(deref, a_sub(addr_b, a_add(value_a, operand_b))));
-    f.assert_zero(a_mul(deref, a_sub(value_b, nu_c)));
+    // constraints that share a gate: the alpha-weighted sum of the differences is multiplied by the gate once
+    // (sum_k alpha^k g d_k = g sum_k alpha^k d_k, exact)
+    Folder<T> f_deref(x), f_jc(x), f_njc(x);
+    f_deref.k = 6;
+    f_deref.assert_zero(a_sub(addr_b, a_add(value_a, operand_b)));
+    f_deref.assert_zero(a_sub(value_b, nu_c));
     const T jc = a_mul(jump, nu_a);
-    f.assert_zero(a_mul(jc, a_sub(nu_a, one)));
-    f.assert_zero(a_mul(jc, a_sub(pc_shift, nu_b)));
-    f.assert_zero(a_mul(jc, a_sub(fp_shift, nu_c)));
+    f_jc.k = 8;
+    f_jc.assert_zero(a_sub(nu_a, one));
+    f_jc.assert_zero(a_sub(pc_shift, nu_b));
+    f_jc.assert_zero(a_sub(fp_shift, nu_c));
     const T njc = a_sub(one, jc);
-    f.assert_zero(a_mul(njc, a_sub(pc_shift, a_add(pc, one))));
-    f.assert_zero(a_mul(njc, a_sub(fp_shift, fp)));
-    return f.result();
+    f_njc.k = 11;
+    f_njc.assert_zero(a_sub(pc_shift, a_add(pc, one)));
+    f_njc.assert_zero(a_sub(fp_shift, fp));
+    return kb::ef_add(kb::ef_add(f.result(), a_scale(f_deref.result(), deref)),
+                      kb::ef_add(a_scale(f_jc.result(), jc), a_scale(f_njc.result(), njc)));
 }
 
 // quintic product with plain dot products (extension_op/air.rs:37-42)

@@ -70,19 +70,77 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u3
             data[x] = src[e];
         }
     }
-    for (u32 q = 0; q < K; q++) {
+    // Layers in groups of three (radix 8 in registers: 8 LDS reads + 8 writes and one index computation per 12 butterflies),
+    // the remainder as radix 4 / radix 2.  T(l, idx, lo) = twiddle of layer l for hi-index idx.
+    auto tw_of = [&](u32 l, u32 idx, u32 lo_l) {
+        u32 w = tws[(1u << l) + idx];
+        if (S > 0) w = mul(w, twlo[(l << m) + lo_l]);
+        return w;
+    };
+    auto bfly = [&](u32& a_, u32& b_, u32 w) {
+        const u32 d = mul(sub(b_, a_), w);
+        const u32 t = a_;
+        a_ = add(t, d);
+        b_ = sub(t, d);
+    };
+    u32 q = 0;
+    for (; q + 3 <= K; q += 3) {
+        __syncthreads();
+        const u32 bp = q + m;
+        for (u32 g = tid; g < (tile >> 3); g += 256) {
+            const u32 x0 = ((g >> bp) << (bp + 3)) | (g & ((1u << bp) - 1));
+            const u32 tq = (x0 >> m) & ((1u << q) - 1), lo_l = x0 & ((1u << m) - 1);
+            u32 v[8];
+            if (bp == 0) {  // 8 consecutive words
+                const uint4 p0 = *reinterpret_cast<const uint4*>(data + x0), p1 = *reinterpret_cast<const uint4*>(data + x0 + 4);
+                v[0] = p0.x, v[1] = p0.y, v[2] = p0.z, v[3] = p0.w, v[4] = p1.x, v[5] = p1.y, v[6] = p1.z, v[7] = p1.w;
+            } else {
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) v[k] = data[x0 + (k << bp)];
+            }
+            const u32 wa = tw_of(q, tq, lo_l);
+            bfly(v[0], v[1], wa), bfly(v[2], v[3], wa), bfly(v[4], v[5], wa), bfly(v[6], v[7], wa);
+            const u32 wb0 = tw_of(q + 1, tq, lo_l), wb1 = tw_of(q + 1, tq + (1u << q), lo_l);
+            bfly(v[0], v[2], wb0), bfly(v[1], v[3], wb1), bfly(v[4], v[6], wb0), bfly(v[5], v[7], wb1);
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) bfly(v[k], v[k + 4], tw_of(q + 2, tq + (k << q), lo_l));
+            if (bp == 0) {
+                *reinterpret_cast<uint4*>(data + x0) = make_uint4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint4*>(data + x0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (u32 k = 0; k < 8; k++) data[x0 + (k << bp)] = v[k];
+            }
+        }
+    }
+    if (q + 2 == K) {
+        __syncthreads();
+        const u32 bp = q + m;
+        for (u32 g = tid; g < (tile >> 2); g += 256) {
+            const u32 x0 = ((g >> bp) << (bp + 2)) | (g & ((1u << bp) - 1));
+            const u32 tq = (x0 >> m) & ((1u << q) - 1), lo_l = x0 & ((1u << m) - 1);
+            u32 v[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) v[k] = data[x0 + (k << bp)];
+            const u32 wa = tw_of(q, tq, lo_l);
+            bfly(v[0], v[1], wa), bfly(v[2], v[3], wa);
+            bfly(v[0], v[2], tw_of(q + 1, tq, lo_l)), bfly(v[1], v[3], tw_of(q + 1, tq + (1u << q), lo_l));
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) data[x0 + (k << bp)] = v[k];
+        }
+        q += 2;
+    }
+    for (; q < K; q++) {
         __syncthreads();
         const u32 bp = q + m;
         for (u32 b = tid; b < (tile >> 1); b += 256) {
-            u32 x0 = ((b >> bp) << (bp + 1)) | (b & ((1u << bp) - 1));
-            u32 x1 = x0 | (1u << bp);
-            u32 hi = x0 >> m;
-            u32 w = tws[(1u << q) + (hi & ((1u << q) - 1))];
-            if (S > 0) w = mul(w, twlo[(q << m) + (x0 & ((1u << m) - 1))]);
+            const u32 x0 = ((b >> bp) << (bp + 1)) | (b & ((1u << bp) - 1));
+            const u32 x1 = x0 | (1u << bp);
+            const u32 w = tw_of(q, (x0 >> m) & ((1u << q) - 1), x0 & ((1u << m) - 1));
             u32 va = data[x0], vb = data[x1];
-            u32 d = mul(sub(vb, va), w);
-            data[x0] = add(va, d);
-            data[x1] = sub(va, d);
+            bfly(va, vb, w);
+            data[x0] = va;
+            data[x1] = vb;
         }
     }
     __syncthreads();

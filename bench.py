@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
     args = ap.parse_args()
     os.environ["OMP_NUM_THREADS"] = "1"  # the cpu_baseline leg is a one-thread port (set before any OpenMP runtime loads)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
 
     import torch
     import torch.distributed as dist

@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
                     help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on a single-GPU box "
+                         "together with LM_BENCH_SINGLE_DEVICE=1)")
     ap.add_argument("--host-resident", action="store_true",
                     help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
     ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
@@ -172,10 +175,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("LM_BENCH_SINGLE_DEVICE"):  # test rig: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     import leanmultisig_amd as lm
     from tests import oracle_binding as ob

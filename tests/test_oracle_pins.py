@@ -33,6 +33,18 @@ def test_field_constants(orc):
         acc = orc.mul(acc, w)
 
 
+def test_neon_regression_operands(orc):
+    """crates/backend/koala-bear/src/aarch64_neon/packing.rs:44-50: the dot product whose carries cascade; expected value =
+    the scalar result."""
+    lhs = [P - 1, 1, 8, P - 3, P - 2]
+    rhs = [P - 4, 9, P - 2, P - 5, 6]
+    want = sum(a * b for a, b in zip(lhs, rhs)) % P
+    acc = 0
+    for a, b in zip(lhs, rhs):
+        acc = (acc + orc.lib.orc_from_monty(orc.mul(int(orc.to_monty(a)), int(orc.to_monty(b))))) % P
+    assert acc == want
+
+
 def test_monty_roundtrip_and_inverse(orc):
     rng = np.random.default_rng(0)
     for x in rng.integers(1, P, size=20):

@@ -93,3 +93,15 @@ def test_poseidon_trace_rows_match_oracle(ctx, orc):
     ctx.poseidon_trace(bufs, 1024)
     got = np.stack([b.download() for b in bufs])
     assert np.array_equal(got, ref)
+
+
+def test_poseidon_table_large_paths(ctx, orc):
+    """2^14 rows: the base-field round takes the one-launch-per-segment path (2^13 pairs), the extension-field rounds the
+    multi-workgroup combined kernel with the XCD-aware id mapping, virtual columns are folded over 13 rounds — the same
+    launch shapes as the config-2 table, still word-identical to the textbook oracle."""
+    rng = np.random.default_rng(314)
+    alpha, eq16, beta, eta = _challenges(rng)
+    lr = 14
+    cols = rand_field(rng, (ob.AIR_N_COLUMNS[2], 1 << lr))
+    t = dict(table=2, log_rows=lr, cols=cols, eq_point=rand_field(rng, (lr, 5)), sum=rand_field(rng, 5))
+    _run(ctx, orc, [t], alpha, eq16, beta, eta)

@@ -339,6 +339,8 @@ class Context:
     # ---- ops ----------------------------------------------------------------------------------------
     def poseidon16(self, states, compress=False):
         st = _u32(states).reshape(-1, 16)
+        if st.shape[0] == 0:
+            return st.copy()
         buf = self.to_device(st)
         fn = self.lib.lm_poseidon16_compress if compress else self.lib.lm_poseidon16_permute
         self._check(fn(self.h, buf.ptr, st.shape[0]))

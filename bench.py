@@ -128,22 +128,25 @@ def step_root(pr):
 
 
 def cpu_baseline(orc, ob, log_scale=4):
-    """The oracle's prove_execution (scalar C++ restatement of the reference algorithm, one thread) on a 1/16 sample of the
-    same step: every table, the memory and the bytecode are 16x smaller (the smallest scale at which the VM's minimum
-    memory size 2^16 is still proportional), so stacked 2^22, logup 2^20.  Scaled linearly to the metric's unit."""
+    """The oracle's prove_execution (scalar C++ restatement of the reference algorithm; its data-parallel loops — LDE,
+    Merkle levels, sumcheck rounds, folds — are OpenMP loops over all host cores, as the reference's are rayon loops) on a
+    1/16 sample of the same step: every table, the memory and the bytecode are 16x smaller (the smallest scale at which the
+    VM's minimum memory size 2^16 is still proportional), so stacked 2^22, logup 2^20.  Scaled linearly to the metric's unit."""
     from tests import synth_witness
     rng = np.random.default_rng(1)
     sh = log_scale
     w = synth_witness.build(orc, rng, n_calls=(N_SIGS * 167) >> sh, n_blocks=4096 >> sh, log_exec=20 - sh, log_pos=18 - sh, log_ext=8,
                             log_memory=20 - sh, log_bytecode=19 - sh, fill_rows=None)
+    want = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = ob.set_threads(orc, want)
     t0 = time.time()
     ob.prove_execution(orc, w, synth_witness.header(w), None)
     dt = time.time() - t0
     est_full = dt * (1 << sh)
-    return dict(value=N_SIGS / est_full, unit="xmss_sigs/s", cores=1, kind="port",
+    return dict(value=N_SIGS / est_full, unit="xmss_sigs/s", cores=cores, kind="port",
                 sample=f"oracle prove_execution (commit, logup GKR, AIR sumcheck, WHIR open; 124-bit parameters) on a consistent "
                        f"trace 1/{1 << sh} of the step: tables 2^{20 - sh}/2^{18 - sh}/2^8, memory 2^{20 - sh}, "
-                       f"{dt:.1f} s on one host thread (OMP_NUM_THREADS=1), scaled x{1 << sh}; the fixed-size PoW searches are "
+                       f"{dt:.1f} s on {cores} OpenMP threads, scaled x{1 << sh}; the fixed-size PoW searches are "
                        f"over-counted by the scaling")
 
 
@@ -165,7 +168,6 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
     args = ap.parse_args()
-    os.environ["OMP_NUM_THREADS"] = "1"  # the cpu_baseline leg is a one-thread port (set before any OpenMP runtime loads)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
 
     import torch

@@ -327,16 +327,23 @@ struct AirSession {
         const size_t nc = cols.size();
         std::vector<EF> eqt = eq_table(eq_factor.data(), eq_factor.size() - 1, ef_one());
         std::vector<EF> acc(deg + 1, ef_zero());  // index = z (z = 1 unused)
-        std::vector<EF> point(nc), diff(nc);
-        for (size_t j = 0; j < pairs; j++) {
-            for (size_t c = 0; c < nc; c++) {
-                point[c] = cols[c][2 * j];
-                diff[c] = ef_sub(cols[c][2 * j + 1], cols[c][2 * j]);
+        // (OpenMP: per-thread partial sums, merged at the end — exact arithmetic, the order of the sum does not matter)
+#pragma omp parallel if (pairs >= 64)
+        {
+            std::vector<EF> local(deg + 1, ef_zero()), point(nc), diff(nc);
+#pragma omp for schedule(static)
+            for (size_t j = 0; j < pairs; j++) {
+                for (size_t c = 0; c < nc; c++) {
+                    point[c] = cols[c][2 * j];
+                    diff[c] = ef_sub(cols[c][2 * j + 1], cols[c][2 * j]);
+                }
+                for (size_t z = 0; z <= deg; z++) {
+                    if (z != 1) local[z] = ef_add(local[z], ef_mul(air_eval(table, point.data(), extra), eqt[j]));
+                    for (size_t c = 0; c < nc; c++) point[c] = ef_add(point[c], diff[c]);
+                }
             }
-            for (size_t z = 0; z <= deg; z++) {
-                if (z != 1) acc[z] = ef_add(acc[z], ef_mul(air_eval(table, point.data(), extra), eqt[j]));
-                for (size_t c = 0; c < nc; c++) point[c] = ef_add(point[c], diff[c]);
-            }
+#pragma omp critical
+            for (size_t z = 0; z <= deg; z++) acc[z] = ef_add(acc[z], local[z]);
         }
         std::vector<EF> ev(deg + 1);
         for (size_t z = 0; z <= deg; z++) ev[z] = ef_mul(acc[z], mmf);
@@ -369,7 +376,9 @@ struct AirSession {
         EF eq_eval = ef_add(ef_mul(ef_sub(ef_one(), a), ef_sub(ef_one(), ch)), ef_mul(a, ch));
         sum = ef_mul(poly_eval(bare, ch), eq_eval);
         mmf = ef_mul(mmf, eq_eval);
-        for (auto& col : cols) {
+#pragma omp parallel for schedule(dynamic) if (cols.size() >= 4 && cols[0].size() >= 256)
+        for (size_t ci = 0; ci < cols.size(); ci++) {  // columns are independent (the fold of one column is in place)
+            auto& col = cols[ci];
             size_t h = col.size() / 2;
             for (size_t j = 0; j < h; j++) col[j] = ef_add(col[2 * j], ef_mul(ch, ef_sub(col[2 * j + 1], col[2 * j])));
             col.resize(h);

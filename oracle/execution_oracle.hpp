@@ -5,6 +5,9 @@
 // and ends with the proof.  The VM interpreter / trace builder that precede it are out of scope.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include "logup_oracle.hpp"
 
@@ -129,7 +132,19 @@ static inline void fs_preamble_prover(ProverState& ps, const ExecutionInput& in)
 }
 
 // builder: default_whir_config(rate) unless the test overrides PoW/security to keep the oracle fast
+// ORC_STAGE_TIMES=1: wall clock per stage on stderr (where the CPU baseline spends its time)
+struct OrcStageClock {
+    bool on = getenv("ORC_STAGE_TIMES") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* name) {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "# oracle stage %-24s %9.1f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 static inline void prove_execution(ProverState& ps, const ExecutionInput& in, const WhirConfigBuilder& builder) {
+    OrcStageClock clk;
     fs_preamble_prover(ps, in);
     size_t log_rows[3] = {in.tables[0].log_rows, in.tables[1].log_rows, in.tables[2].log_rows};
     std::vector<int> order = sort_tables_by_height(log_rows);
@@ -148,7 +163,9 @@ static inline void prove_execution(ProverState& ps, const ExecutionInput& in, co
             off += (size_t)1 << log_rows[t];
         }
     WhirConfig cfg = WhirConfig::make(builder, stacked_n_vars);
+    clk.mark("stack");
     Witness wit = whir_commit(cfg, ps, poly.data(), off);
+    clk.mark("whir_commit");
     // logup (prove_execution.rs:123-150, logup.rs)
     EF logup_c = ps.sample();
     ps.duplex();
@@ -162,7 +179,9 @@ static inline void prove_execution(ProverState& ps, const ExecutionInput& in, co
     size_t gkr_n_vars = log2_ceil(nums.size());
     EF quotient, cn, cd;
     std::vector<EF> gkr_point;
+    clk.mark("logup_fill");
     gkr_prove(ps, nums.data(), dens.data(), gkr_n_vars, quotient, gkr_point, cn, cd);
+    clk.mark("logup_gkr");
     if (!ef_eq(quotient, ef_zero())) throw std::runtime_error("logup sum != 0 (inconsistent witness)");
     std::vector<EF> mem_pt = from_end(gkr_point, in.log_memory);
     EF value_memory_acc = mle_eval_base(in.memory_acc, in.log_memory, mem_pt.data());
@@ -210,6 +229,7 @@ static inline void prove_execution(ProverState& ps, const ExecutionInput& in, co
     }
     std::vector<TableStatement> committed[3];
     for (int t = 0; t < 3; t++) committed[t].push_back({from_end(gkr_point, log_rows[t]), columns_values[t], {}});
+    clk.mark("column_evaluations");
     // AIR (prove_execution.rs:152-223)
     EF bus_beta = ps.sample();
     ps.duplex();
@@ -273,7 +293,9 @@ static inline void prove_execution(ProverState& ps, const ExecutionInput& in, co
     prev.push_back(mk(pm_pt, {{0, pm_eval}}));
     prev.push_back(mk(bc_pt, {{(2 * mem) >> in.log_bytecode, value_bytecode_acc}}));
     std::vector<SparseStatement> global = stacked_pcs_global_statements(stacked_n_vars, in.log_memory, in.log_bytecode, in.ending_pc, prev, log_rows, committed);
+    clk.mark("air_sumcheck+statements");
     whir_prove(cfg, ps, global, std::move(wit), poly.data());
+    clk.mark("whir_open");
 }
 
 // verify_execution (verify_execution.rs:14-233) + verify_generic_logup (logup.rs:326-493).  Throws on failure.

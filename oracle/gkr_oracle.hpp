@@ -20,6 +20,7 @@ static inline GkrLayer gkr_layer_up(const GkrLayer& in) {
     size_t m = in.nums.size() / 2;
     out.nums.resize(m);
     out.dens.resize(m);
+#pragma omp parallel for schedule(static) if (m >= 4096)
     for (size_t i = 0; i < m; i++) {
         out.nums[i] = ef_add(ef_mul(in.dens[2 * i + 1], in.nums[2 * i]), ef_mul(in.dens[2 * i], in.nums[2 * i + 1]));
         out.dens[i] = ef_mul(in.dens[2 * i], in.dens[2 * i + 1]);
@@ -55,7 +56,9 @@ static inline void gkr_prove_layer(ProverState& ps, const GkrLayer& layer, std::
         EF eq_alpha = remaining.back();
         std::vector<EF> eqt = eq_table(remaining.data(), remaining.size() - 1, ef_one());
         EF c0n = ef_zero(), c2n = ef_zero(), c0d = ef_zero(), c2d = ef_zero();
-        for (size_t j = 0; j < nl.size() / 2; j++) {
+        const size_t n_pairs = nl.size() / 2;
+#pragma omp parallel for schedule(static) reduction(efsum : c0n, c2n, c0d, c2d) if (n_pairs >= 2048)
+        for (size_t j = 0; j < n_pairs; j++) {
             // pair_coeffs, sumcheck_utils.rs:65-79
             EF dl0 = dl[2 * j], dl1 = dl[2 * j + 1], dr0 = dr[2 * j], dr1 = dr[2 * j + 1];
             EF nl0 = nl[2 * j], nl1 = nl[2 * j + 1], nr0 = nr[2 * j], nr1 = nr[2 * j + 1];
@@ -74,16 +77,20 @@ static inline void gkr_prove_layer(ProverState& ps, const GkrLayer& layer, std::
         sum = ef_mul(eq_eval, poly_eval(bare, r));
         mmf = ef_mul(mmf, eq_eval);
         size_t h = nl.size() / 2;
-        for (size_t j = 0; j < h; j++) {
-            nl[j] = ef_add(nl[2 * j], ef_mul(r, ef_sub(nl[2 * j + 1], nl[2 * j])));
-            nr[j] = ef_add(nr[2 * j], ef_mul(r, ef_sub(nr[2 * j + 1], nr[2 * j])));
-            dl[j] = ef_add(dl[2 * j], ef_mul(r, ef_sub(dl[2 * j + 1], dl[2 * j])));
-            dr[j] = ef_add(dr[2 * j], ef_mul(r, ef_sub(dr[2 * j + 1], dr[2 * j])));
+        {  // fold into fresh vectors (an in-place fold cannot be split across threads)
+            std::vector<EF> tnl(h), tnr(h), tdl(h), tdr(h);
+#pragma omp parallel for schedule(static) if (h >= 2048)
+            for (size_t j = 0; j < h; j++) {
+                tnl[j] = ef_add(nl[2 * j], ef_mul(r, ef_sub(nl[2 * j + 1], nl[2 * j])));
+                tnr[j] = ef_add(nr[2 * j], ef_mul(r, ef_sub(nr[2 * j + 1], nr[2 * j])));
+                tdl[j] = ef_add(dl[2 * j], ef_mul(r, ef_sub(dl[2 * j + 1], dl[2 * j])));
+                tdr[j] = ef_add(dr[2 * j], ef_mul(r, ef_sub(dr[2 * j + 1], dr[2 * j])));
+            }
+            nl.swap(tnl);
+            nr.swap(tnr);
+            dl.swap(tdl);
+            dr.swap(tdr);
         }
-        nl.resize(h);
-        nr.resize(h);
-        dl.resize(h);
-        dr.resize(h);
         q.push_back(r);
         remaining.pop_back();
     }

@@ -87,6 +87,8 @@ static inline EF ef_add(const EF& a, const EF& b) {
     for (int i = 0; i < 5; i++) r.v[i] = add(a.v[i], b.v[i]);
     return r;
 }
+// OpenMP sums of extension-field elements (exact arithmetic: the order of a sum does not matter)
+#pragma omp declare reduction(efsum : EF : omp_out = ef_add(omp_out, omp_in)) initializer(omp_priv = ef_zero())
 static inline EF ef_sub(const EF& a, const EF& b) {
     EF r;
     for (int i = 0; i < 5; i++) r.v[i] = sub(a.v[i], b.v[i]);
@@ -257,12 +259,14 @@ static inline MerkleTree merkle_build(const uint32_t* rows, size_t height, size_
     t.leaves.assign(height * full_width, 0);
     for (size_t r = 0; r < height; r++) std::memcpy(&t.leaves[r * full_width], rows + r * width, width * 4);
     std::vector<uint32_t> lay(height * 8);
+#pragma omp parallel for schedule(static)
     for (size_t r = 0; r < height; r++) hash_slice(&t.leaves[r * full_width], full_width, &lay[r * 8]);
     t.layers.push_back(lay);
     while (t.layers.back().size() > 8) {
         const std::vector<uint32_t>& prev = t.layers.back();
         size_t n = prev.size() / 16;
         std::vector<uint32_t> next(n * 8);
+#pragma omp parallel for schedule(static) if (n >= 256)
         for (size_t i = 0; i < n; i++) compress_pair(&prev[16 * i], &prev[16 * i + 8], &next[8 * i]);
         t.layers.push_back(next);
     }
@@ -324,8 +328,11 @@ static inline void dft_batch_by_evals(uint32_t* mat, size_t h, size_t w) {
         std::vector<uint32_t> tw(half);
         tw[0] = ONE;
         for (size_t j = 1; j < half; j++) tw[j] = mul(tw[j - 1], g);
-        for (size_t blk = 0; blk < h; blk += 2 * half)
-            for (size_t j = 0; j < half; j++) {
+        const size_t n_bfly = h / 2;  // butterfly rows of this layer: index -> (block, j)
+#pragma omp parallel for schedule(static) if (n_bfly * w >= 4096)
+        for (size_t bj = 0; bj < n_bfly; bj++) {
+            {
+                const size_t blk = (bj / half) * 2 * half, j = bj % half;
                 uint32_t* ra = mat + (blk + j) * w;
                 uint32_t* rb = mat + (blk + j + half) * w;
                 for (size_t c = 0; c < w; c++) {
@@ -335,6 +342,7 @@ static inline void dft_batch_by_evals(uint32_t* mat, size_t h, size_t w) {
                     rb[c] = sub(a, d);
                 }
             }
+        }
     }
 }
 

@@ -1,5 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see kb_oracle.hpp header).  C entry points for ctypes.
 #include "kb_oracle.hpp"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 using namespace orc;
 
 extern "C" {
@@ -544,5 +547,15 @@ uint64_t orc_pruned_size_fe(const uint32_t* pruned, uint64_t n_words) {
         snprintf(g_verr, sizeof g_verr, "%s", e.what());
         return 0;
     }
+}
+// OpenMP width of the oracle's data-parallel loops (bench.py's cpu_baseline leg); results do not depend on it
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 }

@@ -470,6 +470,7 @@ static inline void combine_statement(const std::vector<SparseStatement>& st, EF 
         std::vector<EF> inner = s.is_next ? matrix_next_mle_folded(s.point) : eq_table(s.point.data(), s.point.size(), ef_one());
         for (const SparseValue& e : s.values) {
             size_t base = e.selector << s.point.size();
+#pragma omp parallel for schedule(static) if (inner.size() >= 4096)
             for (size_t i = 0; i < inner.size(); i++) W[base + i] = ef_add(W[base + i], ef_mul(inner[i], gp));
             sum = ef_add(sum, ef_mul(e.value, gp));
             gp = ef_mul(gp, gamma);
@@ -526,6 +527,7 @@ static inline std::vector<EF> run_sumcheck_rounds(SumcheckSingle& sc, ProverStat
     for (size_t r = 0; r < n_rounds; r++) {
         size_t half = sc.evals.size() / 2;
         EF c0 = ef_zero(), c2 = ef_zero();
+#pragma omp parallel for schedule(static) reduction(efsum : c0, c2) if (half >= 4096)
         for (size_t i = 0; i < half; i++) {
             c0 = ef_add(c0, ef_mul(sc.evals[i], sc.weights[i]));
             c2 = ef_add(c2, ef_mul(ef_sub(sc.evals[i + half], sc.evals[i]), ef_sub(sc.weights[i + half], sc.weights[i])));
@@ -537,6 +539,7 @@ static inline std::vector<EF> run_sumcheck_rounds(SumcheckSingle& sc, ProverStat
         EF ch = ps.sample();
         challenges.push_back(ch);
         sc.sum = poly_eval(poly, ch);
+#pragma omp parallel for schedule(static) if (half >= 4096)
         for (size_t i = 0; i < half; i++) {
             sc.evals[i] = ef_add(sc.evals[i], ef_mul(ch, ef_sub(sc.evals[i + half], sc.evals[i])));
             sc.weights[i] = ef_add(sc.weights[i], ef_mul(ch, ef_sub(sc.weights[i + half], sc.weights[i])));

@@ -489,3 +489,9 @@ def pruned_size_fe(orc, pruned):
     orc.lib.orc_pruned_size_fe.restype = C.c_uint64
     b = np.ascontiguousarray(pruned, dtype=np.uint32)
     return int(orc.lib.orc_pruned_size_fe(_p(b), C.c_uint64(b.size)))
+
+
+def set_threads(orc, n=0):
+    """OpenMP width of the oracle's loops (n = 0: query only); returns the width in effect."""
+    orc.lib.orc_set_threads.restype = C.c_int
+    return int(orc.lib.orc_set_threads(C.c_int(int(n))))

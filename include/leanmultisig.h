@@ -80,6 +80,13 @@ int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
  * poseidon_16/mod.rs:366-383).  Columns 0..24 (flags, indices, 16 inputs) are inputs; the 84 derived columns are written. */
 int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows);
 
+/* fill_trace_extension_op (crates/lean_vm/src/tables/extension_op/exec.rs:192-203): the five VALUE_A columns of the
+ * ExtensionOp table, value_a[k][row] = memory[idx_a[row] + k] (idx_a = column COL_IDX_A, Montgomery form like every
+ * column).  d_va_cols = host array of the 5 DEVICE column pointers (COL_VA..COL_VA+4, extension_op/air.rs:24).  A row whose
+ * address range leaves [0, memory_len) gets zeros (the reference would panic on the slice index). */
+int lm_extension_op_trace(lm_ctx* ctx, const uint32_t* d_memory, uint64_t memory_len, const uint32_t* d_idx_a,
+                          uint32_t* const* d_va_cols, uint64_t n_rows);
+
 /* ---- WHIR commitment: LDE + Merkle tree -------------------------------------------------------------------------
  * lm_commit replaces reorder_and_dft (crates/whir/src/utils.rs:69-98: prepare_evals_for_fft_unpacked :128-150 +
  * EvalsDft::dft_algebra_batch_by_evals crates/whir/src/dft.rs:79-155) followed by MerkleData::build

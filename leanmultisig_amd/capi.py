@@ -40,6 +40,7 @@ _SIGS = {
     "lm_poseidon16_permute": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon16_compress": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
+    "lm_extension_op_trace": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
     "lm_commit": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp), vp]),
     "lm_tree_free": (None, [vp, vp]),
     "lm_tree_log_height": (C.c_uint32, [vp]),
@@ -350,6 +351,13 @@ class Context:
         ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
         assert ptrs.size == 109
         self._check(self.lib.lm_poseidon_trace(self.h, _ptr(ptrs), int(n_rows)))
+
+    def extension_op_trace(self, d_memory, memory_len, d_idx_a, va_bufs, n_rows):
+        """fill_trace_extension_op: the 5 value_a columns gathered from memory (all arguments device buffers / pointers)."""
+        dev = lambda b: b.ptr if hasattr(b, "ptr") else int(b)  # noqa: E731
+        ptrs = np.array([dev(c) for c in va_bufs], dtype=np.uint64)
+        assert ptrs.size == 5
+        self._check(self.lib.lm_extension_op_trace(self.h, dev(d_memory), int(memory_len), dev(d_idx_a), _ptr(ptrs), int(n_rows)))
 
     def commit(self, d_evals, is_ext, n_vars, folding_factor, log_inv_rate, actual_len=None):
         if actual_len is None:

@@ -132,6 +132,34 @@ extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint
     return LM_OK;
 }
 
+// fill_trace_extension_op (extension_op/exec.rs:192-203): value_a[k][row] = memory[idx_a[row] + k].  A gather; rows are
+// consecutive addresses inside a call (stride 1 or 5), so a wave's reads fall into a few lines.
+struct ExtOpCols {
+    u32* va[5];
+};
+__global__ __launch_bounds__(256) void k_extension_op_trace(const u32* __restrict__ memory, u64 mem_len, const u32* __restrict__ idx_a,
+                                                            ExtOpCols out, u64 n_rows) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (u64)gridDim.x * 256) {
+        const u64 a = from_monty(idx_a[i]);
+#pragma unroll
+        for (u32 k = 0; k < 5; k++) out.va[k][i] = a + k < mem_len ? memory[a + k] : 0u;
+    }
+}
+extern "C" int lm_extension_op_trace(lm_ctx* ctx, const uint32_t* d_memory, uint64_t memory_len, const uint32_t* d_idx_a,
+                                     uint32_t* const* d_va_cols, uint64_t n_rows) {
+    LM_REQUIRE(ctx && d_memory && d_idx_a && d_va_cols);
+    if (n_rows == 0) return LM_OK;
+    ExtOpCols o;
+    for (u32 k = 0; k < 5; k++) {
+        LM_REQUIRE(d_va_cols[k]);
+        o.va[k] = d_va_cols[k];
+    }
+    LM_LAUNCH(ctx, k_extension_op_trace, dim3((unsigned)std::min<u64>((n_rows + 255) / 256, 4096)), dim3(256), 0, d_memory, memory_len,
+              d_idx_a, o, n_rows);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
                               const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
     LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);

@@ -151,3 +151,53 @@ def test_prove_execution_other_rates_verify(ctx, orc, log_inv_rate):
     prod = _device_proof(ctx, orc, w, ob.whir_builder(log_inv_rate=log_inv_rate))
     ok, err = ob.verify_execution(orc, w, prod, None)
     assert ok, err
+
+
+def test_mixed_program_matches_oracle(ctx, orc):
+    """ADD / MUL / DEREF instructions and every ExtensionOp mode (active rows in the 42-column degree-6 AIR, non-trivial
+    bus and memory lookups for all three tables): device proof == oracle proof, word for word."""
+    rng = np.random.default_rng(5)
+    w = synth_witness.build_mixed(orc, rng)
+    b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    ref = ob.prove_execution(orc, w, synth_witness.header(w), b)
+    proof = _device_proof(ctx, orc, w, b)
+    ok, err = ob.verify_execution(orc, w, proof, b)
+    assert ok, err
+    assert proof.size == ref.size and np.array_equal(proof, ref)
+
+
+def test_recursion_shaped_tables_verify(ctx, orc):
+    """BASELINE configs[3] stand-in: the ExtensionOp table is as tall as the execution table (the reference requires execution >= every table, stacked_pcs.rs:111; ~2^15 active rows of long
+    dot products / poly_eq chains), the Poseidon table 32x shorter — the batched AIR sumcheck starts on the execution and
+    ExtensionOp AIRs and the Poseidon AIR joins late.  Production parameters; checked by the oracle verifier."""
+    rng = np.random.default_rng(6)
+    ext = [("mul", False, 64, 200), ("mul", True, 128, 60), ("poly_eq", False, 20, 300), ("add", False, 1, 500), ("poly_eq", True, 9, 100)]
+    w = synth_witness.build(orc, rng, n_calls=500, n_blocks=32, log_exec=15, log_pos=10, log_ext=15, log_memory=18, log_bytecode=12,
+                            n_arith=600, ext_calls=ext)
+    assert sum(s * c for _, _, s, c in ext) > (1 << 14)
+    w["log_inv_rate"] = 2
+    proof = _device_proof(ctx, orc, w, ob.whir_builder(log_inv_rate=2))
+    ok, err = ob.verify_execution(orc, w, proof, None)
+    assert ok, err
+
+
+def test_extension_op_trace_gather(ctx, orc):
+    """lm_extension_op_trace == fill_trace_extension_op (extension_op/exec.rs:192-203) on the mixed witness and on random
+    addresses including the last valid one and an overflowing one (zeros)."""
+    rng = np.random.default_rng(7)
+    w = synth_witness.build_mixed(orc, rng)
+    ext, mem = w["tables"][1], w["memory"]
+    n = ext.shape[1]
+    d_mem, d_idx = ctx.to_device(mem), ctx.to_device(ext[6])
+    va = [ctx.alloc(n) for _ in range(5)]
+    ctx.extension_op_trace(d_mem, mem.size, d_idx, va, n)
+    for k in range(5):
+        assert np.array_equal(va[k].download(), ext[14 + k])
+    addr = np.concatenate([rng.integers(0, mem.size - 5, size=3000), [mem.size - 5, mem.size - 4, mem.size + 9]])
+    d_idx = ctx.to_device(orc.to_monty(addr))
+    va = [ctx.alloc(addr.size) for _ in range(5)]
+    ctx.extension_op_trace(d_mem, mem.size, d_idx, va, addr.size)
+    padded = np.concatenate([mem, np.zeros(32, dtype=np.uint32)])
+    for k in range(5):
+        assert np.array_equal(va[k].download(), padded[np.minimum(addr + k, mem.size + 16)])
+    ctx.extension_op_trace(d_mem, mem.size, d_idx, va, 0)

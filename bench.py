@@ -67,7 +67,14 @@ def signer_ranges(n_total, world):
     return out
 
 
-def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1):
+# BASELINE configs[3] stand-in (SURVEY.md §8(d) "Config 4"): a recursion node's trace is dominated by the in-VM verifier —
+# long dot products / eq polynomials on the ExtensionOp table, Merkle paths on the Poseidon table, a 2x longer execution
+# table.  Real shapes are unknown without the reference VM; these are the survey's synthetic ones.
+RECURSION_EXT_CALLS = [("mul", False, 64, 3000), ("mul", True, 128, 800), ("poly_eq", False, 20, 4000), ("poly_eq", True, 9, 2000),
+                       ("add", False, 1, 20000), ("mul", False, 1, 20000), ("add", True, 2, 3000)]
+
+
+def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss"):
     """A consistent synthetic leanVM execution trace of the config-2 shape (SURVEY.md §8 size table), uploaded once:
     1550 signatures x 167 Poseidon calls = 258 850 active Poseidon rows (table 2^18 x 109), execution table 2^20 x 20,
     extension_op 2^8 x 29, memory 2^20, bytecode 2^19  ->  stacked polynomial 2^26, logup vector 2^24.
@@ -84,8 +91,14 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1):
         for c in range(25, 109):
             rows[:, c] = cols[c].download()
 
-    w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,
-                            log_ext=8, log_memory=max(20 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows)
+    if shape == "recursion":
+        ext = [(op, be, size, max(1, cnt >> sh)) for op, be, size, cnt in RECURSION_EXT_CALLS]
+        w = synth_witness.build(orc, rng, n_calls=100000 >> sh, n_blocks=4096 >> min(sh, 6), log_exec=21 - sh, log_pos=17 - sh,
+                                log_ext=19 - sh, log_memory=max(23 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows,
+                                n_arith=300000 >> sh, ext_calls=ext)
+    else:
+        w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,
+                                log_ext=8, log_memory=max(20 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows)
     w["log_inv_rate"] = log_inv_rate
     tr, keep = lm.make_execution_trace(ctx, w)
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
@@ -165,6 +178,9 @@ def main():
                     help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
     ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
+    ap.add_argument("--shape", choices=["xmss", "recursion"], default="xmss",
+                    help="xmss = BASELINE configs[1]/[2] (the metric); recursion = configs[3] stand-in: ExtensionOp table 2^19, "
+                         "Poseidon 2^17, execution 2^21 (side measurement, reported as proofs/s)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
     args = ap.parse_args()
@@ -193,7 +209,7 @@ def main():
     import threading
     C = max(1, args.inflight)
     ctxs = [lm.Context(local_rank) for _ in range(C)]
-    ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log, args.log_inv_rate) for c in range(C)]
+    ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log, args.log_inv_rate, args.shape) for c in range(C)]
     if args.host_resident:
         for w_ in ws:
             w_["pinned"] = pin_witness(w_)
@@ -341,6 +357,14 @@ def main():
                 "secondary": leaf,
             },
         }
+        if args.shape == "recursion":  # side measurement: not the BASELINE metric
+            lr = w["w"]["log_rows"]
+            out["metric"], out["unit"], out["value"] = "recursion_shaped_proofs_per_sec", "proofs/s", C * world / (dt / args.steps)
+            out["config"]["workload"] = (f"BASELINE configs[3] stand-in (SURVEY.md §8(d)): tables 2^{lr[0]}x20 / 2^{lr[1]}x29 / 2^{lr[2]}x109, "
+                                         f"memory 2^{w['w']['log_memory']}, stacked 2^{w['n_vars']}, rate 1/{1 << args.log_inv_rate}; ADD/MUL/DEREF "
+                                         "instructions, all six ExtensionOp modes, Poseidon calls")
+            out["config"].pop("per_gpu_signatures")
+            out["roofline"]["traffic"] = out["roofline"]["secondary"] = None  # the PMC file is of the xmss shape
         if args.verify:
             ok, err = ob.verify_execution(orc, w["w"], pr.proof(), None)
             out["config"]["proof_verified_by_oracle"] = bool(ok)
@@ -349,7 +373,7 @@ def main():
         # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
         out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
         out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc, ob)
         print(json.dumps(out), flush=True)
         if args.profile_all:

@@ -54,9 +54,16 @@ struct ExtCols {
     u64 n_rows;
     __device__ __forceinline__ EF at(u32 c, u64 j, u32 zm) const {
         EF lo, hi;
+        // The plane stride is made opaque at every access: as a loop invariant, the compiler hoists all (columns x 5) plane
+        // addresses out of the row loop into SGPR pairs — ~1100 of them for the Poseidon table — and spills them to VGPR
+        // lanes (3 k v_readlane + 2.7 k v_writelane per evaluation).  Recomputed next to the loads they are 3 scalar
+        // instructions per plane on the otherwise idle scalar unit.
+        u64 nr = n_rows;
+        asm volatile("" : "+s"(nr));
+        const u32* p = buf + (u64)c * 5 * nr + 2 * j;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            uint2 v = *reinterpret_cast<const uint2*>(buf + ((u64)c * 5 + k) * n_rows + 2 * j);
+            uint2 v = *reinterpret_cast<const uint2*>(p + k * nr);
             lo.v[k] = v.x;
             hi.v[k] = v.y;
         }

@@ -39,12 +39,18 @@ struct BaseCols {
     u64 n_rows;
     u32 n_flat;
     // column c < n_flat: flat; c >= n_flat: shift view of column c - n_flat
+    // RELOAD: the pointer table is re-read next to each use.  Hoisted out of the row loop, the column pointers of the wide
+    // execution / ExtensionOp evaluations are spilled from SGPRs to VGPR lanes (1.5 k v_readlane of 4.9 k instructions,
+    // see ExtCols::at); the per-segment Poseidon kernels touch few columns each and are better off with the hoisted loads.
+    template <bool RELOAD>
     __device__ __forceinline__ u32 at(u32 c, u64 j, u32 zm) const {
+        const u32* const* cp = cols;
+        if constexpr (RELOAD) asm volatile("" : "+s"(cp));
         if (c < n_flat) {
-            uint2 v = *reinterpret_cast<const uint2*>(cols[c] + 2 * j);
+            uint2 v = *reinterpret_cast<const uint2*>(cp[c] + 2 * j);
             return lerp(v.x, v.y, zm);
         }
-        const u32* p = cols[c - n_flat];
+        const u32* p = cp[c - n_flat];
         const u64 i1 = 2 * j + 1, i2 = (2 * j + 2 < n_rows) ? 2 * j + 2 : n_rows - 1;
         return lerp(p[i1], p[i2], zm);
     }
@@ -52,6 +58,7 @@ struct BaseCols {
 struct ExtCols {
     const u32* buf;  // column c plane k at buf + (c * 5 + k) * n_rows
     u64 n_rows;
+    template <bool RELOAD>
     __device__ __forceinline__ EF at(u32 c, u64 j, u32 zm) const {
         EF lo, hi;
         // The plane stride is made opaque at every access: as a loop invariant, the compiler hoists all (columns x 5) plane
@@ -78,7 +85,7 @@ static constexpr u32 AIR_POS_SLOTS = 4 * AIR_POS_POINTS + 4;   // rows of its pa
 template <int TABLE, class T, class Cols, int SEG>
 __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
     if constexpr (TABLE == air::T_POSEIDON16) {
-        auto col = [&](int c) { return cols.at((u32)c, j, zm); };
+        auto col = [&](int c) { return cols.template at<false>((u32)c, j, zm); };
         if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, x);
         // segment is uniform per workgroup (blockIdx.y), so this switch does not diverge
         if (seg == 0) return air::eval_poseidon16_segment<T, 0>(col, x);
@@ -91,9 +98,9 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
         T flat[NF], shift[NS];
 #pragma unroll
-        for (int c = 0; c < NF; c++) flat[c] = cols.at(c, j, zm);
+        for (int c = 0; c < NF; c++) flat[c] = cols.template at<true>(c, j, zm);
 #pragma unroll
-        for (int c = 0; c < NS; c++) shift[c] = cols.at(NF + c, j, zm);
+        for (int c = 0; c < NS; c++) shift[c] = cols.template at<true>(NF + c, j, zm);
         if constexpr (TABLE == air::T_EXECUTION)
             return air::eval_execution<T>(flat, shift, x);
         else

@@ -42,6 +42,7 @@ struct BaseCols {
     // RELOAD: the pointer table is re-read next to each use.  Hoisted out of the row loop, the column pointers of the wide
     // execution / ExtensionOp evaluations are spilled from SGPRs to VGPR lanes (1.5 k v_readlane of 4.9 k instructions,
     // see ExtCols::at); the per-segment Poseidon kernels touch few columns each and are better off with the hoisted loads.
+    __device__ __forceinline__ uint2 raw(u32 c, u64 j) const { return *reinterpret_cast<const uint2*>(cols[c] + 2 * j); }  // flat column
     template <bool RELOAD>
     __device__ __forceinline__ u32 at(u32 c, u64 j, u32 zm) const {
         const u32* const* cp = cols;
@@ -78,13 +79,48 @@ struct ExtCols {
     }
 };
 
+#ifndef AIR_BASE_SEG_WAVES
+#define AIR_BASE_SEG_WAVES 4
+#endif
 static constexpr u64 AIR_SPLIT_LAUNCH_PAIRS = 1ull << 13;
 static constexpr u32 AIR_POS_POINTS = 10;                      // evaluation points of the Poseidon table (degree 10)
 static constexpr u32 AIR_POS_SLOTS = 4 * AIR_POS_POINTS + 4;   // rows of its partial-sum matrix, see k_air_round
 
 template <int TABLE, class T, class Cols, int SEG>
 __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
-    if constexpr (TABLE == air::T_POSEIDON16) {
+    if constexpr (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) {
+        // Base-field round, one segment per launch: a wave evaluates ONE row pair (3-4 k instructions), so its life is the
+        // chain of column loads, not the arithmetic.  All columns of the segment are requested up front (<= 42 loads in
+        // flight per lane, 84 VGPRs) instead of lazily next to their use (~10 dependent waits).
+        u32 val[air::POS_VIRT_E + 16];
+        auto fetch = [&](auto FIRST, auto COUNT) {
+            constexpr int first = decltype(FIRST)::value, count = decltype(COUNT)::value;
+            uint2 raw[count];
+            static_for<0, count>([&](auto I) { raw[decltype(I)::value] = cols.raw(first + decltype(I)::value, j); });
+            static_for<0, count>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                val[first + i] = lerp(raw[i].x, raw[i].y, zm);
+            });
+        };
+        using kb::IntC;
+        if constexpr (SEG == 0) {
+            fetch(IntC<0>{}, IntC<41>{});  // flags, inputs, beginning_full_rounds[0]
+        } else if constexpr (SEG == 1) {
+            fetch(IntC<25>{}, IntC<32>{});
+        } else if constexpr (SEG == 2) {
+            fetch(IntC<57>{}, IntC<20>{});
+            fetch(IntC<air::POS_VIRT_Y>{}, IntC<20>{});
+        } else if constexpr (SEG == 3) {
+            fetch(IntC<77>{}, IntC<16>{});
+            fetch(IntC<air::POS_VIRT_E>{}, IntC<16>{});
+        } else {
+            fetch(IntC<77>{}, IntC<32>{});
+            fetch(IntC<3>{}, IntC<1>{});
+            fetch(IntC<8>{}, IntC<9>{});  // flag_permute, inputs 0..7
+        }
+        auto col = [&](int c) { return val[c]; };
+        return air::eval_poseidon16_segment<T, SEG>(col, x);
+    } else if constexpr (TABLE == air::T_POSEIDON16) {
         auto col = [&](int c) { return cols.template at<false>((u32)c, j, zm); };
         if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, x);
         // segment is uniform per workgroup (blockIdx.y), so this switch does not diverge
@@ -117,7 +153,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // SEG >= 0: one launch per segment (large rounds: each segment gets its own register budget).
 // (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
-__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : 1) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : 1)) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
     u32 tile, y;

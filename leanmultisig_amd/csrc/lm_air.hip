@@ -79,6 +79,9 @@ struct ExtCols {
     }
 };
 
+#ifndef AIR_EXT_WAVES
+#define AIR_EXT_WAVES 1
+#endif
 #ifndef AIR_BASE_SEG_WAVES
 #define AIR_BASE_SEG_WAVES 4
 #endif
@@ -153,7 +156,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // SEG >= 0: one launch per segment (large rounds: each segment gets its own register budget).
 // (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
-__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : 1)) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : (TABLE == air::T_EXECUTION ? 2 : (sizeof(T) == sizeof(u32) ? AIR_EXT_WAVES : 1)))) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32 blocks_x, u32 ny) {
     __shared__ u32 lds[20];
     u32 tile, y;

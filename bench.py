@@ -140,18 +140,19 @@ def step_root(pr):
     return blob[1 + 6:1 + 14]
 
 
-def cpu_baseline(orc, ob, log_scale=4):
+def cpu_baseline(orc, ob, log_scale=3):
     """The oracle's prove_execution (scalar C++ restatement of the reference algorithm; its data-parallel loops — LDE,
     Merkle levels, sumcheck rounds, folds — are OpenMP loops over all host cores, as the reference's are rayon loops) on a
-    1/16 sample of the same step: every table, the memory and the bytecode are 16x smaller (the smallest scale at which the
-    VM's minimum memory size 2^16 is still proportional), so stacked 2^22, logup 2^20.  Scaled linearly to the metric's unit."""
+    1/8 sample of the same step: every table, the memory and the bytecode are 8x smaller, so stacked 2^23, logup 2^21.
+    Scaled linearly to the metric's unit.  16 threads at most: the oracle's loops are fine-grained and stop scaling there
+    (measured on the 256-thread host of the GPU box: 8 threads 5.6 s, 16: 3.7 s, 32: 3.8 s, 64: 4.6 s, 256: 67 s at 1/16)."""
     from tests import synth_witness
     rng = np.random.default_rng(1)
     sh = log_scale
     w = synth_witness.build(orc, rng, n_calls=(N_SIGS * 167) >> sh, n_blocks=4096 >> sh, log_exec=20 - sh, log_pos=18 - sh, log_ext=8,
                             log_memory=20 - sh, log_bytecode=19 - sh, fill_rows=None)
     want = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = ob.set_threads(orc, want)
+    cores = ob.set_threads(orc, min(want, 16))
     t0 = time.time()
     ob.prove_execution(orc, w, synth_witness.header(w), None)
     dt = time.time() - t0
@@ -169,8 +170,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=6,
-                    help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs.  "
+                         "0 = default: 10, fewer if the host has less than 2 hardware threads per prover thread")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on a single-GPU box "
                          "together with LM_BENCH_SINGLE_DEVICE=1)")
@@ -207,7 +209,8 @@ def main():
     # prove leaf after leaf; the ~400 sequential Fiat-Shamir round trips of one proof leave the chip idle between small
     # kernels, a second and third proof fill those gaps).  Each prover has its own lm_ctx (stream, pools, pinned buffers).
     import threading
-    C = max(1, args.inflight)
+    hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    C = args.inflight if args.inflight > 0 else max(1, min(10, hw // (2 * max(1, world))))
     ctxs = [lm.Context(local_rank) for _ in range(C)]
     ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log, args.log_inv_rate, args.shape) for c in range(C)]
     if args.host_resident:
@@ -311,9 +314,15 @@ def main():
                 for r in range(1, lr):
                     lane_ops += vc[f"table{t}_ef"] * deg * (1 << (lr - 1 - r))
             peak = 256 * 4 * 16 * 2.4e9 / 1e12  # CUs x SIMDs x lanes per cycle x clock = 39.3 T lane-instructions/s
+            source = "static v_* count per evaluation (profiles/r01_air_valu_counts.json) x evaluations / HIP-event time"
+            pmc_valu = os.path.join(ROOT, "profiles", "r01_valu_bench.json")
+            if os.path.exists(pmc_valu) and args.scale_log == 0 and args.shape == "xmss":  # measured instruction count of this workload
+                jv = json.load(open(pmc_valu))["per_proof"].get("k_air_round")
+                if jv:
+                    lane_ops = jv["valu_wave_insts"] * 64
+                    source = "SQ_INSTS_VALU of k_air_round per proof (profiles/r01_valu_bench.json, rocprofv3 --pmc) x 64 lanes / HIP-event time"
             ach = lane_ops * args.steps / (k_ms * 1e-3) / 1e12
-            alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak,
-                   "source": "static v_* count per evaluation (profiles/r01_air_valu_counts.json) x evaluations / HIP-event time"}
+            alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak, "source": source}
         single = None
         if args.warmup and k_ms_1 > 0:
             single = {"achieved": alg_bytes * args.warmup / (k_ms_1 * 1e-3) / 1e9, "unit": "GB/s",

@@ -140,10 +140,10 @@ def step_root(pr):
     return blob[1 + 6:1 + 14]
 
 
-def cpu_baseline(orc, ob, log_scale=3):
+def cpu_baseline(orc, ob, log_scale=2):
     """The oracle's prove_execution (scalar C++ restatement of the reference algorithm; its data-parallel loops — LDE,
     Merkle levels, sumcheck rounds, folds — are OpenMP loops over all host cores, as the reference's are rayon loops) on a
-    1/8 sample of the same step: every table, the memory and the bytecode are 8x smaller, so stacked 2^23, logup 2^21.
+    1/4 sample of the same step: every table, the memory and the bytecode are 4x smaller, so stacked 2^24, logup 2^22.
     Scaled linearly to the metric's unit.  16 threads at most: the oracle's loops are fine-grained and stop scaling there
     (measured on the 256-thread host of the GPU box: 8 threads 5.6 s, 16: 3.7 s, 32: 3.8 s, 64: 4.6 s, 256: 67 s at 1/16)."""
     from tests import synth_witness
@@ -358,7 +358,7 @@ def main():
                                   "FETCH x2 per MI355X_MICROARCH.md)",
                 "contention": f"HIP events on stream 0 while {C} proofs share the chip: launch durations include the other "
                               "streams' kernels; single-stream figures are in DESIGN.md §3 / profiles/",
-                "note": "the constraint evaluation is integer-ALU bound (one Poseidon-AIR evaluation = 87 k VALU instructions "
+                "note": "the constraint evaluation is integer-ALU bound (one Poseidon-AIR evaluation = 65 k VALU instructions "
                         "in the extension field), so the HBM fraction is small by construction; `alu` is the utilisation "
                         "that matters — see DESIGN.md §3",
                 "alu": alu,

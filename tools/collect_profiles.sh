@@ -20,6 +20,13 @@ cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --verify > $OUT/bench_verify.json 2> $OUT/bench_verify.err
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > $OUT/bench_inflight1.json 2> $OUT/bench_inflight1.err
+python bench.py --no-cpu-baseline --log-inv-rate 2 > $OUT/bench_config3_rate4.json 2> /dev/null
+python bench.py --no-cpu-baseline --log-inv-rate 2 --inflight 1 --steps 3 > $OUT/bench_config3_rate4_inflight1.json 2> /dev/null
+python bench.py --no-cpu-baseline --host-resident > $OUT/bench_host_resident.json 2> /dev/null
+python bench.py --no-cpu-baseline --host-resident --inflight 1 --steps 3 > $OUT/bench_host_resident_inflight1.json 2> /dev/null
+python bench.py --shape recursion --log-inv-rate 2 --inflight 1 --steps 3 --verify --profile-all > $OUT/bench_recursion_shape_inflight1.json 2> $OUT/bench_recursion_shape_kernels.txt
+python bench.py --shape recursion --log-inv-rate 2 --steps 3 > $OUT/bench_recursion_shape.json 2> /dev/null
+for c in 1 2 4 6 8 10 12; do python bench.py --no-cpu-baseline --inflight $c --steps 4 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['config']['proofs_in_flight_per_gpu'], round(d['value']), round(d['ms_per_step'],2))"; done > $OUT/inflight_sweep.txt
 python tools/pmc_summary.py $OUT 5 $OUT/pmc_bench.json > /dev/null
 python tools/valu_summary.py $OUT 5 $OUT/valu_bench.json > $OUT/valu_bench.txt
 python tools/launch_seq.py $OUT/stats_inflight1 k_air_round 5 60 > $OUT/air_round_launches.txt

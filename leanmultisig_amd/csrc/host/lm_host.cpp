@@ -322,12 +322,12 @@ void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]) { memcpy(out1
 // the siblings below its divergence from path i-1, except the one level where path i+1 joins it (that hash is recomputed
 // by the verifier from path i+1).  Blob layout: include/leanmultisig_host.h.
 namespace {
-unsigned diverge_level(u64 a, u64 b) {  // lca_level: number of low bits to drop until a == b
+static unsigned diverge_level(u64 a, u64 b) {  // lca_level: number of low bits to drop until a == b
     unsigned l = 0;
     for (u64 x = a ^ b; x; x >>= 1) l++;
     return l;
 }
-std::vector<u32> pruned_blob(const lmh_prover* p) {
+static std::vector<u32> pruned_blob(const lmh_prover* p) {
     std::vector<u32> o;
     o.push_back((u32)p->transcript.size());
     o.insert(o.end(), p->transcript.begin(), p->transcript.end());

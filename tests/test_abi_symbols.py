@@ -36,3 +36,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(capi.LmError):
         capi.load()
+
+
+def test_no_undeclared_c_symbols_exported():
+    """Every C-linkage function the library exports is declared in include/*.h (no stray helpers in the ABI)."""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "leanmultisig_amd", "libleanmultisig_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T"}
+    exported = {s for s in exported if not s.startswith(("_Z", "__hip", "_init", "_fini"))}
+    declared = set()
+    for h in ("leanmultisig.h", "leanmultisig_host.h"):
+        declared |= set(re.findall(r"\b(lmh?_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
+    assert exported <= declared, sorted(exported - declared)

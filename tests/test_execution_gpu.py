@@ -201,3 +201,24 @@ def test_extension_op_trace_gather(ctx, orc):
     for k in range(5):
         assert np.array_equal(va[k].download(), padded[np.minimum(addr + k, mem.size + 16)])
     ctx.extension_op_trace(d_mem, mem.size, d_idx, va, 0)
+
+
+@pytest.mark.parametrize("log_inv_rate", [1, 2])
+def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
+    """BASELINE configs[1] (rate 1/2) and configs[2] (rate 1/4) at their FULL size (1550 signatures: Poseidon table 2^18 with 258 850 active rows, execution 2^20,
+    memory 2^20, stacked polynomial 2^26, logup 2^24, production WHIR parameters) — too large for the oracle's prover, so
+    parity is carried by size-independent properties: the oracle's VERIFIER accepts the proof (every sumcheck, GKR layer,
+    Merkle path and PoW witness of the real size), proving twice gives the same words, and the pruned wire form restores to
+    the proof."""
+    import bench
+    w = bench.build_workload(ctx, orc, ob, np.random.default_rng(77), log_inv_rate=log_inv_rate)
+    assert w["n_vars"] == 26
+    p1 = bench.run_step(ctx, lm, w)
+    proof = p1.proof()
+    ok, err = ob.verify_execution(orc, w["w"], proof, None)
+    assert ok, err
+    p2 = bench.run_step(ctx, lm, w)
+    assert np.array_equal(p2.proof(), proof)
+    pruned = p1.proof_pruned()
+    assert np.array_equal(ob.restore_proof(orc, pruned), proof)
+    assert p1.proof_size_fe() == ob.pruned_size_fe(orc, pruned) < proof.size

@@ -29,6 +29,8 @@ struct Extra {
     EF alpha_powers[MAX_ALPHA];
     EF logup_eq[16];  // logup_alphas_eq_poly
     EF bus_beta;
+    // Poseidon table, segments 0 / 1 / 3 (see POS_VIRT_O): beta[s][j] = sum_i alpha^(k_s + i) * MDS[i][j]
+    EF out_beta[3][16];
 };
 
 // ---- small algebra over T ------------------------------------------------------------------------------------------
@@ -315,7 +317,18 @@ static constexpr int POSEIDON_SEGMENTS = 5;
 // recomputing 16 x 36 + 20 x ~26 multiply-adds per plane at every evaluation point of every round.
 static constexpr int POS_VIRT_Y = 109;       // 20 columns: value cubed in partial round r
 static constexpr int POS_VIRT_E = 109 + 20;  // 16 columns: state entering ending_full_rounds
-static constexpr int POS_N_VIRT = 36;
+// Output blocks of segments 0, 1, 3 (s = 0, 1, 2): their 16 constraints  MDS(y)_i - out_i  (y = the S-box layer of the
+// segment's second full round, out = 16 committed columns) enter the round polynomial only through
+//     sum_i alpha^(k_s+i) (MDS(y)_i - out_i)  =  sum_j beta_sj y_j  -  V_s,      V_s = sum_i alpha^(k_s+i) out_i,
+// and V_s is LINEAR in committed columns: it is computed once per table and folded like a column.  Per evaluation this
+// replaces one MDS, 16 column reads and 16 challenge-weighted products by 16 products and one column read (exact field
+// identity, the same round polynomials).  V_s is extension-field valued; its 5 coefficient planes are 5 virtual BASE
+// columns (column POS_VIRT_O + 5 s + k), so the base round reads them as a value and every fold treats them like any
+// column: after folding, V_s = sum_k X^k * (folded plane k).
+static constexpr int POS_VIRT_O = 109 + 36;
+static constexpr int POS_N_VIRT = 36 + 15;
+static constexpr int POS_OUT_K0[3] = {8, 24, 60};    // alpha exponent of the first output constraint of segments 0, 1, 3
+static constexpr int POS_OUT_COL[3] = {25, 41, 77};  // first of their 16 output columns
 
 // Affine forms of the partial block (gen_poseidon_consts.py::linearise): lanes 1..15 see no S-box inside the block and lane 0
 // is re-based on the committed partial_rounds[r] column every round, so over u = (t_0..t_15, q_0..q_19, 1) with
@@ -361,6 +374,61 @@ KB_HD void seg_first(ColFn col, T s[16]) {
     for (int i = 0; i < 16; i++) s[i] = col(SegInfo<SEG>::input_col + i);
     full_round<T, SegInfo<SEG>::round0>(s);
 }
+// p * X^k in the basis 1, X, .., X^4 (X^5 = 1 - X^2): (a0..a4) * X = (a4, a0, a1 - a4, a2, a3)
+template <int K>
+KB_HD EF ef_mul_xk(EF a) {
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        const EF b = a;
+        a.v[0] = b.v[4], a.v[1] = b.v[0], a.v[2] = kb::sub(b.v[1], b.v[4]), a.v[3] = b.v[2], a.v[4] = b.v[3];
+    }
+    return a;
+}
+// V_s at the evaluation point from its 5 plane columns
+template <class T, int S, class ColFn>
+KB_HD EF virt_out(ColFn col) {
+    if constexpr (sizeof(T) == sizeof(u32)) {
+        EF v;
+        static_for<0, 5>([&](auto K) { v.v[decltype(K)::value] = (u32)col(POS_VIRT_O + 5 * S + decltype(K)::value); });
+        return v;
+    } else {
+        EF v = col(POS_VIRT_O + 5 * S);
+        static_for<1, 5>([&](auto K) { v = kb::ef_add(v, ef_mul_xk<decltype(K)::value>(col(POS_VIRT_O + 5 * S + decltype(K)::value))); });
+        return v;
+    }
+}
+// sum_j beta_sj * cube(s_j + rc_j) - V_s: the output block of segment slot S whose second full round is R
+template <class T, int S, int R, class ColFn>
+KB_HD EF out_block(const T s[16], ColFn col, const Extra& x) {
+    const EF v = virt_out<T, S>(col);
+    if constexpr (sizeof(T) == sizeof(u32)) {
+        // base round: 16 x 5 multiply-adds into 64-bit accumulators, folded every 4 / 3 products (kb::fold32)
+        u64 a[5] = {0, 0, 0, 0, 0};
+        static_for<0, 16>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr u32 rc = R < 4 ? kb::kPoseidonHost.rc_init[R & 3][j] : kb::kPoseidonHost.rc_term[R & 3][j];
+            const u32 y = cube(a_addc(s[j], rc));
+            if constexpr (j >= 4 && (j - 4) % 3 == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) a[k] = kb::fold32(a[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[k] += (u64)x.out_beta[S][j].v[k] * y;
+        });
+        EF r;
+#pragma unroll
+        for (int k = 0; k < 5; k++) r.v[k] = kb::reduce(kb::fold32(a[k]));
+        return kb::ef_sub(r, v);
+    } else {
+        EF acc = kb::ef_neg(v);
+        static_for<0, 16>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr u32 rc = R < 4 ? kb::kPoseidonHost.rc_init[R & 3][j] : kb::kPoseidonHost.rc_term[R & 3][j];
+            acc = kb::ef_add(acc, kb::ef_mul(x.out_beta[S][j], cube(a_addc(s[j], rc))));
+        });
+        return acc;
+    }
+}
 template <class T, int SEG, class ColFn>
 KB_HD EF seg_finish(T s[16], ColFn col, const Extra& x) {
     Folder<T> f(x);
@@ -382,19 +450,11 @@ KB_HD EF seg_finish(T s[16], ColFn col, const Extra& x) {
         f.assert_zero(a_mul(flag_permute, a_add(flag_half, flag_left)));
         f.assert_zero(a_mul(flag_left, a_sub(offset_left, eff_first)));
         f.assert_zero(a_mul(omfl, a_sub(index_a, eff_first)));
-        full_round<T, 1>(s);
-#pragma unroll
-        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(25 + i)));
+        return kb::ef_add(f.result(), out_block<T, 0, 1>(s, col, x));  // alpha^8..23: beginning_full_rounds[0]
     } else if constexpr (SEG == 1) {
-        f.k = 24;
-        full_round<T, 3>(s);
-#pragma unroll
-        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(41 + i)));
+        return out_block<T, 1, 3>(s, col, x);  // alpha^24..39: beginning_full_rounds[1]
     } else if constexpr (SEG == 3) {
-        f.k = 60;
-        full_round<T, 5>(s);
-#pragma unroll
-        for (int i = 0; i < 16; i++) f.assert_zero(a_sub(s[i], col(77 + i)));
+        return out_block<T, 2, 5>(s, col, x);  // alpha^60..75: ending_full_rounds[0]
     } else {
         static_assert(SEG == 4, "segment 2 has no full rounds");
         f.k = 76;

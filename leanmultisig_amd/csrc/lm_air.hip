@@ -94,8 +94,9 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
     if constexpr (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) {
         // Base-field round, one segment per launch: a wave evaluates ONE row pair (3-4 k instructions), so its life is the
         // chain of column loads, not the arithmetic.  All columns of the segment are requested up front (<= 42 loads in
-        // flight per lane, 84 VGPRs) instead of lazily next to their use (~10 dependent waits).
-        u32 val[air::POS_VIRT_E + 16];
+        // flight per lane, 84 VGPRs) instead of lazily next to their use (~10 dependent waits).  (Segments 0, 1, 3 read
+        // their output block as the 5 planes of one virtual column, air_tables.h: POS_VIRT_O.)
+        u32 val[air::POS_VIRT_O + 15];
         auto fetch = [&](auto FIRST, auto COUNT) {
             constexpr int first = decltype(FIRST)::value, count = decltype(COUNT)::value;
             uint2 raw[count];
@@ -107,15 +108,17 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         };
         using kb::IntC;
         if constexpr (SEG == 0) {
-            fetch(IntC<0>{}, IntC<41>{});  // flags, inputs, beginning_full_rounds[0]
+            fetch(IntC<0>{}, IntC<25>{});  // flags, inputs
+            fetch(IntC<air::POS_VIRT_O>{}, IntC<5>{});
         } else if constexpr (SEG == 1) {
-            fetch(IntC<25>{}, IntC<32>{});
+            fetch(IntC<25>{}, IntC<16>{});
+            fetch(IntC<air::POS_VIRT_O + 5>{}, IntC<5>{});
         } else if constexpr (SEG == 2) {
             fetch(IntC<57>{}, IntC<20>{});
             fetch(IntC<air::POS_VIRT_Y>{}, IntC<20>{});
         } else if constexpr (SEG == 3) {
-            fetch(IntC<77>{}, IntC<16>{});
             fetch(IntC<air::POS_VIRT_E>{}, IntC<16>{});
+            fetch(IntC<air::POS_VIRT_O + 10>{}, IntC<5>{});
         } else {
             fetch(IntC<77>{}, IntC<32>{});
             fetch(IntC<3>{}, IntC<1>{});
@@ -303,9 +306,11 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
     }
 }
 
-// Virtual columns of the Poseidon table (air_tables.h: POS_VIRT_Y / POS_VIRT_E): per row the 20 + 16 affine forms of the
-// partial block over u = (beginning_full_rounds[1] (16), partial_rounds (20)).  Base-field in, base-field out.
-__global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* __restrict__ cols, u64 n_rows, u32* __restrict__ virt) {
+// Virtual columns of the Poseidon table (air_tables.h: POS_VIRT_Y / POS_VIRT_E / POS_VIRT_O): per row the 20 + 16 affine
+// forms of the partial block over u = (beginning_full_rounds[1] (16), partial_rounds (20)), and the 3 x 5 coefficient planes
+// of the challenge-weighted output blocks V_s = sum_i alpha^(k_s + i) * out_s[i].  Base-field in, base-field out.
+__global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* __restrict__ cols, u64 n_rows, u32* __restrict__ virt,
+                                                             const air::Extra* __restrict__ extra) {
     const u64 r0 = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r0 >= n_rows) return;
     u32 u[36];
@@ -318,6 +323,19 @@ __global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* _
     static_for<0, 16>([&](auto I) {
         constexpr int i = decltype(I)::value;
         virt[(u64)(20 + i) * n_rows + r0] = add(dot_n<36>(u, air::kPoseidonLinear.fin[i]), air::kPoseidonLinear.fin[i][36]);
+    });
+    static_for<0, 3>([&](auto SS) {
+        constexpr int s = decltype(SS)::value;
+        u32 o[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) o[i] = s == 1 ? u[i] : cols[air::POS_OUT_COL[s] + i][r0];  // (segment 1's outputs are u[0..16))
+        static_for<0, 5>([&](auto KK) {
+            constexpr int k = decltype(KK)::value;
+            u32 al[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) al[i] = extra->alpha_powers[air::POS_OUT_K0[s] + i].v[k];
+            virt[(u64)(36 + 5 * s + k) * n_rows + r0] = dot_n<16>(o, al);
+        });
     });
 }
 
@@ -394,6 +412,15 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
         hx.alpha_powers[i] = p;
         p = ef_mul(p, al);
     }
+    // beta[s][j] = sum_i alpha^(k_s + i) * MDS[i][j], MDS[i][j] = col[(i - j) mod 16] (air_tables.h: POS_VIRT_O)
+    static constexpr u32 MDS_COL[16] = {1, 3, 13, 22, 67, 2, 15, 63, 101, 1, 2, 17, 11, 1, 51, 1};
+    for (int sgm = 0; sgm < 3; sgm++)
+        for (int j = 0; j < 16; j++) {
+            EF b = ef_zero();
+            for (int i = 0; i < 16; i++)
+                b = ef_add(b, ef_mul_base(hx.alpha_powers[air::POS_OUT_K0[sgm] + i], to_monty(MDS_COL[(16 + i - j) & 15])));
+            hx.out_beta[sgm][j] = b;
+        }
     memcpy(hx.logup_eq, logup_eq16, 16 * 20);
     memcpy(hx.bus_beta.v, bus_beta, 20);
     bool ok = lm_pool_alloc(ctx, (void**)&a->d_base_cols, (a->n_cols + a->n_virt) * sizeof(u32*)) == hipSuccess &&
@@ -412,10 +439,10 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
     LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*), hipMemcpyHostToDevice,
                           ctx->stream));
+    LM_HIP(hipMemcpyAsync(a->d_extra, &a->h_extra, sizeof(air::Extra), hipMemcpyHostToDevice, ctx->stream));
     if (a->n_virt)
         LM_LAUNCH(ctx, k_air_virtual_columns, dim3((unsigned)(((1ull << log_rows) + 255) / 256)), dim3(256), 0,
-                  (const u32* const*)a->d_base_cols, 1ull << log_rows, a->d_virt);
-    LM_HIP(hipMemcpyAsync(a->d_extra, &a->h_extra, sizeof(air::Extra), hipMemcpyHostToDevice, ctx->stream));
+                  (const u32* const*)a->d_base_cols, 1ull << log_rows, a->d_virt, (const air::Extra*)a->d_extra);
     int rc = a->eqt.build(ctx, eq_point, log_rows);
     if (rc) {
         lm_air_free(ctx, a);

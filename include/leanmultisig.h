@@ -87,6 +87,16 @@ int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows);
 int lm_extension_op_trace(lm_ctx* ctx, const uint32_t* d_memory, uint64_t memory_len, const uint32_t* d_idx_a,
                           uint32_t* const* d_va_cols, uint64_t n_rows);
 
+/* get_execution_trace, main loop (crates/lean_prover/src/trace_gen.rs:27-100): the 24 columns of the execution table
+ * (execution/air.rs:9-37: pc, fp, addr_a/b/c, value_a/b/c, the 12 instruction columns, is_precompile, nu_a/b/c) for cycles
+ * 0..n_cycles from the VM's log — d_pcs / d_fps are CANONICAL integers (the reference's Vec<usize>), everything else is in
+ * Montgomery form.  d_bytecode = instructions_multilinear (bytecode_rows x 16 words, 12 used); d_memory = the padded memory
+ * image (undefined cells are 0, as trace_gen.rs:103).  d_cols = host array of 24 device column pointers, n_cycles words
+ * each; padding rows (pad_table) stay with the caller. */
+int lm_execution_table_trace(lm_ctx* ctx, const uint32_t* d_pcs, const uint32_t* d_fps, uint64_t n_cycles,
+                             const uint32_t* d_bytecode, uint64_t bytecode_rows, const uint32_t* d_memory, uint64_t memory_len,
+                             uint32_t* const* d_cols);
+
 /* ---- WHIR commitment: LDE + Merkle tree -------------------------------------------------------------------------
  * lm_commit replaces reorder_and_dft (crates/whir/src/utils.rs:69-98: prepare_evals_for_fft_unpacked :128-150 +
  * EvalsDft::dft_algebra_batch_by_evals crates/whir/src/dft.rs:79-155) followed by MerkleData::build

@@ -41,6 +41,7 @@ _SIGS = {
     "lm_poseidon16_compress": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_extension_op_trace": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
+    "lm_execution_table_trace": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]),
     "lm_commit": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp), vp]),
     "lm_tree_free": (None, [vp, vp]),
     "lm_tree_log_height": (C.c_uint32, [vp]),
@@ -351,6 +352,14 @@ class Context:
         ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
         assert ptrs.size == 109
         self._check(self.lib.lm_poseidon_trace(self.h, _ptr(ptrs), int(n_rows)))
+
+    def execution_table_trace(self, d_pcs, d_fps, n_cycles, d_bytecode, bytecode_rows, d_memory, memory_len, col_bufs):
+        """get_execution_trace's main loop: 24 execution-table columns from the (pc, fp) log (canonical integers)."""
+        dev = lambda b: b.ptr if hasattr(b, "ptr") else int(b)  # noqa: E731
+        ptrs = np.array([dev(c) for c in col_bufs], dtype=np.uint64)
+        assert ptrs.size == 24
+        self._check(self.lib.lm_execution_table_trace(self.h, dev(d_pcs), dev(d_fps), int(n_cycles), dev(d_bytecode), int(bytecode_rows),
+                                                      dev(d_memory), int(memory_len), _ptr(ptrs)))
 
     def extension_op_trace(self, d_memory, memory_len, d_idx_a, va_bufs, n_rows):
         """fill_trace_extension_op: the 5 value_a columns gathered from memory (all arguments device buffers / pointers)."""

@@ -160,6 +160,70 @@ extern "C" int lm_extension_op_trace(lm_ctx* ctx, const uint32_t* d_memory, uint
     return LM_OK;
 }
 
+// get_execution_trace, main loop (lean_prover/src/trace_gen.rs:27-100): the 20 committed + 4 temporary columns of the
+// execution table from the VM's (pc, fp) log, the instruction table and the memory image.  One cycle per lane: three uint4
+// reads of the instruction row, up to three dependent memory gathers (value_a feeds DEREF's address), 24 column stores
+// (coalesced: consecutive cycles are consecutive rows).
+struct ExecCols {
+    u32* c[24];
+};
+__global__ __launch_bounds__(256) void k_execution_trace(const u32* __restrict__ pcs, const u32* __restrict__ fps, u64 n_cycles,
+                                                         const u32* __restrict__ bytecode, u64 bytecode_rows,
+                                                         const u32* __restrict__ memory, u64 mem_len, ExecCols out) {
+    const u32 TWO = add(ONE, ONE), HALF = to_monty((P + 1) / 2);
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_cycles; i += (u64)gridDim.x * 256) {
+        const u32 pc = pcs[i], fp = to_monty(fps[i]);
+        uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0, f2 = f0;
+        if (pc < bytecode_rows) {
+            const uint4* row = reinterpret_cast<const uint4*>(bytecode + (u64)pc * 16);
+            f0 = row[0], f1 = row[1], f2 = row[2];
+        }
+        const u32 op_a = f0.x, op_b = f0.y, op_c = f0.z, flag_a = f0.w;
+        const u32 flag_b = f1.x, flag_c = f1.y, flag_c_fp = f1.z, flag_ab_fp = f1.w;
+        const u32 mulf = f2.x, jump = f2.y, aux = f2.z, pdata = f2.w;
+        auto mem = [&](u32 addr_m) {  // memory.get(addr).flatten().unwrap_or_default()
+            const u64 a = from_monty(addr_m);
+            return a < mem_len ? memory[a] : 0u;
+        };
+        const u32 fpa = add(fp, op_a), fpb = add(fp, op_b), fpc = add(fp, op_c);
+        const u32 addr_a = (flag_a == 0 && flag_ab_fp == 0) ? fpa : 0u;
+        const u32 value_a = mem(addr_a);
+        u32 addr_b = 0;
+        if (flag_b == 0 && flag_ab_fp == 0)
+            addr_b = fpb;
+        else if (aux == TWO)  // DEREF: addr_B = value_A + operand_B
+            addr_b = add(value_a, op_b);
+        const u32 value_b = mem(addr_b);
+        const u32 addr_c = (flag_c == 0 && flag_c_fp == 0) ? fpc : 0u;
+        const u32 value_c = mem(addr_c);
+        const u32 nu_a = add(add(mul(flag_a, op_a), mul(sub(sub(ONE, flag_a), flag_ab_fp), value_a)), mul(flag_ab_fp, fpa));
+        const u32 nu_b = add(add(mul(flag_b, op_b), mul(sub(sub(ONE, flag_b), flag_ab_fp), value_b)), mul(flag_ab_fp, fpb));
+        const u32 nu_c = add(add(mul(flag_c, op_c), mul(sub(sub(ONE, flag_c), flag_c_fp), value_c)), mul(flag_c_fp, fpc));
+        // is_precompile as the AIR defines it (execution/air.rs:102-104): 1 - (add + mul + deref + jump)
+        const u32 add_ = sub(add(aux, aux), mul(aux, aux)), deref = mul(mul(aux, sub(aux, ONE)), HALF);
+        const u32 is_pre = sub(ONE, add(add(add(add_, mulf), deref), jump));
+        const u32 v[24] = {to_monty(pc), fp, addr_a, addr_b, addr_c, value_a, value_b, value_c, op_a, op_b, op_c, flag_a,
+                           flag_b, flag_c, flag_c_fp, flag_ab_fp, mulf, jump, aux, pdata, is_pre, nu_a, nu_b, nu_c};
+#pragma unroll
+        for (int c = 0; c < 24; c++) out.c[c][i] = v[c];
+    }
+}
+extern "C" int lm_execution_table_trace(lm_ctx* ctx, const uint32_t* d_pcs, const uint32_t* d_fps, uint64_t n_cycles,
+                                        const uint32_t* d_bytecode, uint64_t bytecode_rows, const uint32_t* d_memory,
+                                        uint64_t memory_len, uint32_t* const* d_cols) {
+    LM_REQUIRE(ctx && d_pcs && d_fps && d_bytecode && d_memory && d_cols);
+    if (n_cycles == 0) return LM_OK;
+    ExecCols o;
+    for (int c = 0; c < 24; c++) {
+        LM_REQUIRE(d_cols[c]);
+        o.c[c] = d_cols[c];
+    }
+    LM_LAUNCH(ctx, k_execution_trace, dim3((unsigned)std::min<u64>((n_cycles + 255) / 256, 8192)), dim3(256), 0, d_pcs, d_fps, n_cycles,
+              d_bytecode, bytecode_rows, d_memory, memory_len, o);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
                               const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
     LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);

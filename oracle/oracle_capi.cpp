@@ -432,6 +432,49 @@ void orc_air_eval(const uint32_t* blob_header, uint32_t table, const uint32_t* v
 void orc_poseidon16_fill_rows(uint32_t* rows, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) poseidon16_fill_row(rows + 109 * i);
 }
+// get_execution_trace, main loop (lean_prover/src/trace_gen.rs:27-100), statement by statement.  pcs / fps: canonical
+// integers; bytecode: rows x 16 Montgomery words (12 used); memory: padded image; out: 24 columns x n_cycles, column-major.
+// "Instruction::Precompile" is recognised from the decoded fields: the only instruction kind with aux = mul = jump = 0.
+void orc_execution_table_fill(const uint32_t* pcs, const uint32_t* fps, uint64_t n_cycles, const uint32_t* bytecode,
+                              uint64_t bytecode_rows, const uint32_t* memory, uint64_t mem_len, uint32_t* out) {
+    const uint32_t TWO = add(ONE, ONE);
+    auto mem = [&](uint32_t addr_m) -> uint32_t {
+        const uint64_t a = from_monty(addr_m);
+        return a < mem_len ? memory[a] : 0u;
+    };
+    for (uint64_t i = 0; i < n_cycles; i++) {
+        uint32_t f[12] = {0};
+        if (pcs[i] < bytecode_rows) std::memcpy(f, bytecode + (uint64_t)pcs[i] * 16, 48);
+        const uint32_t operand_a = f[0], operand_b = f[1], operand_c = f[2], flag_a = f[3], flag_b = f[4], flag_c = f[5];
+        const uint32_t flag_c_fp = f[6], flag_ab_fp = f[7], mul_ = f[8], jump = f[9], aux = f[10];
+        const uint32_t fp = to_monty(fps[i]);
+        const bool is_deref = aux == TWO;
+        uint32_t addr_a = 0;
+        if (flag_a == 0 && flag_ab_fp == 0) addr_a = add(fp, operand_a);
+        const uint32_t value_a = mem(addr_a);
+        uint32_t addr_b = 0;
+        if (flag_b == 0 && flag_ab_fp == 0)
+            addr_b = add(fp, operand_b);
+        else if (is_deref)
+            addr_b = add(value_a, operand_b);
+        const uint32_t value_b = mem(addr_b);
+        uint32_t addr_c = 0;
+        if (flag_c == 0 && flag_c_fp == 0) addr_c = add(fp, operand_c);
+        const uint32_t value_c = mem(addr_c);
+        auto nu = [&](uint32_t flag, uint32_t flag_fp, uint32_t operand, uint32_t value) {
+            return add(add(mul(flag, operand), mul(sub(sub(ONE, flag), flag_fp), value)), mul(flag_fp, add(fp, operand)));
+        };
+        auto col = [&](int c) -> uint32_t& { return out[(uint64_t)c * n_cycles + i]; };
+        for (int j = 0; j < 12; j++) col(8 + j) = f[j];
+        col(20) = (aux == 0 && mul_ == 0 && jump == 0) ? ONE : 0;
+        col(21) = nu(flag_a, flag_ab_fp, operand_a, value_a);
+        col(22) = nu(flag_b, flag_ab_fp, operand_b, value_b);
+        col(23) = nu(flag_c, flag_c_fp, operand_c, value_c);
+        col(5) = value_a, col(6) = value_b, col(7) = value_c;
+        col(0) = to_monty(pcs[i]), col(1) = fp;
+        col(2) = addr_a, col(3) = addr_b, col(4) = addr_c;
+    }
+}
 }
 
 // ================================================================================================

@@ -495,3 +495,14 @@ def set_threads(orc, n=0):
     """OpenMP width of the oracle's loops (n = 0: query only); returns the width in effect."""
     orc.lib.orc_set_threads.restype = C.c_int
     return int(orc.lib.orc_set_threads(C.c_int(int(n))))
+
+
+def execution_table_fill(orc, pcs, fps, bytecode, memory):
+    """get_execution_trace's main loop (trace_gen.rs:27-100) -> (24, n_cycles) columns."""
+    pcs, fps = np.ascontiguousarray(pcs, dtype=np.uint32), np.ascontiguousarray(fps, dtype=np.uint32)
+    bc, mem = np.ascontiguousarray(bytecode, dtype=np.uint32), np.ascontiguousarray(memory, dtype=np.uint32)
+    out = np.zeros((24, pcs.size), dtype=np.uint32)
+    orc.lib.orc_execution_table_fill.restype = None
+    orc.lib.orc_execution_table_fill(_p(pcs), _p(fps), C.c_uint64(pcs.size), _p(bc), C.c_uint64(bc.shape[0]), _p(mem),
+                                     C.c_uint64(mem.size), _p(out))
+    return out

@@ -235,18 +235,39 @@ def build(orc, rng, n_calls, n_blocks=8, log_exec=8, log_pos=8, log_ext=8, log_m
         ext[:, :r.shape[1]] = r
     # ---- access counters (prove_execution.rs:91-110) -----------------------------------------------------------------
     tables = {0: ex, 1: ext, 2: pos}
-    memory_acc = np.zeros(mem_len, dtype=np.int64)
+    memory_acc, bytecode_acc = access_counters(orc, tables, mem_len, 1 << log_bytecode)
+    return dict(log_inv_rate=1, log_memory=log_memory, log_bytecode=log_bytecode, ending_pc=ending_pc, public_memory_size=n_pub,
+                public_input=public_input, bytecode_hash=ob.rand_field(rng, 8), bytecode=np.ascontiguousarray(bytecode),
+                bytecode_acc=bytecode_acc, memory=memory, memory_acc=memory_acc, tables=tables,
+                log_rows={0: log_exec, 1: log_ext, 2: log_pos})
+
+
+def access_counters(orc, tables, mem_len, bytecode_len):
+    """memory_acc / bytecode_acc of prove_execution.rs:91-110 as field elements."""
+    M = lambda x: orc.to_monty(np.asarray(x, dtype=np.uint64))  # noqa: E731
     canon = lambda col: orc.from_monty_fast(col).astype(np.int64)  # noqa: E731
+    memory_acc = np.zeros(mem_len, dtype=np.int64)
     for t, cols in tables.items():
         for idx, vals in ob.VM_LOOKUPS[t]:
             addr = canon(cols[idx])
             for j in range(len(vals)):
                 memory_acc += np.bincount(addr + j, minlength=mem_len)
-    bytecode_acc = np.bincount(canon(ex[0]), minlength=1 << log_bytecode).astype(np.int64)
-    return dict(log_inv_rate=1, log_memory=log_memory, log_bytecode=log_bytecode, ending_pc=ending_pc, public_memory_size=n_pub,
-                public_input=public_input, bytecode_hash=ob.rand_field(rng, 8), bytecode=np.ascontiguousarray(bytecode),
-                bytecode_acc=M(bytecode_acc), memory=memory, memory_acc=M(memory_acc), tables=tables,
-                log_rows={0: log_exec, 1: log_ext, 2: log_pos})
+    bytecode_acc = np.bincount(canon(tables[0][0]), minlength=bytecode_len).astype(np.int64)
+    return M(memory_acc), M(bytecode_acc)
+
+
+def vm_log(w):
+    """(pcs, fps) of the straight-line program: the VM's execution log that get_execution_trace starts from."""
+    n = w["tables"][0].shape[1]
+    return np.minimum(np.arange(n), w["ending_pc"]).astype(np.uint32), np.zeros(n, dtype=np.uint32)
+
+
+def with_execution_table(orc, w, ex):
+    """the witness with its execution table replaced (and the access counters recomputed)"""
+    w2 = dict(w, tables=dict(w["tables"]))
+    w2["tables"][0] = ex
+    w2["memory_acc"], w2["bytecode_acc"] = access_counters(orc, w2["tables"], w["memory"].size, w["bytecode_acc"].size)
+    return w2
 
 
 def header(w):

@@ -222,3 +222,41 @@ def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
     pruned = p1.proof_pruned()
     assert np.array_equal(ob.restore_proof(orc, pruned), proof)
     assert p1.proof_size_fe() == ob.pruned_size_fe(orc, pruned) < proof.size
+
+
+def test_execution_table_trace_matches_oracle(ctx, orc):
+    """lm_execution_table_trace == the oracle's restatement of get_execution_trace's main loop (trace_gen.rs:27-100): on the
+    mixed program's VM log, and on random instruction rows that reach every branch (fp-relative operands, DEREF through
+    value_a, immediates, out-of-range addresses and pcs -> 0)."""
+    rng = np.random.default_rng(11)
+    w = synth_witness.build_mixed(orc, rng)
+    pcs, fps = synth_witness.vm_log(w)
+
+    def device(pcs, fps, bytecode, memory):
+        bufs = [ctx.alloc(pcs.size) for _ in range(24)]
+        ctx.execution_table_trace(ctx.to_device(pcs), ctx.to_device(fps), pcs.size, ctx.to_device(bytecode.reshape(-1)), bytecode.shape[0],
+                                  ctx.to_device(memory), memory.size, bufs)
+        return np.stack([b.download() for b in bufs])
+
+    assert np.array_equal(device(pcs, fps, w["bytecode"], w["memory"]), ob.execution_table_fill(orc, pcs, fps, w["bytecode"], w["memory"]))
+    # random rows: flags in {0, 1}, aux in {0, 1, 2}, operands small, fp up to the memory size
+    n_rows, n, mem_len = 512, 20000, 1 << 12
+    M = lambda x: orc.to_monty(np.asarray(x, dtype=np.uint64))  # noqa: E731
+    bc = np.zeros((n_rows, 16), dtype=np.uint32)
+    bc[:, 0:3] = M(rng.integers(0, 64, size=(n_rows, 3)))
+    bc[:, 3:8] = M(rng.integers(0, 2, size=(n_rows, 5)))
+    bc[:, 8:10] = M(rng.integers(0, 2, size=(n_rows, 2)))
+    bc[:, 10] = M(rng.integers(0, 3, size=n_rows))
+    bc[:, 11] = ob.rand_field(rng, n_rows)
+    memory = ob.rand_field(rng, mem_len)
+    memory[: mem_len // 2] = M(rng.integers(0, mem_len + 50, size=mem_len // 2))   # pointers for DEREF, some out of range
+    pcs = rng.integers(0, n_rows + 3, size=n).astype(np.uint32)                    # a few pcs past the table
+    fps = rng.integers(0, mem_len, size=n).astype(np.uint32)
+    got, want = device(pcs, fps, bc, memory), ob.execution_table_fill(orc, pcs, fps, bc, memory)
+    # is_precompile: the device evaluates the AIR's polynomial, the oracle the instruction kind; they agree on every VALID
+    # encoding (at most one of add / mul / deref / jump), random rows are not all valid
+    valid = ((orc.from_monty_fast(want[16]) + orc.from_monty_fast(want[17]) + (orc.from_monty_fast(want[18]) > 0)) <= 1)
+    assert valid.sum() > n // 4
+    for c in range(24):
+        sel = valid if c == 20 else slice(None)
+        assert np.array_equal(got[c][sel], want[c][sel]), c

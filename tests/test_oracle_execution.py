@@ -56,3 +56,28 @@ def test_mixed_program_pins_the_air_restatements(orc):
     assert not outcome(flip(1, 2, first_mul_row + 1))      # len must count down
     assert not outcome(flip(0, 22, 41))                    # nu_b of a MUL instruction (pc 41: kind = 1)
     assert not outcome(flip(0, 6, 42))                     # value_b of a DEREF (breaks the memory lookup)
+
+
+def test_execution_table_fill_follows_the_reference_loop(orc):
+    """The restatement of get_execution_trace's main loop (trace_gen.rs:27-100) reproduces the hand-built execution table of
+    the mixed program column by column — except where the reference makes a different (equally valid) choice: an operand
+    that is an immediate gets address 0 and memory[0] as its value there, the zero vector and 0 in synth_witness — and the
+    witness with the filled table is still proven and verified."""
+    rng = np.random.default_rng(5)
+    w = synth_witness.build_mixed(orc, rng)
+    pcs, fps = synth_witness.vm_log(w)
+    ex, got = w["tables"][0], ob.execution_table_fill(orc, pcs, fps, w["bytecode"], w["memory"])
+    for c in list(range(0, 2)) + list(range(8, 24)):
+        assert np.array_equal(got[c], ex[c]), c
+    two = int(orc.to_monty(2))
+    for k, flag_col in enumerate((11, 12, 13)):          # addr/value of operand k agree wherever it is a memory operand
+        is_mem = (ex[flag_col] == 0) & (ex[14 if k == 2 else 15] == 0)   # not an immediate and not fp-relative
+        if k == 1:
+            is_mem |= ex[18] == two                      # DEREF reads memory at value_a + operand_b although flag_b = 1
+        assert np.array_equal(got[2 + k][is_mem], ex[2 + k][is_mem]) and np.array_equal(got[5 + k][is_mem], ex[5 + k][is_mem])
+        assert not got[2 + k][~is_mem].any() and (got[5 + k][~is_mem] == w["memory"][0]).all()
+    w2 = synth_witness.with_execution_table(orc, w, got)
+    b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    proof = ob.prove_execution(orc, w2, synth_witness.header(w2), b)
+    ok, err = ob.verify_execution(orc, w2, proof, b)
+    assert ok, err

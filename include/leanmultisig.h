@@ -80,6 +80,13 @@ int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
  * poseidon_16/mod.rs:366-383).  Columns 0..24 (flags, indices, 16 inputs) are inputs; the 84 derived columns are written. */
 int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows);
 
+/* The step of get_execution_trace after fill_trace_poseidon_16 (crates/lean_prover/src/trace_gen.rs:118-147): on rows with
+ * flag_permute = 0 (column 8) the unconstrained output columns are overwritten with the memory words their lookup reads:
+ * columns 101..108 <- memory[index_res + 8 ..], and with flag_half_output = 1 (column 3) also 97..100 <- memory[index_res + 4 ..].
+ * d_cols = the same host array of 109 device column pointers as lm_poseidon_trace (index_res = column 2). */
+int lm_poseidon_trace_outputs_from_memory(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows, const uint32_t* d_memory,
+                                          uint64_t memory_len);
+
 /* fill_trace_extension_op (crates/lean_vm/src/tables/extension_op/exec.rs:192-203): the five VALUE_A columns of the
  * ExtensionOp table, value_a[k][row] = memory[idx_a[row] + k] (idx_a = column COL_IDX_A, Montgomery form like every
  * column).  d_va_cols = host array of the 5 DEVICE column pointers (COL_VA..COL_VA+4, extension_op/air.rs:24).  A row whose

@@ -41,6 +41,7 @@ _SIGS = {
     "lm_poseidon16_compress": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_extension_op_trace": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
+    "lm_poseidon_trace_outputs_from_memory": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64]),
     "lm_execution_table_trace": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]),
     "lm_commit": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp), vp]),
     "lm_tree_free": (None, [vp, vp]),
@@ -352,6 +353,11 @@ class Context:
         ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
         assert ptrs.size == 109
         self._check(self.lib.lm_poseidon_trace(self.h, _ptr(ptrs), int(n_rows)))
+
+    def poseidon_trace_outputs_from_memory(self, col_bufs, n_rows, d_memory, memory_len):
+        ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
+        assert ptrs.size == 109
+        self._check(self.lib.lm_poseidon_trace_outputs_from_memory(self.h, _ptr(ptrs), int(n_rows), d_memory.ptr, int(memory_len)))
 
     def execution_table_trace(self, d_pcs, d_fps, n_cycles, d_bytecode, bytecode_rows, d_memory, memory_len, col_bufs):
         """get_execution_trace's main loop: 24 execution-table columns from the (pc, fp) log (canonical integers)."""

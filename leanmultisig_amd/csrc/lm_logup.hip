@@ -224,6 +224,42 @@ extern "C" int lm_execution_table_trace(lm_ctx* ctx, const uint32_t* d_pcs, cons
     return LM_OK;
 }
 
+// get_execution_trace (lean_prover/src/trace_gen.rs:118-147): on rows with flag_permute = 0 the output columns that the
+// AIR leaves unconstrained are overwritten with the memory words their lookup reads — outputs_right (columns 101..108) <-
+// memory[res + 8 ..], and with flag_half_output = 1 also columns 97..100 <- memory[res + 4 ..].
+struct PosOutCols {
+    const u32 *half, *permute, *res;
+    u32* out[12];  // columns 97..108
+};
+__global__ __launch_bounds__(256) void k_poseidon_outputs_from_memory(PosOutCols c, u64 n_rows, const u32* __restrict__ memory, u64 mem_len) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (u64)gridDim.x * 256) {
+        if (c.permute[i] != 0) continue;
+        const u64 base = from_monty(c.res[i]);
+        if (c.half[i] == ONE) {
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) c.out[j][i] = base + 4 + j < mem_len ? memory[base + 4 + j] : 0u;
+        }
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) c.out[4 + j][i] = base + 8 + j < mem_len ? memory[base + 8 + j] : 0u;
+    }
+}
+extern "C" int lm_poseidon_trace_outputs_from_memory(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows, const uint32_t* d_memory,
+                                                     uint64_t memory_len) {
+    LM_REQUIRE(ctx && d_cols && d_memory);
+    if (n_rows == 0) return LM_OK;
+    PosOutCols c;
+    LM_REQUIRE(d_cols[2] && d_cols[3] && d_cols[8]);
+    c.res = d_cols[2], c.half = d_cols[3], c.permute = d_cols[8];
+    for (int j = 0; j < 12; j++) {
+        LM_REQUIRE(d_cols[97 + j]);
+        c.out[j] = d_cols[97 + j];
+    }
+    LM_LAUNCH(ctx, k_poseidon_outputs_from_memory, dim3((unsigned)std::min<u64>((n_rows + 255) / 256, 4096)), dim3(256), 0, c, n_rows,
+              d_memory, memory_len);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
                               const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
     LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);

@@ -432,6 +432,18 @@ void orc_air_eval(const uint32_t* blob_header, uint32_t table, const uint32_t* v
 void orc_poseidon16_fill_rows(uint32_t* rows, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) poseidon16_fill_row(rows + 109 * i);
 }
+// trace_gen.rs:118-147: permute = 0 rows take their unconstrained output columns from memory.  rows: n x 109 row-major.
+void orc_poseidon16_outputs_from_memory(uint32_t* rows, uint64_t n, const uint32_t* memory, uint64_t mem_len) {
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t* row = rows + 109 * i;
+        if (row[8] != 0) continue;  // POSEIDON_16_COL_FLAG_PERMUTE
+        const uint64_t base = from_monty(row[2]);  // POSEIDON_16_COL_INDEX_INPUT_RES
+        auto mem = [&](uint64_t a) { return a < mem_len ? memory[a] : 0u; };
+        if (row[3] == ONE)  // POSEIDON_16_COL_FLAG_HALF_OUTPUT
+            for (int j = 0; j < 4; j++) row[97 + j] = mem(base + 4 + j);
+        for (int j = 0; j < 8; j++) row[101 + j] = mem(base + 8 + j);
+    }
+}
 // get_execution_trace, main loop (lean_prover/src/trace_gen.rs:27-100), statement by statement.  pcs / fps: canonical
 // integers; bytecode: rows x 16 Montgomery words (12 used); memory: padded image; out: 24 columns x n_cycles, column-major.
 // "Instruction::Precompile" is recognised from the decoded fields: the only instruction kind with aux = mul = jump = 0.

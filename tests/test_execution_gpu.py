@@ -260,3 +260,26 @@ def test_execution_table_trace_matches_oracle(ctx, orc):
     for c in range(24):
         sel = valid if c == 20 else slice(None)
         assert np.array_equal(got[c][sel], want[c][sel]), c
+
+
+def test_poseidon_outputs_from_memory(ctx, orc):
+    """lm_poseidon_trace_outputs_from_memory (trace_gen.rs:118-147) vs the oracle's restatement: random flags (permute / half
+    output), result pointers anywhere in memory including the last words (out-of-range reads give 0)."""
+    import ctypes
+    rng = np.random.default_rng(12)
+    n, mem_len = 3000, 1 << 12
+    memory = ob.rand_field(rng, mem_len)
+    rows = ob.rand_field(rng, (n, 109))
+    rows[:, 8] = orc.to_monty(rng.integers(0, 2, size=n))
+    rows[:, 3] = orc.to_monty(rng.integers(0, 2, size=n))
+    res = rng.integers(0, mem_len, size=n)
+    res[:4] = [mem_len - 1, mem_len - 9, mem_len - 16, 0]
+    rows[:, 2] = orc.to_monty(res)
+    want = np.ascontiguousarray(rows.copy())
+    orc.lib.orc_poseidon16_outputs_from_memory(want.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n),
+                                               memory.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(mem_len))
+    assert not np.array_equal(want, rows)
+    cols = [ctx.to_device(np.ascontiguousarray(rows[:, c])) for c in range(109)]
+    ctx.poseidon_trace_outputs_from_memory(cols, n, ctx.to_device(memory), mem_len)
+    got = np.stack([c.download() for c in cols], axis=1)
+    assert np.array_equal(got, want)

@@ -39,9 +39,10 @@ struct BaseCols {
     u64 n_rows;
     u32 n_flat;
     // column c < n_flat: flat; c >= n_flat: shift view of column c - n_flat
-    // RELOAD: the pointer table is re-read next to each use.  Hoisted out of the row loop, the column pointers of the wide
-    // execution / ExtensionOp evaluations are spilled from SGPRs to VGPR lanes (1.5 k v_readlane of 4.9 k instructions,
-    // see ExtCols::at); the per-segment Poseidon kernels touch few columns each and are better off with the hoisted loads.
+    // RELOAD: the pointer table is re-read next to each use.  Hoisted out of the row loop, the 42 column pointers of the
+    // ExtensionOp evaluation are spilled from SGPRs to VGPR lanes (1.5 k v_readlane of 4.9 k instructions, see
+    // ExtCols::at); the execution table (22 columns) and the per-segment Poseidon kernels touch few columns each and are
+    // better off with the hoisted loads (execution base round 241 -> 208 us without the reload).
     __device__ __forceinline__ uint2 raw(u32 c, u64 j) const { return *reinterpret_cast<const uint2*>(cols[c] + 2 * j); }  // flat column
     template <bool RELOAD>
     __device__ __forceinline__ u32 at(u32 c, u64 j, u32 zm) const {
@@ -140,9 +141,9 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
         T flat[NF], shift[NS];
 #pragma unroll
-        for (int c = 0; c < NF; c++) flat[c] = cols.template at<true>(c, j, zm);
+        for (int c = 0; c < NF; c++) flat[c] = cols.template at<(TABLE != air::T_EXECUTION)>(c, j, zm);
 #pragma unroll
-        for (int c = 0; c < NS; c++) shift[c] = cols.template at<true>(NF + c, j, zm);
+        for (int c = 0; c < NS; c++) shift[c] = cols.template at<(TABLE != air::T_EXECUTION)>(NF + c, j, zm);
         if constexpr (TABLE == air::T_EXECUTION)
             return air::eval_execution<T>(flat, shift, x);
         else

@@ -283,3 +283,38 @@ def test_poseidon_outputs_from_memory(ctx, orc):
     ctx.poseidon_trace_outputs_from_memory(cols, n, ctx.to_device(memory), mem_len)
     got = np.stack([c.download() for c in cols], axis=1)
     assert np.array_equal(got, want)
+
+
+def test_config0_full_shape_production_parameters_equals_oracle(ctx, orc):
+    """BASELINE configs[0] (`xmss --n-signatures 128 --log-inv-rate 1`, the top size of the reference's test_aggregation,
+    tests/test_multisignatures.rs:31-41) at its FULL shape and at the PRODUCTION WHIR parameters (default_whir_config:
+    124-bit JohnsonBound, 16 PoW bits, fold 7/5, lean_prover/src/lib.rs:22-50): 128 x 167 Poseidon calls -> Poseidon table
+    2^15, execution 2^17, bytecode 2^19 (rec_aggregation/TYPE1_TYPE2_LAYOUT.md:9), memory 2^19 (>= bytecode,
+    prove_execution.rs:41-45), stacked polynomial 2^23.  The device proof must equal the oracle prover's word for word —
+    every root, sumcheck coefficient, PoW witness, query leaf and sibling of the full-security schedule."""
+    rng = np.random.default_rng(128)
+    w = synth_witness.build(orc, rng, n_calls=128 * 167, n_blocks=1024, log_exec=17, log_pos=15, log_ext=8, log_memory=19,
+                            log_bytecode=19)
+    b = ob.whir_builder(log_inv_rate=1)
+    proof = _device_proof(ctx, orc, w, b)
+    ref = ob.prove_execution(orc, w, synth_witness.header(w), b)
+    assert proof.size == ref.size and np.array_equal(proof, ref)
+    ok, err = ob.verify_execution(orc, w, proof, None)
+    assert ok, err
+
+
+def test_mixed_program_2p15_production_parameters_equals_oracle(ctx, orc):
+    """The mixed program (Poseidon calls, ADD / MUL / DEREF, every ExtensionOp mode with ~2^14 active rows) on 2^15-row
+    tables at the production WHIR parameters, rate 1/4 (the recursion configs' rate): device proof == oracle proof."""
+    rng = np.random.default_rng(215)
+    ext = [("mul", False, 64, 100), ("mul", True, 128, 30), ("poly_eq", False, 20, 150), ("add", False, 1, 250),
+           ("poly_eq", True, 9, 50), ("add", True, 2, 40), ("mul", False, 1, 60)]
+    w = synth_witness.build(orc, rng, n_calls=20000, n_blocks=256, log_exec=15, log_pos=15, log_ext=15, log_memory=18,
+                            log_bytecode=15, n_arith=6000, ext_calls=ext)
+    w["log_inv_rate"] = 2
+    b = ob.whir_builder(log_inv_rate=2)
+    proof = _device_proof(ctx, orc, w, b)
+    ref = ob.prove_execution(orc, w, synth_witness.header(w), b)
+    assert proof.size == ref.size and np.array_equal(proof, ref)
+    ok, err = ob.verify_execution(orc, w, proof, None)
+    assert ok, err

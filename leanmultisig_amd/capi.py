@@ -73,6 +73,8 @@ _SIGS = {
     "lm_air_degree": (C.c_uint32, [vp]),
     "lm_air_n_evals": (C.c_uint32, [vp]),
     "lm_air_round": (C.c_int, [vp, vp, vp]),
+    "lm_air_round_launch": (C.c_int, [vp, vp]),
+    "lm_air_round_wait": (C.c_int, [vp, vp, vp]),
     "lm_air_bind": (C.c_int, [vp, vp, vp]),
     "lm_air_final_evals": (C.c_int, [vp, vp, vp]),
 }

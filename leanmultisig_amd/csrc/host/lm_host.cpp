@@ -838,6 +838,12 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     for (u32 round = 0; round < n_rounds; round++) {
         std::vector<EF> combined(max_full_degree + 1, kb::ef_zero());
         std::vector<std::vector<EF>> bare(n_tables);
+        // the sessions are independent until the challenge: enqueue every active table's round, then collect
+        for (u32 i = 0; i < n_tables; i++)
+            if (round >= n_rounds - ss[i].n_vars) {
+                int rc = lm_air_round_launch(ctx, ss[i].h);
+                if (rc) return cleanup(rc);
+            }
         for (u32 i = 0; i < n_tables; i++) {
             Session& s = ss[i];
             const u32 join = n_rounds - s.n_vars;
@@ -848,7 +854,7 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             }
             // compute_bare_round_poly: raw sums at z = 0, 2, .., deg from the device
             std::vector<u32> raw((size_t)s.deg * 5);
-            int rc = lm_air_round(ctx, s.h, raw.data());
+            int rc = lm_air_round_wait(ctx, s.h, raw.data());
             if (rc) return cleanup(rc);
             const u32 d = s.deg;
             std::vector<EF> ev(d + 1);

@@ -28,7 +28,11 @@ struct lm_air {
     air::Extra h_extra;                  // host copies outlive the asynchronous uploads (no synchronisation in lm_air_new)
     std::vector<const u32*> h_cols;
     PrefixEqTables eqt;
+    u32* d_partial = nullptr;            // per-block partial sums of a round (own buffer: sessions of one batch run back to back)
+    u32 res_off = 0;                     // this session's slice of the pinned result buffer
+    u32 pending_seq = 0;                 // sequence number of the launched, not yet collected round (0 = none)
 };
+static constexpr u32 AIR_MAX_BLOCKS = 2048;
 
 // column value at the evaluation point z of a row pair: lo + z (hi - lo)
 __device__ __forceinline__ u32 lerp(u32 lo, u32 hi, u32 zm) { return add(lo, mul(sub(hi, lo), zm)); }
@@ -231,7 +235,7 @@ struct AirLagrange {
 };
 __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n_main, u32* __restrict__ out,
                                                     u32* __restrict__ done_counter, u32 seq, u32 n_low, u64 low_offset,
-                                                    AirLagrange lag) {
+                                                    AirLagrange lag, u32* __restrict__ flag_base) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.x;
     u32 v[5] = {0, 0, 0, 0, 0};
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ part
         __threadfence_system();
         if (threadIdx.x == 0 && atomicAdd(done_counter, 1u) == gridDim.x - 1) {
             *done_counter = 0;
-            lm_publish_flag(out, seq);
+            lm_publish_flag(flag_base, seq);
         }
     }
 }
@@ -390,6 +394,7 @@ void lm_air_free(lm_ctx* ctx, lm_air* a) {
     for (int i = 0; i < 2; i++) lm_pool_free(ctx, a->ef[i]);
     lm_pool_free(ctx, a->d_extra);
     lm_pool_free(ctx, a->eqt.d_buf);
+    lm_pool_free(ctx, a->d_partial);
     delete a;
 }
 
@@ -429,7 +434,9 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
               lm_pool_alloc_t(ctx, &a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->d_extra, sizeof(air::Extra)) == hipSuccess &&
-              lm_pool_alloc_t(ctx, &a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess;
+              lm_pool_alloc_t(ctx, &a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->d_partial, ((u64)AIR_MAX_BLOCKS * (table == air::T_POSEIDON16 ? AIR_POS_SLOTS : a->deg) * 5 + 64) * 4) == hipSuccess;
+    a->res_off = 256 + 64 * table;
     if (!ok) {
         lm_set_error("lm_air_new: device allocation failed");
         lm_air_free(ctx, a);
@@ -456,17 +463,17 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
 uint32_t lm_air_degree(const lm_air* a) { return a ? a->deg : 0; }
 uint32_t lm_air_n_evals(const lm_air* a) { return a ? a->n_cols + a->n_shift : 0; }
 
-// raw[zi] for z = 0, 2, 3, .., degree  (degree EF values = 5 * degree words)
-int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
-    LM_REQUIRE(ctx && a && out_raw && a->round < a->log_rows);
+// raw[zi] for z = 0, 2, 3, .., degree  (degree EF values = 5 * degree words).  lm_air_round_launch only enqueues the round's
+// kernels (result -> the session's slice of the pinned buffer), lm_air_round_wait collects it: the sessions of one batched
+// round (prove_batched_air_sumcheck) are launched back to back and cost one host round trip instead of one each.
+int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
+    LM_REQUIRE(ctx && a && a->round < a->log_rows && a->pending_seq == 0);
     const u32 p = a->log_rows - a->round - 1;
     const u64 n_pairs = 1ull << p;
     const bool pos = a->table == air::T_POSEIDON16;
-    const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 2048);
-    const u32 slots = pos ? AIR_POS_SLOTS : a->deg;
-    u32* s;
-    int rc = lm_scratch(ctx, (u64)blocks * slots * 5 + 64, &s);
-    if (rc) return rc;
+    const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, AIR_MAX_BLOCKS);
+    u32* s = a->d_partial;
+    int rc;
     const EqSplit eq = a->eqt.at(p);
     if (a->table == air::T_EXECUTION)
         rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s);
@@ -476,9 +483,8 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
     if (rc) return rc;
     const u32 seq = ++ctx->res_seq;
-    AirLagrange lag;
-    memset(&lag, 0, sizeof lag);
-    if (pos) {  // Lagrange basis of the nodes 0,1,2,3 at z = 0,2,3,..,10 (exact field constants)
+    static const AirLagrange pos_lag = [] {  // Lagrange basis of the nodes 0,1,2,3 at z = 0,2,3,..,10 (exact field constants)
+        AirLagrange l;
         for (u32 zi = 0; zi < AIR_POS_POINTS; zi++) {
             const u32 z = zi == 0 ? 0 : zi + 1;
             for (u32 t = 0; t < 4; t++) {
@@ -488,16 +494,33 @@ int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
                     num = mul(num, sub(to_monty(z), to_monty(m)));
                     den = mul(den, sub(to_monty(t), to_monty(m)));
                 }
-                lag.c[zi][t] = mul(num, inv(den));
+                l.c[zi][t] = mul(num, inv(den));
             }
         }
-    }
-    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, pos ? 4 * blocks : blocks, ctx->h_res, ctx->d_sync + 1, seq,
-              pos ? blocks : 0u, (u64)4 * AIR_POS_POINTS * blocks, lag);
+        return l;
+    }();
+    AirLagrange lag;
+    if (pos)
+        lag = pos_lag;
+    else
+        memset(&lag, 0, sizeof lag);
+    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, pos ? 4 * blocks : blocks, ctx->h_res + a->res_off, ctx->d_sync + 1,
+              seq, pos ? blocks : 0u, (u64)4 * AIR_POS_POINTS * blocks, lag, ctx->h_res);
     LM_HIP(hipGetLastError());
-    if ((rc = lm_wait_result(ctx, seq))) return rc;
-    memcpy(out_raw, ctx->h_res, (u64)a->deg * 20);
+    a->pending_seq = seq;
     return LM_OK;
+}
+int lm_air_round_wait(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
+    LM_REQUIRE(ctx && a && out_raw && a->pending_seq != 0);
+    int rc = lm_wait_result(ctx, a->pending_seq);
+    a->pending_seq = 0;
+    if (rc) return rc;
+    memcpy(out_raw, ctx->h_res + a->res_off, (u64)a->deg * 20);
+    return LM_OK;
+}
+int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
+    int rc = lm_air_round_launch(ctx, a);
+    return rc ? rc : lm_air_round_wait(ctx, a, out_raw);
 }
 
 int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {

@@ -260,10 +260,12 @@ void lm_pool_free(lm_ctx* ctx, void* p) {
 
 int lm_wait_result(lm_ctx* ctx, u32 seq) {
     volatile u32* flag = ctx->h_res + lm_ctx::RES_FLAG;
-    for (u64 spins = 0; *flag != seq; spins++) {
+    // several publishers may be in flight on the stream (their sequence numbers increase): "at least seq" is the condition
+    auto reached = [&] { return (int32_t)(*flag - seq) >= 0; };
+    for (u64 spins = 0; !reached(); spins++) {
         if (spins > (1ull << 22)) {  // something is wrong or the kernel is long: fall back to the runtime
             LM_HIP(hipStreamSynchronize(ctx->stream));
-            if (*flag != seq) {
+            if (!reached()) {
                 lm_set_error("lm_wait_result: sequence %u never published (flag %u)", seq, *flag);
                 return LM_E_DEVICE;
             }

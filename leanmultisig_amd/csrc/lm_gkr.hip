@@ -17,15 +17,21 @@ struct lm_gkr {
     const u32* d_nums0 = nullptr;  // caller's input layer (base)
     const u32* d_dens0 = nullptr;  // caller's input layer (SoA EF)
     std::vector<u32*> nums, dens;  // layers n_vars-1 .. 5 (index 0 = 2^(n_vars-1) entries), SoA EF, owned
-    u32* work[2] = {nullptr, nullptr};  // ping-pong: 4 arrays x 5 planes
+    u32* work[2] = {nullptr, nullptr};  // ping-pong: 4 arrays (nl, nr + alpha dr, dl, dr) x 5 planes
     u64 work_words = 0;
     PrefixEqTables eqt;  // prefix eq tables of the current layer
     // state of the layer being proven
     u32 K = 0;        // number of rounds = number of coordinates of the claim point
     u32 round = 0;
     int cur = -1;     // which work buffer holds the current arrays (-1: still in layer storage)
-    u64 m = 0;        // current length of each of the 4 arrays
+    u64 m = 0;        // current length of each of the 4 arrays (before the pending folds)
     EF alpha;
+    std::vector<EF> point;    // the layer's claim point (K coordinates)
+    std::vector<EF> pending;  // challenges received but not yet folded into the arrays (at most 2)
+    bool la_valid = false;    // the next round's (c0, c2) as quadratics in the pending challenge: c0 = la[0..3), c2 = la[3..6)
+    EF la[6];
+    u32 fin_m = 0;            // tail of the layer published by the last launch: fin[array][i], i < fin_m <= 4
+    EF fin[4][4];
 };
 
 // ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
@@ -64,232 +70,256 @@ __global__ __launch_bounds__(256) void k_gkr_layer_up(const u32* __restrict__ n_
     }
 }
 
-// pair_coeffs (sumcheck_utils.rs:65-79) accumulated with weight w into acc[0..4) = (c0_num, c2_num, c0_den, c2_den)
-__device__ __forceinline__ void pair_accumulate(const EF& nl0, const EF& nl1, const EF& nr0, const EF& nr1, const EF& dl0,
-                                                const EF& dl1, const EF& dr0, const EF& dr1, const EF& w, EF acc[4]) {
-    const EF ddl = ef_sub(dl1, dl0), ddr = ef_sub(dr1, dr0);
-    const EF c0d = ef_mul(dl0, dr0);
-    const EF c2d = ef_mul(ddl, ddr);
-    const EF c0n = ef_add(ef_mul(nl0, dr0), ef_mul(nr0, dl0));
-    const EF c2n = ef_add(ef_mul(ef_sub(nl1, nl0), ddr), ef_mul(ef_sub(nr1, nr0), ddl));
-    acc[0] = ef_add(acc[0], ef_mul(c0n, w));
-    acc[1] = ef_add(acc[1], ef_mul(c2n, w));
-    acc[2] = ef_add(acc[2], ef_mul(c0d, w));
-    acc[3] = ef_add(acc[3], ef_mul(c2d, w));
+// ---- the layer sumcheck, two rounds per launch -----------------------------------------------------------------------
+// Round t of a layer (sumcheck_utils.rs:65-109, 278-357) sums, over pairs (a, b) = entries (2j, 2j+1) of the four arrays,
+//     w_t(j) * [ c0 = nl_a dr_a + nr_a dl_a + alpha dl_a dr_a ,  c2 = Dnl Ddr + Dnr Ddl + alpha Ddl Ddr ],  D = b - a.
+// Two exact identities restructure it (field arithmetic: every transcript value is unchanged):
+//  * alpha is folded into one array: with nr~ = nr + alpha dr (linear, so it commutes with every fold) the bracket is
+//    e(a) = nl_a dr_a + nr~_a dl_a and c2 = Dnl Ddr + Dnr~ Ddl — 2 products instead of 3, no separate denominator sums;
+//  * look-ahead: after folding by the challenge r of round t the next round pairs y0 = x0 + r (x1 - x0) with
+//    y1 = x2 + r (x3 - x2).  Its (c0', c2') are QUADRATIC polynomials in r whose coefficients are sums over quads
+//    (x0..x3) that do not depend on r:
+//        c0'(r) = E0 + r (E1 - E0 - C01) + r^2 C01            E_i = sum w' e(x_i),  C01 = sum w' c2(x0, x1)
+//        c2'(r) = T0 + r (T3 - T0 - T2) + r^2 T2              T0 / T3 / T2 = the c2 form on x2 - x0 / x3 - x1 / (x3 - x2) - (x1 - x0)
+//    with the eq weight w'(j') of the quad, and w_t(2j' + b) = w'(j') * (b ? pt : 1 - pt), pt = the last coordinate of round
+//    t's eq prefix.  So ONE pass over the data yields round t AND round t+1: the host evaluates the quadratics at r
+//    (lm_gkr_round below), and the next launch folds by both challenges at once.  A layer of K rounds costs ceil(K/2)
+//    launches / host round trips and reads the big arrays half as often.
+// Thread i owns output entry i (after F folds of 2^F consecutive inputs: one 8/16-byte load per plane); the four lanes of a
+// quad exchange their entries by DPP quad_perm and lane class c = i & 3 computes  c=0: T2 and T3,  c=1: C01,  c=2: T0,
+// c=3: C23 (round t's second pair).  Per-class sums leave the block as 4 classes x 3 slots x 5 words.
+template <int C>
+__device__ __forceinline__ u32 quad_bcast(u32 x) {
+    return (u32)__builtin_amdgcn_mov_dpp((int)x, C * 0x55, 0xf, 0xf, true);  // quad_perm:[C,C,C,C]
 }
-__device__ __forceinline__ void pair_accumulate_base(u32 nl0, u32 nl1, u32 nr0, u32 nr1, const EF& dl0, const EF& dl1,
-                                                     const EF& dr0, const EF& dr1, const EF& w, EF acc[4]) {
-    const EF ddl = ef_sub(dl1, dl0), ddr = ef_sub(dr1, dr0);
-    const EF c0d = ef_mul(dl0, dr0);
-    const EF c2d = ef_mul(ddl, ddr);
-    const EF c0n = ef_add(ef_mul_base(dr0, nl0), ef_mul_base(dl0, nr0));
-    const EF c2n = ef_add(ef_mul_base(ddr, sub(nl1, nl0)), ef_mul_base(ddl, sub(nr1, nr0)));
-    acc[0] = ef_add(acc[0], ef_mul(c0n, w));
-    acc[1] = ef_add(acc[1], ef_mul(c2n, w));
-    acc[2] = ef_add(acc[2], ef_mul(c0d, w));
-    acc[3] = ef_add(acc[3], ef_mul(c2d, w));
-}
-
-// block-sum of 4 EF accumulators -> partial[block][20]
-__device__ __forceinline__ void block_store_acc(const EF acc[4], u32* lds /* 80 words */, u32* dst) {
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 v[20];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[a * 5 + k] = wave_sum_u32(acc[a].v[k]);
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 20; k++) lds[wave * 20 + k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 20) {
-        u32 s = 0;
-        for (u32 w = 0; w < (blockDim.x >> 6); w++) s = add(s, lds[w * 20 + threadIdx.x]);
-        dst[threadIdx.x] = s;
-    }
-}
-// (c0_num + alpha c0_den, c2_num + alpha c2_den) from the 20 summed words
-__device__ __forceinline__ void combine_alpha(const u32* tot, const EF& alpha, u32* out) {
-    EF c0n, c2n, c0d, c2d;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        c0n.v[k] = tot[k];
-        c2n.v[k] = tot[5 + k];
-        c0d.v[k] = tot[10 + k];
-        c2d.v[k] = tot[15 + k];
-    }
-    const EF a = ef_add(c0n, ef_mul(alpha, c0d)), b = ef_add(c2n, ef_mul(alpha, c2d));
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        out[k] = a.v[k];
-        out[5 + k] = b.v[k];
-    }
-}
-// End of a round kernel: a single-block launch finishes the round itself (result straight to the host-visible buffer),
-// a multi-block launch leaves per-block partials for k_gkr_reduce.
-__device__ __forceinline__ void finish_round(const EF acc[4], u32* lds, u32* tot, u32* partial, const EF& alpha, u32* final_out,
-                                             u32 seq) {
-    block_store_acc(acc, lds, tot);
-    __syncthreads();
-    if (gridDim.x == 1) {
-        if (threadIdx.x == 0) {
-            combine_alpha(tot, alpha, final_out);
-            lm_publish_flag(final_out, seq);
-        }
-    } else if (threadIdx.x < 20) {
-        partial[(u64)blockIdx.x * 20 + threadIdx.x] = tot[threadIdx.x];
-    }
-}
-// out[0..5) = c0_num + alpha c0_den ; out[5..10) = c2_num + alpha c2_den
-__global__ __launch_bounds__(256) void k_gkr_reduce(const u32* __restrict__ partial, u32 n, EF alpha, u32* __restrict__ out,
-                                                    u32 seq) {
-    __shared__ u32 lds[80];
-    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
-    for (u32 i = threadIdx.x; i < n; i += 256)
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) acc[a].v[k] = add(acc[a].v[k], partial[(u64)i * 20 + a * 5 + k]);
-    __shared__ u32 tot[20];
-    block_store_acc(acc, lds, tot);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        combine_alpha(tot, alpha, out);
-        lm_publish_flag(out, seq);
-    }
+__device__ __forceinline__ EF fold1(const EF& a, const EF& b, const EF& r) { return ef_add(a, ef_mul(r, ef_sub(b, a))); }
+__device__ __forceinline__ EF fold1_base(u32 a, u32 b, const EF& r) {
+    EF t = ef_mul_base(r, sub(b, a));
+    t.v[0] = add(t.v[0], a);
+    return t;
 }
 
-// ---- round 0 of a layer straight from layer storage: pairs j' < n_pairs, entries 4j' .. 4j'+3 ------------------------
-template <bool BASE>
-__global__ __launch_bounds__(256) void k_gkr_round_storage(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
-                                                           u64 n_pairs, EqSplit eq, u32* __restrict__ partial, EF alpha,
-                                                           u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 lds[80];
-    __shared__ u32 tot[20];
-    const u64 plane = 4 * n_pairs;
-    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
-    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_pairs; j += (u64)gridDim.x * 256) {
-        EF dl0, dr0, dl1, dr1;
+static constexpr u32 GKR_SUM_WORDS = 60;  // [class 4][slot 3][5]
+static constexpr u32 GKR_FIN_AT = 64;     // h_res offset of the last <= 4 entries of each array: [(array * 5 + k) * 4 + i]
+
+// one plane of layer storage: (left, right) children interleaved; N consecutive pairs starting at src
+template <int N>
+__device__ __forceinline__ void load_lr(const u32* __restrict__ src, u32 (&l)[N], u32 (&r)[N]) {
+    if constexpr (N == 1) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src);
+        l[0] = v.x, r[0] = v.y;
+    } else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            uint4 v = *reinterpret_cast<const uint4*>(d_in + (u64)k * plane + 4 * j);
-            dl0.v[k] = v.x;
-            dr0.v[k] = v.y;
-            dl1.v[k] = v.z;
-            dr1.v[k] = v.w;
+        for (int h = 0; h < N / 2; h++) {
+            const uint4 v = reinterpret_cast<const uint4*>(src)[h];
+            l[2 * h] = v.x, r[2 * h] = v.y, l[2 * h + 1] = v.z, r[2 * h + 1] = v.w;
         }
-        const EF w = eq_split_at(eq, j);
-        if (BASE) {
-            uint4 v = *reinterpret_cast<const uint4*>(n_in + 4 * j);
-            pair_accumulate_base(v.x, v.z, v.y, v.w, dl0, dl1, dr0, dr1, w, acc);
-        } else {
-            EF nl0, nr0, nl1, nr1;
+    }
+}
+// N consecutive words of one plane of a work array
+template <int N>
+__device__ __forceinline__ void load_n(const u32* __restrict__ src, u32 (&a)[N]) {
+    if constexpr (N == 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src);
+        a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+    } else if constexpr (N == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src);
+        a[0] = v.x, a[1] = v.y;
+    } else {
+        a[0] = *src;
+    }
+}
+// LSB-first folds of N = 2^F consecutive entries: r0 joins (0,1), (2,3); r1 joins the results
+template <int N>
+__device__ __forceinline__ EF fold_n(const EF (&in)[N], const EF& r0, const EF& r1) {
+    if constexpr (N == 1)
+        return in[0];
+    else if constexpr (N == 2)
+        return fold1(in[0], in[1], r0);
+    else
+        return fold1(fold1(in[0], in[1], r0), fold1(in[2], in[3], r0), r1);
+}
+template <int N>
+__device__ __forceinline__ EF fold_n_base(const u32 (&in)[N], const EF& r0, const EF& r1) {
+    if constexpr (N == 1)
+        return ef_from_base(in[0]);
+    else if constexpr (N == 2)
+        return fold1_base(in[0], in[1], r0);
+    else
+        return fold1(fold1_base(in[0], in[1], r0), fold1_base(in[2], in[3], r0), r1);
+}
+
+// MODE 0: layer storage with base numerators (the caller's input layer), 1: layer storage with EF numerators, 2: the four
+// SoA work arrays (nl, nr~, dl, dr).  F: number of pending challenges folded in first.  LA: compute the look-ahead sums.
+template <int MODE, int F, bool LA>
+__global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
+                                                  const u32* __restrict__ arr_in, u64 m_out, EF r0, EF r1, EF alpha, EqSplit eq,
+                                                  u32* __restrict__ out, u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                                  u32* __restrict__ h_res, u32 seq) {
+    __shared__ u32 lds[4 * GKR_SUM_WORDS];
+    __shared__ u32 tot[GKR_SUM_WORDS];
+    __shared__ u32 is_last;
+    constexpr int NIN = 1 << F;  // inputs per output entry
+    const u64 m_in = m_out << F;
+    const u32 cls = threadIdx.x & 3;
+    EF acc_e = ef_zero(), acc_x = ef_zero(), acc_y = ef_zero();
+    for (u64 base = (u64)blockIdx.x * 256; base < m_out; base += (u64)gridDim.x * 256) {
+        const u64 i = base + threadIdx.x;
+        const bool active = i < m_out;
+        EF x[4];  // nl, nr~, dl, dr at output index i
+        if (active) {
+            if constexpr (MODE == 2) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                uint4 v = *reinterpret_cast<const uint4*>(n_in + (u64)k * plane + 4 * j);
-                nl0.v[k] = v.x;
-                nr0.v[k] = v.y;
-                nl1.v[k] = v.z;
-                nr1.v[k] = v.w;
+                for (int q = 0; q < 4; q++) {
+                    EF in[NIN];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        u32 a[NIN];
+                        load_n<NIN>(arr_in + ((u64)q * 5 + k) * m_in + (i << F), a);
+#pragma unroll
+                        for (int e = 0; e < NIN; e++) in[e].v[k] = a[e];
+                    }
+                    x[q] = fold_n<NIN>(in, r0, r1);
+                }
+            } else {
+                // storage: array index y <-> entries 2y (left), 2y + 1 (right); this thread's inputs y = (i << F) .. + NIN
+                const u64 plane = 2 * m_in;
+                const u64 at = i << (F + 1);
+                {
+                    EF l[NIN], r[NIN];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        u32 a[NIN], b[NIN];
+                        load_lr<NIN>(d_in + (u64)k * plane + at, a, b);
+#pragma unroll
+                        for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
+                    }
+                    x[2] = fold_n<NIN>(l, r0, r1), x[3] = fold_n<NIN>(r, r0, r1);
+                }
+                if constexpr (MODE == 0) {
+                    u32 a[NIN], b[NIN];
+                    load_lr<NIN>(n_in + at, a, b);
+                    x[0] = fold_n_base<NIN>(a, r0, r1), x[1] = fold_n_base<NIN>(b, r0, r1);
+                } else {
+                    EF l[NIN], r[NIN];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        u32 a[NIN], b[NIN];
+                        load_lr<NIN>(n_in + (u64)k * plane + at, a, b);
+#pragma unroll
+                        for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
+                    }
+                    x[0] = fold_n<NIN>(l, r0, r1), x[1] = fold_n<NIN>(r, r0, r1);
+                }
+                x[1] = ef_add(x[1], ef_mul(alpha, x[3]));  // nr~ = nr + alpha dr
             }
-            pair_accumulate(nl0, nl1, nr0, nr1, dl0, dl1, dr0, dr1, w, acc);
-        }
-    }
-    finish_round(acc, lds, tot, partial, alpha, final_out, seq);
-}
-
-// ---- fold by r then compute the next round.  MODE 0: input = layer storage with base nums, 1: layer storage with EF
-// nums, 2: four SoA arrays of length m_in.  Output: four SoA arrays of length m_out = m_in / 2 at `out`
-// (array a at out + a * 5 * m_out).  Thread j' produces outputs 2j', 2j'+1 and (if m_out >= 2) their pair coefficients.
-template <int MODE, bool LAST>
-__global__ __launch_bounds__(256) void k_gkr_fold_round(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
-                                                        const u32* __restrict__ arr_in, u64 m_out, EF r, EqSplit eq,
-                                                        u32* __restrict__ out, u32* __restrict__ partial, EF alpha,
-                                                        u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 lds[80];
-    __shared__ u32 tot[20];
-    const u64 m_in = 2 * m_out;
-    EF acc[4] = {ef_zero(), ef_zero(), ef_zero(), ef_zero()};
-    // LAST: m_out == 1 (the final fold of a layer: one output per array, no pair to accumulate)
-    constexpr int N_OUT = LAST ? 1 : 2;
-    const u64 n_threads_work = LAST ? 1 : m_out / 2;
-    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_threads_work; j += (u64)gridDim.x * 256) {
-        EF o[N_OUT][4];  // [which output][array] — fully unrolled, stays in registers
-#pragma unroll
-        for (int t = 0; t < N_OUT; t++) {
-            const u64 i = 2 * j + t;  // output index; inputs 2i, 2i+1 of each array
-            EF a[4], b[4];
-            if (MODE == 2) {
+            if constexpr (F > 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        uint2 v = *reinterpret_cast<const uint2*>(arr_in + ((u64)q * 5 + k) * m_in + 2 * i);
-                        a[q].v[k] = v.x;
-                        b[q].v[k] = v.y;
-                    }
-            } else {
-                // storage: n_l(x) = n[2x], n_r(x) = n[2x+1]; inputs x = 2i, 2i+1 -> entries 4i .. 4i+3
-                const u64 plane = 2 * m_in;
+                    for (int k = 0; k < 5; k++) out[((u64)q * 5 + k) * m_out + i] = x[q].v[k];
+                if (m_out <= 4) {  // the tail of the layer goes to the host as well (lm_gkr_layer_end folds it)
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    uint4 v = *reinterpret_cast<const uint4*>(d_in + (u64)k * plane + 4 * i);
-                    a[2].v[k] = v.x;
-                    a[3].v[k] = v.y;
-                    b[2].v[k] = v.z;
-                    b[3].v[k] = v.w;
-                }
-                if (MODE == 0) {
-                    uint4 v = *reinterpret_cast<const uint4*>(n_in + 4 * i);
-                    a[0] = ef_from_base(v.x);
-                    a[1] = ef_from_base(v.y);
-                    b[0] = ef_from_base(v.z);
-                    b[1] = ef_from_base(v.w);
-                } else {
+                    for (int q = 0; q < 4; q++)
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        uint4 v = *reinterpret_cast<const uint4*>(n_in + (u64)k * plane + 4 * i);
-                        a[0].v[k] = v.x;
-                        a[1].v[k] = v.y;
-                        b[0].v[k] = v.z;
-                        b[1].v[k] = v.w;
-                    }
+                        for (int k = 0; k < 5; k++) h_res[GKR_FIN_AT + (q * 5 + k) * 4 + i] = x[q].v[k];
+                    __threadfence_system();
                 }
             }
+        } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (MODE == 0 && q < 2) {
-                    // base numerators: r * (b - a) is EF x base
-                    EF t2 = ef_mul_base(r, sub(b[q].v[0], a[q].v[0]));
-                    t2.v[0] = add(t2.v[0], a[q].v[0]);
-                    o[t][q] = t2;
+            for (int q = 0; q < 4; q++) x[q] = ef_zero();
+        }
+        // ---- sums: own entry, then the quad's differences ----
+        const EF e = ef_add(ef_mul(x[0], x[3]), ef_mul(x[1], x[2]));
+        EF A[4], H[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const u32 v = x[q].v[k];
+                const u32 v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v), v3 = quad_bcast<3>(v);
+                const u32 d1 = sub(v1, v0), d3 = sub(v3, v2);
+                if (LA) {
+                    const u32 ee = sub(v2, v0), gg = sub(d3, d1);
+                    A[q].v[k] = cls == 0 ? gg : cls == 1 ? d1 : cls == 2 ? ee : d3;
+                    H[q].v[k] = sub(v3, v1);
                 } else {
-                    o[t][q] = ef_add(a[q], ef_mul(r, ef_sub(b[q], a[q])));
+                    A[q].v[k] = cls == 1 ? d1 : d3;
                 }
-#pragma unroll
-                for (int k = 0; k < 5; k++) out[((u64)q * 5 + k) * m_out + i] = o[t][q].v[k];
             }
-        }
-        if constexpr (!LAST) {
-            const EF w = eq_split_at(eq, j);
-            pair_accumulate(o[0][0], o[N_OUT - 1][0], o[0][1], o[N_OUT - 1][1], o[0][2], o[N_OUT - 1][2], o[0][3], o[N_OUT - 1][3], w, acc);
-        }
-    }
-    if constexpr (!LAST) {
-        finish_round(acc, lds, tot, partial, alpha, final_out, seq);
-    } else {
-        // layer end: the four folded values go straight to the pinned result buffer (one lane wrote them)
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int k = 0; k < 5; k++) final_out[q * 5 + k] = out[((u64)q * 5 + k) * m_out];
-            lm_publish_flag(final_out, seq);
+        const EF X = ef_add(ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
+        const EF w = eq_split_at(eq, active ? (LA ? i >> 2 : i >> 1) : 0);
+        acc_e = ef_add(acc_e, ef_mul(e, w));
+        acc_x = ef_add(acc_x, ef_mul(X, w));
+        if (LA) {
+            const EF Y = ef_add(ef_mul(H[0], H[3]), ef_mul(H[1], H[2]));
+            acc_y = ef_add(acc_y, ef_mul(Y, w));
         }
     }
+    // ---- per-class block sums: lanes of equal (lane & 3) ----
+    u32 v[15];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = acc_e.v[k], v[5 + k] = acc_x.v[k], v[10 + k] = acc_y.v[k];
+#pragma unroll
+    for (int s = 0; s < 15; s++)
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) v[s] = add(v[s], (u32)__shfl_down(v[s], off, 64));
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int s = 0; s < 15; s++) lds[wave * GKR_SUM_WORDS + lane * 15 + s] = v[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < GKR_SUM_WORDS) {
+        u32 s = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) s = add(s, lds[wv * GKR_SUM_WORDS + threadIdx.x]);
+        tot[threadIdx.x] = s;
+    }
+    if (gridDim.x > 1) {
+        // per-block partials; the last block to finish adds them up (no second launch)
+        if (threadIdx.x < GKR_SUM_WORDS) {
+            partial[(u64)blockIdx.x * GKR_SUM_WORDS + threadIdx.x] = tot[threadIdx.x];
+            __threadfence();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+        if (threadIdx.x < 4 * GKR_SUM_WORDS) {
+            const u32 slice = threadIdx.x / GKR_SUM_WORDS, wd = threadIdx.x % GKR_SUM_WORDS;
+            u32 s = 0;
+            for (u32 b = slice; b < gridDim.x; b += 4) s = add(s, __builtin_nontemporal_load(partial + (u64)b * GKR_SUM_WORDS + wd));
+            lds[slice * GKR_SUM_WORDS + wd] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < GKR_SUM_WORDS) {
+            u32 s = 0;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) s = add(s, lds[sl * GKR_SUM_WORDS + threadIdx.x]);
+            tot[threadIdx.x] = s;
+        }
+        if (threadIdx.x == 0) *done_counter = 0;
+    }
+    if (threadIdx.x < GKR_SUM_WORDS) {
+        h_res[threadIdx.x] = tot[threadIdx.x];
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
 }
+
+namespace {
+EF host_ef(const u32* p) {
+    EF r;
+    memcpy(r.v, p, 20);
+    return r;
+}
+// a + r (b + r c)
+EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
+}  // namespace
 
 extern "C" {
 
@@ -329,9 +359,9 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
         n_in = nn;
         d_in = dd;
     }
-    // work buffers: first fold of the biggest layer yields 4 arrays of 2^(n_vars-2) EF
-    g->work_words = 20ull << (n_vars - 2);
-    const u64 w1 = std::max<u64>(g->work_words / 2, 64);
+    // work buffers: the first launch that writes folds the biggest layer (2^(n_vars-1) per array) by two challenges
+    g->work_words = std::max<u64>(20ull << (n_vars - 3), 256);
+    const u64 w1 = std::max<u64>(g->work_words / 4, 256);
     if (lm_pool_alloc_t(ctx, &g->work[0], g->work_words * 4) != hipSuccess ||
         lm_pool_alloc_t(ctx, &g->work[1], w1 * 4) != hipSuccess ||
         lm_pool_alloc_t(ctx, &g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess) {
@@ -340,7 +370,11 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
         return LM_E_NOMEM;
     }
     g->eqt.buf_words = PrefixEqTables::words_needed(n_vars);
-    LM_HIP(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) {
+        lm_set_error("lm_gkr_build: kernel launch failed");
+        lm_gkr_free(ctx, g);
+        return LM_E_DEVICE;
+    }
     *out = g;
     return LM_OK;
 }
@@ -367,84 +401,134 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
     g->cur = -1;
     g->m = 1ull << K;  // length of each of n_l, n_r, d_l, d_r
     memcpy(g->alpha.v, alpha, 20);
+    g->point.resize(K);
+    for (u32 j = 0; j < K; j++) memcpy(g->point[j].v, point + 5 * j, 20);
+    g->pending.clear();
+    g->la_valid = false;
+    g->fin_m = 0;
     // round t uses eq over point[0 .. p), p = K-1-t
     return g->eqt.build(ctx, point, K);
 }
 
-// One round.  prev_r = NULL on the first round of the layer; afterwards the challenge of the previous round (the
-// arrays are folded by it first).  out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109), padding included
-// because the vectors are fully materialised.
+
+// One round.  prev_r = NULL on the first round of the layer; afterwards the challenge of the previous round.
+// out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109), padding included because the vectors are fully
+// materialised.  Every other call is answered on the host from the look-ahead sums of the previous launch (see k_gkr_step);
+// the challenges are folded into the arrays two at a time by the next launch.
 int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
     LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
     LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
+    if (prev_r) g->pending.push_back(host_ef(prev_r));
+    if (g->la_valid) {
+        const EF& r = g->pending.back();
+        const EF c0 = quad_at(g->la[0], g->la[1], g->la[2], r), c2 = quad_at(g->la[3], g->la[4], g->la[5], r);
+        memcpy(out_c0_c2, c0.v, 20);
+        memcpy(out_c0_c2 + 5, c2.v, 20);
+        g->la_valid = false;
+        g->round++;
+        return LM_OK;
+    }
     const u32 t = g->round;
-    const u32 p = g->K - 1 - t;  // prefix coordinates of this round's eq table
-    const u64 n_pairs = 1ull << p;
-    // up to 4096 pairs: one workgroup does the whole round (no partials, no second launch)
-    const u32 blocks = n_pairs <= 512 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, 1024);
-    const u32 seq = ++ctx->res_seq;
+    const u32 F = (u32)g->pending.size();
+    LM_REQUIRE(F == 0 || F == 2);  // the schedule: first launch of a layer has nothing to fold, later ones two challenges
+    const u64 m_out = g->m >> F;
+    LM_REQUIRE(m_out >= 2 && m_out == (2ull << (g->K - 1 - t)));
+    const bool la = m_out >= 4;
+    const u32 p = g->K - 1 - t;  // round t: 2^p pairs, eq over point[0..p)
+    const EqSplit eq = g->eqt.at(la ? p - 1 : p);
+    const u32 blocks = m_out <= 1024 ? 1 : (u32)std::min<u64>(m_out / 256, 1024);
     u32* s;
-    int rc = lm_scratch(ctx, (u64)blocks * 20 + 32, &s);
+    int rc = lm_scratch(ctx, (u64)blocks * GKR_SUM_WORDS + 64, &s);
     if (rc) return rc;
-    u32* d_out = s + (u64)blocks * 20;
-    const EqSplit eq = g->eqt.at(p);
+    const u32 seq = ++ctx->res_seq;
+    const bool input_layer = g->K == g->n_vars - 1;
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
     // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
-    const bool input_layer = g->K == g->n_vars - 1;
     const u32* n_st = input_layer ? g->d_nums0 : g->nums[g->n_vars - g->K - 2];
     const u32* d_st = input_layer ? g->d_dens0 : g->dens[g->n_vars - g->K - 2];
-    if (t == 0) {
-        if (input_layer)
-            LM_LAUNCH(ctx, k_gkr_round_storage<true>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s, g->alpha, ctx->h_res, seq);
-        else
-            LM_LAUNCH(ctx, k_gkr_round_storage<false>, dim3(blocks), dim3(256), 0, n_st, d_st, n_pairs, eq, s, g->alpha, ctx->h_res, seq);
-    } else {
-        EF r;
-        memcpy(r.v, prev_r, 20);
-        const u64 m_out = g->m / 2;
-        const int dst = g->cur < 0 ? 0 : 1 - g->cur;
-        if (g->cur < 0) {
+    const EF r0 = F ? g->pending[0] : ef_zero(), r1 = F ? g->pending[1] : ef_zero();
+    const int dst = g->cur < 0 ? 0 : 1 - g->cur;
+    u32* counter = ctx->d_sync + 1;
+    const u32* nul = nullptr;
+#define GKR_STEP(MODE, FF, LL, NI, DI, AI) \
+    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, r0, r1, g->alpha, eq, g->work[dst], s, counter, ctx->h_res, seq)
+    if (g->cur < 0) {
+        LM_REQUIRE(la);  // K >= 5: the launches that read layer storage always cover two rounds
+        if (F == 0) {
             if (input_layer)
-                LM_LAUNCH(ctx, (k_gkr_fold_round<0, false>), dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
-                          g->work[dst], s, g->alpha, ctx->h_res, seq);
+                GKR_STEP(0, 0, true, n_st, d_st, nul);
             else
-                LM_LAUNCH(ctx, (k_gkr_fold_round<1, false>), dim3(blocks), dim3(256), 0, n_st, d_st, (const u32*)nullptr, m_out, r, eq,
-                          g->work[dst], s, g->alpha, ctx->h_res, seq);
+                GKR_STEP(1, 0, true, n_st, d_st, nul);
         } else {
-            LM_LAUNCH(ctx, (k_gkr_fold_round<2, false>), dim3(blocks), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
-                      (const u32*)g->work[g->cur], m_out, r, eq, g->work[dst], s, g->alpha, ctx->h_res, seq);
+            if (input_layer)
+                GKR_STEP(0, 2, true, n_st, d_st, nul);
+            else
+                GKR_STEP(1, 2, true, n_st, d_st, nul);
         }
-        g->cur = dst;
-        g->m = m_out;
+    } else {
+        LM_REQUIRE(F == 2);
+        if (la)
+            GKR_STEP(2, 2, true, nul, nul, (const u32*)g->work[g->cur]);
+        else
+            GKR_STEP(2, 2, false, nul, nul, (const u32*)g->work[g->cur]);
     }
-    (void)d_out;
-    if (blocks > 1) LM_LAUNCH(ctx, k_gkr_reduce, dim3(1), dim3(256), 0, (const u32*)s, blocks, g->alpha, ctx->h_res, seq);
+#undef GKR_STEP
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
-    memcpy(out_c0_c2, ctx->h_res, 40);
+    const u32* h = ctx->h_res;
+    auto S = [&](u32 cls, u32 slot) { return host_ef(h + cls * 15 + slot * 5); };  // slot 0: e, 1: X, 2: Y
+    EF c0, c2;
+    if (la) {
+        const EF pt = g->point[p - 1], omp = ef_sub(ef_one(), pt);
+        const EF E0 = S(0, 0), E1 = S(1, 0), E2 = S(2, 0), C01 = S(1, 1), C23 = S(3, 1), T2 = S(0, 1), T0 = S(2, 1), T3 = S(0, 2);
+        c0 = ef_add(ef_mul(omp, E0), ef_mul(pt, E2));
+        c2 = ef_add(ef_mul(omp, C01), ef_mul(pt, C23));
+        g->la[0] = E0, g->la[1] = ef_sub(ef_sub(E1, E0), C01), g->la[2] = C01;
+        g->la[3] = T0, g->la[4] = ef_sub(ef_sub(T3, T0), T2), g->la[5] = T2;
+        g->la_valid = true;
+    } else {
+        c0 = ef_add(S(0, 0), S(2, 0));
+        c2 = ef_add(S(1, 1), S(3, 1));
+    }
+    if (F) {
+        g->cur = dst;
+        g->m = m_out;
+        g->pending.clear();
+        if (m_out <= 4) {
+            g->fin_m = (u32)m_out;
+            for (int q = 0; q < 4; q++)
+                for (int k = 0; k < 5; k++)
+                    for (u32 i = 0; i < m_out; i++) g->fin[q][i].v[k] = h[GKR_FIN_AT + (q * 5 + k) * 4 + i];
+        }
+    }
+    memcpy(out_c0_c2, c0.v, 20);
+    memcpy(out_c0_c2 + 5, c2.v, 20);
     g->round++;
     return LM_OK;
 }
 
-// After the last round: fold by the last challenge and return [n_l, n_r, d_l, d_r] (4 EF, mod.rs:129).
+// After the last round: fold by the remaining challenges and return [n_l, n_r, d_l, d_r] (4 EF, mod.rs:129).  The last
+// launch left the <= 4 remaining entries of each array with the host; folding them is two EF multiplications per array.
 int lm_gkr_layer_end(lm_ctx* ctx, lm_gkr* g, const uint32_t last_r[5], uint32_t inner_evals[20]) {
-    LM_REQUIRE(ctx && g && last_r && inner_evals && g->round == g->K && g->m == 2);
-    EF r;
-    memcpy(r.v, last_r, 20);
-    const int dst = 1 - g->cur;
-    EqSplit eq = g->eqt.at(0);
-    u32* s;
-    int rc = lm_scratch(ctx, 64, &s);
-    if (rc) return rc;
-    LM_REQUIRE(g->cur >= 0);  // K >= 5 rounds, so at least one fold happened
-    const u32 seq = ++ctx->res_seq;
-    LM_LAUNCH(ctx, (k_gkr_fold_round<2, true>), dim3(1), dim3(256), 0, (const u32*)nullptr, (const u32*)nullptr,
-              (const u32*)g->work[g->cur], (u64)1, r, eq, g->work[dst], s, g->alpha, ctx->h_res, seq);
-    LM_HIP(hipGetLastError());
-    if ((rc = lm_wait_result(ctx, seq))) return rc;
-    memcpy(inner_evals, ctx->h_res, 80);
-    g->cur = dst;
+    LM_REQUIRE(ctx && g && last_r && inner_evals && g->round == g->K);
+    g->pending.push_back(host_ef(last_r));
+    LM_REQUIRE(g->fin_m == (1u << g->pending.size()) && g->fin_m == g->m);
+    EF v[4];
+    for (int q = 0; q < 4; q++) {
+        EF a[4];
+        u32 n = g->fin_m;
+        for (u32 i = 0; i < n; i++) a[i] = g->fin[q][i];
+        for (const EF& r : g->pending) {
+            n /= 2;
+            for (u32 i = 0; i < n; i++) a[i] = ef_add(a[2 * i], ef_mul(r, ef_sub(a[2 * i + 1], a[2 * i])));
+        }
+        v[q] = a[0];
+    }
+    v[1] = ef_sub(v[1], ef_mul(g->alpha, v[3]));  // the arrays hold nr + alpha dr
+    for (int q = 0; q < 4; q++) memcpy(inner_evals + 5 * q, v[q].v, 20);
+    g->pending.clear();
     g->m = 1;
+    g->fin_m = 0;
     return LM_OK;
 }
 

@@ -260,9 +260,47 @@ __device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, 
     }
 }
 
+// End of a product-sumcheck round kernel: a single block publishes its sums; otherwise every block leaves 10 partial words
+// and the block that finishes last adds them up and publishes (no separate reducing launch).
+__device__ __forceinline__ void finish10(u32 v[10], u32* red /* 256 words */, u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                         u32* __restrict__ h_res, u32 seq) {
+    if (gridDim.x == 1) {
+        block_sum10(v, red, h_res, h_res, seq);
+        return;
+    }
+    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    __shared__ u32 is_last;
+    if (threadIdx.x < 10) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x < 250) {
+        const u32 k = threadIdx.x % 10, slice = threadIdx.x / 10;
+        u32 sum = 0;
+        for (u32 b = slice; b < gridDim.x; b += 25) sum = add(sum, __builtin_nontemporal_load(partial + (u64)b * 10 + k));
+        red[threadIdx.x] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        u32 sum = 0;
+        for (u32 sl = 0; sl < 25; sl++) sum = add(sum, red[sl * 10 + threadIdx.x]);
+        h_res[threadIdx.x] = sum;
+    }
+    if (threadIdx.x < 64) {
+        __threadfence_system();
+        if (threadIdx.x == 0) {
+            *done_counter = 0;
+            lm_publish_flag(h_res, seq);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                         u32* __restrict__ partial, u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[40];
+                                                         u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                                         u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[256];
     const u64 plane = 2 * half;
     u64 a0[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0};
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -281,14 +319,12 @@ __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__
         v[k] = reduce(a0[k]);
         v[5 + k] = reduce(a2[k]);
     }
-    if (gridDim.x == 1)
-        block_sum10(v, red, final_out, final_out, seq);
-    else
-        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    finish10(v, red, partial, done_counter, final_out, seq);
 }
 __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                        u32* __restrict__ partial, u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[40];
+                                                        u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                                        u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[256];
     const u64 plane = 2 * half;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -309,20 +345,8 @@ __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ 
         v[k] = c0.v[k];
         v[5 + k] = c2.v[k];
     }
-    if (gridDim.x == 1)
-        block_sum10(v, red, final_out, final_out, seq);
-    else
-        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    finish10(v, red, partial, done_counter, final_out, seq);
 }
-__global__ __launch_bounds__(256) void k_sum10(const u32* __restrict__ partial, u32 n, u32* __restrict__ out, u32 seq) {
-    __shared__ u32 red[40];
-    u32 v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (u32 i = threadIdx.x; i < n; i += 256)
-#pragma unroll
-        for (int k = 0; k < 10; k++) v[k] = add(v[k], partial[(u64)i * 10 + k]);
-    block_sum10(v, red, out, out, seq);
-}
-
 __global__ __launch_bounds__(256) void k_fold_base(const u32* __restrict__ in, u64 half, EF r, u32* __restrict__ out) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
         const u32 a = in[i], d = sub(in[i + half], a);
@@ -354,8 +378,8 @@ __global__ __launch_bounds__(256) void k_fold_ext(const u32* __restrict__ in, u6
 template <bool F_BASE>
 __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, const u32* __restrict__ W, u64 half, EF r,
                                                     u32* __restrict__ f_out, u32* __restrict__ W_out, u32* __restrict__ partial,
-                                                    u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[40];
+                                                    u32* __restrict__ done_counter, u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[256];
     const u64 plane = 2 * half, quarter = half >> 1;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
@@ -397,10 +421,7 @@ __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, c
         v[k] = c0.v[k];
         v[5 + k] = c2.v[k];
     }
-    if (gridDim.x == 1)
-        block_sum10(v, red, final_out, final_out, seq);
-    else
-        block_sum10(v, red, partial + (u64)blockIdx.x * 10);
+    finish10(v, red, partial, done_counter, final_out, seq);
 }
 
 // =====================================================================================================
@@ -410,19 +431,32 @@ struct PowArgs {
     u32 cap[8];
     u32 base, n, mask, r2;
 };
-__global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ result) {
+// The block that finishes last hands the result to the host (pinned buffer + sequence flag) and re-arms the device word:
+// no separate publishing launch.
+__global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ result, u32* __restrict__ done_counter,
+                                                   u32* __restrict__ h_res, u32 seq) {
     const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
     const u32 w = a.base + i;
-    if (w >= P) return;
-    u32 s[16];
+    if (i < a.n && w < P) {
+        u32 s[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = a.cap[k];
-    s[8] = mul(w, a.r2);  // Montgomery form of the canonical candidate
+        for (int k = 0; k < 8; k++) s[k] = a.cap[k];
+        s[8] = mul(w, a.r2);  // Montgomery form of the canonical candidate
 #pragma unroll
-    for (int k = 9; k < 16; k++) s[k] = 0;
-    poseidon16_permute(s);
-    if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
+        for (int k = 9; k < 16; k++) s[k] = 0;
+        poseidon16_permute(s);
+        if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done_counter, 1u) == gridDim.x - 1) {
+            *done_counter = 0;
+            __threadfence();
+            h_res[0] = atomicExch(result, 0xffffffffu);
+            lm_publish_flag(h_res, seq);
+        }
+    }
 }
 
 // init: W holds garbage on entry and must equal the sum on exit
@@ -568,15 +602,6 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
     return LM_OK;
 }
 
-// result -> pinned host buffer, device word re-armed for the next grind, sequence flag (no copy command, no stream sync)
-__global__ void k_pow_publish(u32* __restrict__ result, u32* __restrict__ h_res, u32 seq) {
-    if (threadIdx.x == 0) {
-        h_res[0] = *result;
-        *result = 0xffffffffu;
-        lm_publish_flag(h_res, seq);
-    }
-}
-
 extern "C" {
 
 int lm_weights_accumulate(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
@@ -599,11 +624,10 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     if (rc) return rc;
     u32* d_out = s + (u64)blocks * 10;
     if (f_is_ext)
-        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
     (void)d_out;
-    if (blocks > 1) LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
@@ -637,10 +661,9 @@ int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     EF rr;
     memcpy(rr.v, r, 20);
     if (f_is_ext)
-        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->h_res, seq);
-    if (blocks > 1) LM_LAUNCH(ctx, k_sum10, dim3(1), dim3(256), 0, (const u32*)s, blocks, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
@@ -663,8 +686,7 @@ int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_
         a.base = (u32)base;
         a.n = (u32)std::min<u64>(batch, (u64)P - base);
         const u32 seq = ++ctx->res_seq;
-        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, ctx->d_sync);
-        LM_LAUNCH(ctx, k_pow_publish, dim3(1), dim3(64), 0, ctx->d_sync, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, ctx->d_sync, ctx->d_sync + 1, ctx->h_res, seq);
         LM_HIP(hipGetLastError());
         int rc = lm_wait_result(ctx, seq);
         if (rc) return rc;

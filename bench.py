@@ -74,7 +74,7 @@ RECURSION_EXT_CALLS = [("mul", False, 64, 3000), ("mul", True, 128, 800), ("poly
                        ("add", False, 1, 20000), ("mul", False, 1, 20000), ("add", True, 2, 3000)]
 
 
-def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss"):
+def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss", capacity=False):
     """A consistent synthetic leanVM execution trace of the config-2 shape (SURVEY.md §8 size table), uploaded once:
     1550 signatures x 167 Poseidon calls = 258 850 active Poseidon rows (table 2^18 x 109), execution table 2^20 x 20,
     extension_op 2^8 x 29, memory 2^20, bytecode 2^19  ->  stacked polynomial 2^26, logup vector 2^24.
@@ -102,10 +102,11 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss")
     w["log_inv_rate"] = log_inv_rate
     tr, keep = lm.make_execution_trace(ctx, w)
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
-    builder = ob.whir_builder(log_inv_rate=log_inv_rate)  # default_whir_config(1): 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50)
-    cfgd = ob.whir_config(orc, builder, n_vars)
-    cfg = lm.WhirConfig.from_dict(cfgd)
-    return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfgd, n_vars=n_vars, builder=builder)
+    # default_whir_config: 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50), integers from the library's own
+    # WhirConfig::new; `builder` is the same parameter set in the oracle's format, for the checker (--verify)
+    cfg = lm.WhirConfig.new(lm.WhirBuilder.default(log_inv_rate, prox_gaps_conjecture=capacity), n_vars)
+    builder = ob.whir_builder(log_inv_rate=log_inv_rate, soundness=ob.CAPACITY if capacity else ob.JOHNSON)
+    return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, builder=builder)
 
 
 def time_trace_fill(ctx, w, reps=5):
@@ -191,21 +192,72 @@ def cpu_baseline(orc, ob, log_scale=2):
                        f"over-counted by the scaling")
 
 
+def source_sha():
+    """sha256 over the kernel sources the profiles under profiles/ were taken from: a counter file recorded for other sources is
+    refused (its traffic / instruction counts would silently describe kernels that no longer exist)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "leanmultisig_amd", "csrc")
+    for dirpath, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".h", ".inc", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(dirpath, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name, sha):
+    """profiles/<name> if it was recorded for the current kernel sources, else (None, reason)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, f"profiles/{name} absent"
+    j = json.load(open(path))
+    if j.get("source_sha") != sha:
+        return None, f"profiles/{name} was recorded for sources {j.get('source_sha')} != current {sha}: refused as stale"
+    return j, None
+
+
+VALU_PEAK_T = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMD-32 units x lanes per cycle x clock = 78.6 T lane-ops/s (MI355X_MICROARCH.md)
+
+
+def exchange_step(root, proof_words, device):
+    """The exchange of the sharded path, once per step: all-gather of the commitment roots (8 words) and of
+    the pruned proofs (to the rank that would run the 8 -> 1 recursion).  Proof lengths differ by a few words: a length word +
+    zero padding to a fixed capacity."""
+    import torch
+    import torch.distributed as dist
+    cap = 1 << 17
+    assert proof_words.size < cap
+    buf = np.zeros(8 + 1 + cap, dtype=np.int64)
+    buf[:8] = np.asarray(root, dtype=np.int64)
+    buf[8] = proof_words.size
+    buf[9:9 + proof_words.size] = proof_words
+    t = torch.from_numpy(buf.astype(np.int32)).to(device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t.cpu().numpy().reshape(1, -1)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.stack(out).cpu().numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="independent proofs in flight per GPU (one host thread + HIP stream each); a step = that many proofs.  "
-                         "0 = default: 10, fewer if the host has less than 2 hardware threads per prover thread")
+                    help="side measurement after the timed region (N = 1 only): independent proofs in flight on the GPU (one host "
+                         "thread + HIP stream each).  0 = default: 10, fewer if the host has less than 2 hardware threads per "
+                         "prover thread; 1 = skip")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on a single-GPU box "
                          "together with LM_BENCH_SINGLE_DEVICE=1)")
     ap.add_argument("--host-resident", action="store_true",
                     help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
     ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
+    ap.add_argument("--soundness", choices=["johnson", "capacity"], default="johnson",
+                    help="capacity = the reference's `prox-gaps-conjecture` feature (lean_prover/src/lib.rs:39-43)")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--shape", choices=["xmss", "recursion"], default="xmss",
                     help="xmss = BASELINE configs[1]/[2] (the metric); recursion = configs[3] stand-in: ExtensionOp table 2^19, "
@@ -231,40 +283,168 @@ def main():
 
     import leanmultisig_amd as lm
     from tests import oracle_binding as ob
-    orc = ob.load()  # only for WhirConfig integers (f64 derivation stays on the caller side) and the cpu_baseline leg
-    # One prover per stream: C independent 1550-signature leaves are proven concurrently on this GPU (aggregation nodes
-    # prove leaf after leaf; the ~400 sequential Fiat-Shamir round trips of one proof leave the chip idle between small
-    # kernels, a second and third proof fill those gaps).  Each prover has its own lm_ctx (stream, pools, pinned buffers).
-    import threading
+    orc = ob.load()  # checker only: witness synthesis, --verify and the cpu_baseline leg (all outside the timed region)
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    C = args.inflight if args.inflight > 0 else max(1, min(10, hw // (2 * max(1, world))))
-    ctxs = [lm.Context(local_rank) for _ in range(C)]
-    ws = [build_workload(ctxs[c], orc, ob, np.random.default_rng(1000 + rank * 64 + c), args.scale_log, args.log_inv_rate, args.shape) for c in range(C)]
+    ctx = lm.Context(local_rank)
+    capacity = args.soundness == "capacity"
+    w = build_workload(ctx, orc, ob, np.random.default_rng(1000 + rank * 64), args.scale_log, args.log_inv_rate, args.shape, capacity)
     if args.host_resident:
-        for w_ in ws:
-            w_["pinned"] = pin_witness(w_)
-    ctx, w = ctxs[0], ws[0]
+        w["pinned"] = pin_witness(w)
 
-    # warmup: every stream once; then W single-stream steps, which also give the latency of one proof alone on the GPU
-    for c in range(C):
-        run_step(ctxs[c], lm, ws[c])
-    ctx.sync()
+    # ---- the timed region: K steps, one step = ONE proof of one 1550-signature leaf on this rank's GPU, which is what the
+    # reference's metric times (n_xmss / mean elapsed of one aggregate_type_1, rec_aggregation/src/benchmark.rs:397-431).
+    # N ranks prove N independent leaves (weak scaling) and exchange roots + pruned proofs after every step.
     dominant = "k_air_round"
-    ctx.profile_select(dominant)
-    t0 = time.perf_counter()
     for _ in range(args.warmup):
-        run_step(ctx, lm, w)
+        pr = run_step(ctx, lm, w)
+        exchange_step(step_root(pr), pr.proof_pruned(), device)
     ctx.sync()
-    single_ms = 1e3 * (time.perf_counter() - t0) / args.warmup if args.warmup else None
-    n_launch_1, k_ms_1 = ctx.profile_read(dominant)  # the dominant kernel alone on the chip (single stream)
     ctx.profile_select(dominant)
-    for c in range(C):
-        ctxs[c].sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    results = [[] for _ in range(C)]
-    last = [None] * C
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(args.steps):
+        pr = run_step(ctx, lm, w)
+        gathered = exchange_step(step_root(pr), pr.proof_pruned(), device)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    n_launch, k_ms = ctx.profile_read(dominant)
+    ctx.profile_select(None)
+    assert gathered.shape[0] == world and int(gathered[rank, 8]) == pr.proof_pruned().size
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        sigs = ((N_SIGS * 167) >> args.scale_log) // 167  # signatures per proof (--scale-log shrinks the leaf)
+        value = sigs * world / (dt / args.steps)
+        sha = source_sha()
+        # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
+        # Algorithmic bytes per step (DESIGN.md §3): every column value of every sumcheck round is read once:
+        # round 0 on base words (4 B), round r >= 1 on EF (20 B) over 2^(log_rows - r) rows, (n_columns + n_shift) columns.
+        alg_bytes = 0
+        for t, ncols in ((0, 22), (1, 42), (2, 109)):
+            lr = w["w"]["log_rows"][t]
+            alg_bytes += ncols * 4 * (1 << lr)
+            for r in range(1, lr):
+                alg_bytes += ncols * 20 * (1 << (lr - r))
+        achieved = alg_bytes * args.steps / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # counters of the same kernels (rocprofv3 --pmc passes of `bench.py --inflight 1`, summarised under profiles/ together
+        # with the sha of the kernel sources they were taken from)
+        traffic, alu, notes = None, None, []
+        full = args.scale_log == 0 and args.shape == "xmss" and args.log_inv_rate == 1 and not capacity
+        pmc, why = load_profile("r02_pmc_bench.json", sha) if full else (None, "counter profiles are of the default workload")
+        if pmc and dominant in pmc["per_step"] and n_launch:
+            traffic = pmc["per_step"][dominant]["hbm_bytes"] / pmc["per_step"][dominant]["launches"]
+        elif why:
+            notes.append(why)
+        valu, why = load_profile("r02_valu_bench.json", sha) if full else (None, None)
+        if valu and dominant in valu["per_proof"] and k_ms > 0:
+            jv = valu["per_proof"][dominant]
+            lane_ops = jv["valu_wave_insts"] * 64
+            ach = lane_ops * args.steps / (k_ms * 1e-3) / 1e12
+            wf = jv.get("issue_cycle_weight")  # issue cycles per instruction / 2, from the kernel's ISA mix (tools/isa_mix.py)
+            alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": VALU_PEAK_T, "frac": ach / VALU_PEAK_T,
+                   "issue_cycle_weight": wf, "frac_issue_weighted": ach * wf / VALU_PEAK_T if wf else None,
+                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r02_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
+                             "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
+                             "v_mul_lo/hi_u32, v_mad_u64_u32 at 4 cycles per wave64, v_lshl_add_u64 at its measured 7.4, the rest 2 "
+                             "(profiles/r02_int_rates.txt)"}
+        elif why:
+            notes.append(why)
+        out = {
+            "metric": "xmss_sigs_aggregated_per_sec", "value": value, "unit": "xmss_sigs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"xmss --n-signatures 1550 --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): ONE prove_execution "
+                            "per step, from the execution trace to the pruned proof, on a consistent synthetic leanVM trace — 258850 "
+                            "Poseidon rows, tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
+                            + (" (CapacityBound: prox-gaps-conjecture)" if capacity else "")
+                            + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
+                "value_definition": "signatures of one leaf x ranks / latency of one proof (the reference's n_xmss / mean elapsed of "
+                                    "one aggregate_type_1); `inflight` below is the throughput with several independent leaves "
+                                    "queued on the same GPU",
+                "stages": ["fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
+                           "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)", "merkle_path_pruning",
+                           "exchange(roots+pruned proofs)"],
+                "missing": ["witness generation: the VM interpreter (pc/fp log, memory image, precompile call lists; CPU, SURVEY §8(f) "
+                            "rank 1/4) — the reference's whole-node number includes it; the columns get_execution_trace derives from "
+                            "that log have device entry points, timed as config.device_trace_fill_ms"],
+                "per_gpu_signatures": sigs,
+                "witness": "re-uploaded from pinned host memory every step (PCIe inclusive)" if args.host_resident
+                           else "resident in HBM before the timed region",
+                "whir_config": "lmh_whir_config_new (the library's own WhirConfig::new)",
+                "source_sha": sha,
+            },
+            "roofline": {
+                "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
+                "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None,
+                "traffic_source": "profiles/r02_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                  "FETCH x2 per MI355X_MICROARCH.md); refused when recorded for other kernel sources",
+                "note": "live: HIP events on the prover's stream around every k_air_round launch of the timed region (one proof "
+                        "alone on the chip).  The constraint evaluation is integer-ALU bound, so the HBM fraction is small by "
+                        "construction; `alu` is the utilisation that matters — see DESIGN.md §3",
+                "alu": alu,
+                "profile_notes": notes,
+            },
+        }
+        out["config"]["device_trace_fill_ms"] = round(time_trace_fill(ctx, w), 3)  # untimed side measurement, see time_trace_fill
+        if args.shape == "recursion":  # side measurement: not the BASELINE metric
+            lr = w["w"]["log_rows"]
+            out["metric"], out["unit"], out["value"] = "recursion_shaped_proofs_per_sec", "proofs/s", world / (dt / args.steps)
+            out["config"]["workload"] = (f"BASELINE configs[3] stand-in (SURVEY.md §8(d)): tables 2^{lr[0]}x20 / 2^{lr[1]}x29 / 2^{lr[2]}x109, "
+                                         f"memory 2^{w['w']['log_memory']}, stacked 2^{w['n_vars']}, rate 1/{1 << args.log_inv_rate}; ADD/MUL/DEREF "
+                                         "instructions, all six ExtensionOp modes, Poseidon calls")
+            out["config"].pop("per_gpu_signatures")
+        if args.verify:
+            ok, err = ob.verify_execution(orc, w["w"], pr.proof(), w["builder"])
+            out["config"]["proof_verified_by_oracle"] = bool(ok)
+            if not ok:
+                print("VERIFY FAILED:", err, file=sys.stderr)
+        # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
+        out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
+        out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
+        # ---- side measurement (N = 1): independent leaves in flight on the same GPU, one lm_ctx (stream, pools, pinned buffers,
+        # host thread) each — the node-level throughput when several leaves are queued
+        C = args.inflight if args.inflight > 0 else max(1, min(10, hw // 2))
+        if world == 1 and C > 1:
+            out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctx, w, C, max(3, args.steps // 2), args, sigs)
+        if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(orc, ob)
+        print(json.dumps(out), flush=True)
+        if args.profile_all:
+            ctx.profile_select("*")
+            run_step(ctx, lm, w)
+            ctx.sync()
+            for k in ctx.profile_names():
+                cnt, ms = ctx.profile_read(k)
+                if cnt:
+                    print(f"# {k:24s} launches {cnt:5d} total {ms:9.3f} ms", file=sys.stderr)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_inflight(lm, orc, ob, local_rank, ctx0, w0, C, steps, args, sigs):
+    """C provers (own lm_ctx each) prove `steps` leaves each, concurrently; returns the aggregate rate."""
+    import threading
+    import torch
+    ctxs = [ctx0] + [lm.Context(local_rank) for _ in range(C - 1)]
+    ws = [w0] + [build_workload(ctxs[c], orc, ob, np.random.default_rng(2000 + c), args.scale_log, args.log_inv_rate, args.shape,
+                                args.soundness == "capacity") for c in range(1, C)]
+    for c in range(C):
+        run_step(ctxs[c], lm, ws[c])
+        ctxs[c].sync()
     errors = []
     start = threading.Barrier(C + 1)
 
@@ -272,9 +452,8 @@ def main():
         try:
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
             start.wait()
-            for _ in range(args.steps):
-                last[c] = run_step(ctxs[c], lm, ws[c])
-                results[c].append(step_root(last[c]))
+            for _ in range(steps):
+                run_step(ctxs[c], lm, ws[c]).proof_pruned()
             ctxs[c].sync()
         except Exception as e:  # noqa: BLE001 — reported after the join
             errors.append(e)
@@ -286,151 +465,11 @@ def main():
     t0 = time.perf_counter()
     for th in threads:
         th.join()
+    dt = time.perf_counter() - t0
     if errors:
         raise errors[0]
-    # the only collective of the sharded path: the commitment roots of all leaves (one all-gather for the whole region)
-    my_roots = np.concatenate([np.asarray(r, dtype=np.int64) for rs in results for r in rs])
-    roots = exchange_roots_block(my_roots, device)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    n_launch, k_ms = ctx.profile_read(dominant)
-    ctx.profile_select(None)
-    assert roots.shape == (world, C * args.steps * 8)
-    pr = last[0]  # a proof of the timed region (checked by --verify)
-
-    if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        sigs = ((N_SIGS * 167) >> args.scale_log) // 167  # signatures per proof (--scale-log shrinks the leaf)
-        value = sigs * C * world / (dt / args.steps)
-        # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
-        # Algorithmic bytes per step (DESIGN.md §3): every column value of every sumcheck round is read once:
-        # round 0 on base words (4 B), round r >= 1 on EF (20 B) over 2^(log_rows - r) rows, (n_columns + n_shift) columns.
-        alg_bytes = 0
-        for t, ncols in ((0, 22), (1, 42), (2, 109)):
-            lr = w["w"]["log_rows"][t]
-            alg_bytes += ncols * 4 * (1 << lr)
-            for r in range(1, lr):
-                alg_bytes += ncols * 20 * (1 << (lr - r))
-        achieved = alg_bytes * args.steps / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # measured HBM traffic of the same kernels (PMC passes of this command, profiles/) and the integer-ALU view: the
-        # kernel family is VALU bound, so the meaningful utilisation is lane-instructions issued / peak issue rate
-        traffic, alu, leaf = None, None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
-        if os.path.exists(pmc_path) and args.scale_log == 0:
-            j = json.load(open(pmc_path))["per_step"]
-            if "k_air_round" in j and n_launch:
-                traffic = j["k_air_round"]["hbm_bytes"] / j["k_air_round"]["launches"]
-            if "k_leaf_sponge" in j:
-                lf = j["k_leaf_sponge"]
-                leaf = {"kernel": "k_leaf_sponge (4 trees per step)", "bound": "hbm", "traffic_bytes_per_step": lf["hbm_bytes"],
-                        "kernel_ms_per_step": lf["kernel_ms_under_pmc"],
-                        "note": "Poseidon sponge is int-ALU bound: ~21.5 M permutations per step at ~5 G perm/s"}
-        valu_path = os.path.join(ROOT, "profiles", "r01_air_valu_counts.json")
-        if os.path.exists(valu_path) and k_ms > 0:
-            vc = json.load(open(valu_path))["valu_per_evaluation"]
-            lane_ops = 0
-            for t, deg in ((0, 5), (1, 6), (2, 10)):
-                lr = w["w"]["log_rows"][t]
-                lane_ops += vc[f"table{t}_base"] * deg * (1 << (lr - 1))
-                for r in range(1, lr):
-                    lane_ops += vc[f"table{t}_ef"] * deg * (1 << (lr - 1 - r))
-            peak = 256 * 4 * 16 * 2.4e9 / 1e12  # CUs x SIMDs x lanes per cycle x clock = 39.3 T lane-instructions/s
-            source = "static v_* count per evaluation (profiles/r01_air_valu_counts.json) x evaluations / HIP-event time"
-            pmc_valu = os.path.join(ROOT, "profiles", "r01_valu_bench.json")
-            if os.path.exists(pmc_valu) and args.scale_log == 0 and args.shape == "xmss":  # measured instruction count of this workload
-                jv = json.load(open(pmc_valu))["per_proof"].get("k_air_round")
-                if jv:
-                    lane_ops = jv["valu_wave_insts"] * 64
-                    source = "SQ_INSTS_VALU of k_air_round per proof (profiles/r01_valu_bench.json, rocprofv3 --pmc) x 64 lanes / HIP-event time"
-            ach = lane_ops * args.steps / (k_ms * 1e-3) / 1e12
-            alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak, "source": source}
-        single = None
-        if args.warmup and k_ms_1 > 0:
-            single = {"achieved": alg_bytes * args.warmup / (k_ms_1 * 1e-3) / 1e9, "unit": "GB/s",
-                      "avg_launch_ms": k_ms_1 / n_launch_1,
-                      "alu_frac": (alu["achieved"] * k_ms / args.steps) / (k_ms_1 / args.warmup) / alu["peak"] if alu else None,
-                      "note": "same kernels during the single-stream warmup steps (no other proof on the chip)"}
-        out = {
-            "metric": "xmss_sigs_aggregated_per_sec", "value": value, "unit": "xmss_sigs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
-            "data": "synthetic",
-            "config": {
-                "workload": f"xmss --n-signatures 1550 --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): prove_execution from the "
-                            "execution trace to the proof on a consistent synthetic leanVM trace — 258850 Poseidon rows, "
-                            "tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
-                            + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
-                "stages": ["fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
-                           "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)"],
-                "missing": ["witness generation: the VM interpreter (pc/fp log, memory image, precompile call lists; CPU, SURVEY §8(f) "
-                            "rank 1/4) — the reference's whole-node number includes it; the columns get_execution_trace derives from "
-                            "that log have device entry points, timed as config.device_trace_fill_ms"],
-                "per_gpu_signatures": sigs * C,
-                "proofs_in_flight_per_gpu": C,
-                "witness": "re-uploaded from pinned host memory every step (PCIe inclusive)" if args.host_resident
-                           else "resident in HBM before the timed region",
-                "single_proof_latency_ms": single_ms,
-            },
-            "roofline": {
-                "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
-                "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None,
-                "traffic_source": "profiles/r01_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                  "FETCH x2 per MI355X_MICROARCH.md)",
-                "contention": f"HIP events on stream 0 while {C} proofs share the chip: launch durations include the other "
-                              "streams' kernels; single-stream figures are in DESIGN.md §3 / profiles/",
-                "note": "the constraint evaluation is integer-ALU bound (one Poseidon-AIR evaluation = 65 k VALU instructions "
-                        "in the extension field), so the HBM fraction is small by construction; `alu` is the utilisation "
-                        "that matters — see DESIGN.md §3",
-                "alu": alu,
-                "single_stream": single,
-                "secondary": leaf,
-            },
-        }
-        out["config"]["device_trace_fill_ms"] = round(time_trace_fill(ctx, w), 3)  # untimed side measurement, see time_trace_fill
-        if args.shape == "recursion":  # side measurement: not the BASELINE metric
-            lr = w["w"]["log_rows"]
-            out["metric"], out["unit"], out["value"] = "recursion_shaped_proofs_per_sec", "proofs/s", C * world / (dt / args.steps)
-            out["config"]["workload"] = (f"BASELINE configs[3] stand-in (SURVEY.md §8(d)): tables 2^{lr[0]}x20 / 2^{lr[1]}x29 / 2^{lr[2]}x109, "
-                                         f"memory 2^{w['w']['log_memory']}, stacked 2^{w['n_vars']}, rate 1/{1 << args.log_inv_rate}; ADD/MUL/DEREF "
-                                         "instructions, all six ExtensionOp modes, Poseidon calls")
-            out["config"].pop("per_gpu_signatures")
-            out["roofline"]["traffic"] = out["roofline"]["secondary"] = None  # the PMC file is of the xmss shape
-        if args.verify:
-            ok, err = ob.verify_execution(orc, w["w"], pr.proof(), None)
-            out["config"]["proof_verified_by_oracle"] = bool(ok)
-            if not ok:
-                print("VERIFY FAILED:", err, file=sys.stderr)
-        # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
-        out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
-        out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
-        if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(orc, ob)
-        print(json.dumps(out), flush=True)
-        if args.profile_all:
-            ctx.profile_select("*")
-            run_step(ctx, lm, w)
-            ctx.sync()
-            names = ["k_access_count", "k_counts_to_field", "k_stack_columns", "k_ntt_pass", "k_leaf_sponge", "k_leaf_sponge_coop",
-                     "k_compress_layer", "k_compress_layer_coop", "k_merkle_top_coop", "k_weight_tables", "k_weights_init",
-                     "k_weights_accumulate", "k_prod_round_base", "k_prod_round_ext", "k_fold_round", "k_sum10", "k_fold_base",
-                     "k_fold_ext", "k_pow_grind", "k_pow_publish", "k_mle_partial_base", "k_mle_partial_ext", "k_eq_table_small",
-                     "k_sum_partials", "k_tree_open", "k_gkr_layer_up", "k_prefix_eq_tables", "k_gkr_round_storage",
-                     "k_gkr_fold_round", "k_gkr_reduce", "k_logup_fill", "k_logup_neutral", "k_mle_partial_cols",
-                     "k_air_virtual_columns", "k_air_round", "k_air_reduce", "k_air_fold_base", "k_air_fold_ext"]
-            for k in names:
-                cnt, ms = ctx.profile_read(k)
-                if cnt:
-                    print(f"# {k:24s} launches {cnt:5d} total {ms:9.3f} ms", file=sys.stderr)
-    if world > 1:
-        dist.destroy_process_group()
+    return {"proofs_in_flight": C, "value": sigs * C * steps / dt, "unit": "xmss_sigs/s", "ms_per_proof": 1e3 * dt / (C * steps),
+            "proofs": C * steps}
 
 
 if __name__ == "__main__":

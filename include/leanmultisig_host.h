@@ -17,8 +17,8 @@ extern "C" {
 
 #define LM_MAX_WHIR_ROUNDS 8
 
-/* The integers of WhirConfig (crates/whir/src/config.rs:118-134) — derived by the caller (f64 maths stays on the
- * caller's side). */
+/* The integers of WhirConfig (crates/whir/src/config.rs:118-134).  A Rust caller passes the ones its own WhirConfig::new
+ * derived; a standalone caller obtains them from lmh_whir_config_new below. */
 typedef struct {
     uint32_t num_variables;
     uint32_t starting_log_inv_rate;
@@ -32,6 +32,26 @@ typedef struct {
         uint32_t query_pow_bits, folding_pow_bits, num_queries, ood_samples;
     } rounds[LM_MAX_WHIR_ROUNDS]; /* RoundConfig, config.rs:104-116 */
 } lm_whir_config;
+
+/* WhirConfigBuilder (config.rs:82-102) and WhirConfig::new (config.rs:186-334): the schedule integers from the security
+ * parameters.  lmh_default_whir_builder = default_whir_config (crates/lean_prover/src/lib.rs:22-50): 124-bit, 16 grinding
+ * bits, folding 7 then 5, first RS-domain reduction 5, coefficients sent at <= 8 variables, JohnsonBound — or CapacityBound
+ * when the reference is built with its `prox-gaps-conjecture` feature. */
+#define LM_SOUNDNESS_UNIQUE_DECODING 0
+#define LM_SOUNDNESS_JOHNSON_BOUND 1
+#define LM_SOUNDNESS_CAPACITY_BOUND 2
+typedef struct {
+    uint32_t starting_log_inv_rate;
+    uint32_t max_num_variables_to_send_coeffs;
+    uint32_t rs_domain_initial_reduction_factor;
+    uint32_t folding_factor_first, folding_factor_subsequent;
+    uint32_t soundness_type; /* LM_SOUNDNESS_* (SecurityAssumption, config.rs:445-455) */
+    uint32_t security_level;
+    uint32_t pow_bits;
+} lm_whir_builder;
+void lmh_default_whir_builder(uint32_t starting_log_inv_rate, int prox_gaps_conjecture, lm_whir_builder* out);
+/* LM_E_INVALID (with lm_last_error) where the reference asserts / unwraps (config.rs:187-206, 311-314) */
+int lmh_whir_config_new(const lm_whir_builder* builder, uint32_t num_variables, lm_whir_config* out);
 
 /* SparseStatement / SparseValue (crates/whir/src/lib.rs:31-108), flattened:
  * statement s uses point coordinates points[point_offset .. +point_len) and values [values_offset .. +n_values) of

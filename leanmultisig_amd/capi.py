@@ -102,6 +102,8 @@ _HOST_SIGS = {
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
+    "lmh_default_whir_builder": (None, [C.c_uint32, C.c_int, vp]),
+    "lmh_whir_config_new": (C.c_int, [vp, C.c_uint32, vp]),
     "lmh_prove_gkr_quotient": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "lmh_prove_batched_air_sumcheck": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "lmh_stacked_n_vars": (C.c_uint32, [vp]),
@@ -146,6 +148,47 @@ class WhirConfig(C.Structure):
             c.rounds[i].num_queries = r["num_queries"]
             c.rounds[i].ood_samples = r["ood_samples"]
         return c
+
+
+    def to_dict(self):
+        return dict(num_variables=self.num_variables, starting_log_inv_rate=self.starting_log_inv_rate,
+                    fold_first=self.folding_factor_first, fold_sub=self.folding_factor_subsequent,
+                    rs_red=self.rs_domain_initial_reduction_factor, commitment_ood_samples=self.commitment_ood_samples,
+                    starting_folding_pow_bits=self.starting_folding_pow_bits, n_rounds=self.n_rounds,
+                    final_queries=self.final_queries, final_query_pow_bits=self.final_query_pow_bits,
+                    final_sumcheck_rounds=self.final_sumcheck_rounds,
+                    rounds=[dict(query_pow_bits=r.query_pow_bits, folding_pow_bits=r.folding_pow_bits, num_queries=r.num_queries,
+                                 ood_samples=r.ood_samples) for r in list(self.rounds)[:self.n_rounds]])
+
+    @classmethod
+    def new(cls, builder, num_variables):
+        """WhirConfig::new (crates/whir/src/config.rs:186-334) through lmh_whir_config_new."""
+        lib = load()
+        c = cls()
+        rc = lib.lmh_whir_config_new(C.byref(builder), num_variables, C.byref(c))
+        if rc != 0:
+            raise LmError(f"lmh_whir_config_new -> {rc}: {lib.lm_last_error().decode()}")
+        return c
+
+
+SOUNDNESS = {"UniqueDecoding": 0, "JohnsonBound": 1, "CapacityBound": 2}
+
+
+class WhirBuilder(C.Structure):
+    """lm_whir_builder (WhirConfigBuilder, crates/whir/src/config.rs:82-102)"""
+    _fields_ = [("starting_log_inv_rate", C.c_uint32), ("max_num_variables_to_send_coeffs", C.c_uint32),
+                ("rs_domain_initial_reduction_factor", C.c_uint32), ("folding_factor_first", C.c_uint32),
+                ("folding_factor_subsequent", C.c_uint32), ("soundness_type", C.c_uint32), ("security_level", C.c_uint32),
+                ("pow_bits", C.c_uint32)]
+
+    @classmethod
+    def default(cls, log_inv_rate, prox_gaps_conjecture=False, **over):
+        """default_whir_config (crates/lean_prover/src/lib.rs:22-50); keyword arguments override single fields."""
+        b = cls()
+        load().lmh_default_whir_builder(log_inv_rate, int(prox_gaps_conjecture), C.byref(b))
+        for k, v in over.items():
+            setattr(b, k, v)
+        return b
 
 
 class SparseStatement(C.Structure):

@@ -7,54 +7,15 @@
 #include <algorithm>
 #include <chrono>
 #include <vector>
-#include "../../../include/leanmultisig_host.h"
-#include "../kb.h"
-#include "../poseidon16.h"
+#include "lm_host_internal.h"
 
 using kb::EF;
 using kb::u32;
 using kb::u64;
+using lmh::Challenger;
+using lmh::Opening;
 
 namespace {
-
-// ---- Challenger (crates/backend/fiat-shamir/src/challenger.rs:9-76): overwrite-mode duplex, plain permutation -----
-struct Challenger {
-    u32 state[16];
-    bool rate_fresh = false;
-    Challenger() { memset(state, 0, sizeof state); }
-    void observe(const u32 v[8]) {
-        memcpy(state + 8, v, 32);
-        kb::poseidon16_permute(state);
-        rate_fresh = true;
-    }
-    void observe_many(const u32* s, u64 n) {
-        for (u64 off = 0; off < n; off += 8) {
-            u32 buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            memcpy(buf, s + off, (size_t)std::min<u64>(8, n - off) * 4);
-            observe(buf);
-        }
-    }
-    void duplex() {
-        const u32 z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        observe(z);
-    }
-    bool sample(u32 out[8]) {
-        if (!rate_fresh) return false;  // "stale rate. insert a duplex() before."
-        memcpy(out, state + 8, 32);
-        rate_fresh = false;
-        return true;
-    }
-    bool sample_many(u64 n_blocks, std::vector<u32>& out) {
-        out.clear();
-        for (u64 i = 0; i < n_blocks; i++) {
-            if (i) duplex();
-            u32 b[8];
-            if (!sample(b)) return false;
-            out.insert(out.end(), b, b + 8);
-        }
-        return true;
-    }
-};
 
 // LM_STAGE_TIMES=1: wall clock per stage on stderr (each mark synchronises the stream, so the total is slightly pessimistic)
 struct StageClock {
@@ -77,10 +38,6 @@ struct StageClock {
     }
 };
 
-struct Opening {
-    u64 index;
-    std::vector<u32> leaf, path;
-};
 
 EF ef_load(const u32* p) {
     EF r;
@@ -118,12 +75,6 @@ u32 ilog2(u64 x) {
 
 }  // namespace
 
-struct lmh_prover {
-    Challenger ch;
-    std::vector<u32> transcript;
-    std::vector<Opening> openings;
-    std::vector<u32> batch_sizes;  // openings per hint_merkle_paths call (one query set of one commitment), in order
-};
 struct lmh_witness {
     lm_tree* tree = nullptr;
     u32 root[8];
@@ -321,17 +272,15 @@ void lmh_challenger_state(const lmh_prover* p, uint32_t out16[16]) { memcpy(out1
 // Per batch: sort by leaf index, drop repeated leaves, cut the all-zero tail shared by every leaf, and keep for path i only
 // the siblings below its divergence from path i-1, except the one level where path i+1 joins it (that hash is recomputed
 // by the verifier from path i+1).  Blob layout: include/leanmultisig_host.h.
-namespace {
+}  // extern "C"
+namespace lmh {
 static unsigned diverge_level(u64 a, u64 b) {  // lca_level: number of low bits to drop until a == b
     unsigned l = 0;
     for (u64 x = a ^ b; x; x >>= 1) l++;
     return l;
 }
-static std::vector<u32> pruned_blob(const lmh_prover* p) {
-    std::vector<u32> o;
-    o.push_back((u32)p->transcript.size());
-    o.insert(o.end(), p->transcript.begin(), p->transcript.end());
-    o.push_back((u32)p->batch_sizes.size());
+std::vector<PrunedBatch> prune(const lmh_prover* p) {
+    std::vector<PrunedBatch> out;
     size_t first = 0;
     for (u32 bs : p->batch_sizes) {
         const Opening* ops = p->openings.data() + first;
@@ -339,10 +288,12 @@ static std::vector<u32> pruned_blob(const lmh_prover* p) {
         std::vector<u32> by_index(bs);
         for (u32 i = 0; i < bs; i++) by_index[i] = i;
         std::stable_sort(by_index.begin(), by_index.end(), [&](u32 a, u32 b) { return ops[a].index < ops[b].index; });
-        std::vector<u32> kept, original_order(bs);  // kept: distinct leaves in index order
+        std::vector<u32> kept;  // distinct leaves in index order
+        PrunedBatch pb;
+        pb.original_order.resize(bs);
         for (u32 i : by_index) {
             if (kept.empty() || ops[kept.back()].index != ops[i].index) kept.push_back(i);
-            original_order[i] = (u32)kept.size() - 1;
+            pb.original_order[i] = (u32)kept.size() - 1;
         }
         const size_t leaf_len = ops[kept[0]].leaf.size();
         size_t live = leaf_len;  // length after cutting the common zero tail
@@ -352,34 +303,52 @@ static std::vector<u32> pruned_blob(const lmh_prover* p) {
             if (!zero) break;
             live--;
         }
-        const u32 height = (u32)(ops[kept[0]].path.size() / 8);
-        o.push_back(height);
-        o.push_back((u32)(leaf_len - live));
-        o.push_back(bs);
-        o.insert(o.end(), original_order.begin(), original_order.end());
-        o.push_back((u32)kept.size());
+        pb.merkle_height = (u32)(ops[kept[0]].path.size() / 8);
+        pb.n_trailing_zeros = (u32)(leaf_len - live);
         for (size_t k = 0; k < kept.size(); k++) {
             const Opening& me = ops[kept[k]];
-            const unsigned top = k == 0 ? height : diverge_level(ops[kept[k - 1]].index, me.index);
+            const unsigned top = k == 0 ? pb.merkle_height : diverge_level(ops[kept[k - 1]].index, me.index);
             const int hole = k + 1 < kept.size() ? (int)diverge_level(me.index, ops[kept[k + 1]].index) - 1 : -1;
-            o.push_back((u32)me.index);
-            o.push_back((u32)(me.index >> 32));
-            o.push_back((u32)live);
-            o.insert(o.end(), me.leaf.begin(), me.leaf.begin() + live);
-            const size_t n_sib_at = o.size();
-            o.push_back(0);
-            u32 n_sib = 0;
+            PrunedPath pp;
+            pp.leaf_index = me.index;
+            pp.leaf.assign(me.leaf.begin(), me.leaf.begin() + live);
             for (unsigned lvl = 0; lvl < top; lvl++) {
                 if ((int)lvl == hole) continue;
-                o.insert(o.end(), me.path.begin() + 8 * lvl, me.path.begin() + 8 * lvl + 8);
-                n_sib++;
+                pp.siblings.insert(pp.siblings.end(), me.path.begin() + 8 * lvl, me.path.begin() + 8 * lvl + 8);
             }
-            o[n_sib_at] = n_sib;
+            pb.paths.push_back(std::move(pp));
+        }
+        out.push_back(std::move(pb));
+    }
+    return out;
+}
+}  // namespace lmh
+namespace {
+std::vector<u32> pruned_blob(const lmh_prover* p) {
+    std::vector<u32> o;
+    o.push_back((u32)p->transcript.size());
+    o.insert(o.end(), p->transcript.begin(), p->transcript.end());
+    const std::vector<lmh::PrunedBatch> batches = lmh::prune(p);
+    o.push_back((u32)batches.size());
+    for (const lmh::PrunedBatch& pb : batches) {
+        o.push_back(pb.merkle_height);
+        o.push_back(pb.n_trailing_zeros);
+        o.push_back((u32)pb.original_order.size());
+        o.insert(o.end(), pb.original_order.begin(), pb.original_order.end());
+        o.push_back((u32)pb.paths.size());
+        for (const lmh::PrunedPath& pp : pb.paths) {
+            o.push_back((u32)pp.leaf_index);
+            o.push_back((u32)(pp.leaf_index >> 32));
+            o.push_back((u32)pp.leaf.size());
+            o.insert(o.end(), pp.leaf.begin(), pp.leaf.end());
+            o.push_back((u32)(pp.siblings.size() / 8));
+            o.insert(o.end(), pp.siblings.begin(), pp.siblings.end());
         }
     }
     return o;
 }
 }  // namespace
+extern "C" {
 
 uint64_t lmh_proof_pruned_words(const lmh_prover* p) { return p ? pruned_blob(p).size() : 0; }
 void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out) {
@@ -389,24 +358,9 @@ void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out) {
 // Proof::proof_size_fe (fiat-shamir/src/transcript.rs:39-53): transcript + pruned leaf data + 8 words per kept sibling
 uint64_t lmh_proof_size_fe(const lmh_prover* p) {
     if (!p) return 0;
-    const std::vector<u32> b = pruned_blob(p);
-    size_t k = 1 + b[0];
-    u64 fe = b[0];
-    const u32 B = b[k++];
-    for (u32 bi = 0; bi < B; bi++) {
-        k += 2;
-        const u32 n_orig = b[k++];
-        k += n_orig;
-        const u32 n_paths = b[k++];
-        for (u32 i = 0; i < n_paths; i++) {
-            k += 2;
-            const u32 ll = b[k++];
-            k += ll;
-            const u32 ns = b[k++];
-            k += 8ull * ns;
-            fe += ll + 8ull * ns;
-        }
-    }
+    u64 fe = p->transcript.size();
+    for (const lmh::PrunedBatch& pb : lmh::prune(p))
+        for (const lmh::PrunedPath& pp : pb.paths) fe += pp.leaf.size() + pp.siblings.size();
     return fe;
 }
 uint32_t lmh_proof_n_batches(const lmh_prover* p) { return p ? (uint32_t)p->batch_sizes.size() : 0; }

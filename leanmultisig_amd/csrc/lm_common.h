@@ -47,6 +47,8 @@ struct lm_ctx {
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
     u32* d_sync = nullptr;      // [0] PoW result (0xffffffff when idle), [1] "writers done" counter of multi-block publishers
+    unsigned long long* d_acc = nullptr;  // LM_ACC_WORDS 64-bit accumulators (zero between kernels): multi-block round kernels add
+                                          // their per-block sums here with integer atomics; the last block reduces mod p, publishes, re-zeroes
     u32* d_coop = nullptr;      // COOP_TAB_WORDS: per-lane coefficient table of the 16-lane Poseidon (poseidon16_coop.h)
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
@@ -87,7 +89,30 @@ struct lm_ctx {
 // Publish / wait protocol for small per-round results: the last kernel of a round writes its values into the pinned
 // host-visible buffer, fences at system scope and stores the round's sequence number; the host spins on that word
 // instead of paying a stream-synchronise per sumcheck round (~300 rounds per proof).
+static constexpr u32 LM_ACC_WORDS = 64;
 #if defined(__HIPCC__)
+// Multi-block reduction without a second launch and without a serial pass over per-block partials: every block adds its
+// N field words (< 2^31 each, so 2^33 blocks fit) into 64-bit accumulators in L2; the block that finishes last (device-scope
+// counter) takes the totals mod p — the representation is additive, so the sum of Montgomery residues is the residue of
+// the sum — and re-zeroes the accumulators for the next kernel on the stream.  `vals` must be valid in threads < N of every
+// block; returns true in ALL threads of the last block, with the totals in out_lds[0..N).
+template <int N>
+__device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned long long* acc, kb::u32* done_counter, kb::u32* out_lds) {
+    __shared__ kb::u32 lm_is_last;
+    if (threadIdx.x < N) {
+        atomicAdd(acc + threadIdx.x, (unsigned long long)vals_lds[threadIdx.x]);
+        __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lm_is_last = atomicAdd(done_counter, 1u) == gridDim.x * gridDim.y - 1;
+    __syncthreads();
+    if (!lm_is_last) return false;
+    __threadfence();
+    if (threadIdx.x < N) out_lds[threadIdx.x] = (kb::u32)(atomicExch(acc + threadIdx.x, 0ull) % kb::P);
+    if (threadIdx.x == 0) *done_counter = 0;
+    __syncthreads();
+    return true;
+}
 __device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) {
     __threadfence_system();
     __hip_atomic_store(h_res + lm_ctx::RES_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

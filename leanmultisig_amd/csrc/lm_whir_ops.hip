@@ -260,47 +260,28 @@ __device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, 
     }
 }
 
-// End of a product-sumcheck round kernel: a single block publishes its sums; otherwise every block leaves 10 partial words
-// and the block that finishes last adds them up and publishes (no separate reducing launch).
-__device__ __forceinline__ void finish10(u32 v[10], u32* red /* 256 words */, u32* __restrict__ partial, u32* __restrict__ done_counter,
-                                         u32* __restrict__ h_res, u32 seq) {
+// End of a product-sumcheck round kernel: a single block publishes its sums; otherwise every block adds its 10 words into
+// the context's 64-bit accumulators and the block that finishes last publishes the totals (lm_grid_sum: no reducing launch).
+__device__ __forceinline__ void finish10(u32 v[10], u32* red /* 64 words */, unsigned long long* __restrict__ acc,
+                                         u32* __restrict__ done_counter, u32* __restrict__ h_res, u32 seq) {
     if (gridDim.x == 1) {
         block_sum10(v, red, h_res, h_res, seq);
         return;
     }
-    block_sum10(v, red, partial + (u64)blockIdx.x * 10);
-    __shared__ u32 is_last;
-    if (threadIdx.x < 10) __threadfence();
+    block_sum10(v, red, red + 40);
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    if (threadIdx.x < 250) {
-        const u32 k = threadIdx.x % 10, slice = threadIdx.x / 10;
-        u32 sum = 0;
-        for (u32 b = slice; b < gridDim.x; b += 25) sum = add(sum, __builtin_nontemporal_load(partial + (u64)b * 10 + k));
-        red[threadIdx.x] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 10) {
-        u32 sum = 0;
-        for (u32 sl = 0; sl < 25; sl++) sum = add(sum, red[sl * 10 + threadIdx.x]);
-        h_res[threadIdx.x] = sum;
-    }
+    if (!lm_grid_sum<10>(red + 40, acc, done_counter, red)) return;
     if (threadIdx.x < 64) {
+        if (threadIdx.x < 10) h_res[threadIdx.x] = red[threadIdx.x];
         __threadfence_system();
-        if (threadIdx.x == 0) {
-            *done_counter = 0;
-            lm_publish_flag(h_res, seq);
-        }
+        if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
     }
 }
 
 __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                         u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                                         unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                          u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[256];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half;
     u64 a0[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0};
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -319,12 +300,12 @@ __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__
         v[k] = reduce(a0[k]);
         v[5 + k] = reduce(a2[k]);
     }
-    finish10(v, red, partial, done_counter, final_out, seq);
+    finish10(v, red, acc, done_counter, final_out, seq);
 }
 __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                        u32* __restrict__ partial, u32* __restrict__ done_counter,
+                                                        unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                         u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[256];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -345,7 +326,7 @@ __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ 
         v[k] = c0.v[k];
         v[5 + k] = c2.v[k];
     }
-    finish10(v, red, partial, done_counter, final_out, seq);
+    finish10(v, red, acc, done_counter, final_out, seq);
 }
 __global__ __launch_bounds__(256) void k_fold_base(const u32* __restrict__ in, u64 half, EF r, u32* __restrict__ out) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -377,9 +358,9 @@ __global__ __launch_bounds__(256) void k_fold_ext(const u32* __restrict__ in, u6
 // Lane i < quarter produces outputs i and i + quarter (the next round's pair) from inputs i, i+quarter, i+half, i+half+quarter.
 template <bool F_BASE>
 __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, const u32* __restrict__ W, u64 half, EF r,
-                                                    u32* __restrict__ f_out, u32* __restrict__ W_out, u32* __restrict__ partial,
+                                                    u32* __restrict__ f_out, u32* __restrict__ W_out, unsigned long long* __restrict__ acc,
                                                     u32* __restrict__ done_counter, u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[256];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half, quarter = half >> 1;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
@@ -421,7 +402,7 @@ __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, c
         v[k] = c0.v[k];
         v[5 + k] = c2.v[k];
     }
-    finish10(v, red, partial, done_counter, final_out, seq);
+    finish10(v, red, acc, done_counter, final_out, seq);
 }
 
 // =====================================================================================================
@@ -624,9 +605,9 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     if (rc) return rc;
     u32* d_out = s + (u64)blocks * 10;
     if (f_is_ext)
-        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     (void)d_out;
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
@@ -661,9 +642,9 @@ int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     EF rr;
     memcpy(rr.v, r, 20);
     if (f_is_ext)
-        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);

@@ -10,7 +10,7 @@ What is NOT in the step: the VM interpreter and trace builder (CPU side of the r
 config["missing"].
 
 Multi-GPU (north_star / SURVEY.md §8(e)): independent 1550-signature leaves, one per GPU, no data-path collective; the
-only exchange is an RCCL all-gather of the 8-word commitment roots at the end of each step.  scaling = "weak".
+only exchange is an RCCL all-gather of the commitment roots and the pruned proofs at the end of each step.  scaling = "weak".
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -29,31 +29,6 @@ sys.path.insert(0, ROOT)
 N_SIGS = 1550
 P = 0x7F000001
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
-
-def exchange_roots(root_words, device):
-    """All-gather of the per-rank 8-word commitment roots (the only collective of the sharded path).
-    Works on any backend (nccl = RCCL on the GPUs, gloo in the CPU tests)."""
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor(np.asarray(root_words, dtype=np.int64), device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return t.cpu().numpy().reshape(1, 8)
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return torch.stack(out).cpu().numpy()
-
-
-def exchange_roots_block(words, device):
-    """All-gather of a rank's commitment-root words (8 per proven leaf) -> (world, n_words)."""
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor(np.asarray(words, dtype=np.int64), device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return t.cpu().numpy().reshape(1, -1)
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return torch.stack(out).cpu().numpy()
 
 
 def signer_ranges(n_total, world):

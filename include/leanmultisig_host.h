@@ -99,6 +99,34 @@ uint64_t lmh_proof_size_fe(const lmh_prover* p);
 uint32_t lmh_proof_n_batches(const lmh_prover* p);
 void lmh_proof_batch_sizes(const lmh_prover* p, uint32_t* out);
 
+/* Load a proof produced elsewhere (the un-pruned u32 blob of lmh_proof_copy + the openings per batch) into a prover object,
+ * e.g. to prune / serialise it.  The challenger is not replayed. */
+int lmh_prover_load_raw(lmh_prover* p, const uint32_t* blob, uint64_t n_words, const uint32_t* batch_sizes, uint32_t n_batches);
+
+/* ---- proof bytes -------------------------------------------------------------------------------
+ * lmh_proof_postcard: the reference's serialised ExecutionProof — serde + postcard of Proof { transcript: Vec<F>,
+ * merkle_paths: Vec<PrunedMerklePaths<F, F>> } (crates/backend/fiat-shamir/src/transcript.rs:33-36, merkle_pruning.rs:5-12,
+ * crates/lean_prover/src/prove_execution.rs:12-18; a field element is the varint of its Montgomery word, monty_31.rs:152-157).
+ * lmh_proof_compressed: the same bytes through lz4_flex::compress_prepend_size (u32 LE length + one LZ4 block,
+ * rec_aggregation/src/type_1_aggregation.rs:81-89) — any valid block decodes to the same postcard stream.
+ * lmh_proof_from_postcard / lmh_proof_decompress: the inverse (postcard::from_bytes / decompress_size_prepended), NULL with
+ * lm_last_error on malformed input. */
+uint64_t lmh_proof_postcard_size(const lmh_prover* p);
+void lmh_proof_postcard(const lmh_prover* p, uint8_t* out);
+uint64_t lmh_proof_compressed_size(const lmh_prover* p);
+void lmh_proof_compressed(const lmh_prover* p, uint8_t* out);
+uint64_t lmh_lz4_compress_bound(uint64_t n);
+uint64_t lmh_lz4_compress_prepend_size(const uint8_t* in, uint64_t n, uint8_t* out);
+/* out == NULL: returns the size prefix; else the number of bytes written (== prefix) or -1 */
+int64_t lmh_lz4_decompress_size_prepended(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap);
+typedef struct lmh_proof lmh_proof; /* a decoded Proof<F> */
+lmh_proof* lmh_proof_from_postcard(const uint8_t* bytes, uint64_t n);
+lmh_proof* lmh_proof_decompress(const uint8_t* bytes, uint64_t n);
+void lmh_proof_free(lmh_proof* p);
+uint64_t lmh_proof_decoded_size_fe(const lmh_proof* p);
+/* the decoded proof in the word layout of lmh_proof_pruned_copy; out may be NULL (size query) */
+uint64_t lmh_proof_decoded_pruned_words(const lmh_proof* p, uint32_t* out);
+
 /* ---- WHIR ------------------------------------------------------------------------------------------------------- */
 typedef struct lmh_witness lmh_witness; /* Witness, commit.rs:49-57: device-resident tree + OOD points/answers */
 /* WhirConfig::commit (commit.rs:64-99): d_poly = 2^num_variables base words in HBM. */

@@ -99,6 +99,19 @@ _HOST_SIGS = {
     "lmh_proof_n_batches": (C.c_uint32, [vp]),
     "lmh_proof_batch_sizes": (None, [vp, vp]),
     "lmh_proof_copy": (None, [vp, vp]),
+    "lmh_prover_load_raw": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint32]),
+    "lmh_proof_postcard_size": (C.c_uint64, [vp]),
+    "lmh_proof_postcard": (None, [vp, vp]),
+    "lmh_proof_compressed_size": (C.c_uint64, [vp]),
+    "lmh_proof_compressed": (None, [vp, vp]),
+    "lmh_lz4_compress_bound": (C.c_uint64, [C.c_uint64]),
+    "lmh_lz4_compress_prepend_size": (C.c_uint64, [vp, C.c_uint64, vp]),
+    "lmh_lz4_decompress_size_prepended": (C.c_int64, [vp, C.c_uint64, vp, C.c_uint64]),
+    "lmh_proof_from_postcard": (vp, [vp, C.c_uint64]),
+    "lmh_proof_decompress": (vp, [vp, C.c_uint64]),
+    "lmh_proof_free": (None, [vp]),
+    "lmh_proof_decoded_size_fe": (C.c_uint64, [vp]),
+    "lmh_proof_decoded_pruned_words": (C.c_uint64, [vp, vp]),
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
@@ -189,6 +202,51 @@ class WhirBuilder(C.Structure):
         for k, v in over.items():
             setattr(b, k, v)
         return b
+
+
+def lz4_compress(data: bytes) -> bytes:
+    lib = load()
+    src = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(lib.lmh_lz4_compress_bound(src.size), dtype=np.uint8)
+    n = lib.lmh_lz4_compress_prepend_size(src.ctypes.data_as(C.c_void_p), src.size, out.ctypes.data_as(C.c_void_p))
+    return out[:n].tobytes()
+
+
+def lz4_decompress(data: bytes):
+    """lz4_flex::decompress_size_prepended; None on malformed input"""
+    lib = load()
+    src = np.frombuffer(data, dtype=np.uint8)
+    size = lib.lmh_lz4_decompress_size_prepended(src.ctypes.data_as(C.c_void_p), src.size, None, 0)
+    if size < 0 or size > (1 << 30):
+        return None
+    out = np.empty(max(size, 1), dtype=np.uint8)
+    n = lib.lmh_lz4_decompress_size_prepended(src.ctypes.data_as(C.c_void_p), src.size, out.ctypes.data_as(C.c_void_p), size)
+    return out[:n].tobytes() if n == size else None
+
+
+class DecodedProof:
+    """lmh_proof: a Proof<F> decoded from the reference's bytes (postcard, optionally lz4 size-prepended)."""
+
+    def __init__(self, data: bytes, compressed=False):
+        self.lib = load()
+        src = np.frombuffer(data, dtype=np.uint8)
+        f = self.lib.lmh_proof_decompress if compressed else self.lib.lmh_proof_from_postcard
+        self.h = f(src.ctypes.data_as(C.c_void_p), src.size)
+        if not self.h:
+            raise LmError("proof decode: " + self.lib.lm_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.lmh_proof_free(self.h)
+            self.h = None
+
+    def pruned_words(self):
+        out = np.empty(self.lib.lmh_proof_decoded_pruned_words(self.h, None), dtype=np.uint32)
+        self.lib.lmh_proof_decoded_pruned_words(self.h, _ptr(out))
+        return out
+
+    def size_fe(self):
+        return int(self.lib.lmh_proof_decoded_size_fe(self.h))
 
 
 class SparseStatement(C.Structure):
@@ -582,6 +640,29 @@ class Prover:
         out = np.empty(self.lib.lmh_proof_pruned_words(self.h), dtype=np.uint32)
         self.lib.lmh_proof_pruned_copy(self.h, _ptr(out))
         return out
+
+    def proof_bytes(self, compressed=False):
+        """The reference's serialised ExecutionProof: postcard(Proof<F>), optionally lz4 size-prepended."""
+        if compressed:
+            out = np.empty(self.lib.lmh_proof_compressed_size(self.h), dtype=np.uint8)
+            self.lib.lmh_proof_compressed(self.h, out.ctypes.data_as(C.c_void_p))
+        else:
+            out = np.empty(self.lib.lmh_proof_postcard_size(self.h), dtype=np.uint8)
+            self.lib.lmh_proof_postcard(self.h, out.ctypes.data_as(C.c_void_p))
+        return out.tobytes()
+
+    @classmethod
+    def from_raw(cls, raw_words, batch_sizes, lib=None):
+        """A prover object holding a proof produced elsewhere (un-pruned blob + openings per batch): host only, no context."""
+        self = cls.__new__(cls)
+        self.ctx = None
+        self.lib = lib or load()
+        self.h = self.lib.lmh_prover_new()
+        raw, bs = _u32(raw_words).reshape(-1), _u32(batch_sizes).reshape(-1)
+        rc = self.lib.lmh_prover_load_raw(self.h, _ptr(raw), raw.size, _ptr(bs), bs.size)
+        if rc != 0:
+            raise LmError(f"lmh_prover_load_raw -> {rc}")
+        return self
 
     def proof_size_fe(self):
         """Proof::proof_size_fe of the reference (field elements of the pruned proof)."""

@@ -368,6 +368,36 @@ void lmh_proof_batch_sizes(const lmh_prover* p, uint32_t* out) {
     if (p && !p->batch_sizes.empty()) memcpy(out, p->batch_sizes.data(), p->batch_sizes.size() * 4);
 }
 
+int lmh_prover_load_raw(lmh_prover* p, const uint32_t* blob, uint64_t n_words, const uint32_t* batch_sizes, uint32_t n_batches) {
+    if (!p || !blob || n_words < 2 || (n_batches && !batch_sizes)) return LM_E_INVALID;
+    u64 k = 0;
+    const u64 T = blob[k++];
+    if (T + 2 > n_words) return LM_E_INVALID;
+    p->transcript.assign(blob + k, blob + k + T);
+    k += T;
+    const u64 M = blob[k++];
+    p->openings.clear();
+    for (u64 i = 0; i < M; i++) {
+        if (k + 4 > n_words) return LM_E_INVALID;
+        Opening o;
+        o.index = blob[k] | (u64)blob[k + 1] << 32;
+        const u64 ll = blob[k + 2], pl = blob[k + 3];
+        k += 4;
+        if (k + ll + pl > n_words || pl % 8) return LM_E_INVALID;
+        o.leaf.assign(blob + k, blob + k + ll);
+        o.path.assign(blob + k + ll, blob + k + ll + pl);
+        k += ll + pl;
+        p->openings.push_back(std::move(o));
+    }
+    u64 total = 0;
+    for (u32 b = 0; b < n_batches; b++) total += batch_sizes[b];
+    if (total != M || k != n_words) return LM_E_INVALID;
+    for (u32 b = 0; b < n_batches; b++)
+        if (batch_sizes[b] == 0) return LM_E_INVALID;
+    p->batch_sizes.assign(batch_sizes, batch_sizes + n_batches);
+    return LM_OK;
+}
+
 uint64_t lmh_proof_words(const lmh_prover* p) {
     u64 n = 2 + p->transcript.size();
     for (const Opening& o : p->openings) n += 4 + o.leaf.size() + o.path.size();

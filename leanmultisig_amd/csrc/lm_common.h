@@ -47,8 +47,6 @@ struct lm_ctx {
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
     u32* d_sync = nullptr;      // [0] PoW result (0xffffffff when idle), [1] "writers done" counter of multi-block publishers
-    unsigned long long* d_acc = nullptr;  // LM_ACC_WORDS 64-bit accumulators (zero between kernels): multi-block round kernels add
-                                          // their per-block sums here with integer atomics; the last block reduces mod p, publishes, re-zeroes
     u32* d_coop = nullptr;      // COOP_TAB_WORDS: per-lane coefficient table of the 16-lane Poseidon (poseidon16_coop.h)
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
@@ -89,26 +87,57 @@ struct lm_ctx {
 // Publish / wait protocol for small per-round results: the last kernel of a round writes its values into the pinned
 // host-visible buffer, fences at system scope and stores the round's sequence number; the host spins on that word
 // instead of paying a stream-synchronise per sumcheck round (~300 rounds per proof).
-static constexpr u32 LM_ACC_WORDS = 64;
 #if defined(__HIPCC__)
-// Multi-block reduction without a second launch and without a serial pass over per-block partials: every block adds its
-// N field words (< 2^31 each, so 2^33 blocks fit) into 64-bit accumulators in L2; the block that finishes last (device-scope
-// counter) takes the totals mod p — the representation is additive, so the sum of Montgomery residues is the residue of
-// the sum — and re-zeroes the accumulators for the next kernel on the stream.  `vals` must be valid in threads < N of every
-// block; returns true in ALL threads of the last block, with the totals in out_lds[0..N).
+// Multi-block reduction without a second launch: every block stores its N field words to partial[block][N] (plain stores),
+// then takes a ticket from a device-scope counter — ONE atomic per block; adding the N words themselves with atomics was
+// measured at ~5.5 ns per atomic on a handful of addresses, 250 us for a 4096-block launch.  The block that draws the last
+// ticket sums the partials: thread t takes blocks t, t + 256, .. (independent loads, N running sums in registers), then a
+// wave + LDS reduction.  `vals_lds` must be valid in threads < N of every block.  Returns true in ALL threads of the last
+// block, with the totals in out_lds[0..N) (may alias vals_lds); work_lds: 4 N words.
 template <int N>
-__device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned long long* acc, kb::u32* done_counter, kb::u32* out_lds) {
+__device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, kb::u32* __restrict__ partial, kb::u32* done_counter, kb::u32* out_lds,
+                                            kb::u32* work_lds) {
     __shared__ kb::u32 lm_is_last;
     if (threadIdx.x < N) {
-        atomicAdd(acc + threadIdx.x, (unsigned long long)vals_lds[threadIdx.x]);
+        partial[(kb::u64)blockIdx.x * N + threadIdx.x] = vals_lds[threadIdx.x];
         __threadfence();
     }
     __syncthreads();
-    if (threadIdx.x == 0) lm_is_last = atomicAdd(done_counter, 1u) == gridDim.x * gridDim.y - 1;
+    if (threadIdx.x == 0) lm_is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!lm_is_last) return false;
     __threadfence();
-    if (threadIdx.x < N) out_lds[threadIdx.x] = (kb::u32)(atomicExch(acc + threadIdx.x, 0ull) % kb::P);
+    // CH words at a time: the tail must not raise the register count of the kernel it ends
+    constexpr int CH = N <= 20 ? N : 20;
+    static_assert(N % CH == 0, "N must be a multiple of the chunk");
+    const kb::u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int c0 = 0; c0 < N; c0 += CH) {
+        kb::u32 acc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) acc[k] = 0;
+        for (kb::u32 b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+            kb::u32 v[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) v[k] = __builtin_nontemporal_load(partial + (kb::u64)b * N + c0 + k);
+#pragma unroll
+            for (int k = 0; k < CH; k++) acc[k] = kb::add(acc[k], v[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[k] = kb::add(acc[k], (kb::u32)__shfl_down(acc[k], off, 64));
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) work_lds[wave * N + c0 + k] = acc[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        kb::u32 t = 0;
+        for (kb::u32 w = 0; w < (blockDim.x >> 6); w++) t = kb::add(t, work_lds[w * N + threadIdx.x]);
+        out_lds[threadIdx.x] = t;
+    }
     if (threadIdx.x == 0) *done_counter = 0;
     __syncthreads();
     return true;

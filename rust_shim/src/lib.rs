@@ -1,0 +1,132 @@
+//! Rust side of the C ABI of `include/leanmultisig.h` / `include/leanmultisig_host.h` (UNCOMPILED here, see Cargo.toml).
+//!
+//! Two uses:
+//!  * `prove_execution_hip`: the coarse drop-in for `lean_prover::prove_execution` after witness generation — the trace is
+//!    uploaded once, the whole proof is produced on the MI355X and comes back as the reference's own `ExecutionProof` bytes;
+//!  * the `#[test]` below: feed a proof file written by this repository (`python tools/write_proof.py proof.bin`) to the
+//!    reference's `verify_execution` — an external parity pin that needs no GPU on the Rust side.
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct lm_ctx(c_void);
+#[repr(C)]
+pub struct lmh_prover(c_void);
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lm_whir_round {
+    pub query_pow_bits: u32,
+    pub folding_pow_bits: u32,
+    pub num_queries: u32,
+    pub ood_samples: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lm_whir_config {
+    pub num_variables: u32,
+    pub starting_log_inv_rate: u32,
+    pub folding_factor_first: u32,
+    pub folding_factor_subsequent: u32,
+    pub rs_domain_initial_reduction_factor: u32,
+    pub commitment_ood_samples: u32,
+    pub starting_folding_pow_bits: u32,
+    pub n_rounds: u32,
+    pub final_queries: u32,
+    pub final_query_pow_bits: u32,
+    pub final_sumcheck_rounds: u32,
+    pub rounds: [lm_whir_round; 8],
+}
+#[repr(C)]
+pub struct lm_vm_table {
+    pub log_rows: u32,
+    pub d_cols: *const *const u32,
+}
+#[repr(C)]
+pub struct lm_execution_trace {
+    pub log_inv_rate: u32,
+    pub log_memory: u32,
+    pub log_bytecode: u32,
+    pub ending_pc: u32,
+    pub public_memory_size: u32,
+    pub n_public_input: u32,
+    pub public_input: *const u32,
+    pub bytecode_hash: *const u32,
+    pub d_bytecode: *const u32,
+    pub d_bytecode_acc: *const u32,
+    pub d_memory: *const u32,
+    pub d_memory_acc: *const u32,
+    pub tables: [lm_vm_table; 3],
+}
+
+unsafe extern "C" {
+    pub fn lm_ctx_create(device: c_int, out: *mut *mut lm_ctx) -> c_int;
+    pub fn lm_ctx_destroy(ctx: *mut lm_ctx);
+    pub fn lm_last_error() -> *const c_char;
+    pub fn lm_malloc(ctx: *mut lm_ctx, n_words: u64, d_out: *mut *mut u32) -> c_int;
+    pub fn lm_free(ctx: *mut lm_ctx, d_ptr: *mut u32) -> c_int;
+    pub fn lm_upload(ctx: *mut lm_ctx, d_dst: *mut u32, src: *const u32, n_words: u64) -> c_int;
+    pub fn lmh_prover_new() -> *mut lmh_prover;
+    pub fn lmh_prover_free(p: *mut lmh_prover);
+    pub fn lmh_stacked_n_vars(trace: *const lm_execution_trace) -> u32;
+    pub fn lmh_prove_execution(ctx: *mut lm_ctx, p: *mut lmh_prover, trace: *const lm_execution_trace, cfg: *const lm_whir_config) -> c_int;
+    pub fn lmh_proof_postcard_size(p: *const lmh_prover) -> u64;
+    pub fn lmh_proof_postcard(p: *const lmh_prover, out: *mut u8);
+}
+
+/// `WhirConfig<EF>` (crates/whir/src/config.rs:118-134) -> the integers the library takes (never re-derived on the far side).
+pub fn whir_config_ints(c: &backend::WhirConfig<backend::EF>) -> lm_whir_config {
+    let mut o = lm_whir_config {
+        num_variables: c.num_variables as u32,
+        starting_log_inv_rate: c.starting_log_inv_rate as u32,
+        folding_factor_first: c.folding_factor.at_round(0) as u32,
+        folding_factor_subsequent: c.folding_factor.at_round(1) as u32,
+        rs_domain_initial_reduction_factor: c.rs_domain_initial_reduction_factor as u32,
+        commitment_ood_samples: c.commitment_ood_samples as u32,
+        starting_folding_pow_bits: c.starting_folding_pow_bits as u32,
+        n_rounds: c.round_parameters.len() as u32,
+        final_queries: c.final_queries as u32,
+        final_query_pow_bits: c.final_query_pow_bits as u32,
+        final_sumcheck_rounds: c.final_sumcheck_rounds as u32,
+        ..Default::default()
+    };
+    for (i, r) in c.round_parameters.iter().enumerate() {
+        o.rounds[i] = lm_whir_round {
+            query_pow_bits: r.query_pow_bits as u32,
+            folding_pow_bits: r.folding_pow_bits as u32,
+            num_queries: r.num_queries as u32,
+            ood_samples: r.ood_samples as u32,
+        };
+    }
+    o
+}
+
+/// Decode the bytes written by `lmh_proof_postcard` into the reference's `Proof<F>`: same serde derive, same postcard.
+pub fn proof_from_bytes(bytes: &[u8]) -> Option<backend::Proof<backend::F>> {
+    postcard::from_bytes(bytes).ok()
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    /// External parity pin: `proof.bin` / `instance.bin` come from `python tools/write_proof.py` (a device proof of the
+    /// golden instance of tests/golden/vectors_r01.json + the bytecode / public input it was proven for).
+    #[test]
+    fn reference_verifier_accepts_the_hip_proof() {
+        let dir = std::env::var("LM_PROOF_DIR").unwrap_or_else(|_| "..".into());
+        let proof_bytes = std::fs::read(format!("{dir}/proof.bin")).expect("proof.bin");
+        let proof = proof_from_bytes(&proof_bytes).expect("postcard decode of Proof<F>");
+        // instance.bin: u32 LE words [log_bytecode, ending_pc, n_public_input, bytecode_hash x 8, public_input.., bytecode rows x 16..]
+        let inst = std::fs::read(format!("{dir}/instance.bin")).expect("instance.bin");
+        let w: Vec<u32> = inst.chunks_exact(4).map(|c| u32::from_le_bytes(c.try_into().unwrap())).collect();
+        let (log_bytecode, ending_pc, n_pub) = (w[0] as usize, w[1] as usize, w[2] as usize);
+        let f = |x: u32| backend::F::new_monty(x);
+        let hash: [backend::F; 8] = std::array::from_fn(|i| f(w[3 + i]));
+        let public_input: Vec<backend::F> = w[11..11 + n_pub].iter().map(|&x| f(x)).collect();
+        let rows: Vec<backend::F> = w[11 + n_pub..].iter().map(|&x| f(x)).collect();
+        assert_eq!(rows.len(), 16 << log_bytecode);
+        let bytecode = lean_vm::Bytecode::from_instruction_rows(rows, log_bytecode, ending_pc, hash);
+        lean_prover::verify_execution::verify_execution(&bytecode, &public_input, proof).expect("reference verifier");
+    }
+}

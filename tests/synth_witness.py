@@ -287,3 +287,11 @@ def build_mixed(orc, rng, **kw):
                 ext_calls=ALL_EXT_MODES)
     args.update(kw)
     return build(orc, rng, **args)
+
+
+def stacked_n_vars(w):
+    """compute_stacked_n_vars (sub_protocols/src/stacked_pcs.rs:183-196) of a witness dict"""
+    lr = w["log_rows"]
+    total = (2 << w["log_memory"]) + (1 << max(w["log_bytecode"], max(lr.values())))
+    total += (20 << lr[0]) + (29 << lr[1]) + (109 << lr[2])
+    return int(total - 1).bit_length()

@@ -68,8 +68,16 @@ def test_device_prove_execution_matches_fixture(ctx, orc):
     w = synth_witness.build(orc, np.random.default_rng(e["seed"]), n_calls=e["n_calls"])  # input generation only
     b = np.array(e["builder"], dtype=np.uint32)
     tr, keep = lm.make_execution_trace(ctx, w)
-    cfg = lm.WhirConfig.from_dict(ob.whir_config(orc, b, ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))))
+    # the WHIR schedule comes from the library's own WhirConfig::new: nothing of the oracle is consulted after input generation
+    cfg = lm.WhirConfig.new(lm.WhirBuilder.default(int(b[0]), security_level=int(b[6]), pow_bits=int(b[7])),
+                            ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr)))
     pr = lm.Prover(ctx)
     pr.prove_execution(tr, cfg)
     proof = pr.proof()
     assert proof.size == e["proof_words"] and digest(proof) == e["proof_sha256"]
+    # ... and the reference's wire bytes (postcard of Proof<F>) of that proof, tests/golden/vectors_r02.json
+    g = json.load(open(os.path.join(GOLD, "vectors_r02.json")))["proof_bytes"]
+    data = pr.proof_bytes()
+    assert list(pr.batch_sizes()) == g["batch_sizes"] and pr.proof_size_fe() == g["proof_size_fe"]
+    assert len(data) == g["postcard_len"] and hashlib.sha256(data).hexdigest() == g["postcard_sha256"]
+    assert np.array_equal(lm.DecodedProof(pr.proof_bytes(compressed=True), compressed=True).pruned_words(), pr.proof_pruned())

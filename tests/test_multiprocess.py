@@ -1,5 +1,5 @@
 """CPU test of the N > 1 path: world_size = 2 over gloo — signer partition and the only collective of the sharded path
-(all-gather of the per-rank commitment roots, bench.py:exchange_roots)."""
+(all-gather of the per-rank commitment root + pruned proof after every step, bench.py:exchange_step)."""
 import os
 import subprocess
 import sys
@@ -15,17 +15,16 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 ranges = bench.signer_ranges(2 * 1550 + 1, world)
 assert ranges[0][0] == 0 and ranges[-1][1] == 2 * 1550 + 1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
-root = np.arange(8, dtype=np.uint32) + 100 * rank + 0x7E000000      # words near p: int64 transport must be lossless
-allr = bench.exchange_roots(root, torch.device("cpu"))
-assert allr.shape == (world, 8)
+root = np.arange(8, dtype=np.uint32) + 100 * rank + 0x7E000000      # words near p: the int32 transport must be lossless
+proof = (np.arange(5000 + 37 * rank, dtype=np.uint32) * 2654435761 % 0x7F000001).astype(np.uint32)  # ranks send different lengths
+allg = bench.exchange_step(root, proof, torch.device("cpu"))
+assert allg.shape[0] == world
 for r in range(world):
-    assert list(allr[r]) == list(np.arange(8) + 100 * r + 0x7E000000), allr
-# the bench's timed region gathers the roots of all leaves of a rank at once (C streams x K steps x 8 words)
-blk = np.arange(3 * 2 * 8, dtype=np.int64) + 1000 * rank + 0x7E000000
-allb = bench.exchange_roots_block(blk, torch.device("cpu"))
-assert allb.shape == (world, 48)
-for r in range(world):
-    assert list(allb[r]) == list(np.arange(48) + 1000 * r + 0x7E000000)
+    assert list(allg[r, :8]) == list(np.arange(8) + 100 * r + 0x7E000000), allg[r, :8]
+    n = int(allg[r, 8])
+    assert n == 5000 + 37 * r
+    want = (np.arange(n, dtype=np.uint32) * 2654435761 % 0x7F000001).astype(np.uint32)
+    assert np.array_equal(allg[r, 9:9 + n].astype(np.uint32), want) and not allg[r, 9 + n:].any()
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

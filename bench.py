@@ -79,9 +79,10 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss",
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
     # default_whir_config: 124-bit, 16 PoW bits, fold 7/5 (lean_prover/src/lib.rs:22-50), integers from the library's own
     # WhirConfig::new; `builder` is the same parameter set in the oracle's format, for the checker (--verify)
-    cfg = lm.WhirConfig.new(lm.WhirBuilder.default(log_inv_rate, prox_gaps_conjecture=capacity), n_vars)
+    lm_builder = lm.WhirBuilder.default(log_inv_rate, prox_gaps_conjecture=capacity)
+    cfg = lm.WhirConfig.new(lm_builder, n_vars)
     builder = ob.whir_builder(log_inv_rate=log_inv_rate, soundness=ob.CAPACITY if capacity else ob.JOHNSON)
-    return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, builder=builder)
+    return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, builder=builder, lm_builder=lm_builder)
 
 
 def time_trace_fill(ctx, w, reps=5):
@@ -387,8 +388,14 @@ def main():
             out["config"]["proof_verified_by_oracle"] = bool(ok)
             if not ok:
                 print("VERIFY FAILED:", err, file=sys.stderr)
+            ok, err = lm.verify_execution(w["w"], pr.proof_bytes(compressed=True), w["lm_builder"], compressed=True)
+            out["config"]["proof_verified_by_library"] = bool(ok)
+            if not ok:
+                print("VERIFY (lmh_verify_execution) FAILED:", err, file=sys.stderr)
         # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
         out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
+        out["config"]["proof_bytes_postcard"] = len(pr.proof_bytes())
+        out["config"]["proof_bytes_lz4"] = len(pr.proof_bytes(compressed=True))
         out["config"]["proof_KiB_unpruned"] = round(int(pr.proof().size) * 31 / (8 * 1024), 1)
         # ---- side measurement (N = 1): independent leaves in flight on the same GPU, one lm_ctx (stream, pools, pinned buffers,
         # host thread) each — the node-level throughput when several leaves are queued

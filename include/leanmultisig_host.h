@@ -188,6 +188,25 @@ uint32_t lmh_stacked_n_vars(const lm_execution_trace* trace); /* compute_stacked
 /* returns LM_E_INVALID with lm_last_error "logup sum != 0" when the witness is inconsistent (prove_generic_logup asserts) */
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* trace, const lm_whir_config* cfg);
 
+/* ---- verifier --------------------------------------------------------------------------------
+ * verify_execution (crates/lean_prover/src/verify_execution.rs:14-214) with everything below it — VerifierState and Merkle
+ * path restoration (fiat-shamir/src/{verifier,merkle_pruning}.rs), verify_gkr_quotient, verify_generic_logup, the batched
+ * AIR check, stacked_pcs_global_statements, WhirConfig::verify (whir/src/verify.rs:83-435) — on the host (the reference's
+ * verifier is CPU code; it is a few ms plus one pass over the bytecode table).  The instance is what the reference's
+ * `Bytecode` + public input provide.  builder = NULL: default_whir_config(rate read from the proof), as the reference does.
+ * LM_OK = accepted; LM_E_INVALID with the failing check in lm_last_error otherwise. */
+typedef struct {
+    uint32_t log_bytecode, ending_pc, n_public_input, reserved;
+    const uint32_t* public_input;  /* n_public_input words */
+    const uint32_t* bytecode_hash; /* 8 words */
+    const uint32_t* bytecode;      /* instructions_multilinear: 2^log_bytecode rows x 16 words (12 used), host */
+} lm_verify_instance;
+int lmh_verify_execution(const lm_verify_instance* instance, const lmh_proof* proof, const lm_whir_builder* builder);
+int lmh_verify_execution_bytes(const lm_verify_instance* instance, const uint8_t* bytes, uint64_t n, int compressed,
+                               const lm_whir_builder* builder);
+/* the proof still held by a prover object (pruned and restored on the way, like a proof that travelled) */
+int lmh_verify_execution_prover(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,9 @@ _HOST_SIGS = {
     "lmh_proof_free": (None, [vp]),
     "lmh_proof_decoded_size_fe": (C.c_uint64, [vp]),
     "lmh_proof_decoded_pruned_words": (C.c_uint64, [vp, vp]),
+    "lmh_verify_execution": (C.c_int, [vp, vp, vp]),
+    "lmh_verify_execution_bytes": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp]),
+    "lmh_verify_execution_prover": (C.c_int, [vp, vp, vp]),
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
@@ -247,6 +250,33 @@ class DecodedProof:
 
     def size_fe(self):
         return int(self.lib.lmh_proof_decoded_size_fe(self.h))
+
+
+class VerifyInstance(C.Structure):
+    """lm_verify_instance: what the reference's `Bytecode` + public input give its verifier"""
+    _fields_ = [("log_bytecode", C.c_uint32), ("ending_pc", C.c_uint32), ("n_public_input", C.c_uint32), ("reserved", C.c_uint32),
+                ("public_input", C.c_void_p), ("bytecode_hash", C.c_void_p), ("bytecode", C.c_void_p)]
+
+
+def verify_execution(w, proof, builder=None, compressed=False):
+    """lmh_verify_execution*: the library's verifier.  w: witness dict (log_bytecode, ending_pc, public_input, bytecode_hash,
+    bytecode); proof: bytes (postcard, or lz4-framed with compressed=True), a DecodedProof or a Prover.
+    Returns (accepted, message)."""
+    lib = load()
+    pi = np.ascontiguousarray(w["public_input"], dtype=np.uint32)
+    bh = np.ascontiguousarray(w["bytecode_hash"], dtype=np.uint32)
+    bc = np.ascontiguousarray(w["bytecode"], dtype=np.uint32).reshape(-1)
+    assert bc.size == 16 << w["log_bytecode"]
+    inst = VerifyInstance(w["log_bytecode"], w["ending_pc"], pi.size, 0, pi.ctypes.data, bh.ctypes.data, bc.ctypes.data)
+    b = C.byref(builder) if builder is not None else None
+    if isinstance(proof, (bytes, bytearray)):
+        src = np.frombuffer(proof, dtype=np.uint8)
+        rc = lib.lmh_verify_execution_bytes(C.byref(inst), src.ctypes.data_as(C.c_void_p), src.size, int(compressed), b)
+    elif isinstance(proof, DecodedProof):
+        rc = lib.lmh_verify_execution(C.byref(inst), proof.h, b)
+    else:
+        rc = lib.lmh_verify_execution_prover(C.byref(inst), proof.h, b)
+    return rc == 0, ("" if rc == 0 else lib.lm_last_error().decode())
 
 
 class SparseStatement(C.Structure):

@@ -14,6 +14,11 @@ using kb::u32;
 using kb::u64;
 using lmh::Challenger;
 using lmh::Opening;
+using lmh::ColVal;
+using lmh::VmTableDef;
+using lmh::kVmTables;
+using lmh::kSnarkDomainSep;
+using lmh::log2_ceil_u64;
 
 namespace {
 
@@ -914,36 +919,6 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
 }  // extern "C" (helpers below have C++ linkage)
 
 namespace {
-// ---- leanVM table metadata the prover needs (bus and memory lookups) ------------------------------------------------
-// lean_vm/src/tables/execution/mod.rs:29-60, extension_op/mod.rs:90-123, poseidon_16/mod.rs:126-174
-struct VmLookup {
-    u32 index, first_value, n_values;
-};
-struct VmTableDef {
-    u32 n_columns, n_shift, n_total;
-    u32 n_lookups;
-    VmLookup lookups[4];
-    bool pull;
-    u32 selector, bus_data[4];
-};
-const VmTableDef kVmTables[3] = {
-    {20, 2, 24, 3, {{2, 5, 1}, {3, 6, 1}, {4, 7, 1}, {0, 0, 0}}, false, 20, {19, 21, 22, 23}},
-    {29, 13, 31, 3, {{6, 14, 5}, {7, 19, 5}, {13, 24, 5}, {0, 0, 0}}, true, 29, {30, 6, 7, 13}},
-    {109, 0, 111, 4, {{6, 9, 4}, {7, 13, 4}, {1, 17, 8}, {2, 93, 16}}, true, 0, {110, 109, 1, 2}},
-};
-const u32 kSnarkDomainSep[8] = {130704175, 1303721200, 493664240, 1035493700,
-                                2063844858, 1410214009, 1938905908, 1696767928};  // lean_prover/src/lib.rs:30-32
-u32 log2_ceil_u64(u64 x) {
-    u32 l = 0;
-    while ((1ull << l) < x) l++;
-    return l;
-}
-void sorted_tables(const lm_execution_trace* t, int order[3]) {  // sort_tables_by_height (stable, descending)
-    order[0] = 0;
-    order[1] = 1;
-    order[2] = 2;
-    std::stable_sort(order, order + 3, [&](int a, int b) { return t->tables[a].log_rows > t->tables[b].log_rows; });
-}
 struct DevBuf {  // RAII device allocation
     lm_ctx* ctx;
     u32* p = nullptr;
@@ -969,12 +944,29 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     if ((rc = lm_bind_thread(ctx))) return rc;
     StageClock clk(ctx);
     int order[3];
-    sorted_tables(tr, order);
+    const u32 log_rows[3] = {tr->tables[0].log_rows, tr->tables[1].log_rows, tr->tables[2].log_rows};
+    lmh::sorted_tables(log_rows, order);
     const u32 log_mem = tr->log_memory, log_bc = tr->log_bytecode;
-    // assertions of stack_polynomials_and_commit (stacked_pcs.rs:108-112)
-    if (log_mem < tr->tables[0].log_rows || tr->tables[0].log_rows < tr->tables[order[0]].log_rows) return LM_E_INVALID;
+    auto invalid = [](const char* why) {
+        lm_set_error("lmh_prove_execution: %s", why);
+        return LM_E_INVALID;
+    };
+    // assertions of stack_polynomials_and_commit (stacked_pcs.rs:108-112) and of prove_execution (prove_execution.rs:41-46,
+    // 64-76: memory >= bytecode and >= 2^MIN_LOG_MEMORY_SIZE, table heights within [MIN_LOG_N_ROWS_PER_TABLE, limit])
+    if (log_mem < tr->tables[0].log_rows || tr->tables[0].log_rows < tr->tables[order[0]].log_rows)
+        return invalid("memory must be at least as tall as the execution table, which must be the tallest table");
+    if (log_mem < log_bc) return invalid("memory must be at least as large as the bytecode (prove_execution.rs:41-45)");
+    if (log_mem < lmh::MIN_LOG_MEMORY_SIZE || log_mem > lmh::MAX_LOG_MEMORY_SIZE) return invalid("log_memory outside [MIN_LOG_MEMORY_SIZE, MAX_LOG_MEMORY_SIZE]");
+    if (log_bc < lmh::MIN_BYTECODE_LOG_SIZE) return invalid("bytecode smaller than 2^MIN_BYTECODE_LOG_SIZE");
+    for (int t = 0; t < 3; t++)
+        if (log_rows[t] < lmh::MIN_LOG_N_ROWS_PER_TABLE || log_rows[t] > lmh::max_log_n_rows_per_table(t))
+            return invalid("table height outside [MIN_LOG_N_ROWS_PER_TABLE, max_log_n_rows_per_table]");
+    if (tr->public_memory_size == 0 || (tr->public_memory_size & (tr->public_memory_size - 1)))
+        return invalid("public_memory_size must be a power of two (log2_strict_usize, prove_execution.rs:225)");
+    if (!lmh::rate_ok(tr->log_inv_rate)) return invalid("log_inv_rate outside [MIN_WHIR_LOG_INV_RATE, MAX_WHIR_LOG_INV_RATE]");
     const u32 stacked_n_vars = lmh_stacked_n_vars(tr);
-    if (cfg->num_variables != stacked_n_vars || cfg->starting_log_inv_rate != tr->log_inv_rate) return LM_E_INVALID;
+    if (cfg->num_variables != stacked_n_vars || cfg->starting_log_inv_rate != tr->log_inv_rate)
+        return invalid("the WhirConfig is not for this trace (num_variables / starting_log_inv_rate)");
     // ---- Fiat-Shamir preamble (prove_execution.rs:47-63) ----
     p->ch.observe_many(tr->public_input, tr->n_public_input);
     {
@@ -1121,7 +1113,10 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     std::vector<u32> gkr_pt((size_t)gkr_n_vars * 5);
     if ((rc = lmh_prove_gkr_quotient(ctx, p, nums.p, dens.p, gkr_n_vars, quotient, gkr_pt.data(), claims))) return fail(rc);
     clk.mark("logup_gkr");
-    if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) return fail(LM_E_INVALID);  // assert_eq!(sum, ZERO)
+    if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) {  // assert_eq!(sum, ZERO)
+        lm_set_error("logup sum != 0: the witness is inconsistent (a lookup reads a value the memory / bytecode does not hold, or the access counters are wrong)");
+        return fail(LM_E_INVALID);
+    }
     auto from_end = [&](u32 n) { return gkr_pt.data() + (size_t)(gkr_n_vars - n) * 5; };
     // column evaluations (logup.rs:224-308)
     EF value_memory_acc, value_memory, value_bytecode_acc;
@@ -1131,10 +1126,6 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     add_base(p, value_memory.v, 5);
     if ((rc = lm_mle_eval(ctx, d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail(rc);
     add_base(p, value_bytecode_acc.v, 5);
-    struct ColVal {
-        u32 col;
-        EF v;
-    };
     std::vector<ColVal> columns_values[3];
     EF bus_num[3], bus_den[3];
     for (int k = 0; k < 3; k++) {
@@ -1215,66 +1206,15 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     if (!sample_vec(p, lpm, pm_pt)) return fail(LM_E_INVALID);
     EF pm_eval;
     if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, lpm, 1, 0, lpm ? pm_pt[0].v : nullptr, pm_eval.v))) return fail(rc);
-    std::vector<lm_sparse_statement> sts;
-    std::vector<u32> pts, vals;
-    std::vector<u64> sels;
-    auto begin_statement = [&](const u32* point, u32 point_len, u32 is_next) {
-        lm_sparse_statement s;
-        memset(&s, 0, sizeof s);
-        s.point_len = point_len;
-        s.is_next = is_next;
-        s.point_offset = pts.size() / 5;
-        s.values_offset = sels.size();
-        pts.insert(pts.end(), point, point + (size_t)point_len * 5);
-        sts.push_back(s);
-    };
-    auto add_value = [&](u64 selector, const EF& v) {
-        sels.push_back(selector);
-        vals.insert(vals.end(), v.v, v.v + 5);
-        sts.back().n_values++;
-    };
-    begin_statement(from_end(log_mem), log_mem, 0);
-    add_value(0, value_memory);
-    add_value(1, value_memory_acc);
-    begin_statement(lpm ? pm_pt[0].v : nullptr, lpm, 0);
-    add_value(0, pm_eval);
-    begin_statement(from_end(log_bc), log_bc, 0);
-    add_value((2 * mem) >> log_bc, value_bytecode_acc);
-    u64 soff = 2 * mem + (1ull << std::max(log_bc, tr->tables[order[0]].log_rows));
-    const u32* ce = col_evals.data();
-    for (int k = 0; k < 3; k++) {
-        const int t = order[k];
-        const VmTableDef& def = kVmTables[t];
-        const u32 nv = tr->tables[t].log_rows;
-        if (t == 0) {
-            begin_statement(nullptr, 0, 0);  // unique_value(STARTING_PC = 0)
-            add_value(soff + (0ull << nv), kb::ef_zero());
-            begin_statement(nullptr, 0, 0);
-            add_value(soff + (1ull << nv) - 1, kb::ef_from_base(kb::to_monty(tr->ending_pc)));
-        }
-        // first committed statement: logup column values at from_end(gkr_point, nv), ascending column index (BTreeMap)
-        std::vector<ColVal> cvs = columns_values[t];
-        std::sort(cvs.begin(), cvs.end(), [](const ColVal& a, const ColVal& b) { return a.col < b.col; });
-        begin_statement(from_end(nv), nv, 0);
-        for (const ColVal& c : cvs) add_value((soff >> nv) + c.col, c.v);
-        // second: AIR point (natural_ordering_point_for_session: last nv challenges reversed), next values then eq values
-        std::vector<u32> nat((size_t)nv * 5);
-        for (u32 j = 0; j < nv; j++) memcpy(&nat[5 * j], &air_point[(size_t)(n_max - 1 - j) * 5], 20);
-        if (def.n_shift) {
-            begin_statement(nat.data(), nv, 1);
-            for (u32 c = 0; c < def.n_shift; c++) add_value((soff >> nv) + c, ef_load(ce + (size_t)(def.n_columns + c) * 5));
-        }
-        begin_statement(nat.data(), nv, 0);
-        for (u32 c = 0; c < def.n_columns; c++) add_value((soff >> nv) + c, ef_load(ce + (size_t)c * 5));
-        ce += (size_t)(def.n_columns + def.n_shift) * 5;
-        soff += (u64)def.n_columns << nv;
-    }
+    lmh::Statements S;
+    lmh::assemble_statements(S, log_rows, log_mem, log_bc, tr->ending_pc, gkr_pt.data(), gkr_n_vars, value_memory, value_memory_acc,
+                             value_bytecode_acc, lpm ? pm_pt[0].v : nullptr, lpm, pm_eval, columns_values, air_point.data(), col_evals.data());
     clk.mark("statement_assembly");
     std::vector<u32> out_point((size_t)stacked_n_vars * 5);
     lmh_witness* w = wit;
     wit = nullptr;  // consumed by lmh_whir_prove
-    rc = lmh_whir_prove(ctx, p, cfg, sts.data(), (u32)sts.size(), pts.data(), pts.size() / 5, sels.data(), vals.data(), sels.size(), w,
-                        poly.p, out_point.data());
+    rc = lmh_whir_prove(ctx, p, cfg, S.sts.data(), (u32)S.sts.size(), S.pts.data(), S.pts.size() / 5, S.sels.data(), S.vals.data(),
+                        S.sels.size(), w, poly.p, out_point.data());
     clk.mark("whir_open");
     return rc;
 }

@@ -47,6 +47,7 @@ struct lm_ctx {
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
     u32* d_sync = nullptr;      // [0] PoW result (0xffffffff when idle), [1] "writers done" counter of multi-block publishers
+    unsigned long long* d_acc = nullptr;  // LM_ACC_WORDS accumulators of lm_grid_sum (zero between kernels)
     u32* d_coop = nullptr;      // COOP_TAB_WORDS: per-lane coefficient table of the 16-lane Poseidon (poseidon16_coop.h)
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
@@ -88,57 +89,46 @@ struct lm_ctx {
 // host-visible buffer, fences at system scope and stores the round's sequence number; the host spins on that word
 // instead of paying a stream-synchronise per sumcheck round (~300 rounds per proof).
 #if defined(__HIPCC__)
-// Multi-block reduction without a second launch: every block stores its N field words to partial[block][N] (plain stores),
-// then takes a ticket from a device-scope counter — ONE atomic per block; adding the N words themselves with atomics was
-// measured at ~5.5 ns per atomic on a handful of addresses, 250 us for a 4096-block launch.  The block that draws the last
-// ticket sums the partials: thread t takes blocks t, t + 256, .. (independent loads, N running sums in registers), then a
-// wave + LDS reduction.  `vals_lds` must be valid in threads < N of every block.  Returns true in ALL threads of the last
-// block, with the totals in out_lds[0..N) (may alias vals_lds); work_lds: 4 N words.
+// Cross-block hand-over inside one kernel WITHOUT release / acquire fences.  On this multi-XCD part an agent-scope release
+// fence is `buffer_wbl2`: it writes back every dirty line of the XCD's L2 — in a kernel that is streaming hundreds of MB of
+// outputs that costs ~70 ns per block (k_fold_round with 4096 blocks: 504 -> 850 us).  The few words that actually cross
+// blocks are instead written with agent-scope relaxed atomic stores (write-through, sc1), the wave waits until they are
+// acknowledged (s_waitcnt vmcnt(0): what the memory model's release sequence does after its write-back), and the consumer
+// reads them with agent-scope atomic loads (served past the non-coherent L2s).
+__device__ __forceinline__ void lm_store_agent(kb::u32* p, kb::u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ kb::u32 lm_load_agent(const kb::u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lm_store_system(kb::u32* p, kb::u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void lm_wait_stores() {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ __forceinline__ kb::u32 lm_ticket(kb::u32* counter) { return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Multi-block reduction without a second launch and without a pass over per-block partials: every block adds its N field
+// words (< 2^31 each: 2^33 blocks fit) into 64-bit accumulators with agent-scope integer atomics, waits until they are
+// performed, and takes a ticket; the block that draws the last ticket swaps the totals out (re-zeroing the accumulators for
+// the next kernel on the stream) and reduces them mod p — the representation is additive, so the sum of Montgomery residues
+// is the residue of the sum.  (Measured alternatives, profiles/r02_gridsum_notes.txt: per-block partials + a reducing pass by
+// the last block costs ~7 us more per launch — three dependent trips to memory; a separate reducing kernel ~6 us + a launch.)
+// `vals_lds` must be valid in threads < N of every block.  Returns true in ALL threads of the last block, totals in
+// out_lds[0..N) (may alias vals_lds).
+static constexpr kb::u32 LM_ACC_WORDS = 64;
 template <int N>
-__device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, kb::u32* __restrict__ partial, kb::u32* done_counter, kb::u32* out_lds,
-                                            kb::u32* work_lds) {
+__device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned long long* acc, kb::u32* done_counter, kb::u32* out_lds) {
+    static_assert(N <= (int)LM_ACC_WORDS, "accumulator count");
     __shared__ kb::u32 lm_is_last;
     if (threadIdx.x < N) {
-        partial[(kb::u64)blockIdx.x * N + threadIdx.x] = vals_lds[threadIdx.x];
-        __threadfence();
+        (void)__hip_atomic_fetch_add(acc + threadIdx.x, (unsigned long long)vals_lds[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lm_wait_stores();
     }
     __syncthreads();
-    if (threadIdx.x == 0) lm_is_last = atomicAdd(done_counter, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) lm_is_last = lm_ticket(done_counter) == gridDim.x - 1;
     __syncthreads();
     if (!lm_is_last) return false;
-    __threadfence();
-    // CH words at a time: the tail must not raise the register count of the kernel it ends
-    constexpr int CH = N <= 20 ? N : 20;
-    static_assert(N % CH == 0, "N must be a multiple of the chunk");
-    const kb::u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int c0 = 0; c0 < N; c0 += CH) {
-        kb::u32 acc[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) acc[k] = 0;
-        for (kb::u32 b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-            kb::u32 v[CH];
-#pragma unroll
-            for (int k = 0; k < CH; k++) v[k] = __builtin_nontemporal_load(partial + (kb::u64)b * N + c0 + k);
-#pragma unroll
-            for (int k = 0; k < CH; k++) acc[k] = kb::add(acc[k], v[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < CH; k++)
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) acc[k] = kb::add(acc[k], (kb::u32)__shfl_down(acc[k], off, 64));
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < CH; k++) work_lds[wave * N + c0 + k] = acc[k];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < N) {
-        kb::u32 t = 0;
-        for (kb::u32 w = 0; w < (blockDim.x >> 6); w++) t = kb::add(t, work_lds[w * N + threadIdx.x]);
-        out_lds[threadIdx.x] = t;
-    }
-    if (threadIdx.x == 0) *done_counter = 0;
+    if (threadIdx.x < N)
+        out_lds[threadIdx.x] = (kb::u32)(__hip_atomic_exchange(acc + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % kb::P);
+    if (threadIdx.x == 0) lm_store_agent(done_counter, 0);  // re-armed for the next kernel on the stream (kernel boundary orders it)
     __syncthreads();
     return true;
 }

@@ -348,6 +348,8 @@ int lm_ctx_create(int device, lm_ctx** out) {
         const u32 init[4] = {0xffffffffu, 0, 0, 0};
         LM_HIP(hipMalloc(&c->d_sync, sizeof init));
         LM_HIP(hipMemcpy(c->d_sync, init, sizeof init, hipMemcpyHostToDevice));
+        LM_HIP(hipMalloc(&c->d_acc, LM_ACC_WORDS * 8));
+        LM_HIP(hipMemset(c->d_acc, 0, LM_ACC_WORDS * 8));
     }
     {  // 16-lane Poseidon: probe the DPP rotation direction, build the coefficient table for it
         LM_HIP(hipMalloc(&c->d_coop, COOP_TAB_WORDS * 4));
@@ -376,6 +378,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
     if (c->d_coop) (void)hipFree(c->d_coop);
     if (c->d_sync) (void)hipFree(c->d_sync);
+    if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);

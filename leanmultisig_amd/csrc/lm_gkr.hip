@@ -154,7 +154,7 @@ __device__ __forceinline__ EF fold_n_base(const u32 (&in)[N], const EF& r0, cons
 template <int MODE, int F, bool LA>
 __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
                                                   const u32* __restrict__ arr_in, u64 m_out, EF r0, EF r1, EF alpha, EqSplit eq,
-                                                  u32* __restrict__ out, u32* __restrict__ acc, u32* __restrict__ done_counter,
+                                                  u32* __restrict__ out, unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                   u32* __restrict__ h_res, u32 seq) {
     __shared__ u32 lds[4 * GKR_SUM_WORDS];
     __shared__ u32 tot[GKR_SUM_WORDS];
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
 #pragma unroll
                     for (int q = 0; q < 4; q++)
 #pragma unroll
-                        for (int k = 0; k < 5; k++) h_res[GKR_FIN_AT + (q * 5 + k) * 4 + i] = x[q].v[k];
-                    __threadfence_system();
+                        for (int k = 0; k < 5; k++) lm_store_system(h_res + GKR_FIN_AT + (q * 5 + k) * 4 + i, x[q].v[k]);
+                    lm_wait_stores();
                 }
             }
         } else {
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
         tot[threadIdx.x] = s;
     }
     __syncthreads();
-    if (gridDim.x > 1 && !lm_grid_sum<GKR_SUM_WORDS>(tot, acc, done_counter, tot, lds)) return;
+    if (gridDim.x > 1 && !lm_grid_sum<GKR_SUM_WORDS>(tot, acc, done_counter, tot)) return;
     if (threadIdx.x < GKR_SUM_WORDS) {
-        h_res[threadIdx.x] = tot[threadIdx.x];
-        __threadfence_system();
+        lm_store_system(h_res + threadIdx.x, tot[threadIdx.x]);
+        lm_wait_stores();
     }
     __syncthreads();
     if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
@@ -412,9 +412,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32 p = g->K - 1 - t;  // round t: 2^p pairs, eq over point[0..p)
     const EqSplit eq = g->eqt.at(la ? p - 1 : p);
     const u32 blocks = (u32)std::min<u64>((m_out + 255) / 256, 1024);
-    u32* s;
-    int rc = lm_scratch(ctx, (u64)blocks * GKR_SUM_WORDS + 64, &s);
-    if (rc) return rc;
+    int rc;
     const u32 seq = ++ctx->res_seq;
     const bool input_layer = g->K == g->n_vars - 1;
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
@@ -426,7 +424,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     u32* counter = ctx->d_sync + 1;
     const u32* nul = nullptr;
 #define GKR_STEP(MODE, FF, LL, NI, DI, AI) \
-    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, r0, r1, g->alpha, eq, g->work[dst], s, counter, ctx->h_res, seq)
+    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq)
     if (g->cur < 0) {
         LM_REQUIRE(la);  // K >= 5: the launches that read layer storage always cover two rounds
         if (F == 0) {

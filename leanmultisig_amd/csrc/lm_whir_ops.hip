@@ -261,8 +261,8 @@ __device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, 
 }
 
 // End of a product-sumcheck round kernel: a single block publishes its sums; otherwise every block adds its 10 words into
-// the partial buffer and the block that finishes last publishes the totals (lm_grid_sum: no reducing launch).
-__device__ __forceinline__ void finish10(u32 v[10], u32* red /* 96 words */, u32* __restrict__ acc,
+// the context's accumulators and the block that finishes last publishes the totals (lm_grid_sum: no reducing launch).
+__device__ __forceinline__ void finish10(u32 v[10], u32* red /* 64 words */, unsigned long long* __restrict__ acc,
                                          u32* __restrict__ done_counter, u32* __restrict__ h_res, u32 seq) {
     if (gridDim.x == 1) {
         block_sum10(v, red, h_res, h_res, seq);
@@ -270,7 +270,7 @@ __device__ __forceinline__ void finish10(u32 v[10], u32* red /* 96 words */, u32
     }
     block_sum10(v, red, red + 40);
     __syncthreads();
-    if (!lm_grid_sum<10>(red + 40, acc, done_counter, red, red + 56)) return;
+    if (!lm_grid_sum<10>(red + 40, acc, done_counter, red)) return;
     if (threadIdx.x < 64) {
         if (threadIdx.x < 10) h_res[threadIdx.x] = red[threadIdx.x];
         __threadfence_system();
@@ -279,9 +279,9 @@ __device__ __forceinline__ void finish10(u32 v[10], u32* red /* 96 words */, u32
 }
 
 __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                         u32* __restrict__ acc, u32* __restrict__ done_counter,
+                                                         unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                          u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[96];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half;
     u64 a0[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0};
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -303,9 +303,9 @@ __global__ __launch_bounds__(256) void k_prod_round_base(const u32* __restrict__
     finish10(v, red, acc, done_counter, final_out, seq);
 }
 __global__ __launch_bounds__(256) void k_prod_round_ext(const u32* __restrict__ f, const u32* __restrict__ W, u64 half,
-                                                        u32* __restrict__ acc, u32* __restrict__ done_counter,
+                                                        unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                         u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[96];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < half; i += (u64)gridDim.x * 256) {
@@ -358,9 +358,9 @@ __global__ __launch_bounds__(256) void k_fold_ext(const u32* __restrict__ in, u6
 // Lane i < quarter produces outputs i and i + quarter (the next round's pair) from inputs i, i+quarter, i+half, i+half+quarter.
 template <bool F_BASE>
 __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, const u32* __restrict__ W, u64 half, EF r,
-                                                    u32* __restrict__ f_out, u32* __restrict__ W_out, u32* __restrict__ acc,
+                                                    u32* __restrict__ f_out, u32* __restrict__ W_out, unsigned long long* __restrict__ acc,
                                                     u32* __restrict__ done_counter, u32* __restrict__ final_out, u32 seq) {
-    __shared__ u32 red[96];
+    __shared__ u32 red[64];
     const u64 plane = 2 * half, quarter = half >> 1;
     EF c0 = ef_zero(), c2 = ef_zero();
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
@@ -428,13 +428,13 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ 
         poseidon16_permute(s);
         if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
     }
+    lm_wait_stores();  // the atomicMin of this wave has been performed
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(done_counter, 1u) == gridDim.x - 1) {
-            *done_counter = 0;
-            __threadfence();
-            h_res[0] = atomicExch(result, 0xffffffffu);
+        if (lm_ticket(done_counter) == gridDim.x - 1) {
+            lm_store_agent(done_counter, 0);
+            lm_store_system(h_res, atomicExch(result, 0xffffffffu));
+            lm_wait_stores();
             lm_publish_flag(h_res, seq);
         }
     }
@@ -605,9 +605,9 @@ int lm_prod_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     if (rc) return rc;
     u32* d_out = s + (u64)blocks * 10;
     if (f_is_ext)
-        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_ext, dim3(blocks), dim3(256), 0, d_f, d_W, half, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, k_prod_round_base, dim3(blocks), dim3(256), 0, d_f, d_W, half, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     (void)d_out;
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
@@ -642,9 +642,9 @@ int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     EF rr;
     memcpy(rr.v, r, 20);
     if (f_is_ext)
-        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<false>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     else
-        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, s, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_LAUNCH(ctx, (k_fold_round<true>), dim3(blocks), dim3(256), 0, d_f, d_W, half, rr, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
@@ -661,8 +661,10 @@ int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_
     memcpy(a.cap, capacity, 32);
     a.mask = (1u << bits) - 1;
     a.r2 = to_monty(to_monty(1));  // 2^64 mod p
-    // batch sized to the expected work (2^bits candidates), at least one full wave of the chip
-    u64 batch = std::max<u64>(1ull << 16, std::min<u64>(1ull << bits, 1ull << 22));
+    // batch = twice the expected work (2^bits candidates): a 2^16 batch is one workgroup per CU — one wave per SIMD, a pure
+    // latency chain — so the second workgroup per CU is nearly free, and the chance of needing another round trip drops from
+    // 1/e to 1/e^2
+    u64 batch = std::max<u64>(1ull << 17, std::min<u64>(2ull << bits, 1ull << 22));
     for (u64 base = 0; base < P; base += batch) {
         a.base = (u32)base;
         a.n = (u32)std::min<u64>(batch, (u64)P - base);

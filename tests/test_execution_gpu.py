@@ -10,12 +10,25 @@ from tests import synth_witness
 pytestmark = pytest.mark.gpu
 
 
+def _lm_builder(b):
+    """the oracle's 8-integer builder as the library's lm_whir_builder"""
+    return lm.WhirBuilder.default(int(b[0]), max_num_variables_to_send_coeffs=int(b[1]), rs_domain_initial_reduction_factor=int(b[2]),
+                                  folding_factor_first=int(b[3]), folding_factor_subsequent=int(b[4]), soundness_type=int(b[5]),
+                                  security_level=int(b[6]), pow_bits=int(b[7]))
+
+
 def _device_proof(ctx, orc, w, builder, device_counters=True):
+    """prove on the device with the WHIR schedule of the library's own WhirConfig::new; every proof is also put through the
+    library's verifier in its wire form (postcard bytes)"""
     tr, keep = lm.make_execution_trace(ctx, w, device_counters=device_counters)
     n = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
-    cfg = lm.WhirConfig.from_dict(ob.whir_config(orc, builder, n))
+    cfg = lm.WhirConfig.new(_lm_builder(builder), n)
+    assert cfg.to_dict() == {k: v for k, v in ob.whir_config(orc, builder, n).items() if k != "final_log_inv_rate"} | {
+        "rounds": [{k: r[k] for k in ("query_pow_bits", "folding_pow_bits", "num_queries", "ood_samples")} for r in ob.whir_config(orc, builder, n)["rounds"]]}
     pr = lm.Prover(ctx)
     pr.prove_execution(tr, cfg)
+    ok, err = lm.verify_execution(w, pr.proof_bytes(), _lm_builder(builder))
+    assert ok, err
     return pr.proof()
 
 
@@ -219,6 +232,13 @@ def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
     assert ok, err
     p2 = bench.run_step(ctx, lm, w)
     assert np.array_equal(p2.proof(), proof)
+    # the wire form: lz4-framed postcard bytes through the library's own verifier (default_whir_config read off the proof)
+    wire = p1.proof_bytes(compressed=True)
+    ok, err = lm.verify_execution(w["w"], wire, compressed=True)
+    assert ok, err
+    assert abs(len(p1.proof_bytes()) / p1.proof_size_fe() - 4.87) < 0.05  # random Montgomery words: 87.5 % need 5 varint bytes
+    bad = dict(w["w"], public_input=np.roll(w["w"]["public_input"], 1))
+    assert not lm.verify_execution(bad, wire, compressed=True)[0]
     pruned = p1.proof_pruned()
     assert np.array_equal(ob.restore_proof(orc, pruned), proof)
     assert p1.proof_size_fe() == ob.pruned_size_fe(orc, pruned) < proof.size

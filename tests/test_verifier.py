@@ -1,0 +1,95 @@
+"""The library's verifier (lmh_verify_execution), CPU: it accepts the ORACLE prover's proofs — two
+independent restatements of the reference's prover / verifier pair meeting in the middle — through every entry form (prover
+object, decoded proof, postcard bytes, lz4 frame), agrees with the oracle's verifier on tampered proofs, and rejects a wrong
+instance (public input, bytecode, bytecode hash, ending pc, security parameters)."""
+import numpy as np
+import pytest
+
+import leanmultisig_amd as lm
+from tests import oracle_binding as ob
+from tests import synth_witness
+
+
+def _batch_sizes(w, builder):
+    cfg = lm.WhirConfig.new(builder, synth_witness.stacked_n_vars(w)).to_dict()
+    return [r["num_queries"] for r in cfg["rounds"]] + [cfg["final_queries"]]
+
+
+@pytest.fixture(scope="module")
+def small(orc):
+    w = synth_witness.build(orc, np.random.default_rng(31), n_calls=40)
+    ob_b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    lm_b = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    raw = ob.prove_execution(orc, w, synth_witness.header(w), ob_b)
+    return w, raw, ob_b, lm_b
+
+
+def test_accepts_oracle_proof_in_every_form(orc, small):
+    w, raw, ob_b, lm_b = small
+    pr = lm.Prover.from_raw(raw, _batch_sizes(w, lm_b))
+    ok, err = lm.verify_execution(w, pr, lm_b)
+    assert ok, err
+    data, comp = pr.proof_bytes(), pr.proof_bytes(compressed=True)
+    for proof, kw in ((data, {}), (comp, dict(compressed=True)), (lm.DecodedProof(data), {})):
+        ok, err = lm.verify_execution(w, proof, lm_b, **kw)
+        assert ok, err
+    # default builder (124-bit) on a 60-bit proof: the schedule differs, so the transcript cannot line up
+    ok, err = lm.verify_execution(w, data)
+    assert not ok and err
+
+
+def test_mixed_program_and_other_rate(orc):
+    w = synth_witness.build_mixed(orc, np.random.default_rng(32))
+    w["log_inv_rate"] = 2
+    ob_b = ob.whir_builder(log_inv_rate=2, pow_bits=5, security=50)
+    lm_b = lm.WhirBuilder.default(2, security_level=50, pow_bits=5)
+    raw = ob.prove_execution(orc, w, synth_witness.header(w), ob_b)
+    ok, err = lm.verify_execution(w, lm.Prover.from_raw(raw, _batch_sizes(w, lm_b)), lm_b)
+    assert ok, err
+
+
+def test_rejects_wrong_instance(orc, small):
+    w, raw, ob_b, lm_b = small
+    pr = lm.Prover.from_raw(raw, _batch_sizes(w, lm_b))
+    for key, mutate in (("public_input", lambda a: np.concatenate([a[:3], [(int(a[3]) + 1) % 0x7F000001], a[4:]]).astype(np.uint32)),
+                        ("public_input", lambda a: a[:-1]),
+                        ("bytecode_hash", lambda a: np.roll(a, 1)),
+                        ("ending_pc", lambda v: v + 1)):
+        w2 = dict(w)
+        w2[key] = mutate(w[key])
+        ok, err = lm.verify_execution(w2, pr, lm_b)
+        assert not ok and err, key
+    w2 = dict(w, bytecode=w["bytecode"].copy())
+    w2["bytecode"][3, 1] ^= 1  # an instruction the program executes
+    ok, err = lm.verify_execution(w2, pr, lm_b)
+    assert not ok and "logup" in err
+    ok, err = lm.verify_execution(w, pr, lm.WhirBuilder.default(1, security_level=60, pow_bits=7))
+    assert not ok
+
+
+def test_tampering_matches_the_oracle_verifier(orc, small):
+    """single-word corruptions all over the proof: both verifiers must reject every one of them"""
+    w, raw, ob_b, lm_b = small
+    sizes = _batch_sizes(w, lm_b)
+    rng = np.random.default_rng(33)
+    T = int(raw[0])
+    positions = list(rng.integers(1, 1 + T, size=25)) + list(rng.integers(2 + T, raw.size, size=25))
+    rejected = 0
+    for pos in positions:
+        bad = raw.copy()
+        bad[pos] = (int(bad[pos]) + 1 + int(rng.integers(0, 1000))) % 0x7F000001
+        try:
+            pr = lm.Prover.from_raw(bad, sizes)
+        except lm.LmError:
+            rejected += 1  # a structural word (length / index) no longer parses
+            continue
+        ok_lm, _ = lm.verify_execution(w, pr, lm_b)
+        try:
+            # what travels is the pruned proof: a corrupted sibling that pruning drops (the verifier recomputes it from the
+            # neighbouring path) is not part of it, so the oracle checks the same restored proof
+            ok_orc, _ = ob.verify_execution(orc, w, ob.restore_proof(orc, ob.prune_proof(orc, bad, sizes)), ob_b)
+        except Exception:  # noqa: BLE001 — the oracle binding raises on unparsable blobs
+            ok_orc = False
+        assert ok_lm == ok_orc, pos
+        rejected += not ok_lm
+    assert rejected >= 30  # (redundant siblings are pruned away before the proof travels: corrupting one changes nothing)

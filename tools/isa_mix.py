@@ -2,7 +2,8 @@
 Issue-cycle weight = sum(count x cycles per wave64) / (2 x count): v_mul_lo_u32 / v_mul_hi_u32 / v_mad_u64_u32 issue in 4
 cycles, v_lshl_add_u64 at its measured 7.4 (tools/ubench/int_rates.hip, profiles/r02_int_rates.txt), everything else in 2
 (SIMD-32, /opt/skills/guides/MI355X_MICROARCH.md).  Straight-line kernels: static mix ~ dynamic mix.
-usage: python tools/isa_mix.py file.s [name-substring]"""
+usage: python tools/isa_mix.py file.s [name-substring]
+       python tools/isa_mix.py --all out.json     (compiles every csrc/*.hip to assembly; keys = demangled kernel names)"""
 import collections
 import json
 import re
@@ -36,6 +37,34 @@ def mixes(path, want=""):
     return out
 
 
+def all_kernels(out_path):
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    res = {}
+    for f in sorted(os.listdir(os.path.join(root, "leanmultisig_amd", "csrc"))):
+        if not f.endswith(".hip"):
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                   os.path.join(root, "leanmultisig_amd", "csrc", f), "-o", tmp.name], stderr=subprocess.DEVNULL)
+            mx = mixes(tmp.name)
+        names = list(mx)
+        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout.split("\n")
+        for n, d in zip(names, dem):
+            v = mx[n]
+            v.pop("top")
+            res[d.replace("void ", "").split("(")[0]] = v
+    json.dump({"source_sha": bench.source_sha(), "cycles_per_wave64": {**CYCLES, "other": 2}, "kernels": res}, open(out_path, "w"), indent=1)
+    print("wrote", out_path, len(res), "kernels")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--all":
+        all_kernels(sys.argv[2])
+        sys.exit(0)
     for k, v in mixes(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "").items():
         print(k[:60], json.dumps(v))

@@ -3,7 +3,11 @@ guide prescribes) of the bench command.  usage: python tools/pmc_summary.py <dir
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
 
 base, n_steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
@@ -14,7 +18,7 @@ def family(name):
 
 
 def collect(sub, counter):
-    f = glob.glob(f"{base}/{sub}/*/*_counter_collection.csv")[0]
+    f = glob.glob(f"{base}/{sub}/**/*_counter_collection.csv", recursive=True)[0]
     agg = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -30,11 +34,12 @@ def collect(sub, counter):
 fetch, write = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_SIZE")
 out = {
     "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
-               "--no-cpu-baseline (two separate passes)",
+               "--no-cpu-baseline --inflight 1 (two separate passes)",
     "unit_note": "counters are KiB. On gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streams "
                  "(MI355X_MICROARCH.md §HBM): calibrated on k_leaf_sponge (4 B/lane column reads: 2 x raw matches the byte count "
                  "to 0.2 %); the same x2 is applied to the other kernels and is an upper bound where requests are 64 B. "
                  "WRITE_SIZE matches byte counts exactly.",
+    "source_sha": bench.source_sha(),
     "steps_in_trace": n_steps,
     "per_step": {},
 }

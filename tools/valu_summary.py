@@ -1,43 +1,66 @@
-"""Per-kernel-family VALU work from one rocprofv3 --pmc SQ_INSTS_VALU pass of the bench command (one prover alone):
-wave-level VALU instructions x 64 lanes / peak issue rate = the time the family would take at the integer-ALU roofline.
-usage: python tools/valu_summary.py <dir with pmc_valu/> <proofs in trace> <out.json>"""
+"""Per-kernel-family VALU work from one rocprofv3 --pmc SQ_INSTS_VALU pass of `bench.py --inflight 1` (one prover alone):
+wave-level VALU instructions x 64 lanes against the chip's issue rate 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+(/opt/skills/guides/MI355X_MICROARCH.md), unweighted and weighted by the issue cycles of each kernel's static ISA mix
+(profiles/r02_isa_mix.json from tools/isa_mix.py --all: v_mul_lo/hi_u32 and v_mad_u64_u32 take 4 cycles per wave64,
+v_lshl_add_u64 7.4, everything else 2).
+usage: python tools/valu_summary.py <dir with pmc_valu/> <proofs in trace> <out.json> [isa_mix.json]"""
 import csv
 import glob
 import json
+import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
 base, n_steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-PEAK = 256 * 4 * 16 * 2.4e9  # lane-instructions / s
+mix = json.load(open(sys.argv[4]))["kernels"] if len(sys.argv) > 4 else {}
+PEAK = 256 * 4 * 32 * 2.4e9  # lane-instructions / s
 
 
 def family(name):
     return name.replace("void ", "").split("(")[0].split("<")[0]
 
 
-f = glob.glob(f"{base}/pmc_valu/*/*_counter_collection.csv")[0]
+def weight(name):
+    k = name.replace("void ", "").split("(")[0]
+    return mix[k]["issue_cycle_weight"] if k in mix else None
+
+
+f = glob.glob(f"{base}/pmc_valu/**/*_counter_collection.csv", recursive=True)[0]
 agg = {}
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "SQ_INSTS_VALU":
         continue
-    a = agg.setdefault(family(r["Kernel_Name"]), [0, 0.0, 0])
+    a = agg.setdefault(family(r["Kernel_Name"]), [0, 0.0, 0, 0.0])
+    w = weight(r["Kernel_Name"])
     a[0] += 1
     a[1] += float(r["Counter_Value"])
     a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    a[3] += float(r["Counter_Value"]) * (w if w else 1.0)
 out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline --inflight 1",
-       "note": "SQ_INSTS_VALU counts wave-level instructions; x64 lanes; peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz",
-       "proofs_in_trace": n_steps, "per_proof": {}}
-tot_alu, tot_ms = 0.0, 0.0
-for k, (n, v, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+       "note": "SQ_INSTS_VALU counts wave-level instructions; x64 lanes; peak = 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s; "
+               "issue_cycle_weight = issue cycles per instruction / 2 from the static ISA mix of each kernel instantiation",
+       "source_sha": bench.source_sha(), "proofs_in_trace": n_steps, "per_proof": {}}
+tot_alu, tot_w, tot_ms = 0.0, 0.0, 0.0
+for k, (n, v, ns, vw) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
     alu_ms = v * 64 / PEAK * 1e3 / n_steps
+    w_ms = vw * 64 / PEAK * 1e3 / n_steps
     ms = ns * 1e-6 / n_steps
     tot_alu += alu_ms
+    tot_w += w_ms
     tot_ms += ms
-    out["per_proof"][k] = {"launches": n / n_steps, "valu_wave_insts": v / n_steps, "alu_roofline_ms": round(alu_ms, 4),
-                           "kernel_ms_under_pmc": round(ms, 4), "alu_frac": round(alu_ms / ms, 3) if ms else None}
+    out["per_proof"][k] = {"launches": n / n_steps, "valu_wave_insts": v / n_steps, "issue_cycle_weight": round(vw / v, 3) if v else None,
+                           "alu_roofline_ms": round(alu_ms, 4), "alu_roofline_issue_weighted_ms": round(w_ms, 4),
+                           "kernel_ms_under_pmc": round(ms, 4), "alu_frac": round(alu_ms / ms, 3) if ms else None,
+                           "alu_frac_issue_weighted": round(w_ms / ms, 3) if ms else None}
 out["total_alu_roofline_ms_per_proof"] = round(tot_alu, 3)
+out["total_alu_roofline_issue_weighted_ms_per_proof"] = round(tot_w, 3)
 out["total_kernel_ms_per_proof_under_pmc"] = round(tot_ms, 3)
 json.dump(out, open(out_path, "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("total_alu_roofline_ms_per_proof", "total_kernel_ms_per_proof_under_pmc")}))
-for k, v in list(out["per_proof"].items())[:14]:
-    print(f"{k:28s} alu {v['alu_roofline_ms']:8.3f} ms  kernel {v['kernel_ms_under_pmc']:8.3f} ms  frac {v['alu_frac']}")
+print(json.dumps({k: out[k] for k in ("total_alu_roofline_ms_per_proof", "total_alu_roofline_issue_weighted_ms_per_proof",
+                                      "total_kernel_ms_per_proof_under_pmc")}))
+for k, v in list(out["per_proof"].items())[:16]:
+    print(f"{k:26s} alu {v['alu_roofline_ms']:7.3f} ms  weighted {v['alu_roofline_issue_weighted_ms']:7.3f} ms  kernel {v['kernel_ms_under_pmc']:7.3f} ms  "
+          f"frac {v['alu_frac']}  weighted {v['alu_frac_issue_weighted']}")

@@ -56,6 +56,8 @@ void* lm_ctx_stream(lm_ctx* ctx);
  * lm_profile_read synchronises, returns launch count and summed duration for one kernel and clears its records. */
 int lm_profile_select(lm_ctx* ctx, const char* kernel_name);
 int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms);
+/* names of the kernels with recorded launches, '\n'-separated; returns the buffer size needed (buf may be NULL) */
+uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap);
 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr);

@@ -28,6 +28,7 @@ _SIGS = {
     "lm_bind_thread": (C.c_int, [vp]),
     "lm_ctx_stream": (vp, [vp]),
     "lm_profile_select": (C.c_int, [vp, C.c_char_p]),
+    "lm_profile_names": (C.c_uint64, [vp, vp, C.c_uint64]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lm_free": (C.c_int, [vp, vp]),
@@ -452,6 +453,12 @@ class Context:
 
     def profile_select(self, kernel_name):
         self._check(self.lib.lm_profile_select(self.h, kernel_name.encode() if kernel_name else None))
+
+    def profile_names(self):
+        n = self.lib.lm_profile_names(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        self.lib.lm_profile_names(self.h, buf, n)
+        return sorted(set(x for x in buf.value.decode().split("\n") if x))
 
     def profile_read(self, kernel_name):
         """-> (n_launches, total_ms) of the selected kernel since the last read"""

@@ -1,5 +1,6 @@
 // Context, memory helpers, twiddle tables, multilinear evaluation.
 #include <stdarg.h>
+#include <algorithm>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
 
@@ -401,6 +402,28 @@ int lm_profile_select(lm_ctx* ctx, const char* kernel_name) {
     LM_REQUIRE(ctx);
     ctx->prof_select = kernel_name ? kernel_name : "";
     return LM_OK;
+}
+// names of the kernels that have recorded launches, '\n'-separated (template arguments stripped); returns the length needed
+uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap) {
+    if (!ctx) return 0;
+    std::string all;
+    std::string last;
+    for (auto& kv : ctx->prof_events) {
+        std::string k = kv.first;
+        if (!k.empty() && k[0] == '(') k = k.substr(1);
+        const size_t lt = k.find('<');
+        if (lt != std::string::npos) k = k.substr(0, lt);
+        if (k == last) continue;
+        last = k;
+        all += k;
+        all += '\n';
+    }
+    if (buf && cap) {
+        const size_t n = std::min<size_t>(all.size(), cap - 1);
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size() + 1;
 }
 int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms) {
     LM_REQUIRE(ctx && kernel_name && n_launches && total_ms);

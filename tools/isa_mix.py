@@ -53,7 +53,7 @@ def all_kernels(out_path):
                                    os.path.join(root, "leanmultisig_amd", "csrc", f), "-o", tmp.name], stderr=subprocess.DEVNULL)
             mx = mixes(tmp.name)
         names = list(mx)
-        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout.split("\n")
+        dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
         for n, d in zip(names, dem):
             v = mx[n]
             v.pop("top")

@@ -5,7 +5,7 @@ import glob
 import sys
 
 base, pat, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-f = glob.glob(f"{base}/*/*_kernel_trace.csv")[0]
+f = glob.glob(f"{base}/**/*_kernel_trace.csv", recursive=True)[0]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
 per = len(d) // n
 last = sorted(d[-per:], reverse=True)

@@ -49,7 +49,7 @@ RECURSION_EXT_CALLS = [("mul", False, 64, 3000), ("mul", True, 128, 800), ("poly
                        ("add", False, 1, 20000), ("mul", False, 1, 20000), ("add", True, 2, 3000)]
 
 
-def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss", capacity=False):
+def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss", capacity=False, witness="xmss"):
     """A consistent synthetic leanVM execution trace of the config-2 shape (SURVEY.md §8 size table), uploaded once:
     1550 signatures x 167 Poseidon calls = 258 850 active Poseidon rows (table 2^18 x 109), execution table 2^20 x 20,
     extension_op 2^8 x 29, memory 2^20, bytecode 2^19  ->  stacked polynomial 2^26, logup vector 2^24.
@@ -66,7 +66,14 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss",
         for c in range(25, 109):
             rows[:, c] = cols[c].download()
 
-    if shape == "recursion":
+    if shape == "xmss" and witness == "xmss":
+        # REAL XMSS signatures: the Poseidon16 table holds the 166 hash calls of each signature's verification with the
+        # precompile variants and memory layout of the aggregation program, ~19 copy_5 ExtensionOp rows and ~330 other
+        # cycles per signature (tests/xmss_witness.py; SURVEY.md §8(f) rank 4, first step).  Hashing on the device.
+        from tests import xmss_witness
+        n_sigs = max(2, N_SIGS >> sh)
+        w = xmss_witness.build(orc, rng, n_sigs=n_sigs, compress=lambda x: ctx.poseidon16(x, compress=True), fill_rows=fill_rows)
+    elif shape == "recursion":
         ext = [(op, be, size, max(1, cnt >> sh)) for op, be, size, cnt in RECURSION_EXT_CALLS]
         w = synth_witness.build(orc, rng, n_calls=100000 >> sh, n_blocks=4096 >> min(sh, 6), log_exec=21 - sh, log_pos=17 - sh,
                                 log_ext=19 - sh, log_memory=max(23 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows,
@@ -234,6 +241,10 @@ def main():
     ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
     ap.add_argument("--soundness", choices=["johnson", "capacity"], default="johnson",
                     help="capacity = the reference's `prox-gaps-conjecture` feature (lean_prover/src/lib.rs:39-43)")
+    ap.add_argument("--witness", choices=["xmss", "synthetic"], default="xmss",
+                    help="xmss (default): real XMSS signatures, the hash calls / copies / cycle count of the aggregation program "
+                         "(tests/xmss_witness.py); synthetic: round 1's straight-line program of Poseidon calls on random inputs "
+                         "(4096 operand blocks, 75 %% padding rows)")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--shape", choices=["xmss", "recursion"], default="xmss",
                     help="xmss = BASELINE configs[1]/[2] (the metric); recursion = configs[3] stand-in: ExtensionOp table 2^19, "
@@ -263,7 +274,7 @@ def main():
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ctx = lm.Context(local_rank)
     capacity = args.soundness == "capacity"
-    w = build_workload(ctx, orc, ob, np.random.default_rng(1000 + rank * 64), args.scale_log, args.log_inv_rate, args.shape, capacity)
+    w = build_workload(ctx, orc, ob, np.random.default_rng(1000 + rank * 64), args.scale_log, args.log_inv_rate, args.shape, capacity, args.witness)
     if args.host_resident:
         w["pinned"] = pin_witness(w)
 
@@ -299,7 +310,8 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        sigs = ((N_SIGS * 167) >> args.scale_log) // 167  # signatures per proof (--scale-log shrinks the leaf)
+        ww = w["w"]
+        sigs = ww.get("n_sigs", ((N_SIGS * 167) >> args.scale_log) // 167)  # signatures per proof (--scale-log shrinks the leaf)
         value = sigs * world / (dt / args.steps)
         sha = source_sha()
         # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
@@ -341,9 +353,14 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
             "data": "synthetic",
             "config": {
-                "workload": f"xmss --n-signatures 1550 --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): ONE prove_execution "
-                            "per step, from the execution trace to the pruned proof, on a consistent synthetic leanVM trace — 258850 "
-                            "Poseidon rows, tables 2^20x20 / 2^18x109 / 2^8x29, memory 2^20, stacked 2^26, logup 2^24, 124-bit WHIR"
+                "workload": f"xmss --n-signatures {sigs} --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): ONE prove_execution "
+                            "per step, from the execution trace to the pruned proof, "
+                            + (f"on the trace of verifying {sigs} REAL XMSS signatures (tests/xmss_witness.py: {ww['counts']['poseidon']} Poseidon16 "
+                               f"calls = 166 per signature with the program's precompile variants and memory layout, "
+                               f"{ww['counts']['extension_op']} copy_5 ExtensionOp rows, {ww['counts']['cycles']} cycles; straight-line bytecode) — "
+                               if "counts" in ww else "on a consistent synthetic leanVM trace (258850 Poseidon calls on random inputs) — ")
+                            + f"tables 2^{ww['log_rows'][0]}x20 / 2^{ww['log_rows'][2]}x109 / 2^{ww['log_rows'][1]}x29, memory 2^{ww['log_memory']}, "
+                              f"bytecode 2^{ww['log_bytecode']}, stacked 2^{w['n_vars']}, 124-bit WHIR"
                             + (" (CapacityBound: prox-gaps-conjecture)" if capacity else "")
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
                 "value_definition": "signatures of one leaf x ranks / latency of one proof (the reference's n_xmss / mean elapsed of "
@@ -423,7 +440,7 @@ def measure_inflight(lm, orc, ob, local_rank, ctx0, w0, C, steps, args, sigs):
     import torch
     ctxs = [ctx0] + [lm.Context(local_rank) for _ in range(C - 1)]
     ws = [w0] + [build_workload(ctxs[c], orc, ob, np.random.default_rng(2000 + c), args.scale_log, args.log_inv_rate, args.shape,
-                                args.soundness == "capacity") for c in range(1, C)]
+                                args.soundness == "capacity", args.witness) for c in range(1, C)]
     for c in range(C):
         run_step(ctxs[c], lm, ws[c])
         ctxs[c].sync()

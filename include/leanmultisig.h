@@ -199,6 +199,16 @@ int lm_fold(lm_ctx* ctx, const uint32_t* d_in, int in_is_ext, uint32_t n_vars, c
 int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars,
                   const uint32_t r[LM_EF_DIM], uint32_t* d_f_out, uint32_t* d_W_out, uint32_t out_c0_c2[10]);
 
+/* Two rounds per pass over the tables (exact identities, the transcript is unchanged; see lm_whir_ops.hip).
+ * lm_prod_round2: eight sums over quads (x[i], x[i + n/4], x[i + n/2], x[i + 3n/4]) of the tables as they are, n = 2^n_vars:
+ *   out = P00, P01, P10, Q0, Q1, T0, T2, T3 (8 EF).  This round: c0 = P00 + P01, c2 = Q0 + Q1.  Next round, as polynomials
+ *   in this round's challenge r: c0'(r) = P00 + r (P10 - P00 - Q0) + r^2 Q0,  c2'(r) = T0 + r (T3 - T0 - T2) + r^2 T2.
+ * lm_fold2_round: fold f and W by r0 then r1 (2^(n_vars-2) entries out), and on the folded tables compute
+ *   sums = 2: the eight sums (40 words, n_vars >= 4), sums = 1: (c0, c2) of the next round (10 words, n_vars >= 3), 0: nothing. */
+int lm_prod_round2(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, uint32_t out_sums[40]);
+int lm_fold2_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, const uint32_t r0[LM_EF_DIM],
+                   const uint32_t r1[LM_EF_DIM], uint32_t* d_f_out, uint32_t* d_W_out, int sums, uint32_t* out_sums);
+
 /* ---- logup numerators / denominators -----------------------------------------------------------------------------
  * The fill loops of prove_generic_logup (crates/sub_protocols/src/logup.rs:88-199) as a list of sections, natural order:
  *     num[out_offset + i] = 0 | 1 | +col[i] | -col[i]

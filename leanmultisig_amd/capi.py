@@ -55,6 +55,8 @@ _SIGS = {
     "lm_copy_d2d": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_mle_eval": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]),
     "lm_weights_accumulate": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
+    "lm_prod_round2": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
+    "lm_fold2_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp]),
     "lm_fold_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]),
     "lm_access_counts": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lm_stack_columns": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),

@@ -159,41 +159,85 @@ struct Sumcheck {  // SumcheckSingle, open.rs:322-330 — device resident
     }
 };
 
-// run_product_sumcheck / run_sumcheck_many_rounds (product_computation.rs:37-125, open.rs:384-409)
+// run_product_sumcheck / run_sumcheck_many_rounds (product_computation.rs:37-125, open.rs:384-409).
+// Two rounds per pass over the tables (lm_prod_round2 / lm_fold2_round): the device returns round t's (c0, c2) together with
+// round t+1's as quadratics in the challenge of round t, which are evaluated here once that challenge is sampled; the two
+// challenges are folded in by the next pass.  The weights change between calls (add_new_equality), so the look-ahead never
+// crosses a call, and the tables are brought up to date before returning.
 int sumcheck_rounds(lm_ctx* ctx, lmh_prover* p, Sumcheck& sc, u32 n_rounds, u32 pow_bits, std::vector<EF>& challenges) {
-    u32 c[10];
-    bool have_c = false;  // (c0, c2) of this round already produced by the previous round's fused fold
-    for (u32 r = 0; r < n_rounds; r++) {
-        int rc;
-        if (!have_c && (rc = lm_prod_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, c))) return rc;
-        EF c0 = ef_load(c), c2 = ef_load(c + 5);
-        EF c1 = kb::ef_sub(kb::ef_sub(sc.sum, kb::ef_dbl(c0)), c2);
-        add_sumcheck_poly(p, {c0, c1, c2}, nullptr);
-        rc = pow_grinding(ctx, p, pow_bits);
-        if (rc) return rc;
-        std::vector<EF> chv;
-        if (!sample_vec(p, 1, chv)) return LM_E_INVALID;
-        EF ch = chv[0];
-        challenges.push_back(ch);
-        sc.sum = kb::ef_add(c0, kb::ef_mul(ch, kb::ef_add(c1, kb::ef_mul(ch, c2))));
-        int fn = sc.f_cur < 0 ? 0 : 1 - sc.f_cur, wn = 1 - sc.w_cur;
-        // the weights change between calls (add_new_equality), so the fused look-ahead is only valid inside this loop
-        have_c = r + 1 < n_rounds && sc.n_vars >= 2;
-        if (have_c) {
-            rc = lm_fold_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, ch.v, sc.f_buf[fn], sc.w_buf[wn], c);
-            if (rc) return rc;
-        } else {
-            rc = lm_fold(ctx, sc.f, sc.f_is_ext, sc.n_vars, ch.v, sc.f_buf[fn]);
-            if (rc) return rc;
-            rc = lm_fold(ctx, sc.W, 1, sc.n_vars, ch.v, sc.w_buf[wn]);
-            if (rc) return rc;
-        }
+    std::vector<EF> pending;  // sampled, not yet folded into the tables
+    bool la_valid = false;
+    EF la[6];
+    auto advance = [&](int fn, int wn, u32 vars) {
         sc.f = sc.f_buf[fn];
         sc.f_is_ext = true;
         sc.f_cur = fn;
         sc.W = sc.w_buf[wn];
         sc.w_cur = wn;
-        sc.n_vars -= 1;
+        sc.n_vars -= vars;
+        pending.clear();
+    };
+    for (u32 r = 0; r < n_rounds; r++) {
+        int rc;
+        EF c0, c2;
+        const u32 remaining = n_rounds - r;
+        const int fn = sc.f_cur < 0 ? 0 : 1 - sc.f_cur, wn = 1 - sc.w_cur;
+        if (la_valid) {
+            const EF& x = pending.back();
+            c0 = kb::ef_add(la[0], kb::ef_mul(x, kb::ef_add(la[1], kb::ef_mul(x, la[2]))));
+            c2 = kb::ef_add(la[3], kb::ef_mul(x, kb::ef_add(la[4], kb::ef_mul(x, la[5]))));
+            la_valid = false;
+        } else {
+            u32 s[40];
+            bool eight = false;
+            if (pending.empty()) {
+                eight = remaining >= 2 && sc.n_vars >= 2;
+                rc = eight ? lm_prod_round2(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, s) : lm_prod_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, s);
+                if (rc) return rc;
+            } else if (pending.size() == 1) {
+                if ((rc = lm_fold_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, pending[0].v, sc.f_buf[fn], sc.w_buf[wn], s))) return rc;
+                advance(fn, wn, 1);
+            } else {
+                eight = remaining >= 2 && sc.n_vars >= 4;
+                rc = lm_fold2_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, pending[0].v, pending[1].v, sc.f_buf[fn], sc.w_buf[wn], eight ? 2 : 1, s);
+                if (rc) return rc;
+                advance(fn, wn, 2);
+            }
+            if (eight) {
+                const EF P00 = ef_load(s), P01 = ef_load(s + 5), P10 = ef_load(s + 10), Q0 = ef_load(s + 15), Q1 = ef_load(s + 20);
+                const EF T0 = ef_load(s + 25), T2 = ef_load(s + 30), T3 = ef_load(s + 35);
+                c0 = kb::ef_add(P00, P01);
+                c2 = kb::ef_add(Q0, Q1);
+                la[0] = P00, la[1] = kb::ef_sub(kb::ef_sub(P10, P00), Q0), la[2] = Q0;
+                la[3] = T0, la[4] = kb::ef_sub(kb::ef_sub(T3, T0), T2), la[5] = T2;
+                la_valid = true;
+            } else {
+                c0 = ef_load(s), c2 = ef_load(s + 5);
+            }
+        }
+        const EF c1 = kb::ef_sub(kb::ef_sub(sc.sum, kb::ef_dbl(c0)), c2);
+        add_sumcheck_poly(p, {c0, c1, c2}, nullptr);
+        rc = pow_grinding(ctx, p, pow_bits);
+        if (rc) return rc;
+        std::vector<EF> chv;
+        if (!sample_vec(p, 1, chv)) return LM_E_INVALID;
+        const EF ch = chv[0];
+        challenges.push_back(ch);
+        sc.sum = kb::ef_add(c0, kb::ef_mul(ch, kb::ef_add(c1, kb::ef_mul(ch, c2))));
+        pending.push_back(ch);
+    }
+    // bring the tables up to date (the caller commits to / reads the folded polynomial next)
+    if (!pending.empty()) {
+        int rc;
+        const int fn = sc.f_cur < 0 ? 0 : 1 - sc.f_cur, wn = 1 - sc.w_cur;
+        if (pending.size() == 1) {
+            if ((rc = lm_fold(ctx, sc.f, sc.f_is_ext, sc.n_vars, pending[0].v, sc.f_buf[fn]))) return rc;
+            if ((rc = lm_fold(ctx, sc.W, 1, sc.n_vars, pending[0].v, sc.w_buf[wn]))) return rc;
+            advance(fn, wn, 1);
+        } else {
+            if ((rc = lm_fold2_round(ctx, sc.f, sc.f_is_ext, sc.W, sc.n_vars, pending[0].v, pending[1].v, sc.f_buf[fn], sc.w_buf[wn], 0, nullptr))) return rc;
+            advance(fn, wn, 2);
+        }
     }
     return LM_OK;
 }

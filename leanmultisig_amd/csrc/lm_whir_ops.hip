@@ -406,6 +406,173 @@ __global__ __launch_bounds__(256) void k_fold_round(const u32* __restrict__ f, c
 }
 
 // =====================================================================================================
+// Two product-sumcheck rounds per pass (MSB-first folding: round t pairs i with i + n/2, round t+1 pairs i with i + n/4).
+// Over a quad (x00, x01, x10, x11) = x[i], x[i + n/4], x[i + n/2], x[i + 3n/4], i < n/4, with D0 = x10 - x00, D1 = x11 - x01:
+//   round t   : c0 = sum f00 W00 + f01 W01                c2 = sum D0f D0W + D1f D1W
+//   round t+1 , after folding by the challenge r of round t (x'0 = x00 + r D0, x'1 = x01 + r D1):
+//               c0'(r) = P00 + r (P10 - P00 - Q0) + r^2 Q0         P00 = sum f00 W00, P10 = sum f10 W10, Q0 = sum D0f D0W
+//               c2'(r) = T0 + r (T3 - T0 - T2) + r^2 T2            T0 / T3 / T2 = sum of (f, W) products of x01 - x00 / x11 - x10 / D1 - D0
+// Eight sums (P00, P01, P10, Q0, Q1, T0, T2, T3; 40 words) give both rounds: the host evaluates the quadratics at r
+// (lm_host.cpp: sumcheck_rounds) and the next pass folds by two challenges at once — half the passes over f and W, half
+// the host round trips.  Exact field identities: the transcript is unchanged.
+// =====================================================================================================
+static constexpr int PR2_WORDS = 40;
+struct Quad2 {
+    EF p00, p01, p10, q0, q1, t0, t2, t3;
+};
+__device__ __forceinline__ void quad_accumulate(const EF f[4], const EF w[4], Quad2& a) {  // order: 00, 01, 10, 11
+    const EF d0f = ef_sub(f[2], f[0]), d1f = ef_sub(f[3], f[1]), d0w = ef_sub(w[2], w[0]), d1w = ef_sub(w[3], w[1]);
+    a.p00 = ef_add(a.p00, ef_mul(f[0], w[0]));
+    a.p01 = ef_add(a.p01, ef_mul(f[1], w[1]));
+    a.p10 = ef_add(a.p10, ef_mul(f[2], w[2]));
+    a.q0 = ef_add(a.q0, ef_mul(d0f, d0w));
+    a.q1 = ef_add(a.q1, ef_mul(d1f, d1w));
+    a.t0 = ef_add(a.t0, ef_mul(ef_sub(f[1], f[0]), ef_sub(w[1], w[0])));
+    a.t3 = ef_add(a.t3, ef_mul(ef_sub(f[3], f[2]), ef_sub(w[3], w[2])));
+    a.t2 = ef_add(a.t2, ef_mul(ef_sub(d1f, d0f), ef_sub(d1w, d0w)));
+}
+__device__ __forceinline__ void quad_accumulate_base(const u32 f[4], const EF w[4], Quad2& a) {
+    const u32 d0f = sub(f[2], f[0]), d1f = sub(f[3], f[1]);
+    const EF d0w = ef_sub(w[2], w[0]), d1w = ef_sub(w[3], w[1]);
+    a.p00 = ef_add(a.p00, ef_mul_base(w[0], f[0]));
+    a.p01 = ef_add(a.p01, ef_mul_base(w[1], f[1]));
+    a.p10 = ef_add(a.p10, ef_mul_base(w[2], f[2]));
+    a.q0 = ef_add(a.q0, ef_mul_base(d0w, d0f));
+    a.q1 = ef_add(a.q1, ef_mul_base(d1w, d1f));
+    a.t0 = ef_add(a.t0, ef_mul_base(ef_sub(w[1], w[0]), sub(f[1], f[0])));
+    a.t3 = ef_add(a.t3, ef_mul_base(ef_sub(w[3], w[2]), sub(f[3], f[2])));
+    a.t2 = ef_add(a.t2, ef_mul_base(ef_sub(d1w, d0w), sub(d1f, d0f)));
+}
+// block sum of the 40 words, then the grid sum / publication (like finish10)
+__device__ __forceinline__ void finish40(const Quad2& a, u32* red /* 4 * 40 + 40 words */, unsigned long long* __restrict__ acc,
+                                         u32* __restrict__ done_counter, u32* __restrict__ h_res, u32 seq) {
+    const EF* e = &a.p00;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u32 v = wave_sum(e[q].v[k]);
+            if (lane == 0) red[wave * PR2_WORDS + q * 5 + k] = v;
+        }
+    __syncthreads();
+    u32* tot = red + 4 * PR2_WORDS;
+    if (threadIdx.x < PR2_WORDS) {
+        u32 t = 0;
+        for (u32 w = 0; w < (blockDim.x >> 6); w++) t = add(t, red[w * PR2_WORDS + threadIdx.x]);
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (gridDim.x > 1 && !lm_grid_sum<PR2_WORDS>(tot, acc, done_counter, tot)) return;
+    if (threadIdx.x < 64) {
+        if (threadIdx.x < PR2_WORDS) lm_store_system(h_res + threadIdx.x, tot[threadIdx.x]);
+        lm_wait_stores();
+        if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
+    }
+}
+// the eight sums on the tables as they are (no fold): lane i < n/4
+template <bool F_BASE>
+__global__ __launch_bounds__(256) void k_prod_round2(const u32* __restrict__ f, const u32* __restrict__ W, u64 quarter,
+                                                     unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
+                                                     u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[5 * PR2_WORDS];
+    const u64 plane = 4 * quarter;
+    Quad2 a;
+    a.p00 = a.p01 = a.p10 = a.q0 = a.q1 = a.t0 = a.t2 = a.t3 = ef_zero();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
+        EF w[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) w[t].v[k] = W[(u64)k * plane + i + t * quarter];
+        if (F_BASE) {
+            u32 fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) fb[t] = f[i + t * quarter];
+            quad_accumulate_base(fb, w, a);
+        } else {
+            EF fe[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) fe[t].v[k] = f[(u64)k * plane + i + t * quarter];
+            quad_accumulate(fe, w, a);
+        }
+    }
+    finish40(a, red, acc, done_counter, final_out, seq);
+}
+// Fold f and W by two challenges (r0: the variable pairing i with i + n/2, then r1: i with i + n/4) and, on the folded
+// tables of m = n/4 entries, compute the eight sums (SUMS = 2, needs m >= 4), only (c0, c2) of the next round (SUMS = 1,
+// m >= 2: words 0..9 of the result) or nothing (SUMS = 0).  Lane j < max(m/4, 1) produces outputs j + t * (m/4), t < 4.
+template <bool F_BASE, int SUMS>
+__global__ __launch_bounds__(256) void k_fold2_round(const u32* __restrict__ f, const u32* __restrict__ W, u64 m, EF r0, EF r1,
+                                                     u32* __restrict__ f_out, u32* __restrict__ W_out,
+                                                     unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
+                                                     u32* __restrict__ final_out, u32 seq) {
+    __shared__ u32 red[5 * PR2_WORDS];
+    const u64 plane = 4 * m;                      // input entries per plane; inputs of output x: x, x + m, x + 2m, x + 3m
+    const u64 step = m >= 4 ? m / 4 : 1;          // distance between the outputs of one lane
+    const int n_out = m >= 4 ? 4 : (int)m;        // outputs per lane (m = 1 or 2: a single lane)
+    Quad2 a;
+    a.p00 = a.p01 = a.p10 = a.q0 = a.q1 = a.t0 = a.t2 = a.t3 = ef_zero();
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < step; j += (u64)gridDim.x * 256) {
+        EF fo[4], wo[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (t >= n_out) {
+                fo[t] = wo[t] = ef_zero();
+                continue;
+            }
+            const u64 x = j + t * step;
+            EF in[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) in[s].v[k] = W[(u64)k * plane + x + s * m];
+            // bit order: s = 2 b0 + b1 with b0 the variable of r0 (distance 2m), b1 that of r1 (distance m)
+            wo[t] = ef_add(ef_add(in[0], ef_mul(r0, ef_sub(in[2], in[0]))),
+                           ef_mul(r1, ef_sub(ef_add(in[1], ef_mul(r0, ef_sub(in[3], in[1]))), ef_add(in[0], ef_mul(r0, ef_sub(in[2], in[0]))))));
+            if (F_BASE) {
+                u32 b[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) b[s] = f[x + s * m];
+                EF y0 = ef_mul_base(r0, sub(b[2], b[0])), y1 = ef_mul_base(r0, sub(b[3], b[1]));
+                y0.v[0] = add(y0.v[0], b[0]);
+                y1.v[0] = add(y1.v[0], b[1]);
+                fo[t] = ef_add(y0, ef_mul(r1, ef_sub(y1, y0)));
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) in[s].v[k] = f[(u64)k * plane + x + s * m];
+                const EF y0 = ef_add(in[0], ef_mul(r0, ef_sub(in[2], in[0]))), y1 = ef_add(in[1], ef_mul(r0, ef_sub(in[3], in[1])));
+                fo[t] = ef_add(y0, ef_mul(r1, ef_sub(y1, y0)));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                f_out[(u64)k * m + x] = fo[t].v[k];
+                W_out[(u64)k * m + x] = wo[t].v[k];
+            }
+            // one output at a time: without the fence the ~100 loads (and their 64-bit addresses) of all four outputs are
+            // requested up front — 256 VGPRs, 2 waves per SIMD, 2.7 TB/s; 24 loads in flight per lane are plenty at 4 waves
+            asm volatile("" ::: "memory");
+        }
+        if (SUMS == 2) {
+            quad_accumulate(fo, wo, a);
+        } else if (SUMS == 1) {  // m = 2 (one pair) or larger: pairs (x, x + m/2) = outputs (0, 2) and (1, 3) of the lane when m >= 4
+            if (m >= 4) {
+                a.p00 = ef_add(a.p00, ef_add(ef_mul(fo[0], wo[0]), ef_mul(fo[1], wo[1])));
+                a.p01 = ef_add(a.p01, ef_add(ef_mul(ef_sub(fo[2], fo[0]), ef_sub(wo[2], wo[0])), ef_mul(ef_sub(fo[3], fo[1]), ef_sub(wo[3], wo[1]))));
+            } else {
+                a.p00 = ef_add(a.p00, ef_mul(fo[0], wo[0]));
+                a.p01 = ef_add(a.p01, ef_mul(ef_sub(fo[1], fo[0]), ef_sub(wo[1], wo[0])));
+            }
+        }
+    }
+    if (SUMS) finish40(a, red, acc, done_counter, final_out, seq);
+}
+
+// =====================================================================================================
 // PoW: candidates base .. base + n; result = min hit (or 0xffffffff)
 // =====================================================================================================
 struct PowArgs {
@@ -648,6 +815,60 @@ int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out_c0_c2, ctx->h_res, 40);
+    return LM_OK;
+}
+
+int lm_prod_round2(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, uint32_t out_sums[40]) {
+    LM_REQUIRE(ctx && d_f && d_W && out_sums && n_vars >= 2 && n_vars <= 40);
+    const u64 quarter = 1ull << (n_vars - 2);
+    const u32 blocks = (u32)std::min<u64>((quarter + 255) / 256, 2048);
+    const u32 seq = ++ctx->res_seq;
+    if (f_is_ext)
+        LM_LAUNCH(ctx, (k_prod_round2<false>), dim3(blocks), dim3(256), 0, d_f, d_W, quarter, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
+    else
+        LM_LAUNCH(ctx, (k_prod_round2<true>), dim3(blocks), dim3(256), 0, d_f, d_W, quarter, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
+    LM_HIP(hipGetLastError());
+    int rc;
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
+    memcpy(out_sums, ctx->h_res, PR2_WORDS * 4);
+    return LM_OK;
+}
+
+int lm_fold2_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, const uint32_t r0[LM_EF_DIM],
+                   const uint32_t r1[LM_EF_DIM], uint32_t* d_f_out, uint32_t* d_W_out, int sums, uint32_t* out_sums) {
+    LM_REQUIRE(ctx && d_f && d_W && d_f_out && d_W_out && r0 && r1 && n_vars >= 2 && n_vars <= 40 && sums >= 0 && sums <= 2);
+    LM_REQUIRE(sums == 0 || out_sums);
+    const u64 m = 1ull << (n_vars - 2);
+    LM_REQUIRE(sums < 2 || m >= 4);
+    LM_REQUIRE(sums < 1 || m >= 2);
+    const u64 lanes = m >= 4 ? m / 4 : 1;
+    const u32 blocks = (u32)std::min<u64>((lanes + 255) / 256, 2048);
+    EF a, b;
+    memcpy(a.v, r0, 20);
+    memcpy(b.v, r1, 20);
+    const u32 seq = sums ? ++ctx->res_seq : 0;
+#define F2(FB, S) LM_LAUNCH(ctx, (k_fold2_round<FB, S>), dim3(blocks), dim3(256), 0, d_f, d_W, m, a, b, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq)
+    if (f_is_ext) {
+        if (sums == 2)
+            F2(false, 2);
+        else if (sums == 1)
+            F2(false, 1);
+        else
+            F2(false, 0);
+    } else {
+        if (sums == 2)
+            F2(true, 2);
+        else if (sums == 1)
+            F2(true, 1);
+        else
+            F2(true, 0);
+    }
+#undef F2
+    LM_HIP(hipGetLastError());
+    if (!sums) return LM_OK;
+    int rc;
+    if ((rc = lm_wait_result(ctx, seq))) return rc;
+    memcpy(out_sums, ctx->h_res, (sums == 2 ? PR2_WORDS : 10) * 4);
     return LM_OK;
 }
 

@@ -110,8 +110,9 @@ pub fn proof_from_bytes(bytes: &[u8]) -> Option<backend::Proof<backend::F>> {
 mod tests {
     use super::*;
 
-    /// External parity pin: `proof.bin` / `instance.bin` come from `python tools/write_proof.py` (a device proof of the
-    /// golden instance of tests/golden/vectors_r01.json + the bytecode / public input it was proven for).
+    /// External parity pin: `proof.bin` / `instance.bin` come from `python tools/write_proof.py` (a device proof, at the
+    /// reference's default_whir_config parameters, of the witness of tests/golden/vectors_r01.json + the bytecode / public
+    /// input it was proven for).
     #[test]
     fn reference_verifier_accepts_the_hip_proof() {
         let dir = std::env::var("LM_PROOF_DIR").unwrap_or_else(|_| "..".into());
@@ -126,7 +127,19 @@ mod tests {
         let public_input: Vec<backend::F> = w[11..11 + n_pub].iter().map(|&x| f(x)).collect();
         let rows: Vec<backend::F> = w[11 + n_pub..].iter().map(|&x| f(x)).collect();
         assert_eq!(rows.len(), 16 << log_bytecode);
-        let bytecode = lean_vm::Bytecode::from_instruction_rows(rows, log_bytecode, ending_pc, hash);
+        // verify_execution reads four things of `Bytecode` (crates/lean_vm/src/isa/bytecode.rs:18-30): instructions_multilinear,
+        // hash, ending_pc and log_size() = log2_ceil(code.len()); `code` itself is only the VM's
+        let bytecode = lean_vm::Bytecode {
+            code: vec![Default::default(); 1 << log_bytecode],
+            instructions_multilinear: rows,
+            starting_frame_memory: 0,
+            ending_pc,
+            hash,
+            function_locations: Default::default(),
+            filepaths: Default::default(),
+            source_code: Default::default(),
+            pc_to_location: Vec::new(),
+        };
         lean_prover::verify_execution::verify_execution(&bytecode, &public_input, proof).expect("reference verifier");
     }
 }

@@ -107,3 +107,22 @@ def test_batches_with_duplicates_and_zero_tails(orc):
     assert np.array_equal(lm.DecodedProof(data).pruned_words(), pruned)
     with pytest.raises(lm.LmError):
         lm.Prover.from_raw(blob, [len(ia)])  # batch sizes must cover every opening
+
+
+def test_external_pin_fixture_is_current(orc, tmp_path):
+    """tests/golden/external_pin/{proof,instance}.bin — what rust_shim's #[test] feeds to the REFERENCE's verify_execution
+    (default_whir_config, 124-bit): the committed files are what tools/write_proof.py produces, and the library's own
+    verifier accepts them with the builder read off the proof."""
+    import subprocess
+    import sys
+    pin = os.path.join(GOLD, "external_pin")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "write_proof.py"), str(tmp_path), "--cpu"], cwd=root)
+    for f in ("proof.bin", "instance.bin"):
+        assert open(os.path.join(pin, f), "rb").read() == open(tmp_path / f, "rb").read(), f
+    inst = np.frombuffer(open(os.path.join(pin, "instance.bin"), "rb").read(), dtype="<u4")
+    log_bc, ending_pc, n_pub = int(inst[0]), int(inst[1]), int(inst[2])
+    w = dict(log_bytecode=log_bc, ending_pc=ending_pc, bytecode_hash=inst[3:11], public_input=inst[11:11 + n_pub],
+             bytecode=inst[11 + n_pub:].reshape(-1, 16))
+    ok, err = lm.verify_execution(w, open(os.path.join(pin, "proof.bin"), "rb").read())
+    assert ok, err

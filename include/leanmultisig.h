@@ -234,6 +234,11 @@ typedef struct {
 int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[LM_EF_DIM],
                    const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens);
 
+/* Same, but only the prefix that holds sections is written (holes between sections get the neutral pair); *out_active_len =
+ * end of the last section.  For lm_gkr_build_active: the tail [active_len, 2^n_vars) is never read. */
+int lm_logup_build_active(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[LM_EF_DIM],
+                          const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens, uint64_t* out_active_len);
+
 /* ---- GKR for a sum of fractions (logup) -----------------------------------------------------------------------------
  * prove_gkr_quotient (crates/sub_protocols/src/quotient_gkr/mod.rs:31-78).  The transcript stays with the caller; the
  * device holds the layers and runs the per-round kernels.  d_nums: 2^n_vars base words, d_dens: SoA EF of 2^n_vars,
@@ -247,6 +252,11 @@ int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sec
  *   lm_gkr_layer_end    fold by the last challenge; inner_evals = [n_l, n_r, d_l, d_r] (4 EF) */
 typedef struct lm_gkr lm_gkr;
 int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out);
+/* Same with an ACTIVE PREFIX: entries [active_len, 2^n_vars) are the neutral pair (0, 1) and are never read (they need not
+ * exist in memory beyond active_len rounded up to a multiple of 8); layers, folds and round sums only touch the prefix, the
+ * all-padding part enters the round polynomials in closed form — what the reference does with its symbolic padding
+ * (quotient_gkr/sumcheck_utils.rs:136,225,331).  Identical transcript. */
+int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, uint64_t active_len, lm_gkr** out);
 void lm_gkr_free(lm_ctx* ctx, lm_gkr* g);
 int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32);
 int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point, const uint32_t alpha[LM_EF_DIM]);

@@ -147,6 +147,10 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* cfg, const 
 int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
                            uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]);
 
+/* entries [active_len, 2^n_vars) are the neutral pair (0, 1) and are never read (lm_gkr_build_active) */
+int lmh_prove_gkr_quotient_active(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
+                                  uint64_t active_len, uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]);
+
 /* ---- batched AIR sumcheck -----------------------------------------------------------------------------------------
  * prove_batched_air_sumcheck (crates/sub_protocols/src/air_sumcheck.rs:636-681) over one session per table, followed by
  * sending every table's final column evaluations (crates/lean_prover/src/prove_execution.rs:212-214).  Tables must be

@@ -66,6 +66,8 @@ _SIGS = {
     "lm_pow_grind": (C.c_int, [vp, vp, C.c_uint32, u32p]),
     "lm_logup_build": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp]),
     "lm_gkr_build": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(vp)]),
+    "lm_logup_build_active": (C.c_int, [vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp]),
+    "lm_gkr_build_active": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.POINTER(vp)]),
     "lm_gkr_free": (None, [vp, vp]),
     "lm_gkr_top": (C.c_int, [vp, vp, vp, vp]),
     "lm_gkr_layer_begin": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
@@ -123,6 +125,7 @@ _HOST_SIGS = {
     "lmh_witness_root": (None, [vp, vp]),
     "lmh_default_whir_builder": (None, [C.c_uint32, C.c_int, vp]),
     "lmh_whir_config_new": (C.c_int, [vp, C.c_uint32, vp]),
+    "lmh_prove_gkr_quotient_active": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp, vp]),
     "lmh_prove_gkr_quotient": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, vp]),
     "lmh_prove_batched_air_sumcheck": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "lmh_stacked_n_vars": (C.c_uint32, [vp]),
@@ -718,12 +721,16 @@ class Prover:
         self.lib.lmh_challenger_state(self.h, _ptr(out))
         return out
 
-    def prove_gkr_quotient(self, d_nums, d_dens, n_vars):
+    def prove_gkr_quotient(self, d_nums, d_dens, n_vars, active_len=None):
+        """active_len: entries beyond it are the neutral pair (0, 1) and are never read (lm_gkr_build_active)"""
         q = np.empty(5, dtype=np.uint32)
         pt = np.empty((n_vars, 5), dtype=np.uint32)
         cl = np.empty((2, 5), dtype=np.uint32)
-        self.ctx._check(self.lib.lmh_prove_gkr_quotient(self.ctx.h, self.h, d_nums.ptr, d_dens.ptr, n_vars, _ptr(q), _ptr(pt),
-                                                        _ptr(cl)))
+        if active_len is None:
+            self.ctx._check(self.lib.lmh_prove_gkr_quotient(self.ctx.h, self.h, d_nums.ptr, d_dens.ptr, n_vars, _ptr(q), _ptr(pt), _ptr(cl)))
+        else:
+            self.ctx._check(self.lib.lmh_prove_gkr_quotient_active(self.ctx.h, self.h, d_nums.ptr, d_dens.ptr, n_vars, active_len, _ptr(q),
+                                                                   _ptr(pt), _ptr(cl)))
         return q, pt, cl
 
     def prove_batched_air_sumcheck(self, tables, alpha, logup_eq16, bus_beta, eta):

@@ -500,11 +500,29 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
                    uint32_t n_statements, const uint32_t* points, uint64_t n_point_coords, const uint64_t* selectors,
                    const uint32_t* values, uint64_t n_values, lmh_witness* witness, const uint32_t* d_poly,
                    uint32_t* out_point) {
-    if (!ctx || !p || !c || !witness || !d_poly || !out_point) return LM_E_INVALID;
+    // "Consumes the witness": on EVERY path out of this function the witness and the tree it owns are released
+    struct WitnessGuard {
+        lm_ctx* ctx;
+        lmh_witness* w;
+        ~WitnessGuard() {
+            if (w) lmh_witness_free(ctx, w);
+        }
+    } witness_guard{ctx, witness};
+    if (!ctx || !p || !c || !witness || !d_poly || !out_point) {
+        witness_guard.w = ctx ? witness : nullptr;
+        lm_set_error("lmh_whir_prove: null argument");
+        return LM_E_INVALID;
+    }
     const u32 n = c->num_variables;
-    if (c->n_rounds > LM_MAX_WHIR_ROUNDS) return LM_E_INVALID;
+    if (c->n_rounds > LM_MAX_WHIR_ROUNDS) {
+        lm_set_error("lmh_whir_prove: more than LM_MAX_WHIR_ROUNDS rounds");
+        return LM_E_INVALID;
+    }
     // validate_parameters, open.rs:18-20
-    if (n != total_fold(c, c->n_rounds) + c->final_sumcheck_rounds) return LM_E_INVALID;
+    if (n != total_fold(c, c->n_rounds) + c->final_sumcheck_rounds) {
+        lm_set_error("lmh_whir_prove: folding factors and final sumcheck rounds do not add up to num_variables (validate_parameters)");
+        return LM_E_INVALID;
+    }
     int rc;
 
     // ---- initialize_first_round_state (open.rs:467-510): OOD statements first, then the caller's --------------
@@ -539,10 +557,16 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         const lm_sparse_statement& st = statements[s];
         if (st.point_len > n || st.n_values == 0 || st.point_offset + st.point_len > n_point_coords ||
             st.values_offset + st.n_values > n_values)
-            return LM_E_INVALID;  // validate_statement, open.rs:22-28
+        {
+            lm_set_error("lmh_whir_prove: statement %u is malformed (validate_statement)", s);
+            return LM_E_INVALID;  // open.rs:22-28
+        }
         for (u32 v = 0; v < st.n_values; v++) {
             u64 sel = selectors[st.values_offset + v];
-            if (sel >= (1ull << (n - st.point_len))) return LM_E_INVALID;
+            if (sel >= (1ull << (n - st.point_len))) {
+                lm_set_error("lmh_whir_prove: selector of statement %u does not fit", s);
+                return LM_E_INVALID;
+            }
             push_item(sel << st.point_len, st.point_len, st.is_next, user_pt_base + st.point_offset, gp);
             sum = kb::ef_add(sum, kb::ef_mul(ef_load(values + (st.values_offset + v) * 5), gp));
             gp = kb::ef_mul(gp, gamma);
@@ -587,8 +611,7 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
     };
     auto fail = [&](int code) {
         if (tree) lm_tree_free(ctx, tree);
-        lmh_witness_free(ctx, witness);
-        return code;
+        return code;  // (the witness itself goes with witness_guard)
     };
 
     for (u32 round = 0; round <= c->n_rounds; round++) {
@@ -725,7 +748,6 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         tree_is_ext = true;
     }
     if (tree) lm_tree_free(ctx, tree);
-    lmh_witness_free(ctx, witness);
     if (randomness.size() != n) return LM_E_INVALID;
     for (u32 i = 0; i < n; i++) memcpy(out_point + 5 * i, randomness[i].v, 20);
     return LM_OK;
@@ -735,9 +757,13 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
 // prove_gkr_quotient (quotient_gkr/mod.rs:31-141) — transcript order of SURVEY.md App. B step 4.
 int lmh_prove_gkr_quotient(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
                            uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]) {
+    return lmh_prove_gkr_quotient_active(ctx, p, d_nums, d_dens, n_vars, n_vars <= 30 ? 1ull << n_vars : 0, out_quotient, out_point, out_claims);
+}
+int lmh_prove_gkr_quotient_active(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars,
+                                  uint64_t active_len, uint32_t out_quotient[5], uint32_t* out_point, uint32_t out_claims[10]) {
     if (!ctx || !p || !d_nums || !d_dens || !out_quotient || !out_point || !out_claims) return LM_E_INVALID;
     lm_gkr* g = nullptr;
-    int rc = lm_gkr_build(ctx, d_nums, d_dens, n_vars, &g);
+    int rc = lm_gkr_build_active(ctx, d_nums, d_dens, n_vars, active_len, &g);
     if (rc) return rc;
     auto fail = [&](int code) {
         lm_gkr_free(ctx, g);
@@ -1151,11 +1177,12 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     DevBuf nums(ctx), dens(ctx);
     if ((rc = lm_malloc(ctx, 1ull << gkr_n_vars, &nums.p))) return fail(rc);
     if ((rc = lm_malloc(ctx, 5ull << gkr_n_vars, &dens.p))) return fail(rc);
-    if ((rc = lm_logup_build(ctx, secs.data(), (u32)secs.size(), logup_c.v, aeq[0].v, gkr_n_vars, nums.p, dens.p))) return fail(rc);
+    u64 gkr_active = 0;  // = loff: the tail up to 2^gkr_n_vars is neutral padding, never materialised
+    if ((rc = lm_logup_build_active(ctx, secs.data(), (u32)secs.size(), logup_c.v, aeq[0].v, gkr_n_vars, nums.p, dens.p, &gkr_active))) return fail(rc);
     clk.mark("logup_fill");
     u32 quotient[5], claims[10];
     std::vector<u32> gkr_pt((size_t)gkr_n_vars * 5);
-    if ((rc = lmh_prove_gkr_quotient(ctx, p, nums.p, dens.p, gkr_n_vars, quotient, gkr_pt.data(), claims))) return fail(rc);
+    if ((rc = lmh_prove_gkr_quotient_active(ctx, p, nums.p, dens.p, gkr_n_vars, gkr_active, quotient, gkr_pt.data(), claims))) return fail(rc);
     clk.mark("logup_gkr");
     if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) {  // assert_eq!(sum, ZERO)
         lm_set_error("logup sum != 0: the witness is inconsistent (a lookup reads a value the memory / bytecode does not hold, or the access counters are wrong)");

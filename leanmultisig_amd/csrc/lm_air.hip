@@ -94,6 +94,49 @@ static constexpr u64 AIR_SPLIT_LAUNCH_PAIRS = 1ull << 13;
 static constexpr u32 AIR_POS_POINTS = 10;                      // evaluation points of the Poseidon table (degree 10)
 static constexpr u32 AIR_POS_SLOTS = 4 * AIR_POS_POINTS + 4;   // rows of its partial-sum matrix, see k_air_round
 
+struct AirLagrange {
+    u32 c[AIR_POS_POINTS][4];
+};
+// Small rounds finish inside k_air_round: the workgroup that takes the last ticket adds up the per-workgroup partial sums
+// (at most AIR_INLINE_MAX_BLOCKS x slots of them), applies the degree-3 extrapolation of the Poseidon partial-round segment
+// and publishes — no k_air_reduce launch.  out == nullptr: the partials are left for k_air_reduce (large rounds, thousands
+// of partials per point).
+struct AirFinish {
+    u32* out;            // this session's slice of the pinned result buffer, or nullptr
+    u32* flag_base;      // h_res (the sequence flag lives behind it)
+    u32* done_counter;
+    u32 seq, deg, n_main, n_low;
+    u64 low_offset;
+    AirLagrange lag;
+};
+static constexpr u32 AIR_INLINE_MAX_BLOCKS = 8;
+__device__ __forceinline__ void air_finish_inline(const u32* __restrict__ partial, u32 blocks_x, const AirFinish& fin) {
+    __shared__ u32 last;
+    __syncthreads();
+    if (threadIdx.x == 0) last = lm_ticket(fin.done_counter) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x < fin.deg * 5) {
+        const u32 zi = threadIdx.x / 5, k = threadIdx.x % 5;
+        u32 v = 0;
+        for (u32 b = 0; b < fin.n_main; b++) v = add(v, lm_load_agent(partial + ((u64)zi * fin.n_main + b) * 5 + k));
+        if (fin.n_low) {
+            for (u32 t = 0; t < 4; t++) {
+                u32 w = 0;
+                for (u32 b = 0; b < fin.n_low; b++) w = add(w, lm_load_agent(partial + (fin.low_offset + (u64)t * fin.n_low + b) * 5 + k));
+                v = add(v, mul(w, fin.lag.c[zi][t]));
+            }
+        }
+        lm_store_system(fin.out + threadIdx.x, v);
+        lm_wait_stores();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lm_store_agent(fin.done_counter, 0);
+        lm_publish_flag(fin.flag_base, fin.seq);
+    }
+}
+
 template <int TABLE, class T, class Cols, int SEG>
 __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 seg, const air::Extra& x) {
     if constexpr (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) {
@@ -165,7 +208,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
 __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : (TABLE == air::T_EXECUTION ? 2 : (sizeof(T) == sizeof(u32) ? AIR_EXT_WAVES : 1)))) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
-                                                   u32* __restrict__ partial, u32 blocks_x, u32 ny) {
+                                                   u32* __restrict__ partial, u32 blocks_x, u32 ny, AirFinish fin) {
     __shared__ u32 lds[20];
     u32 tile, y;
     if ((blocks_x & 7) == 0) {
@@ -223,16 +266,19 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        partial[((u64)slot * blocks_x + tile) * 5 + threadIdx.x] = s;
+        if (fin.out) {
+            lm_store_agent(partial + ((u64)slot * blocks_x + tile) * 5 + threadIdx.x, s);
+            lm_wait_stores();
+        } else {
+            partial[((u64)slot * blocks_x + tile) * 5 + threadIdx.x] = s;
+        }
     }
+    if (fin.out) air_finish_inline(partial, blocks_x, fin);
 }
 // one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
 // out = pinned result buffer; the block that finishes last publishes the sequence number.
 // Block zi sums the n_main consecutive partials of point zi and, for the Poseidon table, adds the degree-3 segment:
 // sum_t lag[zi][t] * (sum of the n_low partials of its slot t), lag = Lagrange basis of the nodes 0..3 at the point.
-struct AirLagrange {
-    u32 c[AIR_POS_POINTS][4];
-};
 __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n_main, u32* __restrict__ out,
                                                     u32* __restrict__ done_counter, u32 seq, u32 n_low, u64 low_offset,
                                                     AirLagrange lag, u32* __restrict__ flag_base) {
@@ -346,12 +392,12 @@ __global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* _
 
 template <int TABLE, class T, class Cols, int SEG>
 static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
-                          u32* partial) {
-    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, grid.x, grid.y);
+                          u32* partial, const AirFinish& fin) {
+    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, grid.x, grid.y, fin);
     return LM_OK;
 }
 template <int TABLE, class T, class Cols>
-static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial, const AirFinish& fin) {
     const air::Extra* extra = a->d_extra;
     if constexpr (TABLE == air::T_POSEIDON16) {
         // Base-field rounds, large: one launch per segment (the combined kernel needs 256 VGPRs there, the per-segment ones
@@ -360,28 +406,30 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
         // 256 + AGPRs (1 wave), and small rounds are latency bound anyway (the five chains run side by side).
         if (sizeof(T) == sizeof(u32) && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
             const dim3 grid(blocks, AIR_POS_POINTS);
-            launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial);
-            launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial);
-            launch_segment<TABLE, T, Cols, 2>(ctx, c, dim3(blocks, 4), n_pairs, extra, eq, partial);
-            launch_segment<TABLE, T, Cols, 3>(ctx, c, grid, n_pairs, extra, eq, partial);
-            launch_segment<TABLE, T, Cols, 4>(ctx, c, grid, n_pairs, extra, eq, partial);
+            AirFinish none = fin;   // five launches: the partials are summed by k_air_reduce (blocks > AIR_INLINE_MAX_BLOCKS here)
+            none.out = nullptr;
+            launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 2>(ctx, c, dim3(blocks, 4), n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 3>(ctx, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 4>(ctx, c, grid, n_pairs, extra, eq, partial, none);
         } else {
-            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial);
+            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial, fin);
         }
     } else {
-        launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial);
+        launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial, fin);
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
 template <int TABLE>
-static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial) {
+static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial, const AirFinish& fin) {
     if (a->cur < 0) {
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
-        return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial);
+        return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
     }
     ExtCols c{a->ef[a->cur], 2 * n_pairs};
-    return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial);
+    return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
 }
 
 extern "C" {
@@ -475,14 +523,6 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     u32* s = a->d_partial;
     int rc;
     const EqSplit eq = a->eqt.at(p);
-    if (a->table == air::T_EXECUTION)
-        rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s);
-    else if (a->table == air::T_EXTENSION_OP)
-        rc = launch_round<air::T_EXTENSION_OP>(ctx, a, n_pairs, blocks, eq, s);
-    else
-        rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s);
-    if (rc) return rc;
-    const u32 seq = ++ctx->res_seq;
     static const AirLagrange pos_lag = [] {  // Lagrange basis of the nodes 0,1,2,3 at z = 0,2,3,..,10 (exact field constants)
         AirLagrange l;
         for (u32 zi = 0; zi < AIR_POS_POINTS; zi++) {
@@ -499,13 +539,29 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
         }
         return l;
     }();
-    AirLagrange lag;
-    if (pos)
-        lag = pos_lag;
+    const u32 seq = ++ctx->res_seq;
+    AirFinish fin;
+    memset(&fin, 0, sizeof fin);
+    if (pos) fin.lag = pos_lag;
+    const bool inline_finish = blocks <= AIR_INLINE_MAX_BLOCKS && !(pos && a->cur < 0 && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS);
+    fin.out = inline_finish ? ctx->h_res + a->res_off : nullptr;
+    fin.flag_base = ctx->h_res;
+    fin.done_counter = ctx->d_sync + 1;
+    fin.seq = seq;
+    fin.deg = a->deg;
+    fin.n_main = pos ? 4 * blocks : blocks;
+    fin.n_low = pos ? blocks : 0u;
+    fin.low_offset = (u64)4 * AIR_POS_POINTS * blocks;
+    if (a->table == air::T_EXECUTION)
+        rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s, fin);
+    else if (a->table == air::T_EXTENSION_OP)
+        rc = launch_round<air::T_EXTENSION_OP>(ctx, a, n_pairs, blocks, eq, s, fin);
     else
-        memset(&lag, 0, sizeof lag);
-    LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, pos ? 4 * blocks : blocks, ctx->h_res + a->res_off, ctx->d_sync + 1,
-              seq, pos ? blocks : 0u, (u64)4 * AIR_POS_POINTS * blocks, lag, ctx->h_res);
+        rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s, fin);
+    if (rc) return rc;
+    if (!inline_finish)
+        LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, fin.n_main, ctx->h_res + a->res_off, ctx->d_sync + 1, seq, fin.n_low,
+                  fin.low_offset, fin.lag, ctx->h_res);
     LM_HIP(hipGetLastError());
     a->pending_seq = seq;
     return LM_OK;

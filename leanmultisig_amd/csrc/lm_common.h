@@ -60,7 +60,8 @@ struct lm_ctx {
     // caching device allocator: freed blocks are kept per size class and reused (hipMalloc/hipFree synchronise the
     // device; a proof performs ~100 allocations).  Single stream => reuse is stream-ordered and safe.
     std::multimap<u64, void*> pool_free;
-    std::map<void*, u64> pool_size;
+    std::map<void*, u64> pool_size;   // every block this pool owns -> its size class
+    std::map<void*, bool> pool_in_use;  // handed out and not yet freed (a second lm_pool_free of the same pointer is ignored)
     u64 pool_bytes = 0;
     // optional per-kernel HIP-event timing (bench.py roofline leg): only launches whose kernel name is selected
     std::string prof_select;    // empty = profiling off; "*" = every kernel

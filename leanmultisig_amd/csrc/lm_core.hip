@@ -227,6 +227,7 @@ hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
     auto it = ctx->pool_free.find(cls);
     if (it != ctx->pool_free.end()) {
         *out = it->second;
+        ctx->pool_in_use[it->second] = true;
         ctx->pool_free.erase(it);
         return hipSuccess;
     }
@@ -238,6 +239,7 @@ hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
         for (auto& kv : ctx->pool_free) {
             (void)hipFree(kv.second);
             ctx->pool_size.erase(kv.second);
+            ctx->pool_in_use.erase(kv.second);
             ctx->pool_bytes -= kv.first;
         }
         ctx->pool_free.clear();
@@ -245,6 +247,7 @@ hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
         if (e != hipSuccess) return e;
     }
     ctx->pool_size[p] = cls;
+    ctx->pool_in_use[p] = true;
     ctx->pool_bytes += cls;
     *out = p;
     return hipSuccess;
@@ -256,6 +259,9 @@ void lm_pool_free(lm_ctx* ctx, void* p) {
         (void)hipFree(p);
         return;
     }
+    bool& in_use = ctx->pool_in_use[p];
+    if (!in_use) return;  // double free: the block is already in the free list (inserting it twice would alias two later allocations)
+    in_use = false;
     ctx->pool_free.emplace(it->second, p);
 }
 
@@ -330,10 +336,20 @@ extern "C" {
 
 const char* lm_last_error(void) { return g_err; }
 
+static int ctx_create_impl(int device, lm_ctx* c);
 int lm_ctx_create(int device, lm_ctx** out) {
     LM_REQUIRE(out);
     LM_HIP(hipSetDevice(device));
     lm_ctx* c = new lm_ctx();
+    const int rc = ctx_create_impl(device, c);
+    if (rc) {
+        lm_ctx_destroy(c);  // releases whatever was allocated before the failure
+        return rc;
+    }
+    *out = c;
+    return LM_OK;
+}
+static int ctx_create_impl(int device, lm_ctx* c) {
     c->device = device;
     LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
@@ -369,12 +385,11 @@ int lm_ctx_create(int device, lm_ctx** out) {
         LM_HIP(hipMemcpyAsync(c->d_coop, tab.data(), COOP_TAB_WORDS * 4, hipMemcpyHostToDevice, c->stream));
         LM_HIP(hipStreamSynchronize(c->stream));
     }
-    *out = c;
     return LM_OK;
 }
 void lm_ctx_destroy(lm_ctx* c) {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
     if (c->d_coop) (void)hipFree(c->d_coop);
@@ -383,7 +398,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 int lm_bind_thread(lm_ctx* ctx) {

@@ -17,6 +17,13 @@ struct lm_gkr {
     const u32* d_nums0 = nullptr;  // caller's input layer (base)
     const u32* d_dens0 = nullptr;  // caller's input layer (SoA EF)
     std::vector<u32*> nums, dens;  // layers n_vars-1 .. 5 (index 0 = 2^(n_vars-1) entries), SoA EF, owned
+    // Active prefix (sub_protocols/src/quotient_gkr/sumcheck_utils.rs:136,225,331 do the same symbolically): only the first
+    // valid0 entries of the input layer / valid[i] of layer i exist in memory — the rest is the neutral pair (0, 1), which stays
+    // (0, 1) under layer construction and (after the alpha shift) (0, alpha, 1, 1) under every fold, so kernels synthesise it
+    // and the sums over the all-padding part are closed forms (alpha * sum of eq weights) added on the host.  Multiples of 8.
+    u64 valid0 = 0;
+    std::vector<u64> valid;
+    u64 arr_valid = 0;  // valid length of the current work arrays
     u32* work[2] = {nullptr, nullptr};  // ping-pong: 4 arrays (nl, nr + alpha dr, dl, dr) x 5 planes
     u64 work_words = 0;
     PrefixEqTables eqt;  // prefix eq tables of the current layer
@@ -37,9 +44,17 @@ struct lm_gkr {
 // ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
 template <bool BASE>
 __global__ __launch_bounds__(256) void k_gkr_layer_up(const u32* __restrict__ n_in, const u32* __restrict__ d_in, u64 m_out,
-                                                      u32* __restrict__ n_out, u32* __restrict__ d_out) {
+                                                      u32* __restrict__ n_out, u32* __restrict__ d_out, u64 valid_in, u64 valid_out) {
     const u64 plane_in = 2 * m_out;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < m_out; i += (u64)gridDim.x * 256) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < valid_out; i += (u64)gridDim.x * 256) {
+        if (2 * i >= valid_in) {  // both children are padding (0, 1): so is the parent
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                n_out[(u64)k * m_out + i] = 0;
+                d_out[(u64)k * m_out + i] = k == 0 ? ONE : 0;
+            }
+            continue;
+        }
         EF d0, d1;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
@@ -153,7 +168,8 @@ __device__ __forceinline__ EF fold_n_base(const u32 (&in)[N], const EF& r0, cons
 // SoA work arrays (nl, nr~, dl, dr).  F: number of pending challenges folded in first.  LA: compute the look-ahead sums.
 template <int MODE, int F, bool LA>
 __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
-                                                  const u32* __restrict__ arr_in, u64 m_out, EF r0, EF r1, EF alpha, EqSplit eq,
+                                                  const u32* __restrict__ arr_in, u64 m_out, u64 n_threads, u64 valid_in, EF r0, EF r1, EF alpha,
+                                                  EqSplit eq,
                                                   u32* __restrict__ out, unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
                                                   u32* __restrict__ h_res, u32 seq) {
     __shared__ u32 lds[4 * GKR_SUM_WORDS];
@@ -162,11 +178,18 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
     const u64 m_in = m_out << F;
     const u32 cls = threadIdx.x & 3;
     EF acc_e = ef_zero(), acc_x = ef_zero(), acc_y = ef_zero();
-    for (u64 base = (u64)blockIdx.x * 256; base < m_out; base += (u64)gridDim.x * 256) {
+    // n_threads <= m_out outputs are computed (a multiple of 8 or m_out itself); outputs whose inputs all lie beyond
+    // valid_in are the folded padding (0, alpha, 1, 1), synthesised without touching memory
+    for (u64 base = (u64)blockIdx.x * 256; base < n_threads; base += (u64)gridDim.x * 256) {
         const u64 i = base + threadIdx.x;
-        const bool active = i < m_out;
+        const bool active = i < n_threads;
         EF x[4];  // nl, nr~, dl, dr at output index i
+        const bool padding = active && (MODE == 2 ? (i << F) : (i << (F + 1))) >= valid_in;
+        if (padding) {
+            x[0] = ef_zero(), x[1] = alpha, x[2] = ef_one(), x[3] = ef_one();
+        }
         if (active) {
+          if (!padding) {
             if constexpr (MODE == 2) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -212,6 +235,7 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
                 }
                 x[1] = ef_add(x[1], ef_mul(alpha, x[3]));  // nr~ = nr + alpha dr
             }
+          }
             if constexpr (F > 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
                 }
             }
         const EF X = ef_add(ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
-        const EF w = eq_split_at(eq, active ? (LA ? i >> 2 : i >> 1) : 0);
+        const EF w = eq_split_at(eq, active ? (LA ? i >> 2 : i >> 1) : 0);  // (n_threads is a multiple of 4: a quad is all-active or all-idle)
         acc_e = ef_add(acc_e, ef_mul(e, w));
         acc_x = ef_add(acc_x, ef_mul(X, w));
         if (LA) {
@@ -307,16 +331,24 @@ void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
     delete g;
 }
 
+static u64 round_up8(u64 x, u64 cap) { return std::min<u64>((x + 7) & ~7ull, cap); }
+
 int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out) {
-    LM_REQUIRE(ctx && d_nums && d_dens && out && n_vars > 5 && n_vars <= 30);
+    return lm_gkr_build_active(ctx, d_nums, d_dens, n_vars, 1ull << (n_vars <= 30 ? n_vars : 0), out);
+}
+int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, uint64_t active_len, lm_gkr** out) {
+    LM_REQUIRE(ctx && d_nums && d_dens && out && n_vars > 5 && n_vars <= 30 && active_len >= 1 && active_len <= (1ull << n_vars));
     lm_gkr* g = new lm_gkr();
     g->n_vars = n_vars;
     g->d_nums0 = d_nums;
     g->d_dens0 = d_dens;
+    g->valid0 = round_up8(active_len, 1ull << n_vars);
     const u32* n_in = d_nums;
     const u32* d_in = d_dens;
+    u64 valid_in = g->valid0;
     for (u32 v = n_vars - 1; v >= 5; v--) {
         const u64 m = 1ull << v;
+        const u64 valid_out = round_up8((valid_in + 1) / 2, m);
         u32 *nn = nullptr, *dd = nullptr;
         if (lm_pool_alloc_t(ctx, &nn, 5 * m * 4) != hipSuccess || lm_pool_alloc_t(ctx, &dd, 5 * m * 4) != hipSuccess) {
             lm_set_error("lm_gkr_build: device allocation failed");
@@ -326,13 +358,15 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
         }
         g->nums.push_back(nn);
         g->dens.push_back(dd);
-        const u32 blocks = (u32)std::min<u64>((m + 255) / 256, 4096);
+        g->valid.push_back(valid_out);
+        const u32 blocks = (u32)std::min<u64>((valid_out + 255) / 256, 4096);
         if (v == n_vars - 1)
-            LM_LAUNCH(ctx, k_gkr_layer_up<true>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd);
+            LM_LAUNCH(ctx, k_gkr_layer_up<true>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, valid_in, valid_out);
         else
-            LM_LAUNCH(ctx, k_gkr_layer_up<false>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd);
+            LM_LAUNCH(ctx, k_gkr_layer_up<false>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, valid_in, valid_out);
         n_in = nn;
         d_in = dd;
+        valid_in = valid_out;
     }
     // work buffers: the first launch that writes folds the biggest layer (2^(n_vars-1) per array) by two challenges
     g->work_words = std::max<u64>(20ull << (n_vars - 3), 256);
@@ -360,10 +394,12 @@ int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32)
     LM_HIP(hipMemcpyAsync(soa[0], g->nums.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipMemcpyAsync(soa[1], g->dens.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP(hipStreamSynchronize(ctx->stream));
+    const u64 valid = g->valid.back();
     for (int i = 0; i < 32; i++)
         for (int k = 0; k < 5; k++) {
-            nums32[i * 5 + k] = soa[0][k * 32 + i];
-            dens32[i * 5 + k] = soa[1][k * 32 + i];
+            const bool pad = (u64)i >= valid;  // never written: the neutral pair (0, 1)
+            nums32[i * 5 + k] = pad ? 0u : soa[0][k * 32 + i];
+            dens32[i * 5 + k] = pad ? (k == 0 ? ONE : 0u) : soa[1][k * 32 + i];
         }
     return LM_OK;
 }
@@ -411,10 +447,15 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const bool la = m_out >= 4;
     const u32 p = g->K - 1 - t;  // round t: 2^p pairs, eq over point[0..p)
     const EqSplit eq = g->eqt.at(la ? p - 1 : p);
-    const u32 blocks = (u32)std::min<u64>((m_out + 255) / 256, 1024);
+    // valid inputs: storage entries of the layer (array index y <-> entries 2y, 2y + 1) or entries of the work arrays
+    const bool input_layer0 = g->K == g->n_vars - 1;
+    const u64 valid_in = g->cur < 0 ? (input_layer0 ? g->valid0 : g->valid[g->n_vars - g->K - 2]) : g->arr_valid;
+    const u64 arr_in_valid = g->cur < 0 ? valid_in / 2 : valid_in;                      // in array entries
+    const u64 n_threads = round_up8((arr_in_valid + (1ull << F) - 1) >> F, m_out);     // outputs that are computed (rest: closed form)
+    const u32 blocks = (u32)std::min<u64>((n_threads + 255) / 256, 1024);
     int rc;
     const u32 seq = ++ctx->res_seq;
-    const bool input_layer = g->K == g->n_vars - 1;
+    const bool input_layer = input_layer0;
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
     // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
     const u32* n_st = input_layer ? g->d_nums0 : g->nums[g->n_vars - g->K - 2];
@@ -424,7 +465,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     u32* counter = ctx->d_sync + 1;
     const u32* nul = nullptr;
 #define GKR_STEP(MODE, FF, LL, NI, DI, AI) \
-    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq)
+    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq)
     if (g->cur < 0) {
         LM_REQUIRE(la);  // K >= 5: the launches that read layer storage always cover two rounds
         if (F == 0) {
@@ -453,7 +494,29 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     EF c0, c2;
     if (la) {
         const EF pt = g->point[p - 1], omp = ef_sub(ef_one(), pt);
-        const EF E0 = S(0, 0), E1 = S(1, 0), E2 = S(2, 0), C01 = S(1, 1), C23 = S(3, 1), T2 = S(0, 1), T0 = S(2, 1), T3 = S(0, 2);
+        // quads beyond n_threads are pure padding: every entry is (0, alpha, 1, 1), so e = alpha and all differences vanish;
+        // their weights add up to the MLE of "zeros then ones" at the eq point (sumcheck_utils.rs:136,331 use the same closed form)
+        EF pad = ef_zero();
+        if (n_threads < m_out) {
+            // sum_{j >= n_zeros} eq(point[0..p-1), j) = mle_of_zeros_then_ones (poly/src/mle/mle_custom.rs:4-19), iteratively:
+            // walking n_zeros' bits from the most significant, every index that agrees so far and has a 1 where n_zeros has a 0 is larger
+            const u64 n_zeros = n_threads / 4;
+            const u32 nb = p - 1;
+            EF acc = ef_zero(), prefix = ef_one();
+            for (u32 b = 0; b < nb; b++) {
+                const EF x = g->point[b];
+                if ((n_zeros >> (nb - 1 - b)) & 1) {
+                    prefix = ef_mul(prefix, x);
+                } else {
+                    acc = ef_add(acc, ef_mul(prefix, x));
+                    prefix = ef_mul(prefix, ef_sub(ef_one(), x));
+                }
+            }
+            acc = ef_add(acc, prefix);  // the index n_zeros itself
+            pad = ef_mul(g->alpha, acc);
+        }
+        const EF E0 = ef_add(S(0, 0), pad), E1 = ef_add(S(1, 0), pad), E2 = ef_add(S(2, 0), pad), C01 = S(1, 1), C23 = S(3, 1), T2 = S(0, 1),
+                 T0 = S(2, 1), T3 = S(0, 2);
         c0 = ef_add(ef_mul(omp, E0), ef_mul(pt, E2));
         c2 = ef_add(ef_mul(omp, C01), ef_mul(pt, C23));
         g->la[0] = E0, g->la[1] = ef_sub(ef_sub(E1, E0), C01), g->la[2] = C01;
@@ -466,6 +529,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     if (F) {
         g->cur = dst;
         g->m = m_out;
+        g->arr_valid = n_threads;
         g->pending.clear();
         if (m_out <= 4) {
             g->fin_m = (u32)m_out;

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void k_logup_fill(const LogupSec* __restrict__
     }
 }
 // neutral pair (0, 1) everywhere (sections overwrite their ranges afterwards)
-__global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u32* __restrict__ nums, u32* __restrict__ dens) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < plane; i += (u64)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u64 fill_len, u32* __restrict__ nums, u32* __restrict__ dens) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < fill_len; i += (u64)gridDim.x * 256) {
         nums[i] = 0;
         dens[i] = ONE;
 #pragma unroll
@@ -66,68 +66,185 @@ __global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u32* __restric
 }
 
 // ---- access counters (crates/lean_prover/src/prove_execution.rs:90-110) ---------------------------------------------
-// acc[index(row) + j] += 1 for every row of an index column and j < n_values: a histogram.  The reference loops
-// sequentially ("TODO parallelize"); here: integer atomics, with the whole-wave-same-address case (padding rows, which all
-// point at one address) collapsed into one atomic, then one pass converts counts to field elements in place.
+// acc[index(row) + j] += 1 for every row of an index column and j < n_values: a histogram of ~12 M word accesses over the
+// memory image.  The reference loops sequentially ("TODO parallelize").  Round 1 used one device-scope atomic per (pair of)
+// counter(s): on this multi-XCD part those execute memory-side at ~2 G/s — 0.8 ms on round 1's synthetic trace (whole waves
+// on one address) but 4.0 ms on the trace of real XMSS verifications, where every address is touched once or twice.
+// Now: no atomics on HBM in the data path.  The address space is cut into windows of ACC_WIN counters that fit LDS;
+//   1. k_acc_hist     per tile of rows: LDS histogram of window ids -> global totals (a handful of atomics per tile)
+//   2. k_acc_scan     exclusive scan of the window totals (one workgroup)
+//   3. k_acc_scatter  per tile: reserve a range of every window's list (one atomic per touched window), store the accesses
+//                     as packed (n_values - 1, address) words
+//   4. k_acc_window   one workgroup per window: LDS counters, then plain coalesced stores of the finished window (the
+//                     window has exactly one owner); runs that straddle the end of a window leave <= 15 counts in a side array
+//   5. k_acc_finish   adds those boundary counts and converts counts to field elements
 struct AccessJob {
     const u32* index_col;  // Montgomery words, canonical value = address
     u64 n_rows;
-    u32 n_values, pad;
+    u32 n_values, tile_begin;  // first tile (workgroup) of this job
 };
-// (A difference-array variant — +1 at the address, -1 after the last word, prefix sum — was measured SLOWER on MI355X:
-// device-scope atomics are executed memory-side, and n_values atomics on one cache line cost less than two on distant lines.)
-// n consecutive counters += v each: 64-bit atomics cover two adjacent 32-bit counters at once (a counter never carries
-// into its neighbour: counts stay far below 2^32)
-__device__ __forceinline__ void add_run(u32* __restrict__ cnt, u32 a, u32 n, u32 v) {
+static constexpr u32 ACC_WIN_LOG = 13, ACC_WIN = 1u << ACC_WIN_LOG;  // 8192 counters = 32 KiB of LDS
+static constexpr u32 ACC_TILE = 8192;                                // rows per workgroup in passes 1 and 3
+static constexpr u32 ACC_MAX_RUN = 16;
+__device__ __forceinline__ bool acc_tile(const AccessJob* __restrict__ jobs, u32 n_jobs, AccessJob& jb, u64& r0) {
     u32 j = 0;
-    if ((a & 1) && n) {
-        atomicAdd(&cnt[a], v);
-        j = 1;
-    }
-    const unsigned long long vv = ((unsigned long long)v << 32) | v;
-    for (; j + 2 <= n; j += 2) atomicAdd(reinterpret_cast<unsigned long long*>(&cnt[a + j]), vv);
-    if (j < n) atomicAdd(&cnt[a + j], v);
+    while (j + 1 < n_jobs && jobs[j + 1].tile_begin <= blockIdx.x) j++;
+    jb = jobs[j];
+    r0 = (u64)(blockIdx.x - jb.tile_begin) * ACC_TILE;
+    return r0 < jb.n_rows;
 }
-__global__ __launch_bounds__(256) void k_access_count(const AccessJob* __restrict__ jobs, u32* __restrict__ cnt, u64 len) {
-    const AccessJob jb = jobs[blockIdx.y];
-    for (u64 r = (u64)blockIdx.x * 256 + threadIdx.x; r < jb.n_rows; r += (u64)gridDim.x * 256) {
-        const u32 a = from_monty(jb.index_col[r]);
-        const bool ok = (u64)a + jb.n_values <= len;
-        const u32 first = __builtin_amdgcn_readfirstlane(a);
-        const u64 same = __ballot(a == first);
-        if (same == __ballot(1)) {  // every active lane hits the same address: one lane adds for the wave
-            if (ok && (threadIdx.x & 63) == (u32)__builtin_ctzll(same)) add_run(cnt, a, jb.n_values, (u32)__popcll(same));
-        } else if (ok) {
-            add_run(cnt, a, jb.n_values, 1u);
+// MODE 0: count list items per window; MODE 1: scatter them.  `nb` windows.  dynamic LDS: nb words (+ nb in MODE 1).
+// A wave whose lanes all read the same address (padding rows: a quarter of the execution table points at one cell) emits
+// ONE item with a multiplicity instead of 64 — otherwise that cell's window would receive ~10^6 items and its single owner
+// in pass 4 would serialise them.  item = (multiplicity - 1) << 17 | (n_values - 1) << 13 | address inside the window.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_acc_pass(const AccessJob* __restrict__ jobs, u32 n_jobs, u64 len, u32 nb, u32* __restrict__ totals,
+                                                  u32* __restrict__ cursor, u32* __restrict__ items) {
+    extern __shared__ u32 sh[];
+    u32* hist = sh;            // per-window item count of this tile, then (MODE 1) running cursor inside the reserved range
+    u32* base = sh + nb;       // MODE 1: start of this tile's range in each window's list
+    AccessJob jb;
+    u64 r0;
+    const bool live = acc_tile(jobs, n_jobs, jb, r0);
+    for (u32 i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
+    __syncthreads();
+    const u64 r1 = live ? (r0 + ACC_TILE < jb.n_rows ? r0 + ACC_TILE : jb.n_rows) : 0;
+    if (MODE == 1) {
+        // reserve: the counts of pass 1 are recomputed here (same rows, same rule), so the ranges are exact
+        for (u64 rb = r0; rb < r1; rb += 256) {
+            const u64 r = rb + threadIdx.x;
+            const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
+            const bool ok = r < r1 && (u64)a + jb.n_values <= len;
+            const u64 all = __ballot(ok);
+            if (!all) continue;
+            const u32 leader = (u32)__builtin_ctzll(all);
+            const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
+            const bool uni = __ballot(ok && a == fa) == all;
+            if (uni ? (threadIdx.x & 63) == leader : ok) atomicAdd(&hist[a >> ACC_WIN_LOG], 1u);
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nb; i += 256) {
+            base[i] = hist[i] ? atomicAdd(&cursor[i], hist[i]) : 0u;  // cursor starts at the window's offset (k_acc_scan)
+            hist[i] = 0;
+        }
+        __syncthreads();
+    }
+    for (u64 rb = r0; rb < r1; rb += 256) {
+        const u64 r = rb + threadIdx.x;
+        const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
+        const bool ok = r < r1 && (u64)a + jb.n_values <= len;
+        const u64 all = __ballot(ok);
+        if (!all) continue;
+        const u32 leader = (u32)__builtin_ctzll(all);
+        const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
+        const bool uni = __ballot(ok && a == fa) == all;
+        if (uni ? (threadIdx.x & 63) == leader : ok) {
+            const u32 w = a >> ACC_WIN_LOG;
+            const u32 slot = atomicAdd(&hist[w], 1u);
+            if (MODE == 1) {
+                const u32 mult = uni ? (u32)__popcll(all) : 1u;
+                items[base[w] + slot] = ((mult - 1) << 17) | ((jb.n_values - 1) << 13) | (a & (ACC_WIN - 1));
+            }
         }
     }
+    if (MODE == 0) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nb; i += 256)
+            if (hist[i]) atomicAdd(&totals[i], hist[i]);
+    }
 }
-__global__ __launch_bounds__(256) void k_counts_to_field(u32* __restrict__ v, u64 n) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) v[i] = to_monty(v[i]);
+// offsets[i] = sum_{j < i} totals[j]; cursor = offsets (one workgroup, nb <= 8192)
+__global__ __launch_bounds__(1024) void k_acc_scan(const u32* __restrict__ totals, u32 nb, u32* __restrict__ offsets, u32* __restrict__ cursor) {
+    __shared__ u32 part[1024];
+    const u32 per = (nb + 1023) / 1024, lo = threadIdx.x * per;
+    u32 s = 0;
+    for (u32 i = lo; i < lo + per && i < nb; i++) s += totals[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+        const u32 v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u32 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (u32 i = lo; i < lo + per && i < nb; i++) {
+        offsets[i] = run;
+        cursor[i] = run;
+        run += totals[i];
+    }
+    if (threadIdx.x == 1023) offsets[nb] = part[1023];
+}
+// one workgroup per window: counters in LDS; cnt[w * ACC_WIN ..] stored once, boundary[w][0..16) = counts past the window's end
+__global__ __launch_bounds__(256) void k_acc_window(const u32* __restrict__ items, const u32* __restrict__ offsets, u64 len,
+                                                    u32* __restrict__ cnt, u32* __restrict__ boundary) {
+    __shared__ u32 c[ACC_WIN + ACC_MAX_RUN];
+    const u32 w = blockIdx.x;
+    for (u32 i = threadIdx.x; i < ACC_WIN + ACC_MAX_RUN; i += 256) c[i] = 0;
+    __syncthreads();
+    const u32 w0 = w << ACC_WIN_LOG;
+    for (u32 k = offsets[w] + threadIdx.x; k < offsets[w + 1]; k += 256) {
+        const u32 it = items[k];
+        const u32 a = it & (ACC_WIN - 1), n = ((it >> 13) & 15) + 1, mult = (it >> 17) + 1;
+        for (u32 j = 0; j < n; j++) atomicAdd(&c[a + j], mult);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < ACC_WIN; i += 256)
+        if ((u64)w0 + i < len) cnt[(u64)w0 + i] = c[i];
+    if (threadIdx.x < ACC_MAX_RUN) boundary[w * ACC_MAX_RUN + threadIdx.x] = c[ACC_WIN + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_acc_finish(u32* __restrict__ v, u64 n, const u32* __restrict__ boundary) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        u32 x = v[i];
+        const u32 w = (u32)(i >> ACC_WIN_LOG), o = (u32)i & (ACC_WIN - 1);
+        if (boundary && w > 0 && o < ACC_MAX_RUN) x += boundary[(w - 1) * ACC_MAX_RUN + o];
+        v[i] = to_monty(x);
+    }
 }
 
 extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint32_t n_jobs, const uint32_t* const* d_index_cols,
                                 const uint64_t* n_rows, const uint32_t* n_values) {
-    LM_REQUIRE(ctx && d_acc && len > 0 && len < (1ull << 31));
+    LM_REQUIRE(ctx && d_acc && len > 0 && len < (1ull << 28));
     LM_REQUIRE(n_jobs == 0 || (d_index_cols && n_rows && n_values));
-    LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
-    if (n_jobs) {
-        std::vector<AccessJob> jobs(n_jobs);
-        u64 max_rows = 1;
-        for (u32 i = 0; i < n_jobs; i++) {
-            LM_REQUIRE(d_index_cols[i] && n_values[i] >= 1 && n_values[i] <= len);
-            jobs[i] = {d_index_cols[i], n_rows[i], n_values[i], 0};
-            max_rows = std::max(max_rows, n_rows[i]);
-        }
-        u32* s;
-        int rc = lm_scratch(ctx, (sizeof(AccessJob) * n_jobs + 3) / 4 + 16, &s);
-        if (rc) return rc;
-        LM_HIP(hipMemcpyAsync(s, jobs.data(), sizeof(AccessJob) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-        LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` is a local
-        const u32 blocks = (u32)std::min<u64>((max_rows + 255) / 256, 4096);
-        LM_LAUNCH(ctx, k_access_count, dim3(blocks, n_jobs), dim3(256), 0, (const AccessJob*)s, d_acc, len);
+    const u32 fin_blocks = (unsigned)std::min<u64>((len + 255) / 256, 4096);
+    if (n_jobs == 0) {
+        LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
+        return LM_OK;  // zero is zero in Montgomery form
     }
-    LM_LAUNCH(ctx, k_counts_to_field, dim3((unsigned)std::min<u64>((len + 255) / 256, 4096)), dim3(256), 0, d_acc, len);
+    std::vector<AccessJob> jobs(n_jobs);
+    u64 total_rows = 0;
+    u32 tiles = 0;
+    for (u32 i = 0; i < n_jobs; i++) {
+        LM_REQUIRE(d_index_cols[i] && n_values[i] >= 1 && n_values[i] <= ACC_MAX_RUN && n_values[i] <= len && n_rows[i] < (1ull << 40));
+        jobs[i] = {d_index_cols[i], n_rows[i], n_values[i], tiles};
+        tiles += (u32)((n_rows[i] + ACC_TILE - 1) / ACC_TILE);
+        total_rows += n_rows[i];
+    }
+    if (tiles == 0) {
+        LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
+        return LM_OK;
+    }
+    LM_REQUIRE(total_rows < (1ull << 31));
+    const u32 nb = (u32)((len + ACC_WIN - 1) >> ACC_WIN_LOG);
+    LM_REQUIRE(nb <= 8192);  // 2 nb words of dynamic LDS (64 KiB), memory images up to 2^26 words (MAX_LOG_MEMORY_SIZE)
+    // scratch (words): jobs | totals nb | offsets nb+1 | cursor nb | boundary nb*16 | items total_rows
+    const u64 w_jobs = (sizeof(AccessJob) * n_jobs + 3) / 4 + 16;
+    u32* s;
+    int rc = lm_scratch(ctx, w_jobs + 3ull * nb + 8 + (u64)nb * ACC_MAX_RUN + total_rows + 64, &s);
+    if (rc) return rc;
+    u32* d_totals = s + w_jobs;
+    u32* d_offsets = d_totals + nb;
+    u32* d_cursor = d_offsets + nb + 1;
+    u32* d_boundary = d_cursor + nb;
+    u32* d_items = d_boundary + (u64)nb * ACC_MAX_RUN;
+    LM_HIP(hipMemcpyAsync(s, jobs.data(), sizeof(AccessJob) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    LM_HIP(hipMemsetAsync(d_totals, 0, (u64)nb * 4, ctx->stream));
+    LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` is a local
+    LM_LAUNCH(ctx, (k_acc_pass<0>), dim3(tiles), dim3(256), (size_t)nb * 4, (const AccessJob*)s, n_jobs, len, nb, d_totals, d_cursor, d_items);
+    LM_LAUNCH(ctx, k_acc_scan, dim3(1), dim3(1024), 0, (const u32*)d_totals, nb, d_offsets, d_cursor);
+    LM_LAUNCH(ctx, (k_acc_pass<1>), dim3(tiles), dim3(256), (size_t)nb * 8, (const AccessJob*)s, n_jobs, len, nb, d_totals, d_cursor, d_items);
+    LM_LAUNCH(ctx, k_acc_window, dim3(nb), dim3(256), 0, (const u32*)d_items, (const u32*)d_offsets, len, d_acc, d_boundary);
+    LM_LAUNCH(ctx, k_acc_finish, dim3(fin_blocks), dim3(256), 0, d_acc, len, (const u32*)d_boundary);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
@@ -260,10 +377,27 @@ extern "C" int lm_poseidon_trace_outputs_from_memory(lm_ctx* ctx, uint32_t* cons
     return LM_OK;
 }
 
+static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5], const uint32_t* alphas_eq16,
+                       uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens, uint64_t* out_active_len);
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
                               const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens) {
+    return logup_build(ctx, sections, n_sections, c, alphas_eq16, n_vars, d_nums, d_dens, nullptr);
+}
+extern "C" int lm_logup_build_active(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],
+                                     const uint32_t* alphas_eq16, uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens, uint64_t* out_active_len) {
+    LM_REQUIRE(out_active_len);
+    return logup_build(ctx, sections, n_sections, c, alphas_eq16, n_vars, d_nums, d_dens, out_active_len);
+}
+// out_active_len != NULL: only [0, end of the last section rounded up to 8) is written (neutral pairs in the holes); the tail is
+// left untouched for lm_gkr_build_active
+static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5], const uint32_t* alphas_eq16,
+                       uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens, uint64_t* out_active_len) {
     LM_REQUIRE(ctx && sections && n_sections && c && alphas_eq16 && d_nums && d_dens && n_vars <= 30);
     const u64 plane = 1ull << n_vars;
+    u64 active = 0;
+    for (u32 k = 0; k < n_sections; k++) active = std::max<u64>(active, sections[k].out_offset + (1ull << sections[k].log_len));
+    const u64 fill_len = out_active_len ? std::min<u64>((active + 7) & ~7ull, plane) : plane;
+    if (out_active_len) *out_active_len = active;
     std::vector<LogupSec> hs(n_sections);
     u64 chunks = 0;
     EF a15;
@@ -300,7 +434,7 @@ extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uin
     LM_HIP(hipStreamSynchronize(ctx->stream));
     EF cc;
     memcpy(cc.v, c, 20);
-    LM_LAUNCH(ctx, k_logup_neutral, dim3((unsigned)std::min<u64>((plane + 255) / 256, 4096)), dim3(256), 0, plane, d_nums, d_dens);
+    LM_LAUNCH(ctx, k_logup_neutral, dim3((unsigned)std::min<u64>((fill_len + 255) / 256, 4096)), dim3(256), 0, plane, fill_len, d_nums, d_dens);
     LM_LAUNCH(ctx, k_logup_fill, dim3((unsigned)chunks), dim3(256), 0, (const LogupSec*)s, n_sections, (const EF*)d_al, cc,
               plane, d_nums, d_dens, to_monty(to_monty(1)));
     LM_HIP(hipGetLastError());

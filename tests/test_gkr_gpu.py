@@ -23,6 +23,24 @@ def test_gkr_matches_oracle(ctx, orc, log_n, frac):
     assert ok, err
 
 
+@pytest.mark.parametrize("log_n,frac", [(6, 0.3), (7, 0.7), (9, 0.05), (11, 0.51), (11, 2 / 3), (13, 0.75), (13, 0.126), (15, 0.999), (12, 1.0)])
+def test_gkr_active_prefix_matches_oracle(ctx, orc, log_n, frac):
+    """lm_gkr_build_active: the (0, 1) tail is neither stored nor read (garbage is put there), its contribution enters in closed
+    form — the reference's symbolic padding (sumcheck_utils.rs:136,225,331).  Same transcript as the fully materialised run."""
+    rng = np.random.default_rng(1000 + log_n * 7 + int(frac * 100))
+    nums, dens = ob.gkr_instance(orc, rng, log_n, frac)
+    active = max(1, int((1 << log_n) * frac))
+    ref_proof, rq, rpt, rcl = ob.gkr_prove(orc, nums, dens)
+    tail = (active + 7) & ~7                         # what must exist in memory: the prefix rounded up to 8 entries
+    junk_n, junk_d = nums.copy(), dens.copy()
+    junk_n[tail:] = ob.rand_field(rng, junk_n[tail:].shape)
+    junk_d[tail:] = ob.rand_field(rng, junk_d[tail:].shape)
+    pr = lm.Prover(ctx)
+    q, pt, cl = pr.prove_gkr_quotient(ctx.to_device(junk_n), ctx.ef_to_device_soa(junk_d), log_n, active_len=active)
+    assert np.array_equal(q, rq) and np.array_equal(pt, rpt) and np.array_equal(cl, rcl)
+    assert np.array_equal(pr.proof(), ref_proof)
+
+
 def test_gkr_large_verifies_and_claims_match_mle(ctx, orc):
     """2^20 entries: too slow for the oracle prover; checked by the oracle verifier + device MLE evaluations of the
     inputs at the returned point (the two checks of the reference test, mod.rs:276-279)."""

@@ -74,11 +74,3 @@ def test_device_proof_of_xmss_witness_equals_oracle(ctx, orc):
     assert np.array_equal(pr.proof(), ref)
     ok, err = lm.verify_execution(w, pr.proof_bytes(), lb)
     assert ok, err
-    # the device entry points that replace get_execution_trace's loops reproduce this witness' tables from the VM log
-    pcs, fps = synth_witness.vm_log(w)
-    bufs = [ctx.alloc(pcs.size) for _ in range(24)]
-    ctx.execution_table_trace(ctx.to_device(pcs), ctx.to_device(fps), pcs.size, ctx.to_device(w["bytecode"].reshape(-1)), w["bytecode"].shape[0],
-                              ctx.to_device(w["memory"]), w["memory"].size, bufs)
-    got = np.stack([x.download() for x in bufs])
-    for c in (0, 1, 5, 6, 7, 8, 9, 10, 19, 20, 21, 22, 23):   # (addr columns of immediate operands are unconstrained: the witness parks them on the zero vector)
-        assert np.array_equal(got[c], w["tables"][0][c]), c

@@ -94,9 +94,44 @@ __device__ __forceinline__ bool acc_tile(const AccessJob* __restrict__ jobs, u32
     return r0 < jb.n_rows;
 }
 // MODE 0: count list items per window; MODE 1: scatter them.  `nb` windows.  dynamic LDS: nb words (+ nb in MODE 1).
-// A wave whose lanes all read the same address (padding rows: a quarter of the execution table points at one cell) emits
-// ONE item with a multiplicity instead of 64 — otherwise that cell's window would receive ~10^6 items and its single owner
-// in pass 4 would serialise them.  item = (multiplicity - 1) << 17 | (n_values - 1) << 13 | address inside the window.
+// Runs of rows that read the SAME address are run-length encoded per wave (padding rows: a quarter of the execution table
+// points at one cell — as plain items that cell's window would receive ~10^6 of them and its single owner in pass 4 would
+// serialise them on one LDS counter): a wave whose 64 lanes agree extends its current run instead of emitting 64 items.
+// item = (multiplicity - 1) << 17 | (n_values - 1) << 13 | address inside the window        (multiplicity <= 64 x 32)
+template <int MODE>
+__device__ __forceinline__ void acc_emit(u32 a, u32 mult, u32 n_values, u32* hist, const u32* base, u32* __restrict__ items) {
+    const u32 w = a >> ACC_WIN_LOG;
+    const u32 slot = atomicAdd(&hist[w], 1u);
+    if (MODE == 1) items[base[w] + slot] = ((mult - 1) << 17) | ((n_values - 1) << 13) | (a & (ACC_WIN - 1));
+}
+template <int MODE>
+__device__ __forceinline__ void acc_rows(const AccessJob& jb, u64 r0, u64 r1, u64 len, u32* hist, const u32* base, u32* __restrict__ items) {
+    const u32 lane = threadIdx.x & 63;
+    u32 run_addr = 0, run_cnt = 0;  // wave-uniform
+    for (u64 rb = r0; rb < r1; rb += 256) {
+        const u64 r = rb + threadIdx.x;
+        const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
+        const bool ok = r < r1 && (u64)a + jb.n_values <= len;
+        const u64 all = __ballot(ok);
+        if (!all) continue;
+        const u32 leader = (u32)__builtin_ctzll(all);
+        const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
+        const bool uni = __ballot(ok && a == fa) == all;
+        if (uni && run_cnt && fa == run_addr) {
+            run_cnt += (u32)__popcll(all);
+            continue;
+        }
+        if (run_cnt && lane == 0) acc_emit<MODE>(run_addr, run_cnt, jb.n_values, hist, base, items);
+        run_cnt = 0;
+        if (uni) {
+            run_addr = fa;
+            run_cnt = (u32)__popcll(all);
+        } else if (ok) {
+            acc_emit<MODE>(a, 1u, jb.n_values, hist, base, items);
+        }
+    }
+    if (run_cnt && lane == 0) acc_emit<MODE>(run_addr, run_cnt, jb.n_values, hist, base, items);
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void k_acc_pass(const AccessJob* __restrict__ jobs, u32 n_jobs, u64 len, u32 nb, u32* __restrict__ totals,
                                                   u32* __restrict__ cursor, u32* __restrict__ items) {
@@ -109,49 +144,21 @@ __global__ __launch_bounds__(256) void k_acc_pass(const AccessJob* __restrict__ 
     for (u32 i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
     __syncthreads();
     const u64 r1 = live ? (r0 + ACC_TILE < jb.n_rows ? r0 + ACC_TILE : jb.n_rows) : 0;
-    if (MODE == 1) {
-        // reserve: the counts of pass 1 are recomputed here (same rows, same rule), so the ranges are exact
-        for (u64 rb = r0; rb < r1; rb += 256) {
-            const u64 r = rb + threadIdx.x;
-            const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
-            const bool ok = r < r1 && (u64)a + jb.n_values <= len;
-            const u64 all = __ballot(ok);
-            if (!all) continue;
-            const u32 leader = (u32)__builtin_ctzll(all);
-            const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
-            const bool uni = __ballot(ok && a == fa) == all;
-            if (uni ? (threadIdx.x & 63) == leader : ok) atomicAdd(&hist[a >> ACC_WIN_LOG], 1u);
-        }
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < nb; i += 256) {
-            base[i] = hist[i] ? atomicAdd(&cursor[i], hist[i]) : 0u;  // cursor starts at the window's offset (k_acc_scan)
-            hist[i] = 0;
-        }
-        __syncthreads();
-    }
-    for (u64 rb = r0; rb < r1; rb += 256) {
-        const u64 r = rb + threadIdx.x;
-        const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
-        const bool ok = r < r1 && (u64)a + jb.n_values <= len;
-        const u64 all = __ballot(ok);
-        if (!all) continue;
-        const u32 leader = (u32)__builtin_ctzll(all);
-        const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
-        const bool uni = __ballot(ok && a == fa) == all;
-        if (uni ? (threadIdx.x & 63) == leader : ok) {
-            const u32 w = a >> ACC_WIN_LOG;
-            const u32 slot = atomicAdd(&hist[w], 1u);
-            if (MODE == 1) {
-                const u32 mult = uni ? (u32)__popcll(all) : 1u;
-                items[base[w] + slot] = ((mult - 1) << 17) | ((jb.n_values - 1) << 13) | (a & (ACC_WIN - 1));
-            }
-        }
-    }
+    // (each wave walks a fixed quarter of the tile's iterations: the run-length state is per wave)
+    acc_rows<0>(jb, r0, r1, len, hist, base, items);  // count
+    __syncthreads();
     if (MODE == 0) {
-        __syncthreads();
         for (u32 i = threadIdx.x; i < nb; i += 256)
             if (hist[i]) atomicAdd(&totals[i], hist[i]);
+        return;
     }
+    // reserve a range per touched window (the counts are exact: pass 3 repeats the walk of pass 1), then scatter
+    for (u32 i = threadIdx.x; i < nb; i += 256) {
+        base[i] = hist[i] ? atomicAdd(&cursor[i], hist[i]) : 0u;  // cursor starts at the window's offset (k_acc_scan)
+        hist[i] = 0;
+    }
+    __syncthreads();
+    acc_rows<1>(jb, r0, r1, len, hist, base, items);
 }
 // offsets[i] = sum_{j < i} totals[j]; cursor = offsets (one workgroup, nb <= 8192)
 __global__ __launch_bounds__(1024) void k_acc_scan(const u32* __restrict__ totals, u32 nb, u32* __restrict__ offsets, u32* __restrict__ cursor) {

@@ -150,7 +150,8 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
 /* Access counters of prove_execution (crates/lean_prover/src/prove_execution.rs:90-110): d_acc[0..len) = number of times
  * each address is read, as field elements: for every job (an index column of a table lookup, canonical value = address)
  * and every row, d_acc[address + j] += 1 for j < n_values.  Rows whose address range falls outside [0, len) are ignored
- * (the reference would panic).  Used for memory_acc (all table lookups) and bytecode_acc (the pc column, n_values = 1). */
+ * (the reference would panic).  Used for memory_acc (all table lookups) and bytecode_acc (the pc column, n_values = 1).
+ * n_jobs <= 16, n_values <= 16, len < 2^28. */
 int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint32_t n_jobs, const uint32_t* const* d_index_cols,
                      const uint64_t* n_rows, const uint32_t* n_values);
 

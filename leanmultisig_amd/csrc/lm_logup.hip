@@ -85,11 +85,15 @@ struct AccessJob {
 };
 static constexpr u32 ACC_WIN_LOG = 13, ACC_WIN = 1u << ACC_WIN_LOG;  // 8192 counters = 32 KiB of LDS
 static constexpr u32 ACC_TILE = 8192;                                // rows per workgroup in passes 1 and 3
-static constexpr u32 ACC_MAX_RUN = 16;
-__device__ __forceinline__ bool acc_tile(const AccessJob* __restrict__ jobs, u32 n_jobs, AccessJob& jb, u64& r0) {
+static constexpr u32 ACC_MAX_RUN = 16, ACC_MAX_JOBS = 16;
+struct AccessJobs {  // a kernel argument (no upload, no synchronisation)
+    AccessJob j[ACC_MAX_JOBS];
+    u32 n;
+};
+__device__ __forceinline__ bool acc_tile(const AccessJobs& jobs, AccessJob& jb, u64& r0) {
     u32 j = 0;
-    while (j + 1 < n_jobs && jobs[j + 1].tile_begin <= blockIdx.x) j++;
-    jb = jobs[j];
+    while (j + 1 < jobs.n && jobs.j[j + 1].tile_begin <= blockIdx.x) j++;
+    jb = jobs.j[j];
     r0 = (u64)(blockIdx.x - jb.tile_begin) * ACC_TILE;
     return r0 < jb.n_rows;
 }
@@ -104,6 +108,9 @@ __device__ __forceinline__ void acc_emit(u32 a, u32 mult, u32 n_values, u32* his
     const u32 slot = atomicAdd(&hist[w], 1u);
     if (MODE == 1) items[base[w] + slot] = ((mult - 1) << 17) | ((n_values - 1) << 13) | (a & (ACC_WIN - 1));
 }
+// Each wave keeps one RUN (address, count) across its iterations: lanes that read the run's address only bump the count; the
+// run ends when an iteration has no such lane.  Hot addresses are a feature of real traces, not only of padding: every
+// instruction operand that is an immediate looks up memory[0] (trace_gen.rs:46-60), interleaved with real addresses.
 template <int MODE>
 __device__ __forceinline__ void acc_rows(const AccessJob& jb, u64 r0, u64 r1, u64 len, u32* hist, const u32* base, u32* __restrict__ items) {
     const u32 lane = threadIdx.x & 63;
@@ -112,35 +119,46 @@ __device__ __forceinline__ void acc_rows(const AccessJob& jb, u64 r0, u64 r1, u6
         const u64 r = rb + threadIdx.x;
         const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
         const bool ok = r < r1 && (u64)a + jb.n_values <= len;
-        const u64 all = __ballot(ok);
-        if (!all) continue;
-        const u32 leader = (u32)__builtin_ctzll(all);
-        const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
-        const bool uni = __ballot(ok && a == fa) == all;
-        if (uni && run_cnt && fa == run_addr) {
-            run_cnt += (u32)__popcll(all);
-            continue;
+        u64 rest = __ballot(ok);
+        if (!rest) continue;
+        if (run_cnt) {
+            const u64 m = __ballot(ok && a == run_addr);
+            if (m) {
+                run_cnt += (u32)__popcll(m);
+                rest &= ~m;
+            } else {
+                if (lane == 0) acc_emit<MODE>(run_addr, run_cnt, jb.n_values, hist, base, items);
+                run_cnt = 0;
+            }
         }
-        if (run_cnt && lane == 0) acc_emit<MODE>(run_addr, run_cnt, jb.n_values, hist, base, items);
-        run_cnt = 0;
-        if (uni) {
-            run_addr = fa;
-            run_cnt = (u32)__popcll(all);
-        } else if (ok) {
-            acc_emit<MODE>(a, 1u, jb.n_values, hist, base, items);
+        if (rest) {  // one more group: the lanes that agree with the first remaining one
+            const u32 leader = (u32)__builtin_ctzll(rest);
+            const u32 fa = (u32)__shfl((int)a, (int)leader, 64);
+            const u64 g = __ballot(((rest >> lane) & 1) && a == fa);
+            const u32 gn = (u32)__popcll(g);
+            if (gn >= 2) {
+                if (!run_cnt) {
+                    run_addr = fa;
+                    run_cnt = gn;
+                } else if (lane == leader) {
+                    acc_emit<MODE>(fa, gn, jb.n_values, hist, base, items);
+                }
+                rest &= ~g;
+            }
+            if ((rest >> lane) & 1) acc_emit<MODE>(a, 1u, jb.n_values, hist, base, items);
         }
     }
     if (run_cnt && lane == 0) acc_emit<MODE>(run_addr, run_cnt, jb.n_values, hist, base, items);
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_acc_pass(const AccessJob* __restrict__ jobs, u32 n_jobs, u64 len, u32 nb, u32* __restrict__ totals,
+__global__ __launch_bounds__(256) void k_acc_pass(const AccessJobs jobs, u64 len, u32 nb, u32* __restrict__ totals,
                                                   u32* __restrict__ cursor, u32* __restrict__ items) {
     extern __shared__ u32 sh[];
     u32* hist = sh;            // per-window item count of this tile, then (MODE 1) running cursor inside the reserved range
     u32* base = sh + nb;       // MODE 1: start of this tile's range in each window's list
     AccessJob jb;
     u64 r0;
-    const bool live = acc_tile(jobs, n_jobs, jb, r0);
+    const bool live = acc_tile(jobs, jb, r0);
     for (u32 i = threadIdx.x; i < nb; i += 256) hist[i] = 0;
     __syncthreads();
     const u64 r1 = live ? (r0 + ACC_TILE < jb.n_rows ? r0 + ACC_TILE : jb.n_rows) : 0;
@@ -182,23 +200,37 @@ __global__ __launch_bounds__(1024) void k_acc_scan(const u32* __restrict__ total
     }
     if (threadIdx.x == 1023) offsets[nb] = part[1023];
 }
-// one workgroup per window: counters in LDS; cnt[w * ACC_WIN ..] stored once, boundary[w][0..16) = counts past the window's end
-__global__ __launch_bounds__(256) void k_acc_window(const u32* __restrict__ items, const u32* __restrict__ offsets, u64 len,
+// one workgroup per window: counters in LDS; cnt[w * ACC_WIN ..] stored once, boundary[w][0..16) = counts past the window's end.
+// A window whose list is long (real traces have them: the window of the public input, the constants and the zero vector
+// receives ~4 x 10^5 items where the others get ~6 x 10^3) is split between up to ACC_SPLIT workgroups, which ADD their
+// non-zero counters to the (pre-zeroed) output instead — the only HBM atomics left, a few 10^4 per proof.
+static constexpr u32 ACC_SPLIT = 16, ACC_HEAVY = 16384;
+__global__ __launch_bounds__(256) void k_acc_window(const u32* __restrict__ items, const u32* __restrict__ offsets, u64 len, u32 nb,
                                                     u32* __restrict__ cnt, u32* __restrict__ boundary) {
     __shared__ u32 c[ACC_WIN + ACC_MAX_RUN];
-    const u32 w = blockIdx.x;
+    const u32 w = blockIdx.x % nb, part = blockIdx.x / nb;  // part-major: the workgroups that always have work come first
+    const u32 k0 = offsets[w], k1 = offsets[w + 1], n = k1 - k0;
+    const u32 parts = n <= ACC_HEAVY ? 1u : min(ACC_SPLIT, (n + ACC_HEAVY / 2 - 1) / (ACC_HEAVY / 2));
+    if (part >= parts) return;
+    const u32 per = (n + parts - 1) / parts, lo = k0 + part * per, hi = min(k1, lo + per);
     for (u32 i = threadIdx.x; i < ACC_WIN + ACC_MAX_RUN; i += 256) c[i] = 0;
     __syncthreads();
     const u32 w0 = w << ACC_WIN_LOG;
-    for (u32 k = offsets[w] + threadIdx.x; k < offsets[w + 1]; k += 256) {
+    for (u32 k = lo + threadIdx.x; k < hi; k += 256) {
         const u32 it = items[k];
-        const u32 a = it & (ACC_WIN - 1), n = ((it >> 13) & 15) + 1, mult = (it >> 17) + 1;
-        for (u32 j = 0; j < n; j++) atomicAdd(&c[a + j], mult);
+        const u32 a = it & (ACC_WIN - 1), nv = ((it >> 13) & 15) + 1, mult = (it >> 17) + 1;
+        for (u32 j = 0; j < nv; j++) atomicAdd(&c[a + j], mult);
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < ACC_WIN; i += 256)
-        if ((u64)w0 + i < len) cnt[(u64)w0 + i] = c[i];
-    if (threadIdx.x < ACC_MAX_RUN) boundary[w * ACC_MAX_RUN + threadIdx.x] = c[ACC_WIN + threadIdx.x];
+    if (parts == 1) {
+        for (u32 i = threadIdx.x; i < ACC_WIN; i += 256)
+            if ((u64)w0 + i < len) cnt[(u64)w0 + i] = c[i];
+        if (threadIdx.x < ACC_MAX_RUN) boundary[w * ACC_MAX_RUN + threadIdx.x] = c[ACC_WIN + threadIdx.x];
+    } else {
+        for (u32 i = threadIdx.x; i < ACC_WIN; i += 256)
+            if (c[i] && (u64)w0 + i < len) atomicAdd(&cnt[(u64)w0 + i], c[i]);
+        if (threadIdx.x < ACC_MAX_RUN && c[ACC_WIN + threadIdx.x]) atomicAdd(&boundary[w * ACC_MAX_RUN + threadIdx.x], c[ACC_WIN + threadIdx.x]);
+    }
 }
 __global__ __launch_bounds__(256) void k_acc_finish(u32* __restrict__ v, u64 n, const u32* __restrict__ boundary) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
@@ -218,12 +250,14 @@ extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint
         LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
         return LM_OK;  // zero is zero in Montgomery form
     }
-    std::vector<AccessJob> jobs(n_jobs);
+    LM_REQUIRE(n_jobs <= ACC_MAX_JOBS);
+    AccessJobs jobs{};
+    jobs.n = n_jobs;
     u64 total_rows = 0;
     u32 tiles = 0;
     for (u32 i = 0; i < n_jobs; i++) {
         LM_REQUIRE(d_index_cols[i] && n_values[i] >= 1 && n_values[i] <= ACC_MAX_RUN && n_values[i] <= len && n_rows[i] < (1ull << 40));
-        jobs[i] = {d_index_cols[i], n_rows[i], n_values[i], tiles};
+        jobs.j[i] = {d_index_cols[i], n_rows[i], n_values[i], tiles};
         tiles += (u32)((n_rows[i] + ACC_TILE - 1) / ACC_TILE);
         total_rows += n_rows[i];
     }
@@ -234,23 +268,22 @@ extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint
     LM_REQUIRE(total_rows < (1ull << 31));
     const u32 nb = (u32)((len + ACC_WIN - 1) >> ACC_WIN_LOG);
     LM_REQUIRE(nb <= 8192);  // 2 nb words of dynamic LDS (64 KiB), memory images up to 2^26 words (MAX_LOG_MEMORY_SIZE)
-    // scratch (words): jobs | totals nb | offsets nb+1 | cursor nb | boundary nb*16 | items total_rows
-    const u64 w_jobs = (sizeof(AccessJob) * n_jobs + 3) / 4 + 16;
+    // scratch (words): totals nb | offsets nb+1 | cursor nb | boundary nb*16 | items total_rows
     u32* s;
-    int rc = lm_scratch(ctx, w_jobs + 3ull * nb + 8 + (u64)nb * ACC_MAX_RUN + total_rows + 64, &s);
+    int rc = lm_scratch(ctx, 3ull * nb + 8 + (u64)nb * ACC_MAX_RUN + total_rows + 64, &s);
     if (rc) return rc;
-    u32* d_totals = s + w_jobs;
+    u32* d_totals = s;
     u32* d_offsets = d_totals + nb;
     u32* d_cursor = d_offsets + nb + 1;
     u32* d_boundary = d_cursor + nb;
     u32* d_items = d_boundary + (u64)nb * ACC_MAX_RUN;
-    LM_HIP(hipMemcpyAsync(s, jobs.data(), sizeof(AccessJob) * n_jobs, hipMemcpyHostToDevice, ctx->stream));
     LM_HIP(hipMemsetAsync(d_totals, 0, (u64)nb * 4, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` is a local
-    LM_LAUNCH(ctx, (k_acc_pass<0>), dim3(tiles), dim3(256), (size_t)nb * 4, (const AccessJob*)s, n_jobs, len, nb, d_totals, d_cursor, d_items);
+    LM_HIP(hipMemsetAsync(d_boundary, 0, (u64)nb * ACC_MAX_RUN * 4, ctx->stream));  // split windows add into these two
+    LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
+    LM_LAUNCH(ctx, (k_acc_pass<0>), dim3(tiles), dim3(256), (size_t)nb * 4, jobs, len, nb, d_totals, d_cursor, d_items);
     LM_LAUNCH(ctx, k_acc_scan, dim3(1), dim3(1024), 0, (const u32*)d_totals, nb, d_offsets, d_cursor);
-    LM_LAUNCH(ctx, (k_acc_pass<1>), dim3(tiles), dim3(256), (size_t)nb * 8, (const AccessJob*)s, n_jobs, len, nb, d_totals, d_cursor, d_items);
-    LM_LAUNCH(ctx, k_acc_window, dim3(nb), dim3(256), 0, (const u32*)d_items, (const u32*)d_offsets, len, d_acc, d_boundary);
+    LM_LAUNCH(ctx, (k_acc_pass<1>), dim3(tiles), dim3(256), (size_t)nb * 8, jobs, len, nb, d_totals, d_cursor, d_items);
+    LM_LAUNCH(ctx, k_acc_window, dim3(nb * ACC_SPLIT), dim3(256), 0, (const u32*)d_items, (const u32*)d_offsets, len, nb, d_acc, d_boundary);
     LM_LAUNCH(ctx, k_acc_finish, dim3(fin_blocks), dim3(256), 0, d_acc, len, (const u32*)d_boundary);
     LM_HIP(hipGetLastError());
     return LM_OK;

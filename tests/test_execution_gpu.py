@@ -66,6 +66,27 @@ def test_access_counts_match_histogram(ctx):
     assert np.array_equal(ctx.access_counts(64, []).download(), np.zeros(64, dtype=np.uint32))
 
 
+def test_access_counts_hot_window(ctx):
+    """the shape of a real trace: most lookups scattered, but one window (public input, constants, the zero vector) receives
+    a large share — hot addresses interleaved with real ones inside a wave, runs that straddle the window's end — so that
+    window's list is split between several workgroups."""
+    rng = np.random.default_rng(5)
+    P = 0x7F000001
+    length = (1 << 16) + 100
+    to_m = lambda a: ((a.astype(np.uint64) << np.uint64(32)) % np.uint64(P)).astype(np.uint32)  # noqa: E731
+    n = 200000
+    scattered = rng.integers(0, length - 16, size=n)
+    low = rng.integers(8192 - 40, 2 * 8192, size=n)           # window 1, some runs end in window 2
+    hot = np.where(rng.random(n) < 0.3, 8192 + 64, np.where(rng.random(n) < 0.2, 8192 + 65, scattered))
+    jobs, want = [], np.zeros(length, dtype=np.int64)
+    for addr, nv in ((scattered, 1), (low, 16), (hot, 5), (low, 1), (hot, 1)):
+        jobs.append((ctx.to_device(to_m(addr)), addr.size, nv))
+        for j in range(nv):
+            want += np.bincount(addr + j, minlength=length)
+    got = ctx.access_counts(length, jobs).download()
+    assert np.array_equal(got, to_m(want))
+
+
 def test_prove_execution_production_parameters_verifies(ctx, orc):
     """default_whir_config (124-bit, 16 PoW bits, lean_prover/src/lib.rs:22-50), different table heights, bigger program:
     too slow for the oracle PROVER, checked by the oracle VERIFIER."""

@@ -211,6 +211,14 @@ int lmh_verify_execution_bytes(const lm_verify_instance* instance, const uint8_t
 /* the proof still held by a prover object (pruned and restored on the way, like a proof that travelled) */
 int lmh_verify_execution_prover(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder);
 
+/* ---- host Poseidon1-16 (poseidon1_koalabear_16.rs:873-1030) ----------------------------------------------------------------
+ * The transcript's permutation: ~1300 strictly sequential calls per proof between device launches, so its latency is on the
+ * critical path.  "avx512-ifma" when the CPU has AVX-512 F/DQ/BW/VL/IFMA (the reference's own Poseidon is AVX2/AVX-512/NEON
+ * code), else "scalar"; LM_HOST_POSEIDON_SCALAR=1 forces the scalar code.  Both are the same function. */
+const char* lmh_poseidon_backend(void);
+void lmh_poseidon16_permute(uint32_t state[16]);        /* the backend in use */
+void lmh_poseidon16_permute_scalar(uint32_t state[16]); /* always the scalar code */
+
 #ifdef __cplusplus
 }
 #endif

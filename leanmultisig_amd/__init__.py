@@ -4,6 +4,6 @@ The product is the HIP shared library `libleanmultisig_hip.so` (C ABI: include/l
 ctypes binding used by the tests and bench; it never falls back to a CPU implementation: if the library is missing
 `load()` raises.
 """
-from .capi import Context, Prover, WhirConfig, WhirBuilder, DecodedProof, lz4_compress, lz4_decompress, verify_execution, load, LIB_PATH, LmError, make_execution_trace  # noqa: F401
+from .capi import Context, Prover, WhirConfig, WhirBuilder, DecodedProof, lz4_compress, lz4_decompress, verify_execution, host_poseidon_backend, host_poseidon16_permute, load, LIB_PATH, LmError, make_execution_trace  # noqa: F401
 
 __all__ = ["Context", "Prover", "WhirConfig", "WhirBuilder", "load", "LIB_PATH", "LmError"]

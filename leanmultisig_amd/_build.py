@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libleanmultisig_hip.so")
-SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_air.hip", "lm_logup.hip", "host/lm_host.cpp", "host/lm_whir_config.cpp", "host/lm_wire.cpp", "host/lm_verify.cpp"]
+SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_air.hip", "lm_logup.hip", "host/lm_host.cpp", "host/lm_whir_config.cpp", "host/lm_wire.cpp", "host/lm_verify.cpp", "host/lm_poseidon_x86.cpp"]
 
 
 def _sources():

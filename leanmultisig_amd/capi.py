@@ -86,6 +86,9 @@ _SIGS = {
 
 # include/leanmultisig_host.h
 _HOST_SIGS = {
+    "lmh_poseidon_backend": (C.c_char_p, []),
+    "lmh_poseidon16_permute": (None, [vp]),
+    "lmh_poseidon16_permute_scalar": (None, [vp]),
     "lmh_prover_new": (vp, []),
     "lmh_prover_free": (None, [vp]),
     "lmh_add_base_scalars": (None, [vp, vp, C.c_uint64]),
@@ -211,6 +214,20 @@ class WhirBuilder(C.Structure):
         for k, v in over.items():
             setattr(b, k, v)
         return b
+
+
+def host_poseidon_backend() -> str:
+    """which host permutation the transcript uses: "avx512-ifma" or "scalar" (lmh_poseidon_backend)"""
+    return load().lmh_poseidon_backend().decode()
+
+
+def host_poseidon16_permute(state, scalar=False):
+    """one Poseidon1-16 permutation on the host (Montgomery words), with the transcript's backend or the scalar code"""
+    lib = load()
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    assert s.shape == (16,)
+    (lib.lmh_poseidon16_permute_scalar if scalar else lib.lmh_poseidon16_permute)(s.ctypes.data_as(C.c_void_p))
+    return s
 
 
 def lz4_compress(data: bytes) -> bytes:

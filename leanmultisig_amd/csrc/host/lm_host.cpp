@@ -1043,7 +1043,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
         u32 st[16];
         memcpy(st, tr->bytecode_hash, 32);
         for (int i = 0; i < 8; i++) st[8 + i] = kb::to_monty(kSnarkDomainSep[i]);
-        kb::poseidon16_compress(st);  // poseidon16_compress_pair(bytecode.hash, SNARK_DOMAIN_SEP)
+        lmh::host_compress(st);  // poseidon16_compress_pair(bytecode.hash, SNARK_DOMAIN_SEP)
         p->ch.observe_many(st, 8);
         u32 dims[6] = {kb::to_monty(tr->log_inv_rate), kb::to_monty(log_mem), kb::to_monty(tr->n_public_input),
                        kb::to_monty(tr->tables[0].log_rows), kb::to_monty(tr->tables[1].log_rows), kb::to_monty(tr->tables[2].log_rows)};

@@ -16,13 +16,22 @@ using kb::u32;
 using kb::u64;
 
 // ---- Challenger (crates/backend/fiat-shamir/src/challenger.rs:9-76): overwrite-mode duplex, plain permutation -----
+// Poseidon1-16 permutation on the host: AVX-512 when the CPU has it, else the scalar code (lm_poseidon_x86.cpp)
+void host_permute(u32 state[16]);
+inline void host_compress(u32 s[16]) {  // perm(x) + x (poseidon1_koalabear_16.rs:1018-1030)
+    u32 in[16];
+    memcpy(in, s, sizeof in);
+    host_permute(s);
+    for (int i = 0; i < 16; i++) s[i] = kb::add(s[i], in[i]);
+}
+
 struct Challenger {
     u32 state[16];
     bool rate_fresh = false;
     Challenger() { memset(state, 0, sizeof state); }
     void observe(const u32 v[8]) {
         memcpy(state + 8, v, 32);
-        kb::poseidon16_permute(state);
+        host_permute(state);
         rate_fresh = true;
     }
     void observe_many(const u32* s, u64 n) {

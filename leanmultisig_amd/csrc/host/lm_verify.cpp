@@ -138,10 +138,10 @@ void hash_slice(const u32* data, size_t n, u32 out[8]) {
     require(n % 8 == 0 && n >= 16, "hash_slice: leaf length must be a multiple of 8, at least 16");
     u32 st[16];
     memcpy(st, data + n - 16, 64);
-    kb::poseidon16_compress(st);
+    lmh::host_compress(st);
     for (size_t chunk = n / 8 - 2; chunk-- > 0;) {
         memcpy(st + 8, data + chunk * 8, 32);
-        kb::poseidon16_compress(st);
+        lmh::host_compress(st);
     }
     memcpy(out, st, 32);
 }
@@ -149,7 +149,7 @@ void compress_pair(const u32 l[8], const u32 r[8], u32 out[8]) {
     u32 st[16];
     memcpy(st, l, 32);
     memcpy(st + 8, r, 32);
-    kb::poseidon16_compress(st);
+    lmh::host_compress(st);
     memcpy(out, st, 32);
 }
 bool merkle_verify(const u32 root[8], u32 log_height, u64 index, const std::vector<u32>& leaf, const std::vector<u32>& path) {
@@ -589,7 +589,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         u32 st[16];
         memcpy(st, in->bytecode_hash, 32);
         for (int i = 0; i < 8; i++) st[8 + i] = to_monty(kSnarkDomainSep[i]);
-        kb::poseidon16_compress(st);
+        lmh::host_compress(st);
         vs.observe(st, 8);
     }
     const std::vector<u32> dims_m = vs.next_base(6);

@@ -310,12 +310,12 @@ __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ part
     if (threadIdx.x < 5) {
         u32 s = 0;
         for (u32 w = 0; w < 4; w++) s = add(s, lds[w * 5 + threadIdx.x]);
-        out[zi * 5 + threadIdx.x] = s;
+        lm_store_system(out + zi * 5 + threadIdx.x, s);
     }
     if (threadIdx.x < 64) {  // the five writers are in wave 0
-        __threadfence_system();
-        if (threadIdx.x == 0 && atomicAdd(done_counter, 1u) == gridDim.x - 1) {
-            *done_counter = 0;
+        lm_wait_stores();
+        if (threadIdx.x == 0 && lm_ticket(done_counter) == gridDim.x - 1) {
+            lm_store_agent(done_counter, 0);
             lm_publish_flag(flag_base, seq);
         }
     }

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(256) void k_merkle_top_coop(u32* __restrict__ lvl, 
         cur = nxt;
     }
     if (threadIdx.x < 64) {
-        if (threadIdx.x < 8) h_res[threadIdx.x] = cur[threadIdx.x];
-        __threadfence_system();
+        if (threadIdx.x < 8) lm_store_system(h_res + threadIdx.x, cur[threadIdx.x]);
+        lm_wait_stores();
         if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
     }
 }

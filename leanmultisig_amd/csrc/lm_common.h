@@ -133,9 +133,13 @@ __device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned lo
     __syncthreads();
     return true;
 }
+// Publishing is fence-free as well (a system-scope release is a write-back of the XCD's L2 plus an invalidate: microseconds
+// when the previous kernel left it dirty, paid ~250 times per proof).  Contract: the payload is written with lm_store_system
+// (write-through), every writing wave executes lm_wait_stores() (its stores are acknowledged) before the barrier that
+// precedes this call, and ONE thread then stores the sequence number.  Payload and flag travel the same posted-write path.
 __device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) {
-    __threadfence_system();
-    __hip_atomic_store(h_res + lm_ctx::RES_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    lm_wait_stores();
+    __hip_atomic_store(h_res + lm_ctx::RES_FLAG, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);

@@ -204,11 +204,16 @@ __global__ __launch_bounds__(256) void k_sum_partials(const u32* __restrict__ pa
     EF r = block_reduce_ef(s, red);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) out[poly * 5 + k] = r.v[k];
+        for (int k = 0; k < 5; k++) {
+            if (publish_to)
+                lm_store_system(out + poly * 5 + k, r.v[k]);
+            else
+                out[poly * 5 + k] = r.v[k];
+        }
         if (publish_to) {
-            __threadfence_system();
-            if (atomicAdd(done_counter, 1u) == gridDim.x - 1) {
-                *done_counter = 0;
+            lm_wait_stores();
+            if (lm_ticket(done_counter) == gridDim.x - 1) {
+                lm_store_agent(done_counter, 0);
                 lm_publish_flag(publish_to, seq);
             }
         }

@@ -250,11 +250,14 @@ __device__ __forceinline__ void block_sum10(u32 v[10], u32* lds /* 40 words */, 
     if (threadIdx.x < 10) {
         u32 s = 0;
         for (u32 w = 0; w < (blockDim.x >> 6); w++) s = add(s, lds[w * 10 + threadIdx.x]);
-        dst[threadIdx.x] = s;
+        if (publish_to)
+            lm_store_system(dst + threadIdx.x, s);
+        else
+            dst[threadIdx.x] = s;
     }
-    if (publish_to) {  // all ten writers are in wave 0: fence each, then one lane stores the sequence number
+    if (publish_to) {  // all ten writers are in wave 0, which waits for its stores before one lane stores the sequence number
         if (threadIdx.x < 64) {
-            __threadfence_system();
+            lm_wait_stores();
             if (threadIdx.x == 0) lm_publish_flag(publish_to, seq);
         }
     }
@@ -272,8 +275,8 @@ __device__ __forceinline__ void finish10(u32 v[10], u32* red /* 64 words */, uns
     __syncthreads();
     if (!lm_grid_sum<10>(red + 40, acc, done_counter, red)) return;
     if (threadIdx.x < 64) {
-        if (threadIdx.x < 10) h_res[threadIdx.x] = red[threadIdx.x];
-        __threadfence_system();
+        if (threadIdx.x < 10) lm_store_system(h_res + threadIdx.x, red[threadIdx.x]);
+        lm_wait_stores();
         if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
     }
 }

@@ -31,6 +31,12 @@ struct lm_air {
     u32* d_partial = nullptr;            // per-block partial sums of a round (own buffer: sessions of one batch run back to back)
     u32 res_off = 0;                     // this session's slice of the pinned result buffer
     u32 pending_seq = 0;                 // sequence number of the launched, not yet collected round (0 = none)
+    // The session runs on its own stream (ctx->aux_stream[aux]) from the end of lm_air_new on: the sessions of a batched
+    // round are independent chains (round kernel -> host -> fold kernel -> ...), and in the last ~12 rounds each of them is
+    // one latency-bound workgroup — side by side they cost the longest of the three instead of the sum.
+    int aux = 0;
+    hipStream_t stream = nullptr;
+    u32* d_sync = nullptr;               // this session's "writers done" counter (two words, zero between kernels)
 };
 static constexpr u32 AIR_MAX_BLOCKS = 2048;
 
@@ -103,7 +109,7 @@ struct AirLagrange {
 // of partials per point).
 struct AirFinish {
     u32* out;            // this session's slice of the pinned result buffer, or nullptr
-    u32* flag_base;      // h_res (the sequence flag lives behind it)
+    u32* flag_word;      // the sequence flag of this session's stream
     u32* done_counter;
     u32 seq, deg, n_main, n_low;
     u64 low_offset;
@@ -133,7 +139,7 @@ __device__ __forceinline__ void air_finish_inline(const u32* __restrict__ partia
     __syncthreads();
     if (threadIdx.x == 0) {
         lm_store_agent(fin.done_counter, 0);
-        lm_publish_flag(fin.flag_base, fin.seq);
+        lm_publish_flag_word(fin.flag_word, fin.seq);
     }
 }
 
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
 // sum_t lag[zi][t] * (sum of the n_low partials of its slot t), lag = Lagrange basis of the nodes 0..3 at the point.
 __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ partial, u32 n_main, u32* __restrict__ out,
                                                     u32* __restrict__ done_counter, u32 seq, u32 n_low, u64 low_offset,
-                                                    AirLagrange lag, u32* __restrict__ flag_base) {
+                                                    AirLagrange lag, u32* __restrict__ flag_word) {
     __shared__ u32 lds[20];
     const u32 zi = blockIdx.x;
     u32 v[5] = {0, 0, 0, 0, 0};
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void k_air_reduce(const u32* __restrict__ part
         lm_wait_stores();
         if (threadIdx.x == 0 && lm_ticket(done_counter) == gridDim.x - 1) {
             lm_store_agent(done_counter, 0);
-            lm_publish_flag(flag_base, seq);
+            lm_publish_flag_word(flag_word, seq);
         }
     }
 }
@@ -391,9 +397,9 @@ __global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* _
 }
 
 template <int TABLE, class T, class Cols, int SEG>
-static int launch_segment(lm_ctx* ctx, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
+static int launch_segment(lm_ctx* ctx, hipStream_t stream, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
                           u32* partial, const AirFinish& fin) {
-    LM_LAUNCH(ctx, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, grid.x, grid.y, fin);
+    LM_LAUNCH_ON(ctx, stream, (k_air_round<TABLE, T, Cols, SEG>), dim3(grid.x * grid.y), dim3(256), 0, c, n_pairs, extra, eq, partial, grid.x, grid.y, fin);
     return LM_OK;
 }
 template <int TABLE, class T, class Cols>
@@ -408,16 +414,16 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
             const dim3 grid(blocks, AIR_POS_POINTS);
             AirFinish none = fin;   // five launches: the partials are summed by k_air_reduce (blocks > AIR_INLINE_MAX_BLOCKS here)
             none.out = nullptr;
-            launch_segment<TABLE, T, Cols, 0>(ctx, c, grid, n_pairs, extra, eq, partial, none);
-            launch_segment<TABLE, T, Cols, 1>(ctx, c, grid, n_pairs, extra, eq, partial, none);
-            launch_segment<TABLE, T, Cols, 2>(ctx, c, dim3(blocks, 4), n_pairs, extra, eq, partial, none);
-            launch_segment<TABLE, T, Cols, 3>(ctx, c, grid, n_pairs, extra, eq, partial, none);
-            launch_segment<TABLE, T, Cols, 4>(ctx, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 0>(ctx, a->stream, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 1>(ctx, a->stream, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 2>(ctx, a->stream, c, dim3(blocks, 4), n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 3>(ctx, a->stream, c, grid, n_pairs, extra, eq, partial, none);
+            launch_segment<TABLE, T, Cols, 4>(ctx, a->stream, c, grid, n_pairs, extra, eq, partial, none);
         } else {
-            launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial, fin);
+            launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial, fin);
         }
     } else {
-        launch_segment<TABLE, T, Cols, -1>(ctx, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial, fin);
+        launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial, fin);
     }
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -437,6 +443,8 @@ extern "C" {
 void lm_air_free(lm_ctx* ctx, lm_air* a) {
     if (!a) return;
     (void)hipStreamSynchronize(ctx->stream);  // the uploads of lm_air_new read from *a
+    if (a->stream) (void)hipStreamSynchronize(a->stream);  // the pool is ordered on ctx->stream: nothing of this session may still run
+    lm_pool_free(ctx, a->d_sync);
     lm_pool_free(ctx, (void*)a->d_base_cols);
     lm_pool_free(ctx, a->d_virt);
     for (int i = 0; i < 2; i++) lm_pool_free(ctx, a->ef[i]);
@@ -482,6 +490,7 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
               lm_pool_alloc_t(ctx, &a->ef[0], std::max<u64>(ef_words0, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->ef[1], std::max<u64>(ef_words0 / 2, 64) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->d_extra, sizeof(air::Extra)) == hipSuccess &&
+              lm_pool_alloc_t(ctx, &a->d_sync, 256) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->eqt.d_buf, PrefixEqTables::words_needed(log_rows) * 4) == hipSuccess &&
               lm_pool_alloc_t(ctx, &a->d_partial, ((u64)AIR_MAX_BLOCKS * (table == air::T_POSEIDON16 ? AIR_POS_SLOTS : a->deg) * 5 + 64) * 4) == hipSuccess;
     a->res_off = 256 + 64 * table;
@@ -504,6 +513,26 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
         lm_air_free(ctx, a);
         return rc;
     }
+    // fork: everything above (and the caller's columns) was produced on ctx->stream; the session continues on its own stream
+    // (LM_AIR_SINGLE_STREAM=1 keeps the session on ctx->stream: for A/B measurements)
+    static const bool single = getenv("LM_AIR_SINGLE_STREAM") != nullptr;
+    a->aux = single ? -1 : (int)(table % lm_ctx::N_AUX);
+    hipError_t e = hipMemsetAsync(a->d_sync, 0, 256, ctx->stream);
+    hipStream_t side = ctx->stream;
+    if (!single) {
+        if ((rc = lm_aux_stream(ctx, a->aux, &side))) {
+            lm_air_free(ctx, a);
+            return rc;
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->fork_event, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side, ctx->fork_event, 0);
+    }
+    if (e != hipSuccess) {
+        lm_set_error("lm_air_new: stream fork failed: %s", hipGetErrorString(e));
+        lm_air_free(ctx, a);
+        return LM_E_DEVICE;
+    }
+    a->stream = side;
     *out = a;
     return LM_OK;
 }
@@ -545,8 +574,8 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     if (pos) fin.lag = pos_lag;
     const bool inline_finish = blocks <= AIR_INLINE_MAX_BLOCKS && !(pos && a->cur < 0 && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS);
     fin.out = inline_finish ? ctx->h_res + a->res_off : nullptr;
-    fin.flag_base = ctx->h_res;
-    fin.done_counter = ctx->d_sync + 1;
+    fin.flag_word = ctx->h_res + lm_ctx::RES_FLAG + 1 + a->aux;
+    fin.done_counter = a->d_sync;
     fin.seq = seq;
     fin.deg = a->deg;
     fin.n_main = pos ? 4 * blocks : blocks;
@@ -560,15 +589,15 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
         rc = launch_round<air::T_POSEIDON16>(ctx, a, n_pairs, blocks, eq, s, fin);
     if (rc) return rc;
     if (!inline_finish)
-        LM_LAUNCH(ctx, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, fin.n_main, ctx->h_res + a->res_off, ctx->d_sync + 1, seq, fin.n_low,
-                  fin.low_offset, fin.lag, ctx->h_res);
+        LM_LAUNCH_ON(ctx, a->stream, k_air_reduce, dim3(a->deg), dim3(256), 0, (const u32*)s, fin.n_main, ctx->h_res + a->res_off, a->d_sync, seq,
+                     fin.n_low, fin.low_offset, fin.lag, fin.flag_word);
     LM_HIP(hipGetLastError());
     a->pending_seq = seq;
     return LM_OK;
 }
 int lm_air_round_wait(lm_ctx* ctx, lm_air* a, uint32_t* out_raw) {
     LM_REQUIRE(ctx && a && out_raw && a->pending_seq != 0);
-    int rc = lm_wait_result(ctx, a->pending_seq);
+    int rc = lm_wait_result_aux(ctx, a->aux, a->pending_seq);
     a->pending_seq = 0;
     if (rc) return rc;
     memcpy(out_raw, ctx->h_res + a->res_off, (u64)a->deg * 20);
@@ -588,11 +617,11 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
     const dim3 grid(blocks, a->n_cols + a->n_virt + a->n_shift);
     if (a->cur < 0) {
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
-        LM_LAUNCH(ctx, k_air_fold_base, grid, dim3(256), 0, c, n_out, r, a->ef[0]);
+        LM_LAUNCH_ON(ctx, a->stream, k_air_fold_base, grid, dim3(256), 0, c, n_out, r, a->ef[0]);
         a->cur = 0;
     } else {
         ExtCols c{a->ef[a->cur], 2 * n_out};
-        LM_LAUNCH(ctx, k_air_fold_ext, grid, dim3(256), 0, c, n_out, r, a->ef[1 - a->cur]);
+        LM_LAUNCH_ON(ctx, a->stream, k_air_fold_ext, grid, dim3(256), 0, c, n_out, r, a->ef[1 - a->cur]);
         a->cur = 1 - a->cur;
     }
     LM_HIP(hipGetLastError());
@@ -603,8 +632,8 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
 // final_column_evals (air_sumcheck.rs:294-296): (n_cols + n_shift) EF values after log_rows bindings
 int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out) {
     LM_REQUIRE(ctx && a && out && a->round == a->log_rows && a->cur >= 0);
-    LM_HIP(hipMemcpyAsync(out, a->ef[a->cur], (u64)(a->n_cols + a->n_shift) * 20, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    LM_HIP(hipMemcpyAsync(out, a->ef[a->cur], (u64)(a->n_cols + a->n_shift) * 20, hipMemcpyDeviceToHost, a->stream));
+    LM_HIP(hipStreamSynchronize(a->stream));
     return LM_OK;
 }
 

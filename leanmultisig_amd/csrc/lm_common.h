@@ -57,6 +57,11 @@ struct lm_ctx {
     static constexpr u64 RES_WORDS = 4096;
     static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
     u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
+    // side streams: independent chains of one protocol step (the AIR sessions of a batched sumcheck round) run concurrently,
+    // each publishing into its own flag word h_res[RES_FLAG + 1 + k].  Forked from / joined to `stream` with events.
+    static constexpr int N_AUX = 3;
+    hipStream_t aux_stream[N_AUX] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
     // caching device allocator: freed blocks are kept per size class and reused (hipMalloc/hipFree synchronise the
     // device; a proof performs ~100 allocations).  Single stream => reuse is stream-ordered and safe.
     std::multimap<u64, void*> pool_free;
@@ -68,20 +73,22 @@ struct lm_ctx {
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
 
-#define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...)                                                  \
+#define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)
+#define LM_LAUNCH_ON(ctx, strm, kernel, grid, block, shmem, ...)                                         \
     do {                                                                                                 \
         lm_ctx* c__ = (ctx);                                                                             \
+        hipStream_t s__ = (strm);                                                                        \
         const bool p__ = !c__->prof_select.empty() &&                                                    \
                          (c__->prof_select == "*" || lm_prof_match(c__->prof_select.c_str(), #kernel));  \
         hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                       \
         if (p__) {                                                                                       \
             (void)hipEventCreate(&e0__);                                                                 \
             (void)hipEventCreate(&e1__);                                                                 \
-            (void)hipEventRecord(e0__, c__->stream);                                                     \
+            (void)hipEventRecord(e0__, s__);                                                     \
         }                                                                                                \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, c__->stream, __VA_ARGS__);                        \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, s__, __VA_ARGS__);                        \
         if (p__) {                                                                                       \
-            (void)hipEventRecord(e1__, c__->stream);                                                     \
+            (void)hipEventRecord(e1__, s__);                                                     \
             c__->prof_events[#kernel].emplace_back(e0__, e1__);                                          \
         }                                                                                                \
     } while (0)
@@ -137,12 +144,16 @@ __device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned lo
 // when the previous kernel left it dirty, paid ~250 times per proof).  Contract: the payload is written with lm_store_system
 // (write-through), every writing wave executes lm_wait_stores() (its stores are acknowledged) before the barrier that
 // precedes this call, and ONE thread then stores the sequence number.  Payload and flag travel the same posted-write path.
-__device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) {
+__device__ __forceinline__ void lm_publish_flag_word(kb::u32* flag_word, kb::u32 seq) {
     lm_wait_stores();
-    __hip_atomic_store(h_res + lm_ctx::RES_FLAG, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(flag_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) { lm_publish_flag_word(h_res + lm_ctx::RES_FLAG, seq); }
 #endif
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
+// the same on flag word h_res[RES_FLAG + 1 + aux] (aux >= 0), published by work on aux_stream[aux]
+int lm_wait_result_aux(lm_ctx* ctx, int aux, kb::u32 seq);
+int lm_aux_stream(lm_ctx* ctx, int aux, hipStream_t* out);  // created on first use
 
 static inline bool lm_prof_match(const char* want, const char* name) {
     if (name[0] == '(') name++;  // template kernels are launched as (k<...>)

@@ -502,13 +502,16 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->eqt.buf_words = PrefixEqTables::words_needed(log_rows);
     a->h_cols.assign(d_cols, d_cols + a->n_cols);
     for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
-    LM_HIP(hipMemcpyAsync((void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*), hipMemcpyHostToDevice,
-                          ctx->stream));
-    LM_HIP(hipMemcpyAsync(a->d_extra, &a->h_extra, sizeof(air::Extra), hipMemcpyHostToDevice, ctx->stream));
+    int rc;
+    if ((rc = lm_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||
+        (rc = lm_upload(ctx, a->d_extra, &a->h_extra, sizeof(air::Extra)))) {
+        lm_air_free(ctx, a);
+        return rc;
+    }
     if (a->n_virt)
         LM_LAUNCH(ctx, k_air_virtual_columns, dim3((unsigned)(((1ull << log_rows) + 255) / 256)), dim3(256), 0,
                   (const u32* const*)a->d_base_cols, 1ull << log_rows, a->d_virt, (const air::Extra*)a->d_extra);
-    int rc = a->eqt.build(ctx, eq_point, log_rows);
+    rc = a->eqt.build(ctx, eq_point, log_rows);
     if (rc) {
         lm_air_free(ctx, a);
         return rc;
@@ -632,9 +635,8 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
 // final_column_evals (air_sumcheck.rs:294-296): (n_cols + n_shift) EF values after log_rows bindings
 int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out) {
     LM_REQUIRE(ctx && a && out && a->round == a->log_rows && a->cur >= 0);
-    LM_HIP(hipMemcpyAsync(out, a->ef[a->cur], (u64)(a->n_cols + a->n_shift) * 20, hipMemcpyDeviceToHost, a->stream));
-    LM_HIP(hipStreamSynchronize(a->stream));
-    return LM_OK;
+    // (n_cols + n_shift) * 5 <= 545 words: the aux slices of the result buffer start at 1024, 1024 words each
+    return lm_fetch_words(ctx, a->aux, a->ef[a->cur], (a->n_cols + a->n_shift) * 5, nullptr, 0, a->aux < 0 ? 1024u : 1024u * (1 + a->aux), out);
 }
 
 }  // extern "C"

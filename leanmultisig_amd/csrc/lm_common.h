@@ -57,6 +57,12 @@ struct lm_ctx {
     static constexpr u64 RES_WORDS = 4096;
     static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
     u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
+    // pinned staging ring for small host -> device tables (pointer lists, job lists, evaluation points): the host image is
+    // written here and copied with ONE asynchronous command — no synchronisation to keep a caller's vector alive, no
+    // pageable-memory staging inside the runtime.  A region stays valid until the ring wraps; wrapping synchronises.
+    uint8_t* h_stage = nullptr;
+    static constexpr size_t STAGE_BYTES = 8u << 20;
+    size_t stage_off = 0;
     // side streams: independent chains of one protocol step (the AIR sessions of a batched sumcheck round) run concurrently,
     // each publishing into its own flag word h_res[RES_FLAG + 1 + k].  Forked from / joined to `stream` with events.
     static constexpr int N_AUX = 3;
@@ -173,6 +179,13 @@ struct lm_tree {
 };
 
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out);
+// bytes of the staging ring (nullptr in *out if the request is too large for it: the caller falls back to a synchronous copy)
+int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out);
+// asynchronous host -> device copy on ctx->stream through the staging ring; `src` may be freed on return
+int lm_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+// device -> host for a few words without a copy command or a stream synchronise: one tiny kernel stores them (and n1 more
+// from a second source) into the pinned result buffer at `res_offset` and publishes; the host spins on the flag.
+int lm_fetch_words(lm_ctx* ctx, int aux, const kb::u32* d_src0, kb::u32 n0, const kb::u32* d_src1, kb::u32 n1, kb::u32 res_offset, kb::u32* out);
 // pooled device memory (see lm_ctx::pool_free); lm_pool_alloc returns hipErrorOutOfMemory on failure
 hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes);
 void lm_pool_free(lm_ctx* ctx, void* p);

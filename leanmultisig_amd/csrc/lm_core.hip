@@ -302,6 +302,58 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
     return LM_OK;
 }
 
+int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out) {
+    *out = nullptr;
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (!ctx->h_stage || bytes > lm_ctx::STAGE_BYTES / 4) return LM_OK;
+    if (ctx->stage_off + bytes > lm_ctx::STAGE_BYTES) {  // wrap: everything that still reads the ring must have finished
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < lm_ctx::N_AUX; i++)
+            if (ctx->aux_stream[i]) LM_HIP(hipStreamSynchronize(ctx->aux_stream[i]));
+        ctx->stage_off = 0;
+    }
+    *out = ctx->h_stage + ctx->stage_off;
+    ctx->stage_off += bytes;
+    return LM_OK;
+}
+int lm_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (bytes == 0) return LM_OK;
+    void* st;
+    int rc = lm_stage_alloc(ctx, bytes, &st);
+    if (rc) return rc;
+    if (!st) {
+        LM_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));
+        return LM_OK;
+    }
+    memcpy(st, src, bytes);
+    LM_HIP(hipMemcpyAsync(d_dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return LM_OK;
+}
+__global__ __launch_bounds__(256) void k_publish_words(const u32* __restrict__ src0, u32 n0, const u32* __restrict__ src1, u32 n1,
+                                                       u32* __restrict__ dst, u32* __restrict__ flag_word, u32 seq) {
+    for (u32 i = threadIdx.x; i < n0 + n1; i += 256) lm_store_system(dst + i, i < n0 ? src0[i] : src1[i - n0]);
+    lm_wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) lm_publish_flag_word(flag_word, seq);
+}
+int lm_fetch_words(lm_ctx* ctx, int aux, const u32* d_src0, u32 n0, const u32* d_src1, u32 n1, u32 res_offset, u32* out) {
+    LM_REQUIRE(ctx && d_src0 && out && aux >= -1 && aux < lm_ctx::N_AUX && (u64)res_offset + n0 + n1 <= lm_ctx::RES_WORDS);
+    hipStream_t stream = ctx->stream;
+    if (aux >= 0) {
+        int rc = lm_aux_stream(ctx, aux, &stream);
+        if (rc) return rc;
+    }
+    const u32 seq = ++ctx->res_seq;
+    LM_LAUNCH_ON(ctx, stream, k_publish_words, dim3(1), dim3(256), 0, d_src0, n0, d_src1, n1, ctx->h_res + res_offset,
+                 ctx->h_res + lm_ctx::RES_FLAG + 1 + aux, seq);
+    LM_HIP(hipGetLastError());
+    int rc = lm_wait_result_aux(ctx, aux, seq);
+    if (rc) return rc;
+    memcpy(out, ctx->h_res + res_offset, (size_t)(n0 + n1) * 4);
+    return LM_OK;
+}
+
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {
     if (words > ctx->scratch_words) {
         LM_HIP(hipStreamSynchronize(ctx->stream));
@@ -372,6 +424,7 @@ static int ctx_create_impl(int device, lm_ctx* c) {
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
     LM_HIP(hipHostMalloc((void**)&c->h_res, (lm_ctx::RES_WORDS + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
     for (int i = 0; i < 16; i++) c->h_res[lm_ctx::RES_FLAG + i] = 0;
+    LM_HIP(hipHostMalloc((void**)&c->h_stage, lm_ctx::STAGE_BYTES, hipHostMallocDefault));
     LM_HIP(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     const u64 n = 1ull << (LM_TW_LOG - 1);
     LM_LAUNCH(c, k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->d_tw, c->d_tw_small,
@@ -420,6 +473,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -604,8 +658,7 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     u32* d_eq_lo = s + ((2ull * n_cols + 15) & ~15ull);
     u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
     u32* d_partial = d_eq_hi + 5ull * n_hi;
-    LM_HIP(hipMemcpyAsync((void*)d_ptrs, d_cols, (u64)n_cols * 8, hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));  // d_cols is the caller's
+    if ((rc = lm_upload(ctx, (void*)d_ptrs, d_cols, (size_t)n_cols * 8))) return rc;
     EqSmallArg p_hi, p_lo;
     if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
     if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
@@ -645,8 +698,7 @@ int lm_stack_columns(lm_ctx* ctx, uint32_t* d_dst, uint64_t total_words, uint32_
     int rc = lm_scratch(ctx, (jobs.size() * sizeof(StackJob) + 3) / 4 + 16, &s);
     if (rc) return rc;
     if (!jobs.empty()) {
-        LM_HIP(hipMemcpyAsync(s, jobs.data(), jobs.size() * sizeof(StackJob), hipMemcpyHostToDevice, ctx->stream));
-        LM_HIP(hipStreamSynchronize(ctx->stream));  // `jobs` must outlive the copy
+        if ((rc = lm_upload(ctx, s, jobs.data(), jobs.size() * sizeof(StackJob)))) return rc;
     }
     const u64 n_vec = total_words / 4;
     const u32 blocks = (u32)std::min<u64>((n_vec + 255) / 256, 16384);

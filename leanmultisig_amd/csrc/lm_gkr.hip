@@ -391,9 +391,8 @@ int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_d
 int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32) {
     LM_REQUIRE(ctx && g && nums32 && dens32);
     u32 soa[2][160];
-    LM_HIP(hipMemcpyAsync(soa[0], g->nums.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipMemcpyAsync(soa[1], g->dens.back(), 640, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = lm_fetch_words(ctx, -1, g->nums.back(), 160, g->dens.back(), 160, 0, &soa[0][0]);
+    if (rc) return rc;
     const u64 valid = g->valid.back();
     for (int i = 0; i < 32; i++)
         for (int k = 0; k < 5; k++) {

@@ -720,15 +720,24 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
     u32* s;
     int rc = lm_scratch(ctx, o_arena + arena_words, &s);
     if (rc) return rc;
-    LM_HIP(hipMemcpyAsync(s + o_items, hit.data(), sizeof(WItem) * n_items, hipMemcpyHostToDevice, ctx->stream));
-    if (!merged.empty())
-        LM_HIP(hipMemcpyAsync(s + o_merged, merged.data(), sizeof(WGroup) * merged.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (!rest.empty())
-        LM_HIP(hipMemcpyAsync(s + o_rest, rest.data(), sizeof(WGroup) * rest.size(), hipMemcpyHostToDevice, ctx->stream));
-    LM_HIP(hipMemcpyAsync(s + o_sc, hsc.data(), w_sc * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (w_pts) LM_HIP(hipMemcpyAsync(s + o_pts, points, w_pts * 4, hipMemcpyHostToDevice, ctx->stream));
-    // the host vectors must outlive the async copies
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        // one host image of all tables (items | merged | rest | scalars | points) in the pinned staging ring, one copy command
+        void* img;
+        if ((rc = lm_stage_alloc(ctx, o_arena * 4, &img))) return rc;
+        std::vector<u32> pageable;
+        if (!img) {
+            pageable.resize(o_arena);
+            img = pageable.data();
+        }
+        u32* im = static_cast<u32*>(img);
+        memcpy(im + o_items, hit.data(), sizeof(WItem) * n_items);
+        if (!merged.empty()) memcpy(im + o_merged, merged.data(), sizeof(WGroup) * merged.size());
+        if (!rest.empty()) memcpy(im + o_rest, rest.data(), sizeof(WGroup) * rest.size());
+        memcpy(im + o_sc, hsc.data(), w_sc * 4);
+        if (w_pts) memcpy(im + o_pts, points, w_pts * 4);
+        LM_HIP(hipMemcpyAsync(s, im, o_arena * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!pageable.empty()) LM_HIP(hipStreamSynchronize(ctx->stream));
+    }
     LM_LAUNCH(ctx, k_weight_tables, dim3((max_table + 255) / 256, n_items, 2), dim3(256), 0, (const WItem*)(s + o_items),
               s + o_pts, s + o_sc, s + o_arena);
     const bool dbg = getenv("LM_DEBUG_WEIGHTS") != nullptr;

@@ -415,11 +415,14 @@ __global__ __launch_bounds__(256) void k_poseidon_trace(u32* const* __restrict__
     }
 }
 
-// batched opening: block b serves indices[b]
+// batched opening: block b serves indices[b].  PINNED: leaves / siblings are host memory (the staging ring): written with
+// system-scope stores, and the block that finishes last publishes the sequence number — no copy commands, no synchronise.
+template <bool PINNED>
 __global__ __launch_bounds__(256) void k_tree_open(const u32* __restrict__ mat, const u32* __restrict__ digests,
                                                    const u64* __restrict__ indices, u32* __restrict__ leaves,
                                                    u32* __restrict__ siblings, u64 h, u32 log_h, u32 is_ext,
-                                                   u32 stored_cols, u32 eff_words, u32 leaf_words) {
+                                                   u32 stored_cols, u32 eff_words, u32 leaf_words, u32* __restrict__ done_counter,
+                                                   u32* __restrict__ h_res, u32 seq) {
     const u64 idx = indices[blockIdx.x];
     for (u32 w = threadIdx.x; w < leaf_words; w += 256) {
         u32 v = 0;
@@ -427,14 +430,29 @@ __global__ __launch_bounds__(256) void k_tree_open(const u32* __restrict__ mat, 
             u32 colidx = is_ext ? (w % 5) * stored_cols + w / 5 : w;
             v = mat[(u64)colidx * h + idx];
         }
-        leaves[(u64)blockIdx.x * leaf_words + w] = v;
+        if (PINNED)
+            lm_store_system(leaves + (u64)blockIdx.x * leaf_words + w, v);
+        else
+            leaves[(u64)blockIdx.x * leaf_words + w] = v;
     }
     for (u32 x = threadIdx.x; x < log_h * 8; x += 256) {
         u32 lvl = x >> 3, k = x & 7;
         // layer lvl starts at offset sum_{i<lvl} (h >> i) = 2h - (h >> (lvl-1)) ... computed incrementally
         u64 off = 2 * h - (2 * h >> lvl);
         u64 node = (idx >> lvl) ^ 1;
-        siblings[(u64)blockIdx.x * log_h * 8 + x] = digests[(off + node) * 8 + k];
+        const u32 v = digests[(off + node) * 8 + k];
+        if (PINNED)
+            lm_store_system(siblings + (u64)blockIdx.x * log_h * 8 + x, v);
+        else
+            siblings[(u64)blockIdx.x * log_h * 8 + x] = v;
+    }
+    if (PINNED) {
+        lm_wait_stores();
+        __syncthreads();
+        if (threadIdx.x == 0 && lm_ticket(done_counter) == gridDim.x - 1) {
+            lm_store_agent(done_counter, 0);
+            lm_publish_flag(h_res, seq);
+        }
     }
 }
 
@@ -598,8 +616,22 @@ int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_
     u32* d_leaves = d_tmp + 2ull * n_idx;
     u32* d_sib = d_leaves + leaf_total;
     if ((rc = lm_upload(ctx, d_idx, indices, (size_t)n_idx * 8))) return rc;
-    LM_LAUNCH(ctx, k_tree_open, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, d_leaves,
-                       d_sib, h, t->log_h, t->is_ext, t->eff_cols, t->stored_words, t->leaf_words);
+    void* pinned;
+    if ((rc = lm_stage_alloc(ctx, (leaf_total + sib_total) * 4, &pinned))) return rc;
+    if (pinned) {  // results straight into pinned host memory
+        u32* p_leaves = static_cast<u32*>(pinned);
+        u32* p_sib = p_leaves + leaf_total;
+        const u32 seq = ++ctx->res_seq;
+        LM_LAUNCH(ctx, k_tree_open<true>, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, p_leaves, p_sib, h, t->log_h,
+                  t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_HIP(hipGetLastError());
+        if ((rc = lm_wait_result(ctx, seq))) return rc;
+        memcpy(leaves, p_leaves, leaf_total * 4);
+        if (sib_total) memcpy(siblings, p_sib, sib_total * 4);
+        return LM_OK;
+    }
+    LM_LAUNCH(ctx, k_tree_open<false>, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, d_leaves, d_sib, h, t->log_h,
+              t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, (u32*)nullptr, (u32*)nullptr, 0u);
     LM_HIP(hipGetLastError());
     LM_HIP(hipMemcpyAsync(leaves, d_leaves, leaf_total * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (sib_total) LM_HIP(hipMemcpyAsync(siblings, d_sib, sib_total * 4, hipMemcpyDeviceToHost, ctx->stream));

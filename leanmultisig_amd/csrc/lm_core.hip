@@ -424,7 +424,7 @@ static int ctx_create_impl(int device, lm_ctx* c) {
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
     LM_HIP(hipHostMalloc((void**)&c->h_res, (lm_ctx::RES_WORDS + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
     for (int i = 0; i < 16; i++) c->h_res[lm_ctx::RES_FLAG + i] = 0;
-    LM_HIP(hipHostMalloc((void**)&c->h_stage, lm_ctx::STAGE_BYTES, hipHostMallocDefault));
+    LM_HIP(hipHostMalloc((void**)&c->h_stage, lm_ctx::STAGE_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     LM_HIP(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     const u64 n = 1ull << (LM_TW_LOG - 1);
     LM_LAUNCH(c, k_init_twiddles, dim3((unsigned)(n / 256)), dim3(256), 0, c->d_tw, c->d_tw_small,

@@ -288,7 +288,10 @@ uint32_t lm_air_n_evals(const lm_air* a);
 int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw);
 /* lm_air_round in two halves: _launch enqueues the round's kernels, _wait collects the result.  The sessions of one batched
  * round (prove_batched_air_sumcheck, air_sumcheck.rs:636-681) are independent until the shared challenge: launch them all,
- * then wait — one host round trip per batched round instead of one per table. */
+ * then wait — one host round trip per batched round instead of one per table.  From the end of lm_air_new on a session
+ * runs on its own HIP stream (one per table, forked from the context's stream with an event; its results carry their own
+ * sequence flag), so the three chains of a batched round execute side by side; lm_air_free joins it.  The caller's columns
+ * must stay untouched until lm_air_free. */
 int lm_air_round_launch(lm_ctx* ctx, lm_air* a);
 int lm_air_round_wait(lm_ctx* ctx, lm_air* a, uint32_t* out_raw);
 int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[LM_EF_DIM]);

@@ -22,14 +22,7 @@ python tools/valu_summary.py $OUT 4 $OUT/valu_bench.json profiles/${TAG%%_*}_isa
 python tools/timeline.py $OUT/stats_inflight1 > $OUT/timeline.txt
 for k in k_gkr_step k_air_round k_fold_round; do python tools/launch_hist.py $OUT/stats_inflight1 $k 4; done > $OUT/launch_hist.txt
 (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 int_rates.hip -o int_rates 2>/dev/null && ./int_rates) > $OUT/int_rates.txt 2>&1
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-python bench.py --no-cpu-baseline --inflight 1 --verify > $OUT/bench_verify.json 2> $OUT/bench_verify.err
-python bench.py --no-cpu-baseline --inflight 1 --log-inv-rate 2 --verify > $OUT/bench_config3_rate4.json 2> /dev/null
-python bench.py --no-cpu-baseline --inflight 1 --soundness capacity --verify > $OUT/bench_capacity.json 2> /dev/null
-python bench.py --no-cpu-baseline --inflight 1 --soundness capacity --log-inv-rate 2 --verify > $OUT/bench_capacity_rate4.json 2> /dev/null
-python bench.py --no-cpu-baseline --inflight 1 --host-resident > $OUT/bench_host_resident.json 2> /dev/null
-python bench.py --shape recursion --log-inv-rate 2 --inflight 1 --steps 5 --verify --profile-all > $OUT/bench_recursion_shape.json 2> $OUT/bench_recursion_shape_kernels.txt
-for c in 2 4 6 8 10 12; do python bench.py --no-cpu-baseline --inflight $c --steps 4 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['inflight']['proofs_in_flight'], round(d['inflight']['value']), round(d['inflight']['ms_per_proof'],2), round(d['ms_per_step'],2))"; done > $OUT/inflight_sweep.txt
+bash tools/bench_lines.sh $TAG
 (nproc; lscpu | grep "Model name") > $OUT/host.txt
 # keep the summaries, drop the raw per-launch CSVs of the counter passes (tens of MB)
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_valu

@@ -176,16 +176,16 @@ def cpu_baseline(orc, ob, log_scale=2):
 
 
 def source_sha():
-    """sha256 over the kernel sources the profiles under profiles/ were taken from: a counter file recorded for other sources is
-    refused (its traffic / instruction counts would silently describe kernels that no longer exist)."""
+    """sha256 over the DEVICE sources (csrc/*.hip, *.h, *.inc — not the host-only csrc/host/) the profiles under profiles/ were
+    taken from: a counter file recorded for other kernels is refused (its traffic / instruction counts would silently describe
+    kernels that no longer exist)."""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "leanmultisig_amd", "csrc")
-    for dirpath, _, files in sorted(os.walk(base)):
-        for f in sorted(files):
-            if f.endswith((".hip", ".h", ".inc", ".cpp")):
-                h.update(f.encode())
-                h.update(open(os.path.join(dirpath, f), "rb").read())
+    for f in sorted(os.listdir(base)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(base, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -203,23 +203,35 @@ def load_profile(name, sha):
 VALU_PEAK_T = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMD-32 units x lanes per cycle x clock = 78.6 T lane-ops/s (MI355X_MICROARCH.md)
 
 
+_XBUF = {}
+
+
 def exchange_step(root, proof_words, device):
     """The exchange of the sharded path, once per step: all-gather of the commitment roots (8 words) and of
     the pruned proofs (to the rank that would run the 8 -> 1 recursion).  Proof lengths differ by a few words: a length word +
-    zero padding to a fixed capacity."""
+    zero padding to a fixed capacity.  One rank: nothing to exchange — the packed buffer is returned as it is (no collective,
+    no device round trip; the same code path whether launched directly or through torch.distributed.run with one process)."""
     import torch
     import torch.distributed as dist
     cap = 1 << 17
     assert proof_words.size < cap
-    buf = np.zeros(8 + 1 + cap, dtype=np.int64)
-    buf[:8] = np.asarray(root, dtype=np.int64)
-    buf[8] = proof_words.size
-    buf[9:9 + proof_words.size] = proof_words
-    t = torch.from_numpy(buf.astype(np.int32)).to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return t.cpu().numpy().reshape(1, -1)
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
+    if "host" not in _XBUF:  # pinned staging buffer, zeroed once; only the words behind a shorter proof are cleared again
+        _XBUF["host"] = torch.zeros(8 + 1 + cap, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(8 + 1 + cap, dtype=torch.int32)
+        _XBUF["len"] = 0
+    t, buf = _XBUF["host"], _XBUF["host"].numpy()
+    n = int(proof_words.size)
+    buf[:8] = np.asarray(root, dtype=np.uint32).view(np.int32)
+    buf[8] = n
+    buf[9:9 + n] = np.asarray(proof_words, dtype=np.uint32).view(np.int32)
+    if _XBUF["len"] > n:
+        buf[9 + n:9 + _XBUF["len"]] = 0
+    _XBUF["len"] = n
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return buf.reshape(1, -1)
+    d = t.to(device, non_blocking=True)
+    out = [torch.empty_like(d) for _ in range(world)]
+    dist.all_gather(out, d)
     return torch.stack(out).cpu().numpy()
 
 

@@ -373,8 +373,11 @@ std::vector<PrunedBatch> prune(const lmh_prover* p) {
 }
 }  // namespace lmh
 namespace {
-std::vector<u32> pruned_blob(const lmh_prover* p) {
-    std::vector<u32> o;
+const std::vector<u32>& pruned_blob(const lmh_prover* p) {
+    const size_t key[3] = {p->transcript.size(), p->openings.size(), p->batch_sizes.size()};
+    if (memcmp(key, p->pruned_key, sizeof key) == 0) return p->pruned_cache;
+    std::vector<u32>& o = p->pruned_cache;
+    o.clear();
     o.push_back((u32)p->transcript.size());
     o.insert(o.end(), p->transcript.begin(), p->transcript.end());
     const std::vector<lmh::PrunedBatch> batches = lmh::prune(p);
@@ -394,6 +397,7 @@ std::vector<u32> pruned_blob(const lmh_prover* p) {
             o.insert(o.end(), pp.siblings.begin(), pp.siblings.end());
         }
     }
+    memcpy(p->pruned_key, key, sizeof key);
     return o;
 }
 }  // namespace
@@ -401,7 +405,7 @@ extern "C" {
 
 uint64_t lmh_proof_pruned_words(const lmh_prover* p) { return p ? pruned_blob(p).size() : 0; }
 void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out) {
-    const std::vector<u32> b = pruned_blob(p);
+    const std::vector<u32>& b = pruned_blob(p);
     memcpy(out, b.data(), b.size() * 4);
 }
 // Proof::proof_size_fe (fiat-shamir/src/transcript.rs:39-53): transcript + pruned leaf data + 8 words per kept sibling
@@ -419,6 +423,7 @@ void lmh_proof_batch_sizes(const lmh_prover* p, uint32_t* out) {
 
 int lmh_prover_load_raw(lmh_prover* p, const uint32_t* blob, uint64_t n_words, const uint32_t* batch_sizes, uint32_t n_batches) {
     if (!p || !blob || n_words < 2 || (n_batches && !batch_sizes)) return LM_E_INVALID;
+    p->pruned_key[0] = ~(size_t)0;  // (the cached pruned blob describes the previous contents)
     u64 k = 0;
     const u64 T = blob[k++];
     if (T + 2 > n_words) return LM_E_INVALID;

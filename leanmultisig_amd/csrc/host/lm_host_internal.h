@@ -87,6 +87,9 @@ struct lmh_prover {
     std::vector<lmh::u32> transcript;
     std::vector<lmh::Opening> openings;
     std::vector<lmh::u32> batch_sizes;  // openings per hint_merkle_paths call (one query set of one commitment), in order
+    // the pruned blob of the current state (size query + copy are two calls): valid while the three sizes are unchanged
+    mutable std::vector<lmh::u32> pruned_cache;
+    mutable size_t pruned_key[3] = {~(size_t)0, 0, 0};
 };
 
 namespace lmh {

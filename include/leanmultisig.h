@@ -151,9 +151,11 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
  * each address is read, as field elements: for every job (an index column of a table lookup, canonical value = address)
  * and every row, d_acc[address + j] += 1 for j < n_values.  Rows whose address range falls outside [0, len) are ignored
  * (the reference would panic).  Used for memory_acc (all table lookups) and bytecode_acc (the pc column, n_values = 1).
- * n_jobs <= 16, n_values <= 16, len < 2^28. */
+ * n_jobs <= 16, n_values <= 16, len < 2^28.  Skipped rows are counted: lm_access_errors returns the number of rows outside
+ * the image since the last reset (it synchronises the stream); lmh_prove_execution fails with LM_E_INVALID if there were any. */
 int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint32_t n_jobs, const uint32_t* const* d_index_cols,
                      const uint64_t* n_rows, const uint32_t* n_values);
+uint32_t lm_access_errors(lm_ctx* ctx, int reset);
 
 /* stack_polynomials (crates/sub_protocols/src/stacked_pcs.rs:99-157): d_dst[0..total_words) = zero everywhere except
  * d_dst[dst_offset[i] .. +n_words[i]) = d_src[i][0..n_words[i]).  d_src is a HOST array of device pointers; jobs must be

@@ -59,6 +59,7 @@ _SIGS = {
     "lm_fold2_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp, C.c_int, vp]),
     "lm_fold_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp, vp, vp, vp]),
     "lm_access_counts": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "lm_access_errors": (C.c_uint32, [vp, C.c_int]),
     "lm_stack_columns": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "lm_weights_init": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint64, vp]),
     "lm_prod_round": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint32, vp]),
@@ -567,6 +568,10 @@ class Context:
         nv = (C.c_uint32 * max(n, 1))(*[v for _, _, v in jobs])
         self._check(self.lib.lm_access_counts(self.h, out.ptr, length, n, cols, rows, nv))
         return out
+
+    def access_errors(self, reset=True):
+        """rows of access_counts jobs that pointed outside the image since the last reset (synchronises)"""
+        return int(self.lib.lm_access_errors(self.h, int(reset)))
 
     def stack_columns(self, total_words, jobs):
         """jobs: list of (DeviceBuffer src, src_word_offset, dst_offset, n_words) sorted by dst_offset -> DeviceBuffer"""

@@ -1066,6 +1066,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
         lens.push_back(n);
     };
     // access counters (prove_execution.rs:90-110) unless the caller already has them
+    (void)lm_access_errors(ctx, 1);  // reset the sticky count of lookup rows that leave the image
     DevBuf mem_acc(ctx), bc_acc(ctx);
     const u32* d_memory_acc = tr->d_memory_acc;
     const u32* d_bytecode_acc = tr->d_bytecode_acc;
@@ -1108,6 +1109,12 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     clk.mark("stack");
     if ((rc = lmh_whir_commit(ctx, p, cfg, poly.p, off, &wit))) return rc;
     clk.mark("whir_commit");
+    // (the root has been published behind the counting kernels on the same stream: the stream is idle, the count final)
+    if (const u32 n_bad = lm_access_errors(ctx, 0)) {
+        lm_set_error("%u lookup rows address words outside the memory / bytecode image (the reference panics on these)", n_bad);
+        lmh_witness_free(ctx, wit);
+        return LM_E_INVALID;
+    }
     auto fail = [&](int code) {
         if (wit) lmh_witness_free(ctx, wit);
         return code;

@@ -56,6 +56,7 @@ struct lm_ctx {
     u32* h_res = nullptr;
     static constexpr u64 RES_WORDS = 4096;
     static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
+    static constexpr u64 ERR_WORD = 8;          // h_res[RES_FLAG + ERR_WORD]: sticky count of data errors seen by kernels (lm_access_errors)
     u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
     // pinned staging ring for small host -> device tables (pointer lists, job lists, evaluation points): the host image is
     // written here and copied with ONE asynchronous command — no synchronisation to keep a caller's vector alive, no

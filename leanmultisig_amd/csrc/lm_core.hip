@@ -483,6 +483,16 @@ int lm_bind_thread(lm_ctx* ctx) {
     LM_HIP(hipSetDevice(ctx->device));
     return LM_OK;
 }
+// rows of lm_access_counts jobs whose address range fell outside the image since the last reset (the reference panics on
+// those; the device skips and counts them).  Synchronises the stream.
+uint32_t lm_access_errors(lm_ctx* ctx, int reset) {
+    if (!ctx) return 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    volatile u32* w = ctx->h_res + lm_ctx::RES_FLAG + lm_ctx::ERR_WORD;
+    const u32 v = *w;
+    if (reset) *w = 0;
+    return v;
+}
 int lm_sync(lm_ctx* ctx) {
     LM_REQUIRE(ctx);
     LM_HIP(hipStreamSynchronize(ctx->stream));

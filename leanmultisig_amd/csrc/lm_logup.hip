@@ -112,13 +112,18 @@ __device__ __forceinline__ void acc_emit(u32 a, u32 mult, u32 n_values, u32* his
 // run ends when an iteration has no such lane.  Hot addresses are a feature of real traces, not only of padding: every
 // instruction operand that is an immediate looks up memory[0] (trace_gen.rs:46-60), interleaved with real addresses.
 template <int MODE>
-__device__ __forceinline__ void acc_rows(const AccessJob& jb, u64 r0, u64 r1, u64 len, u32* hist, const u32* base, u32* __restrict__ items) {
+__device__ __forceinline__ void acc_rows(const AccessJob& jb, u64 r0, u64 r1, u64 len, u32* hist, const u32* base, u32* __restrict__ items,
+                                         u32* __restrict__ out_of_range) {
     const u32 lane = threadIdx.x & 63;
     u32 run_addr = 0, run_cnt = 0;  // wave-uniform
     for (u64 rb = r0; rb < r1; rb += 256) {
         const u64 r = rb + threadIdx.x;
         const u32 a = r < r1 ? from_monty(jb.index_col[r]) : 0u;
         const bool ok = r < r1 && (u64)a + jb.n_values <= len;
+        if (MODE == 0 && out_of_range) {  // rows that point outside the image are skipped AND reported (the reference would panic)
+            const u64 bad = __ballot(r < r1 && !ok);
+            if (bad && lane == 0) atomicAdd(out_of_range, (u32)__popcll(bad));
+        }
         u64 rest = __ballot(ok);
         if (!rest) continue;
         if (run_cnt) {
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void k_acc_pass(const AccessJobs jobs, u64 len
     __syncthreads();
     const u64 r1 = live ? (r0 + ACC_TILE < jb.n_rows ? r0 + ACC_TILE : jb.n_rows) : 0;
     // (each wave walks a fixed quarter of the tile's iterations: the run-length state is per wave)
-    acc_rows<0>(jb, r0, r1, len, hist, base, items);  // count
+    acc_rows<0>(jb, r0, r1, len, hist, base, items, MODE == 0 ? totals + nb : nullptr);  // count (totals[nb]: rows outside the image)
     __syncthreads();
     if (MODE == 0) {
         for (u32 i = threadIdx.x; i < nb; i += 256)
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void k_acc_pass(const AccessJobs jobs, u64 len
         hist[i] = 0;
     }
     __syncthreads();
-    acc_rows<1>(jb, r0, r1, len, hist, base, items);
+    acc_rows<1>(jb, r0, r1, len, hist, base, items, nullptr);
 }
 // offsets[i] = sum_{j < i} totals[j]; cursor = offsets (one workgroup, nb <= 8192)
 __global__ __launch_bounds__(1024) void k_acc_scan(const u32* __restrict__ totals, u32 nb, u32* __restrict__ offsets, u32* __restrict__ cursor) {
@@ -232,7 +237,10 @@ __global__ __launch_bounds__(256) void k_acc_window(const u32* __restrict__ item
         if (threadIdx.x < ACC_MAX_RUN && c[ACC_WIN + threadIdx.x]) atomicAdd(&boundary[w * ACC_MAX_RUN + threadIdx.x], c[ACC_WIN + threadIdx.x]);
     }
 }
-__global__ __launch_bounds__(256) void k_acc_finish(u32* __restrict__ v, u64 n, const u32* __restrict__ boundary) {
+__global__ __launch_bounds__(256) void k_acc_finish(u32* __restrict__ v, u64 n, const u32* __restrict__ boundary,
+                                                    const u32* __restrict__ out_of_range, u32* __restrict__ h_err) {
+    // rows outside the image: added to the context's sticky error word in pinned memory (lm_access_errors)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *out_of_range) lm_store_system(h_err, __hip_atomic_load(h_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + *out_of_range);
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
         u32 x = v[i];
         const u32 w = (u32)(i >> ACC_WIN_LOG), o = (u32)i & (ACC_WIN - 1);
@@ -268,23 +276,24 @@ extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint
     LM_REQUIRE(total_rows < (1ull << 31));
     const u32 nb = (u32)((len + ACC_WIN - 1) >> ACC_WIN_LOG);
     LM_REQUIRE(nb <= 8192);  // 2 nb words of dynamic LDS (64 KiB), memory images up to 2^26 words (MAX_LOG_MEMORY_SIZE)
-    // scratch (words): totals nb | offsets nb+1 | cursor nb | boundary nb*16 | items total_rows
+    // scratch (words): totals nb + 1 (the last: rows outside the image) | offsets nb+1 | cursor nb | boundary nb*16 | items total_rows
     u32* s;
     int rc = lm_scratch(ctx, 3ull * nb + 8 + (u64)nb * ACC_MAX_RUN + total_rows + 64, &s);
     if (rc) return rc;
     u32* d_totals = s;
-    u32* d_offsets = d_totals + nb;
+    u32* d_offsets = d_totals + nb + 1;
     u32* d_cursor = d_offsets + nb + 1;
     u32* d_boundary = d_cursor + nb;
     u32* d_items = d_boundary + (u64)nb * ACC_MAX_RUN;
-    LM_HIP(hipMemsetAsync(d_totals, 0, (u64)nb * 4, ctx->stream));
+    LM_HIP(hipMemsetAsync(d_totals, 0, ((u64)nb + 1) * 4, ctx->stream));
     LM_HIP(hipMemsetAsync(d_boundary, 0, (u64)nb * ACC_MAX_RUN * 4, ctx->stream));  // split windows add into these two
     LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
     LM_LAUNCH(ctx, (k_acc_pass<0>), dim3(tiles), dim3(256), (size_t)nb * 4, jobs, len, nb, d_totals, d_cursor, d_items);
     LM_LAUNCH(ctx, k_acc_scan, dim3(1), dim3(1024), 0, (const u32*)d_totals, nb, d_offsets, d_cursor);
     LM_LAUNCH(ctx, (k_acc_pass<1>), dim3(tiles), dim3(256), (size_t)nb * 8, jobs, len, nb, d_totals, d_cursor, d_items);
     LM_LAUNCH(ctx, k_acc_window, dim3(nb * ACC_SPLIT), dim3(256), 0, (const u32*)d_items, (const u32*)d_offsets, len, nb, d_acc, d_boundary);
-    LM_LAUNCH(ctx, k_acc_finish, dim3(fin_blocks), dim3(256), 0, d_acc, len, (const u32*)d_boundary);
+    LM_LAUNCH(ctx, k_acc_finish, dim3(fin_blocks), dim3(256), 0, d_acc, len, (const u32*)d_boundary, (const u32*)(d_totals + nb),
+              ctx->h_res + lm_ctx::RES_FLAG + lm_ctx::ERR_WORD);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void k_fold2_round(const u32* __restrict__ f, 
 // PoW: candidates base .. base + n; result = min hit (or 0xffffffff)
 // =====================================================================================================
 struct PowArgs {
-    u32 cap[8];
+    u32 pre[16];  // poseidon16_pow_base(capacity): the candidate-independent part of the first full round
     u32 base, n, mask, r2;
 };
 // The block that finishes last hands the result to the host (pinned buffer + sequence flag) and re-arms the device word:
@@ -589,14 +589,8 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ 
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     const u32 w = a.base + i;
     if (i < a.n && w < P) {
-        u32 s[16];
-#pragma unroll
-        for (int k = 0; k < 8; k++) s[k] = a.cap[k];
-        s[8] = mul(w, a.r2);  // Montgomery form of the canonical candidate
-#pragma unroll
-        for (int k = 9; k < 16; k++) s[k] = 0;
-        poseidon16_permute(s);
-        if ((from_monty(s[8]) & a.mask) == 0) atomicMin(result, w);
+        const u32 s8 = poseidon16_pow_word8(a.pre, mul(w, a.r2));  // (Montgomery form of the canonical candidate)
+        if ((from_monty(s8) & a.mask) == 0) atomicMin(result, w);
     }
     lm_wait_stores();  // the atomicMin of this wave has been performed
     __syncthreads();
@@ -891,7 +885,7 @@ int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_
         return LM_OK;
     }
     PowArgs a;
-    memcpy(a.cap, capacity, 32);
+    poseidon16_pow_base(capacity, a.pre);
     a.mask = (1u << bits) - 1;
     a.r2 = to_monty(to_monty(1));  // 2^64 mod p
     // batch = twice the expected work (2^bits candidates): a 2^16 batch is one workgroup per CU — one wave per SIMD, a pure

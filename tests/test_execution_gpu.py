@@ -55,14 +55,18 @@ def test_access_counts_match_histogram(ctx):
     a1 = rng.integers(0, length - 16, size=5000)
     a2 = np.concatenate([np.full(3000, 7), rng.integers(0, 64, size=1000), np.full(777, length - 4)])
     a3 = np.concatenate([rng.integers(0, length, size=300), [length - 1, length - 2, length + 5]])  # last rows overflow with n_values 4
-    jobs, want = [], np.zeros(length, dtype=np.int64)
+    jobs, want, bad = [], np.zeros(length, dtype=np.int64), 0
     for addr, nv in ((a1, 1), (a2, 4), (a3, 4), (a1, 16)):
         jobs.append((ctx.to_device(to_m(addr)), addr.size, nv))
         ok = addr + nv <= length
+        bad += int(np.sum(~ok))
         for j in range(nv):
             want += np.bincount(addr[ok] + j, minlength=length)
+    ctx.access_errors(reset=True)
     got = ctx.access_counts(length, jobs).download()
     assert np.array_equal(got, to_m(want))
+    assert bad >= 3 and ctx.access_errors() == bad   # the skipped rows are counted (the reference would panic on them)
+    assert ctx.access_errors() == 0                  # (reset by the previous call)
     assert np.array_equal(ctx.access_counts(64, []).download(), np.zeros(64, dtype=np.uint32))
 
 
@@ -113,6 +117,12 @@ def test_inconsistent_witness_is_rejected(ctx, orc):
     w["memory"][hot] = (int(w["memory"][hot]) + 1) % 0x7F000001
     with pytest.raises(lm.LmError):
         _device_proof(ctx, orc, w, b, device_counters=True)
+    # a lookup that leaves the memory image is an error of its own (the reference panics in its counting loop)
+    w2 = synth_witness.build(orc, np.random.default_rng(2), n_calls=40)
+    t0 = w2["tables"][0] = w2["tables"][0].copy()
+    t0[2][5] = int(orc.to_monty(np.array([w2["memory"].size + 3]))[0])
+    with pytest.raises(lm.LmError, match="outside the memory"):
+        _device_proof(ctx, orc, w2, b, device_counters=True)
 
 
 def test_concurrent_provers_are_independent(orc):

@@ -76,6 +76,9 @@ int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64
  * (crates/backend/koala-bear/src/poseidon1_koalabear_16.rs:873-912,1018-1030). */
 int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
 int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n);
+/* the same through the 4-lane cooperative kernel (csrc/poseidon16_quad.h: one state per DPP quad) that the proof-of-work
+ * search uses; compress != 0: compression mode.  Exposed for parity tests. */
+int lm_poseidon16_permute_quad(lm_ctx* ctx, uint32_t* d_states, uint64_t n, int compress);
 
 /* fill_trace_poseidon_16 / generate_trace_rows_for_perm (crates/lean_vm/src/tables/poseidon_16/trace_gen.rs:10-165):
  * d_cols = host array of the 109 DEVICE column pointers of the Poseidon16 table (Poseidon1Cols16 order,

@@ -40,6 +40,7 @@ _SIGS = {
     "lm_ef_soa_to_aos": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_poseidon16_permute": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_poseidon16_compress": (C.c_int, [vp, vp, C.c_uint64]),
+    "lm_poseidon16_permute_quad": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
     "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_extension_op_trace": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
     "lm_poseidon_trace_outputs_from_memory": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64]),
@@ -503,13 +504,17 @@ class Context:
         return self.to_device(np.ascontiguousarray(a.T))
 
     # ---- ops ----------------------------------------------------------------------------------------
-    def poseidon16(self, states, compress=False):
+    def poseidon16(self, states, compress=False, quad=False):
+        """quad=True: the 4-lane cooperative kernel of the proof-of-work search (lm_poseidon16_permute_quad)"""
         st = _u32(states).reshape(-1, 16)
         if st.shape[0] == 0:
             return st.copy()
         buf = self.to_device(st)
-        fn = self.lib.lm_poseidon16_compress if compress else self.lib.lm_poseidon16_permute
-        self._check(fn(self.h, buf.ptr, st.shape[0]))
+        if quad:
+            self._check(self.lib.lm_poseidon16_permute_quad(self.h, buf.ptr, st.shape[0], int(compress)))
+        else:
+            fn = self.lib.lm_poseidon16_compress if compress else self.lib.lm_poseidon16_permute
+            self._check(fn(self.h, buf.ptr, st.shape[0]))
         return buf.download().reshape(-1, 16)
 
     def poseidon_trace(self, col_bufs, n_rows):

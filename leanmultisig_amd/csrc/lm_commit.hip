@@ -8,6 +8,7 @@
 // as 5*C base columns in plane-major order (k*C + c); the reference's leaf word 5c+k maps to that column.
 #include "lm_common.h"
 #include "poseidon16_coop.h"
+#include "poseidon16_quad.h"
 
 using namespace kb;
 
@@ -289,6 +290,21 @@ __global__ __launch_bounds__(256) void k_poseidon_batch_coop(u32* __restrict__ s
     const u32 x = states[g * 16 + l];
     states[g * 16 + l] = compress ? coop_compress(x, R) : coop_permute(x, R);
 }
+// 4-lane variant (poseidon16_quad.h): state i on lanes 4i .. 4i+3, four words each
+__global__ __launch_bounds__(256) void k_poseidon_batch_quad(u32* __restrict__ states, u64 n, int compress, const u32* __restrict__ tab) {
+    __shared__ u32 lds[QUAD_TAB_WORDS];
+    quad_load_table(lds, tab);
+    __syncthreads();
+    const u64 g = ((u64)blockIdx.x * 256 + threadIdx.x) >> 2;
+    if (g >= n) return;  // whole quads leave together
+    const u32 q = threadIdx.x & 3;
+    uint4* p = reinterpret_cast<uint4*>(states + g * 16 + 4 * q);
+    const uint4 v = *p;
+    u32 s[4] = {v.x, v.y, v.z, v.w};
+    quad_permute(s, lds + q * QUAD_STRIDE);
+    if (compress) s[0] = add(s[0], v.x), s[1] = add(s[1], v.y), s[2] = add(s[2], v.z), s[3] = add(s[3], v.w);
+    *p = make_uint4(s[0], s[1], s[2], s[3]);
+}
 // one Merkle level, node i on lanes 16i .. 16i+15: the 16 input words are one coalesced 64-byte read
 __global__ __launch_bounds__(256) void k_compress_layer_coop(const u32* __restrict__ prev, u32* __restrict__ next, u64 n,
                                                              const u32* __restrict__ tab) {
@@ -474,6 +490,13 @@ static int poseidon_batch(lm_ctx* ctx, uint32_t* d_states, uint64_t n, int compr
     return LM_OK;
 }
 int lm_poseidon16_permute(lm_ctx* ctx, uint32_t* d_states, uint64_t n) { return poseidon_batch(ctx, d_states, n, 0); }
+int lm_poseidon16_permute_quad(lm_ctx* ctx, uint32_t* d_states, uint64_t n, int compress) {
+    LM_REQUIRE(ctx && d_states);
+    if (n == 0) return LM_OK;
+    LM_LAUNCH(ctx, k_poseidon_batch_quad, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, d_states, n, compress, (const u32*)ctx->d_quad);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
 int lm_poseidon16_compress(lm_ctx* ctx, uint32_t* d_states, uint64_t n) { return poseidon_batch(ctx, d_states, n, 1); }
 
 int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows) {

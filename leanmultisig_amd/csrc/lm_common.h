@@ -49,6 +49,7 @@ struct lm_ctx {
     u32* d_sync = nullptr;      // [0] PoW result (0xffffffff when idle), [1] "writers done" counter of multi-block publishers
     unsigned long long* d_acc = nullptr;  // LM_ACC_WORDS accumulators of lm_grid_sum (zero between kernels)
     u32* d_coop = nullptr;      // COOP_TAB_WORDS: per-lane coefficient table of the 16-lane Poseidon (poseidon16_coop.h)
+    u32* d_quad = nullptr;      // QUAD_TAB_WORDS: per-class coefficient table of the 4-lane Poseidon (poseidon16_quad.h)
     u32* d_scratch = nullptr;   // small reusable scratch (partials, points)
     u64 scratch_words = 0;
     // pinned, device-visible result buffer: final reduction kernels store round results here directly, the host

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
+#include "poseidon16_quad.h"
 
 using namespace kb;
 
@@ -454,6 +455,10 @@ static int ctx_create_impl(int device, lm_ctx* c) {
         }
         LM_HIP(hipMemcpyAsync(c->d_coop, tab.data(), COOP_TAB_WORDS * 4, hipMemcpyHostToDevice, c->stream));
         LM_HIP(hipStreamSynchronize(c->stream));
+        std::vector<u32> qt(QUAD_TAB_WORDS);  // 4-lane Poseidon (quad_perm semantics are fixed: no probe)
+        lm_quad_table_build(qt.data());
+        LM_HIP(hipMalloc(&c->d_quad, QUAD_TAB_WORDS * 4));
+        LM_HIP(hipMemcpy(c->d_quad, qt.data(), QUAD_TAB_WORDS * 4, hipMemcpyHostToDevice));
     }
     return LM_OK;
 }
@@ -469,6 +474,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
     if (c->d_coop) (void)hipFree(c->d_coop);
+    if (c->d_quad) (void)hipFree(c->d_quad);
     if (c->d_sync) (void)hipFree(c->d_sync);
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_scratch) (void)hipFree(c->d_scratch);

@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "lm_common.h"
+#include "poseidon16_quad.h"
 
 using namespace kb;
 
@@ -604,6 +605,38 @@ __global__ __launch_bounds__(256) void k_pow_grind(PowArgs a, u32* __restrict__ 
     }
 }
 
+// The same search with one candidate per DPP quad (poseidon16_quad.h): a ~2.2 k instruction chain on four times the lanes.
+struct PowArgsQ {
+    u32 cap[8];
+    u32 base, n, mask, r2;
+};
+__global__ __launch_bounds__(256) void k_pow_grind_quad(PowArgsQ a, u32* __restrict__ result, u32* __restrict__ done_counter,
+                                                        u32* __restrict__ h_res, u32 seq, const u32* __restrict__ tab) {
+    __shared__ u32 lds[QUAD_TAB_WORDS];
+    quad_load_table(lds, tab);
+    __syncthreads();
+    const u32 i = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3;
+    const u32 w = a.base + i;
+    if (i < a.n && w < P) {  // (whole quads: i is the same in the four lanes)
+        u32 s[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) s[k] = q == 0 ? a.cap[k] : q == 1 ? a.cap[4 + k] : 0u;
+        if (q == 2) s[0] = mul(w, a.r2);  // Montgomery form of the canonical candidate: state word 8
+        quad_permute(s, lds + q * QUAD_STRIDE);
+        if (q == 2 && (from_monty(s[0]) & a.mask) == 0) atomicMin(result, w);
+    }
+    lm_wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lm_ticket(done_counter) == gridDim.x - 1) {
+            lm_store_agent(done_counter, 0);
+            lm_store_system(h_res, atomicExch(result, 0xffffffffu));
+            lm_wait_stores();
+            lm_publish_flag(h_res, seq);
+        }
+    }
+}
+
 // init: W holds garbage on entry and must equal the sum on exit
 static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_weight_item* items, uint32_t n_items,
                         const uint32_t* points, uint64_t n_point_coords, const uint32_t* scalars, bool init) {
@@ -884,19 +917,33 @@ int lm_pow_grind(lm_ctx* ctx, const uint32_t capacity[8], uint32_t bits, uint32_
         *witness = 0;
         return LM_OK;
     }
+    // Two kernels (measured on MI355X, kernel time per launch):
+    //   one candidate per lane   2^17 candidates: 36 us (2 waves per SIMD of a ~6 k instruction chain: latency bound; 5.7 G/s asymptotically)
+    //   one candidate per quad   2^15: 19 us, 2^16: 25 us, 2^17: 43 us (a ~2.4 k chain, 1.6x the instructions: 3.4 G/s asymptotically)
+    // The expected work is 2^bits candidates and a failed batch costs another round trip (~8 us), so batch ~ 2 x 2^bits:
+    // searches of <= 14 bits (half of the 30 per proof) take the quad kernel with 2^15 candidates, the others the lane kernel.
+    // LM_POW_SINGLE_LANE=1 / LM_POW_QUAD=1 force one kernel, LM_POW_BATCH_LOG the batch (experiments).
+    static const bool force_lane = getenv("LM_POW_SINGLE_LANE") != nullptr, force_quad = getenv("LM_POW_QUAD") != nullptr;
+    static const char* batch_env = getenv("LM_POW_BATCH_LOG");
+    const bool single_lane = force_lane || (!force_quad && bits > 14);
     PowArgs a;
+    PowArgsQ aq;
     poseidon16_pow_base(capacity, a.pre);
-    a.mask = (1u << bits) - 1;
-    a.r2 = to_monty(to_monty(1));  // 2^64 mod p
-    // batch = twice the expected work (2^bits candidates): a 2^16 batch is one workgroup per CU — one wave per SIMD, a pure
-    // latency chain — so the second workgroup per CU is nearly free, and the chance of needing another round trip drops from
-    // 1/e to 1/e^2
-    u64 batch = std::max<u64>(1ull << 17, std::min<u64>(2ull << bits, 1ull << 22));
+    memcpy(aq.cap, capacity, 32);
+    a.mask = aq.mask = (1u << bits) - 1;
+    a.r2 = aq.r2 = to_monty(to_monty(1));  // 2^64 mod p
+    u64 batch = single_lane ? std::max<u64>(1ull << 17, std::min<u64>(2ull << bits, 1ull << 22))
+                            : std::min<u64>(std::max<u64>(2ull << bits, 1ull << 13), 1ull << 17);
+    if (batch_env) batch = 1ull << atoi(batch_env);
     for (u64 base = 0; base < P; base += batch) {
-        a.base = (u32)base;
-        a.n = (u32)std::min<u64>(batch, (u64)P - base);
+        a.base = aq.base = (u32)base;
+        a.n = aq.n = (u32)std::min<u64>(batch, (u64)P - base);
         const u32 seq = ++ctx->res_seq;
-        LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, ctx->d_sync, ctx->d_sync + 1, ctx->h_res, seq);
+        if (single_lane)
+            LM_LAUNCH(ctx, k_pow_grind, dim3((a.n + 255) / 256), dim3(256), 0, a, ctx->d_sync, ctx->d_sync + 1, ctx->h_res, seq);
+        else
+            LM_LAUNCH(ctx, k_pow_grind_quad, dim3((unsigned)(((u64)aq.n * 4 + 255) / 256)), dim3(256), 0, aq, ctx->d_sync, ctx->d_sync + 1,
+                      ctx->h_res, seq, (const u32*)ctx->d_quad);
         LM_HIP(hipGetLastError());
         int rc = lm_wait_result(ctx, seq);
         if (rc) return rc;

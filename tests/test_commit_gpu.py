@@ -25,6 +25,20 @@ def test_poseidon_batch_matches_oracle(ctx, orc):
     assert np.array_equal(ctx.poseidon16(st, compress=True), orc.poseidon16_compress(st))
 
 
+@pytest.mark.parametrize("n", [1, 3, 64, 1000, 5000])
+def test_poseidon_quad_matches_oracle(ctx, orc, n):
+    """the 4-lane cooperative permutation (poseidon16_quad.h, used by the proof-of-work search): every word of every state"""
+    rng = np.random.default_rng(100 + n)
+    st = rand_field(rng, (n, 16))
+    st[0] = P - 1
+    if n > 1:
+        st[1] = 0
+    if n > 2:
+        st[2] = orc.to_monty(np.arange(16))
+    assert np.array_equal(ctx.poseidon16(st, quad=True), orc.poseidon16_permute(st))
+    assert np.array_equal(ctx.poseidon16(st, compress=True, quad=True), orc.poseidon16_compress(st))
+
+
 @pytest.mark.parametrize("n_vars,fold,rate,frac", [
     (7, 4, 1, 1.0),      # tiny: h = 16 rows, 16 columns
     (10, 7, 1, 1.0),     # 128 columns, h = 16

@@ -211,6 +211,17 @@ int lmh_verify_execution_bytes(const lm_verify_instance* instance, const uint8_t
 /* the proof still held by a prover object (pruned and restored on the way, like a proof that travelled) */
 int lmh_verify_execution_prover(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder);
 
+/* ---- pad_table (crates/lean_prover/src/trace_gen.rs:170-191) ----------------------------------------------------------------
+ * lmh_table_log_rows = log2_ceil(n_rows + 1).max(MIN_LOG_N_ROWS_PER_TABLE): the height get_execution_trace gives a table.
+ * lmh_pad_table fills rows [n_rows, 2^log_rows) of every committed column (device pointers in the host array d_cols; 20 / 29 /
+ * 109 for table 0 / 1 / 2) with the table's padding row (execution/mod.rs:59-74, extension_op/mod.rs:125-134,
+ * poseidon_16/mod.rs:182-205; canonical pointers in, Montgomery words out).  Poseidon table: the 84 derived columns of the
+ * padded rows are zero-filled — run lm_poseidon_trace (and lm_poseidon_trace_outputs_from_memory) over the whole table
+ * afterwards, exactly as for the active rows (the reference fills them "later with SIMD" too). */
+uint32_t lmh_table_log_rows(uint64_t n_rows);
+int lmh_pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr,
+                  uint32_t null_hash_ptr, uint32_t ending_pc);
+
 /* ---- host Poseidon1-16 (poseidon1_koalabear_16.rs:873-1030) ----------------------------------------------------------------
  * The transcript's permutation: ~1300 strictly sequential calls per proof between device launches, so its latency is on the
  * critical path.  "avx512-ifma" when the CPU has AVX-512 F/DQ/BW/VL/IFMA (the reference's own Poseidon is AVX2/AVX-512/NEON

@@ -88,6 +88,8 @@ _SIGS = {
 
 # include/leanmultisig_host.h
 _HOST_SIGS = {
+    "lmh_table_log_rows": (C.c_uint32, [C.c_uint64]),
+    "lmh_pad_table": (C.c_int, [vp, C.c_uint32, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lmh_poseidon_backend": (C.c_char_p, []),
     "lmh_poseidon16_permute": (None, [vp]),
     "lmh_poseidon16_permute_scalar": (None, [vp]),
@@ -573,6 +575,12 @@ class Context:
         nv = (C.c_uint32 * max(n, 1))(*[v for _, _, v in jobs])
         self._check(self.lib.lm_access_counts(self.h, out.ptr, length, n, cols, rows, nv))
         return out
+
+    def pad_table(self, table, col_bufs, n_rows, log_rows, zero_vec_ptr, null_hash_ptr, ending_pc):
+        """lmh_pad_table: padding rows [n_rows, 2^log_rows) of the committed columns (list of DeviceBuffer)"""
+        ptrs = np.array([c.ptr for c in col_bufs], dtype=np.uint64)
+        self._check(self.lib.lmh_pad_table(self.h, table, _ptr(ptrs), int(n_rows), int(log_rows), int(zero_vec_ptr), int(null_hash_ptr),
+                                           int(ending_pc)))
 
     def access_errors(self, reset=True):
         """rows of access_counts jobs that pointed outside the image since the last reset (synchronises)"""

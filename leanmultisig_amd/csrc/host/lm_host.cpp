@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <vector>
+#include <hip/hip_runtime.h>
 #include "lm_host_internal.h"
 
 using kb::EF;
@@ -1300,6 +1301,58 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
                         S.sels.size(), w, poly.p, out_point.data());
     clk.mark("whir_open");
     return rc;
+}
+
+
+// ---- pad_table (lean_prover/src/trace_gen.rs:170-191) ---------------------------------------------------------------------
+uint32_t lmh_table_log_rows(uint64_t n_rows) {  // log2_ceil(h + 1).max(MIN_LOG_N_ROWS_PER_TABLE)
+    u32 l = 0;
+    while ((1ull << l) < n_rows + 1) l++;
+    return std::max<u32>(l, lmh::MIN_LOG_N_ROWS_PER_TABLE);
+}
+int lmh_pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr,
+                  uint32_t null_hash_ptr, uint32_t ending_pc) {
+    if (!ctx || !d_cols || table > 2 || log_rows > 30 || n_rows >= (1ull << log_rows)) {
+        lm_set_error("lmh_pad_table: bad arguments (a table needs at least one padding row: n_rows < 2^log_rows)");
+        return LM_E_INVALID;
+    }
+    const u32 n_cols = lmh::kVmTables[table].n_columns;
+    std::vector<u32> row(n_cols, 0);  // canonical values
+    if (table == 0) {  // execution/mod.rs:59-74 (committed columns; nu_a, nu_b are virtual)
+        row[0] = ending_pc;                                   // COL_PC
+        row[2] = row[3] = row[4] = zero_vec_ptr;             // COL_MEM_ADDRESS_A/B/C
+        row[8] = 1;                                           // COL_OPERAND_A
+        row[9] = ending_pc;                                   // COL_OPERAND_B: the jump destination
+        row[11] = row[12] = 1;                                // COL_FLAG_A, COL_FLAG_B
+        row[14] = 1;                                          // COL_FLAG_C_FP
+        row[17] = 1;                                          // COL_JUMP
+    } else if (table == 1) {  // extension_op/mod.rs:125-134
+        row[1] = 1;                                           // COL_START
+        row[2] = 1;                                           // COL_LEN
+        row[6] = row[7] = row[13] = zero_vec_ptr;            // COL_IDX_A, COL_IDX_B, COL_IDX_RES
+    } else {  // poseidon_16/mod.rs:182-205: flags 0, inputs 0; the 84 derived columns are left to lm_poseidon_trace
+        row[1] = zero_vec_ptr;                                // index_b (POSEIDON_16_COL_INDEX_INPUT_RIGHT)
+        row[2] = null_hash_ptr;                               // index_res
+        row[6] = zero_vec_ptr;                                // effective_index_left_first
+        row[7] = zero_vec_ptr + 4;                            // effective_index_left_second (+ HALF_DIGEST_LEN)
+    }
+    hipStream_t stream = (hipStream_t)lm_ctx_stream(ctx);
+    const u64 count = (1ull << log_rows) - n_rows;
+    for (u32 c = 0; c < n_cols; c++) {
+        if (!d_cols[c]) {
+            lm_set_error("lmh_pad_table: column %u is null", c);
+            return LM_E_INVALID;
+        }
+        if (row[c] >= kb::P) {
+            lm_set_error("lmh_pad_table: value out of the field");
+            return LM_E_INVALID;
+        }
+        if (hipMemsetD32Async((hipDeviceptr_t)(d_cols[c] + n_rows), (int)kb::to_monty(row[c]), count, stream) != hipSuccess) {
+            lm_set_error("lmh_pad_table: fill failed");
+            return LM_E_DEVICE;
+        }
+    }
+    return LM_OK;
 }
 
 }  // extern "C"

@@ -369,3 +369,33 @@ def test_mixed_program_2p15_production_parameters_equals_oracle(ctx, orc):
     assert proof.size == ref.size and np.array_equal(proof, ref)
     ok, err = ob.verify_execution(orc, w, proof, None)
     assert ok, err
+
+
+def test_pad_table_matches_generator(ctx, orc):
+    """lmh_pad_table (pad_table, trace_gen.rs:170-191) against the padding rows the witness generator wrote from the reference's
+    executor semantics (execution/mod.rs:59-74, extension_op/mod.rs:125-134, poseidon_16/mod.rs:182-205): the padded region of
+    every committed column is overwritten with garbage on the device, padded again by the library, the Poseidon rows
+    re-derived by lm_poseidon_trace + lm_poseidon_trace_outputs_from_memory, and must equal the generator's table."""
+    rng = np.random.default_rng(21)
+    w = synth_witness.build_mixed(orc, rng)
+    Z, NULL = 64, 96   # synth_witness: zero vector, null hash
+    assert not w["memory"][Z:Z + 16].any() and w["memory"][NULL:NULL + 8].any()
+    d_mem = ctx.to_device(w["memory"])
+    for t in (0, 1, 2):
+        tab = np.ascontiguousarray(w["tables"][t])
+        n_cols, n = (20, 29, 109)[t], tab.shape[1]
+        tab = tab[:n_cols]
+        same = np.all(tab == tab[:, -1:], axis=0)               # rows equal to the last (padding) row
+        n_active = n - int(np.argmin(same[::-1])) if not same.all() else 0
+        assert 0 < n_active < n and ctx.lib.lmh_table_log_rows(n_active) <= int(np.log2(n))
+        dirty = tab.copy()
+        dirty[:, n_active:] = ob.rand_field(rng, (n_cols, n - n_active))
+        cols = [ctx.to_device(np.ascontiguousarray(dirty[c])) for c in range(n_cols)]
+        ctx.pad_table(t, cols, n_active, int(np.log2(n)), Z, NULL, w["ending_pc"])
+        if t == 2:
+            ctx.poseidon_trace(cols, n)
+            ctx.poseidon_trace_outputs_from_memory(cols, n, d_mem, w["memory"].size)
+        got = np.stack([c.download() for c in cols])
+        assert np.array_equal(got, tab), f"table {t}: columns {sorted(set(np.nonzero(got != tab)[0]))}"
+    with pytest.raises(lm.LmError):
+        ctx.pad_table(0, cols[:20], 1 << 8, 8, Z, NULL, 0)      # no room for a padding row

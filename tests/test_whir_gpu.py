@@ -275,3 +275,30 @@ def test_whir_run_whir_shape(ctx, orc):
     ok, vpt, err = ob.whir_verify(orc, b, n, pr.proof(), sts)
     assert ok, err
     assert np.array_equal(vpt, pt)
+
+
+def test_staging_ring_wraps_under_queued_work(ctx, orc):
+    """The pinned staging ring behind every host -> device table (lm_upload / lm_stage_alloc: 8 MB, regions valid until the
+    ring wraps, wrapping synchronises): 48 weight accumulations of ~0.5 MB of tables each are queued without any
+    synchronisation in between — the ring wraps three times while copies and kernels that read it are still pending.
+    Every call uploads different scalars (and alternating point sets), so a region reused too early shows up in W."""
+    rng = np.random.default_rng(77)
+    n_vars, n_items, iters = 10, 2000, 48
+    n = 1 << n_vars
+    sets = []
+    for _ in range(2):
+        pts = np.zeros((n_items * n_vars, 5), dtype=np.uint32)
+        pts[:, 0] = rand_field(rng, n_items * n_vars)          # base-field points (the STIR-query shape)
+        sets.append(pts)
+    items = [(0, n_vars, 0, i * n_vars) for i in range(n_items)]
+    W0 = rand_field(rng, (n, 5))
+    dW = ctx.ef_to_device_soa(W0)
+    total = [np.zeros((n_items, 5), dtype=np.uint64), np.zeros((n_items, 5), dtype=np.uint64)]
+    for it in range(iters):
+        sc = rand_field(rng, (n_items, 5))
+        total[it & 1] = (total[it & 1] + sc) % P
+        ctx.weights_accumulate(dW, n_vars, items, sets[it & 1], sc)     # asynchronous: nothing waits here
+    want = W0.copy()
+    for s in range(2):
+        want = _weights_reference(orc, want, items, sets[s], total[s].astype(np.uint32))
+    assert np.array_equal(dW.download().reshape(5, n).T, want)

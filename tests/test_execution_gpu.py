@@ -250,10 +250,10 @@ def test_extension_op_trace_gather(ctx, orc):
 @pytest.mark.parametrize("log_inv_rate", [1, 2])
 def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
     """BASELINE configs[1] (rate 1/2) and configs[2] (rate 1/4) at their FULL size (1550 signatures: Poseidon table 2^18 with 258 850 active rows, execution 2^20,
-    memory 2^20, stacked polynomial 2^26, logup 2^24, production WHIR parameters) — too large for the oracle's prover, so
-    parity is carried by size-independent properties: the oracle's VERIFIER accepts the proof (every sumcheck, GKR layer,
-    Merkle path and PoW witness of the real size), proving twice gives the same words, and the pruned wire form restores to
-    the proof."""
+    memory 2^20, stacked polynomial 2^26, logup 2^24, production WHIR parameters): size-independent properties — the oracle's
+    VERIFIER accepts the proof (every sumcheck, GKR layer, Merkle path and PoW witness of the real size), proving twice gives
+    the same words, and the pruned wire form restores to the proof.  (Word-for-word equality with the oracle PROVER at this
+    size: test_full_size_proof_equals_oracle_prover, rate 1/2.)"""
     import bench
     w = bench.build_workload(ctx, orc, ob, np.random.default_rng(77), log_inv_rate=log_inv_rate)
     assert w["n_vars"] == 26
@@ -273,6 +273,20 @@ def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
     pruned = p1.proof_pruned()
     assert np.array_equal(ob.restore_proof(orc, pruned), proof)
     assert p1.proof_size_fe() == ob.pruned_size_fe(orc, pruned) < proof.size
+
+
+def test_full_size_proof_equals_oracle_prover(ctx, orc):
+    """BASELINE configs[1] at its FULL size and on the default workload of bench.py (1550 real XMSS signatures, stacked 2^26,
+    logup domain 2^25, memory 2^22, production WHIR parameters): the device proof equals the proof of the oracle PROVER word
+    for word — every root, round polynomial, PoW witness, query answer and sibling of the full-size schedule (~1 minute of
+    oracle time on 16 OpenMP threads)."""
+    import bench
+    w = bench.build_workload(ctx, orc, ob, np.random.default_rng(5), log_inv_rate=1)
+    assert w["n_vars"] == 26
+    proof = bench.run_step(ctx, lm, w).proof()
+    ob.set_threads(orc, 16)
+    ref = ob.prove_execution(orc, w["w"], synth_witness.header(w["w"]), ob.whir_builder(log_inv_rate=1))
+    assert proof.size == ref.size and np.array_equal(proof, ref)
 
 
 def test_execution_table_trace_matches_oracle(ctx, orc):

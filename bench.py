@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N > 1 path on a single-GPU box "
                          "together with LM_BENCH_SINGLE_DEVICE=1)")
+    ap.add_argument("--equal-oracle", action="store_true",
+                    help="after the timed region: run the oracle PROVER (CPU, ~1-2 min at full size) on the same witness and report "
+                         "whether the device proof equals its proof word for word (config.proof_equals_oracle_prover)")
     ap.add_argument("--host-resident", action="store_true",
                     help="re-upload the whole witness from pinned host memory in every step (PCIe-inclusive rate)")
     ap.add_argument("--log-inv-rate", type=int, default=1, help="WHIR rate 1/2^k (1 = BASELINE configs[1], 2 = configs[2])")
@@ -424,6 +427,12 @@ def main():
             out["config"]["proof_verified_by_library"] = bool(ok)
             if not ok:
                 print("VERIFY (lmh_verify_execution) FAILED:", err, file=sys.stderr)
+        if args.equal_oracle:  # the oracle PROVER on the same witness and parameters (~1-2 minutes of CPU at full size)
+            from tests import synth_witness
+            ob.set_threads(orc, 16)
+            ref = ob.prove_execution(orc, w["w"], synth_witness.header(w["w"]), w["builder"])
+            mine = pr.proof()
+            out["config"]["proof_equals_oracle_prover"] = bool(ref.size == mine.size and np.array_equal(ref, mine))
         # Proof::proof_size_fe * F::bits() / 8192 as the reference prints it (benchmark.rs:447), Merkle paths pruned
         out["config"]["proof_KiB"] = round(pr.proof_size_fe() * 31 / (8 * 1024), 1)
         out["config"]["proof_bytes_postcard"] = len(pr.proof_bytes())

@@ -302,3 +302,20 @@ def test_staging_ring_wraps_under_queued_work(ctx, orc):
     for s in range(2):
         want = _weights_reference(orc, want, items, sets[s], total[s].astype(np.uint32))
     assert np.array_equal(dW.download().reshape(5, n).T, want)
+
+
+def test_tables_larger_than_a_staging_region_take_the_synchronous_path(ctx, orc):
+    """A host table above a quarter of the staging ring (here 3 MB of points) is not staged: lm_stage_alloc declines and the
+    caller copies synchronously.  Same result."""
+    rng = np.random.default_rng(78)
+    n_vars, n_items = 10, 15000
+    n = 1 << n_vars
+    pts = np.zeros((n_items * n_vars, 5), dtype=np.uint32)
+    pts[:, 0] = rand_field(rng, n_items * n_vars)
+    assert pts.nbytes > (8 << 20) // 4
+    items = [(0, n_vars, 0, i * n_vars) for i in range(n_items)]
+    sc = rand_field(rng, (n_items, 5))
+    W0 = rand_field(rng, (n, 5))
+    dW = ctx.ef_to_device_soa(W0)
+    ctx.weights_accumulate(dW, n_vars, items, pts, sc)
+    assert np.array_equal(dW.download().reshape(5, n).T, _weights_reference(orc, W0, items, pts, sc))

@@ -702,8 +702,20 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
                 EF acc = kb::ef_zero();
                 if (tree_is_ext)
                     for (u64 i = 0; i < m; i++) acc = kb::ef_add(acc, kb::ef_mul(eq[i], ef_load(leaf + 5 * i)));
-                else
-                    for (u64 i = 0; i < m; i++) acc = kb::ef_add(acc, kb::ef_mul_base(eq[i], leaf[i]));
+                else {  // five dot products with delayed reduction (kb::dot_n's schedule: 4 products, then 3 per fold)
+                    u64 a64[5] = {0, 0, 0, 0, 0};
+                    int room = 4;
+                    for (u64 i = 0; i < m; i++) {
+                        if (room == 0) {
+                            for (int k = 0; k < 5; k++) a64[k] = kb::fold32(a64[k]);
+                            room = 3;
+                        }
+                        const u64 x = leaf[i];
+                        for (int k = 0; k < 5; k++) a64[k] += x * eq[i].v[k];
+                        room--;
+                    }
+                    for (int k = 0; k < 5; k++) acc.v[k] = kb::reduce(kb::fold32(a64[k]));
+                }
                 stir_evals[q] = acc;
             }
         }

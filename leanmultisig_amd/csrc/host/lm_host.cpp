@@ -379,6 +379,11 @@ const std::vector<u32>& pruned_blob(const lmh_prover* p) {
     if (memcmp(key, p->pruned_key, sizeof key) == 0) return p->pruned_cache;
     std::vector<u32>& o = p->pruned_cache;
     o.clear();
+    {
+        size_t words = p->transcript.size() + 64;
+        for (const lmh::Opening& op : p->openings) words += op.leaf.size() + op.path.size() + 8;
+        o.reserve(words);  // upper bound: nothing pruned
+    }
     o.push_back((u32)p->transcript.size());
     o.insert(o.end(), p->transcript.begin(), p->transcript.end());
     const std::vector<lmh::PrunedBatch> batches = lmh::prune(p);

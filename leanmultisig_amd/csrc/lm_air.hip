@@ -503,8 +503,8 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->h_cols.assign(d_cols, d_cols + a->n_cols);
     for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
     int rc;
-    if ((rc = lm_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||
-        (rc = lm_upload(ctx, a->d_extra, &a->h_extra, sizeof(air::Extra)))) {
+    if ((rc = lm_stage_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||
+        (rc = lm_stage_upload(ctx, a->d_extra, &a->h_extra, sizeof(air::Extra)))) {
         lm_air_free(ctx, a);
         return rc;
     }

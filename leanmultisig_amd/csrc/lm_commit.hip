@@ -505,7 +505,7 @@ int lm_poseidon_trace(lm_ctx* ctx, uint32_t* const* d_cols, uint64_t n_rows) {
     u32* s;
     int rc = lm_scratch(ctx, 109 * 2 + 16, &s);
     if (rc) return rc;
-    if ((rc = lm_upload(ctx, s, d_cols, 109 * sizeof(u32*)))) return rc;
+    if ((rc = lm_stage_upload(ctx, s, d_cols, 109 * sizeof(u32*)))) return rc;
     LM_LAUNCH(ctx, k_poseidon_trace, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (u32* const*)s, n_rows);
     LM_HIP(hipGetLastError());
     return LM_OK;
@@ -638,7 +638,7 @@ int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_
     u64* d_idx = reinterpret_cast<u64*>(d_tmp);
     u32* d_leaves = d_tmp + 2ull * n_idx;
     u32* d_sib = d_leaves + leaf_total;
-    if ((rc = lm_upload(ctx, d_idx, indices, (size_t)n_idx * 8))) return rc;
+    if ((rc = lm_stage_upload(ctx, d_idx, indices, (size_t)n_idx * 8))) return rc;
     void* pinned;
     if ((rc = lm_stage_alloc(ctx, (leaf_total + sib_total) * 4, &pinned))) return rc;
     if (pinned) {  // results straight into pinned host memory

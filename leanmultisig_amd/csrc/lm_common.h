@@ -183,8 +183,10 @@ struct lm_tree {
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out);
 // bytes of the staging ring (nullptr in *out if the request is too large for it: the caller falls back to a synchronous copy)
 int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out);
-// asynchronous host -> device copy on ctx->stream through the staging ring; `src` may be freed on return
-int lm_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+// asynchronous host -> device copy of `bytes` BYTES on ctx->stream through the staging ring; `src` may be freed on return.
+// (Not an overload of the public lm_upload(ctx, uint32_t*, const uint32_t*, n_words): with u32 pointers overload resolution
+// would silently pick that one and read n_words WORDS.)
+int lm_stage_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 // device -> host for a few words without a copy command or a stream synchronise: one tiny kernel stores them (and n1 more
 // from a second source) into the pinned result buffer at `res_offset` and publishes; the host spins on the flag.
 int lm_fetch_words(lm_ctx* ctx, int aux, const kb::u32* d_src0, kb::u32 n0, const kb::u32* d_src1, kb::u32 n1, kb::u32 res_offset, kb::u32* out);

@@ -317,7 +317,7 @@ int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out) {
     ctx->stage_off += bytes;
     return LM_OK;
 }
-int lm_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+int lm_stage_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     if (bytes == 0) return LM_OK;
     void* st;
     int rc = lm_stage_alloc(ctx, bytes, &st);
@@ -674,7 +674,7 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     u32* d_eq_lo = s + ((2ull * n_cols + 15) & ~15ull);
     u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
     u32* d_partial = d_eq_hi + 5ull * n_hi;
-    if ((rc = lm_upload(ctx, (void*)d_ptrs, d_cols, (size_t)n_cols * 8))) return rc;
+    if ((rc = lm_stage_upload(ctx, (void*)d_ptrs, d_cols, (size_t)n_cols * 8))) return rc;
     EqSmallArg p_hi, p_lo;
     if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
     if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
@@ -714,7 +714,7 @@ int lm_stack_columns(lm_ctx* ctx, uint32_t* d_dst, uint64_t total_words, uint32_
     int rc = lm_scratch(ctx, (jobs.size() * sizeof(StackJob) + 3) / 4 + 16, &s);
     if (rc) return rc;
     if (!jobs.empty()) {
-        if ((rc = lm_upload(ctx, s, jobs.data(), jobs.size() * sizeof(StackJob)))) return rc;
+        if ((rc = lm_stage_upload(ctx, s, jobs.data(), jobs.size() * sizeof(StackJob)))) return rc;
     }
     const u64 n_vec = total_words / 4;
     const u32 blocks = (u32)std::min<u64>((n_vec + 255) / 256, 16384);

@@ -478,7 +478,7 @@ static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n
     int rc = lm_scratch(ctx, w_secs + 16 + 80, &s);
     if (rc) return rc;
     u32* d_al = s + ((w_secs + 15) & ~15ull);
-    if ((rc = lm_upload(ctx, s, hs.data(), sizeof(LogupSec) * n_sections)) || (rc = lm_upload(ctx, d_al, alphas_eq16, 320))) return rc;
+    if ((rc = lm_stage_upload(ctx, s, hs.data(), sizeof(LogupSec) * n_sections)) || (rc = lm_stage_upload(ctx, d_al, alphas_eq16, 320))) return rc;
     EF cc;
     memcpy(cc.v, c, 20);
     LM_LAUNCH(ctx, k_logup_neutral, dim3((unsigned)std::min<u64>((fill_len + 255) / 256, 4096)), dim3(256), 0, plane, fill_len, d_nums, d_dens);

@@ -278,7 +278,7 @@ def test_whir_run_whir_shape(ctx, orc):
 
 
 def test_staging_ring_wraps_under_queued_work(ctx, orc):
-    """The pinned staging ring behind every host -> device table (lm_upload / lm_stage_alloc: 8 MB, regions valid until the
+    """The pinned staging ring behind every host -> device table (lm_stage_upload / lm_stage_alloc: 8 MB, regions valid until the
     ring wraps, wrapping synchronises): 48 weight accumulations of ~0.5 MB of tables each are queued without any
     synchronisation in between — the ring wraps three times while copies and kernels that read it are still pending.
     Every call uploads different scalars (and alternating point sets), so a region reused too early shows up in W."""

@@ -22,7 +22,8 @@ python tools/valu_summary.py $OUT 4 $OUT/valu_bench.json profiles/${TAG%%_*}_isa
 python tools/timeline.py $OUT/stats_inflight1 > $OUT/timeline.txt
 for k in k_gkr_step k_air_round k_fold_round; do python tools/launch_hist.py $OUT/stats_inflight1 $k 4; done > $OUT/launch_hist.txt
 (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 int_rates.hip -o int_rates 2>/dev/null && ./int_rates) > $OUT/int_rates.txt 2>&1
-bash tools/bench_lines.sh $TAG
+# the plain bench lines come AFTER the summaries above have been published (tools/publish_profiles.sh), so that bench.py finds
+# counter files for the current sources: tools/bench_lines.sh
 (nproc; lscpu | grep "Model name") > $OUT/host.txt
 # keep the summaries, drop the raw per-launch CSVs of the counter passes (tens of MB)
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_valu

@@ -11,10 +11,11 @@ cp $SRC/pmc_bench.txt ${P}_pmc_bench.txt
 cp $SRC/timeline.txt ${P}_timeline_single_proof.txt
 cp $SRC/launch_hist.txt ${P}_launch_hist.txt
 cp $SRC/int_rates.txt ${P}_int_rates.txt
-cp $SRC/inflight_sweep.txt ${P}_inflight_sweep.txt
+[ -s $SRC/inflight_sweep.txt ] && cp $SRC/inflight_sweep.txt ${P}_inflight_sweep.txt
 cp $SRC/host.txt ${P}_host.txt
 cp "$(ls -t $SRC/stats_inflight1/*/*_kernel_stats.csv | head -1)" ${P}_kernel_stats_single_proof.csv
-for f in bench_default bench_verify bench_config3_rate4 bench_capacity bench_capacity_rate4 bench_host_resident bench_recursion_shape bench_under_rocprof; do
+# (the plain bench lines are produced by tools/bench_lines.sh AFTER this script and copied from its output directory)
+for f in bench_under_rocprof; do
   [ -s $SRC/$f.json ] && cp $SRC/$f.json ${P}_$f.json
 done
 [ -s $SRC/bench_recursion_shape_kernels.txt ] && cp $SRC/bench_recursion_shape_kernels.txt ${P}_bench_recursion_shape_kernels.txt

@@ -59,3 +59,12 @@ def test_invalid_builders_are_rejected():
         lm.WhirConfig.new(lm.WhirBuilder.default(1, rs_domain_initial_reduction_factor=8), 26)
     with pytest.raises(lm.LmError):
         lm.WhirConfig.new(lm.WhirBuilder.default(1, security_level=160), 26)
+
+
+def test_table_log_rows_matches_pad_table_rule():
+    """lmh_table_log_rows = log2_ceil(n + 1).max(MIN_LOG_N_ROWS_PER_TABLE = 8) (pad_table, trace_gen.rs:185): a table always
+    keeps at least one padding row."""
+    import leanmultisig_amd as lm
+    lib = lm.load()
+    for n, want in ((0, 8), (1, 8), (255, 8), (256, 9), (257, 9), (511, 9), (512, 10), ((1 << 20) - 1, 20), (1 << 20, 21), (799392, 20)):
+        assert lib.lmh_table_log_rows(n) == want, n

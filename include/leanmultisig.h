@@ -288,6 +288,12 @@ typedef struct lm_air lm_air;
 int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint32_t log_rows, const uint32_t* eq_point,
                const uint32_t alpha[LM_EF_DIM], const uint32_t* logup_eq16, const uint32_t bus_beta[LM_EF_DIM], lm_air** out);
 void lm_air_free(lm_ctx* ctx, lm_air* a);
+/* Active prefix (AirSumcheckSession: unpadded_len / constraints_eval_at_padding, air_sumcheck.rs:194-200,236-240): rows
+ * [n_active_rows, 2^log_rows) of every column are the table's padding row (identical rows, as pad_table writes them).  The
+ * round kernels then evaluate only the pairs that contain an active row plus ONE padding pair, weighted with the sum of the
+ * eq weights of all padding pairs (the reference's padding_eq_sum) — same sums as over the full table.  Call before the
+ * first round; default = all rows active. */
+int lm_air_set_active_rows(lm_air* a, uint64_t n_active_rows);
 uint32_t lm_air_degree(const lm_air* a);
 uint32_t lm_air_n_evals(const lm_air* a);
 int lm_air_round(lm_ctx* ctx, lm_air* a, uint32_t* out_raw);

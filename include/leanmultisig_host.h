@@ -162,6 +162,7 @@ typedef struct {
     const uint32_t* const* d_cols; /* host array of device column pointers */
     const uint32_t* eq_point;      /* log_rows x 5 (from_end(gkr_point, log_rows)) */
     uint32_t sum[5];               /* bus_final_value */
+    uint32_t non_padded_n_rows;    /* TableTrace::non_padded_n_rows (rows behind it are the padding row); 0 = unknown: all rows */
 } lm_air_table;
 int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_table* tables, uint32_t n_tables,
                                    const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5],
@@ -176,6 +177,8 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
  * cfg must be the WhirConfig integers for lmh_stacked_n_vars(trace) variables. */
 typedef struct {
     uint32_t log_rows;
+    uint32_t non_padded_n_rows;    /* TableTrace::non_padded_n_rows (trace_gen.rs:183): the rows behind it are the table's padding
+                                      row, as pad_table / lmh_pad_table write them; 0 = unknown (every row is summed) */
     const uint32_t* const* d_cols; /* host array of device column pointers (n_columns_total of the table) */
 } lm_vm_table;
 typedef struct {

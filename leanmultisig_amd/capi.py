@@ -77,6 +77,7 @@ _SIGS = {
     "lm_gkr_layer_end": (C.c_int, [vp, vp, vp, vp]),
     "lm_air_new": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(vp)]),
     "lm_air_free": (None, [vp, vp]),
+    "lm_air_set_active_rows": (C.c_int, [vp, C.c_uint64]),
     "lm_air_degree": (C.c_uint32, [vp]),
     "lm_air_n_evals": (C.c_uint32, [vp]),
     "lm_air_round": (C.c_int, [vp, vp, vp]),
@@ -325,7 +326,8 @@ class LogupSection(C.Structure):
 
 class AirTable(C.Structure):
     """lm_air_table"""
-    _fields_ = [("table", C.c_uint32), ("log_rows", C.c_uint32), ("d_cols", vp), ("eq_point", vp), ("sum", C.c_uint32 * 5)]
+    _fields_ = [("table", C.c_uint32), ("log_rows", C.c_uint32), ("d_cols", vp), ("eq_point", vp), ("sum", C.c_uint32 * 5),
+                ("non_padded_n_rows", C.c_uint32)]
 
 
 AIR_N_COLUMNS = {0: 20, 1: 29, 2: 109}
@@ -335,7 +337,7 @@ AIR_DEGREE = {0: 5, 1: 6, 2: 10}
 
 class VmTable(C.Structure):
     """lm_vm_table"""
-    _fields_ = [("log_rows", C.c_uint32), ("d_cols", vp)]
+    _fields_ = [("log_rows", C.c_uint32), ("non_padded_n_rows", C.c_uint32), ("d_cols", vp)]
 
 
 class ExecutionTrace(C.Structure):
@@ -655,7 +657,7 @@ class Context:
         return w.value
 
 
-def make_execution_trace(ctx, w, device_counters=True):
+def make_execution_trace(ctx, w, device_counters=True, active_prefix=True):
     """Upload a witness dict (tests/synth_witness.py layout) and build the lm_execution_trace; returns (trace, keepalive).
     device_counters: leave memory_acc / bytecode_acc to the library (prove_execution.rs:90-110 on the device) instead of
     uploading the witness's own."""
@@ -680,6 +682,13 @@ def make_execution_trace(ctx, w, device_counters=True):
         keep += [bufs, ptrs]
         tr.tables[t].log_rows = w["log_rows"][t]
         tr.tables[t].d_cols = ptrs.ctypes.data
+        if active_prefix:
+            # TableTrace::non_padded_n_rows: the VM knows it; here it is read off the generator's table (the rows behind it
+            # all equal the last row, the table's padding row)
+            tab = np.asarray(w["tables"][t])[:AIR_N_COLUMNS[t]]
+            same = np.all(tab == tab[:, -1:], axis=0)
+            n_pad = int(same.size if same.all() else np.argmin(same[::-1]))
+            tr.tables[t].non_padded_n_rows = max(1, same.size - n_pad)
     return tr, keep
 
 
@@ -782,6 +791,7 @@ class Prover:
             assert eqp.size == 5 * t["log_rows"]
             keep += [ptrs, eqp]
             arr[i].table, arr[i].log_rows = t["table"], t["log_rows"]
+            arr[i].non_padded_n_rows = int(t.get("non_padded_n_rows", 0))
             arr[i].d_cols, arr[i].eq_point = ptrs.ctypes.data, eqp.ctypes.data
             for k in range(5):
                 arr[i].sum[k] = int(t["sum"][k])

@@ -904,6 +904,13 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
         const lm_air_table& t = tables[i];
         int rc = lm_air_new(ctx, t.table, t.d_cols, t.log_rows, t.eq_point, alpha, logup_eq16, bus_beta, &ss[i].h);
         if (rc) return cleanup(rc);
+        if (t.non_padded_n_rows) {
+            if (t.non_padded_n_rows > (1ull << t.log_rows)) {
+                lm_set_error("lmh_prove_batched_air_sumcheck: non_padded_n_rows exceeds the table");
+                return cleanup(LM_E_INVALID);
+            }
+            if ((rc = lm_air_set_active_rows(ss[i].h, t.non_padded_n_rows))) return cleanup(rc);
+        }
         ss[i].n_vars = t.log_rows;
         ss[i].deg = lm_air_degree(ss[i].h);
         ss[i].eq_factor.resize(t.log_rows);
@@ -1291,6 +1298,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
         at[k].log_rows = tr->tables[t].log_rows;
         at[k].d_cols = tr->tables[t].d_cols;
         at[k].eq_point = from_end(tr->tables[t].log_rows);
+        at[k].non_padded_n_rows = tr->tables[t].non_padded_n_rows;
         const EF dir = kVmTables[t].pull ? kb::ef_neg(kb::ef_one()) : kb::ef_one();
         const EF bfv = kb::ef_add(kb::ef_mul(bus_num[t], dir), kb::ef_mul(bus_beta, kb::ef_sub(bus_den[t], logup_c)));
         memcpy(at[k].sum, bfv.v, 20);

@@ -34,6 +34,8 @@ struct lm_air {
     // The session runs on its own stream (ctx->aux_stream[aux]) from the end of lm_air_new on: the sessions of a batched
     // round are independent chains (round kernel -> host -> fold kernel -> ...), and in the last ~12 rounds each of them is
     // one latency-bound workgroup — side by side they cost the longest of the three instead of the sum.
+    u64 n_active = 0;                    // rows >= n_active are identical padding rows (lm_air_set_active_rows; default: all rows active)
+    std::vector<EF> h_point;             // the eq point (host copy): tail sums of eq weights for the padded pairs
     int aux = 0;
     hipStream_t stream = nullptr;
     u32* d_sync = nullptr;               // this session's "writers done" counter (two words, zero between kernels)
@@ -114,6 +116,12 @@ struct AirFinish {
     u32 seq, deg, n_main, n_low;
     u64 low_offset;
     AirLagrange lag;
+    // Active prefix (air_sumcheck.rs:194-200,236-240): the round sums only the pairs that contain an active row; every pair
+    // behind them consists of identical padding rows and evaluates to the same value, so ONE of them (pad_pair) is evaluated
+    // and weighted with the sum of the eq weights of all of them (pad_w, computed on the host).  pad_on = 0: full domain.
+    u32 pad_on;
+    u64 pad_pair;
+    EF pad_w;
 };
 static constexpr u32 AIR_INLINE_MAX_BLOCKS = 8;
 __device__ __forceinline__ void air_finish_inline(const u32* __restrict__ partial, u32 blocks_x, const AirFinish& fin) {
@@ -256,9 +264,19 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
     }
     const u32 zm = to_monty(z);
     EF acc = ef_zero();
-    for (u64 j = (u64)tile * 256 + threadIdx.x; j < n_pairs; j += (u64)blocks_x * 256) {
-        const EF v = eval_table<TABLE, T, Cols, SEG>(cols, j, zm, seg, *extra);
-        acc = ef_add(acc, ef_mul(v, eq_split_at(eq, j)));
+    // (one call site of the constraint evaluation: thread 0 of tile 0 appends the padding pair to its iterations)
+    bool pad_todo = fin.pad_on && tile == 0 && threadIdx.x == 0;
+    for (u64 j = (u64)tile * 256 + threadIdx.x;; j += (u64)blocks_x * 256) {
+        bool is_pad = false;
+        u64 je = j;
+        if (j >= n_pairs) {
+            if (!pad_todo) break;
+            is_pad = true;
+            je = fin.pad_pair;
+        }
+        const EF v = eval_table<TABLE, T, Cols, SEG>(cols, je, zm, seg, *extra);
+        acc = ef_add(acc, ef_mul(v, is_pad ? fin.pad_w : eq_split_at(eq, je)));
+        if (is_pad) break;
     }
     u32 v[5];
 #pragma unroll
@@ -434,7 +452,7 @@ static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const E
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
     }
-    ExtCols c{a->ef[a->cur], 2 * n_pairs};
+    ExtCols c{a->ef[a->cur], 1ull << (a->log_rows - a->round)};  // (rows of the folded table: n_pairs may be the active prefix only)
     return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
 }
 
@@ -464,6 +482,9 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->n_cols = air::n_columns((int)table);
     a->n_shift = air::n_shift((int)table);
     a->n_virt = table == air::T_POSEIDON16 ? air::POS_N_VIRT : 0;  // (that table has no shift columns)
+    a->n_active = 1ull << log_rows;
+    a->h_point.resize(log_rows);
+    for (u32 j = 0; j < log_rows; j++) memcpy(a->h_point[j].v, eq_point + 5 * j, 20);
     a->deg = air::degree((int)table);
     const u64 half = 1ull << (log_rows - 1);
     const u64 ef_words0 = (u64)(a->n_cols + a->n_virt + a->n_shift) * 5 * half;
@@ -540,6 +561,14 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     return LM_OK;
 }
 
+int lm_air_set_active_rows(lm_air* a, uint64_t n_active_rows) {
+    if (!a || a->round != 0 || n_active_rows == 0 || n_active_rows > (1ull << a->log_rows)) {
+        lm_set_error("lm_air_set_active_rows: before the first round, 1 <= n_active_rows <= 2^log_rows");
+        return LM_E_INVALID;
+    }
+    a->n_active = n_active_rows;
+    return LM_OK;
+}
 uint32_t lm_air_degree(const lm_air* a) { return a ? a->deg : 0; }
 uint32_t lm_air_n_evals(const lm_air* a) { return a ? a->n_cols + a->n_shift : 0; }
 
@@ -549,7 +578,13 @@ uint32_t lm_air_n_evals(const lm_air* a) { return a ? a->n_cols + a->n_shift : 0
 int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     LM_REQUIRE(ctx && a && a->round < a->log_rows && a->pending_seq == 0);
     const u32 p = a->log_rows - a->round - 1;
-    const u64 n_pairs = 1ull << p;
+    const u64 n_pairs_full = 1ull << p;
+    // active prefix: after `round` folds the first ceil(n_active / 2^round) rows can differ from the padding row; the pairs
+    // behind them are identical (folds of identical rows are identical), the last pair of the table among them
+    const u64 rows_active = (a->n_active + (1ull << a->round) - 1) >> a->round;
+    const u64 pairs_active = (rows_active + 1) / 2;
+    const bool prefix = pairs_active + 1 <= n_pairs_full;
+    const u64 n_pairs = prefix ? pairs_active : n_pairs_full;
     const bool pos = a->table == air::T_POSEIDON16;
     const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, AIR_MAX_BLOCKS);
     u32* s = a->d_partial;
@@ -584,6 +619,24 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     fin.n_main = pos ? 4 * blocks : blocks;
     fin.n_low = pos ? blocks : 0u;
     fin.low_offset = (u64)4 * AIR_POS_POINTS * blocks;
+    if (prefix) {
+        // sum_{j >= pairs_active} eq(point[0..p), j) = mle_of_zeros_then_ones (poly/src/mle/mle_custom.rs:4-19; coordinate 0 is
+        // the most significant bit of j, lm_eqsplit.h): walking the bits of the threshold from the top, every index that agrees
+        // so far and has a 1 where the threshold has a 0 is larger
+        EF acc = ef_zero(), prefix_w = ef_one();
+        for (u32 b = 0; b < p; b++) {
+            const EF x = a->h_point[b];
+            if ((pairs_active >> (p - 1 - b)) & 1) {
+                prefix_w = ef_mul(prefix_w, x);
+            } else {
+                acc = ef_add(acc, ef_mul(prefix_w, x));
+                prefix_w = ef_mul(prefix_w, ef_sub(ef_one(), x));
+            }
+        }
+        fin.pad_on = 1;
+        fin.pad_pair = n_pairs_full - 1;
+        fin.pad_w = ef_add(acc, prefix_w);  // (+ the threshold index itself)
+    }
     if (a->table == air::T_EXECUTION)
         rc = launch_round<air::T_EXECUTION>(ctx, a, n_pairs, blocks, eq, s, fin);
     else if (a->table == air::T_EXTENSION_OP)

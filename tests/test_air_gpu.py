@@ -23,7 +23,8 @@ def _run(ctx, orc, tables, alpha, eq16, beta, eta):
     for t in tables:
         bufs = [ctx.to_device(c) for c in t["cols"]]
         keep.append(bufs)
-        dev_tables.append(dict(table=t["table"], log_rows=t["log_rows"], cols=bufs, eq_point=t["eq_point"], sum=t["sum"]))
+        dev_tables.append(dict(table=t["table"], log_rows=t["log_rows"], cols=bufs, eq_point=t["eq_point"], sum=t["sum"],
+                               non_padded_n_rows=t.get("non_padded_n_rows", 0)))
     pt, evs = pr.prove_batched_air_sumcheck(dev_tables, alpha, eq16, beta, eta)
     proof = pr.proof()
     assert np.array_equal(pt, ref_pt)
@@ -39,6 +40,24 @@ def test_single_table_random_columns(ctx, orc, table, log_rows):
     alpha, eq16, beta, eta = _challenges(rng)
     cols = rand_field(rng, (ob.AIR_N_COLUMNS[table], 1 << log_rows))
     t = dict(table=table, log_rows=log_rows, cols=cols, eq_point=rand_field(rng, (log_rows, 5)), sum=rand_field(rng, 5))
+    _run(ctx, orc, [t], alpha, eq16, beta, eta)
+
+
+@pytest.mark.parametrize("table,log_rows,n_active", [(0, 6, 1), (0, 6, 37), (0, 6, 62), (0, 6, 63), (0, 11, 1500), (1, 5, 9), (1, 9, 300),
+                                                     (2, 4, 5), (2, 7, 100), (2, 10, 513), (0, 3, 8)])
+def test_active_prefix_equals_full_sum(ctx, orc, table, log_rows, n_active):
+    """AirSumcheckSession's active prefix (air_sumcheck.rs:194-200,236-240): random (unsatisfied) columns whose rows behind
+    n_active all equal one random padding row — the constraint value there is an arbitrary non-zero constant.  With
+    non_padded_n_rows the device evaluates the active pairs and ONE padding pair weighted by the tail of the eq weights; the
+    transcript must equal the oracle's, which sums every row.  Boundaries: one active row, an odd count, a single padding
+    pair left, no full padding pair (falls back to the full sum), all rows active."""
+    rng = np.random.default_rng(1000 * table + 10 * log_rows + n_active)
+    alpha, eq16, beta, eta = _challenges(rng)
+    n = 1 << log_rows
+    cols = rand_field(rng, (ob.AIR_N_COLUMNS[table], n))
+    cols[:, n_active:] = cols[:, -1:]
+    t = dict(table=table, log_rows=log_rows, cols=cols, eq_point=rand_field(rng, (log_rows, 5)), sum=rand_field(rng, 5),
+             non_padded_n_rows=n_active)
     _run(ctx, orc, [t], alpha, eq16, beta, eta)
 
 

@@ -264,13 +264,14 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
     }
     const u32 zm = to_monty(z);
     EF acc = ef_zero();
-    // (one call site of the constraint evaluation: thread 0 of tile 0 appends the padding pair to its iterations)
-    bool pad_todo = fin.pad_on && tile == 0 && threadIdx.x == 0;
+    // (one call site of the constraint evaluation.  The padding pair takes the grid-stride slot right behind the last active
+    // pair, j == n_pairs: the thread that owns it has no more iterations than any other, so small rounds — one evaluation
+    // per thread, latency bound — do not get twice as long)
     for (u64 j = (u64)tile * 256 + threadIdx.x;; j += (u64)blocks_x * 256) {
         bool is_pad = false;
         u64 je = j;
         if (j >= n_pairs) {
-            if (!pad_todo) break;
+            if (!(fin.pad_on && j == n_pairs)) break;
             is_pad = true;
             je = fin.pad_pair;
         }
@@ -586,7 +587,11 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     const bool prefix = pairs_active + 1 <= n_pairs_full;
     const u64 n_pairs = prefix ? pairs_active : n_pairs_full;
     const bool pos = a->table == air::T_POSEIDON16;
-    const u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, AIR_MAX_BLOCKS);
+    u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, AIR_MAX_BLOCKS);
+    // the padding pair is one more slot of the grid-stride walk (k_air_round): when the active pairs fill every thread's
+    // iterations exactly and those are few, add workgroups so that it lands on an idle thread
+    if (prefix && n_pairs % ((u64)blocks * 256) == 0 && n_pairs / ((u64)blocks * 256) < 4 && blocks < AIR_MAX_BLOCKS)
+        blocks += (blocks & 7) == 0 ? 8 : 1;
     u32* s = a->d_partial;
     int rc;
     const EqSplit eq = a->eqt.at(p);

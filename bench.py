@@ -344,13 +344,17 @@ def main():
         sha = source_sha()
         # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
         # Algorithmic bytes per step: every column value of every sumcheck round is read once:
-        # round 0 on base words (4 B), round r >= 1 on EF (20 B) over 2^(log_rows - r) rows, (n_columns + n_shift) columns.
+        # round 0 on base words (4 B), round r >= 1 on EF (20 B) over the 2^(log_rows - r) rows, (n_columns + n_shift) columns.
+        # With the active prefix (non_padded_n_rows) a round reads the pairs that contain an active row plus one padding pair.
         alg_bytes = 0
         for t, ncols in ((0, 22), (1, 42), (2, 109)):
             lr = w["w"]["log_rows"][t]
-            alg_bytes += ncols * 4 * (1 << lr)
-            for r in range(1, lr):
-                alg_bytes += ncols * 20 * (1 << (lr - r))
+            n_act = int(w["tr"].tables[t].non_padded_n_rows) or (1 << lr)
+            for r in range(lr):
+                full = 1 << (lr - r)
+                pairs = (-(-n_act // (1 << r)) + 1) // 2
+                rows = 2 * pairs + 2 if pairs + 1 <= full // 2 else full
+                alg_bytes += ncols * (4 if r == 0 else 20) * rows
         achieved = alg_bytes * args.steps / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # counters of the same kernels (rocprofv3 --pmc passes of `bench.py --inflight 1`, summarised under profiles/ together
         # with the sha of the kernel sources they were taken from)

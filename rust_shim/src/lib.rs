@@ -40,6 +40,7 @@ pub struct lm_whir_config {
 #[repr(C)]
 pub struct lm_vm_table {
     pub log_rows: u32,
+    pub non_padded_n_rows: u32, // TableTrace::non_padded_n_rows (0 = unknown: every row is summed)
     pub d_cols: *const *const u32,
 }
 #[repr(C)]

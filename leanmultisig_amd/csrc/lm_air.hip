@@ -588,6 +588,10 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     const u64 n_pairs = prefix ? pairs_active : n_pairs_full;
     const bool pos = a->table == air::T_POSEIDON16;
     u32 blocks = n_pairs <= 256 ? 1 : (u32)std::min<u64>((n_pairs + 255) / 256, AIR_MAX_BLOCKS);
+    // an active prefix is not a power of two: keep the tile count a multiple of 8 (the XCD-aware workgroup mapping of
+    // k_air_round needs it — without it the workgroups that share a row tile spread over all XCDs and the round's HBM
+    // traffic grows 6x; surplus tiles find no pairs and write zero partials)
+    if (blocks > 8) blocks = std::min<u32>((blocks + 7) & ~7u, AIR_MAX_BLOCKS);
     // the padding pair is one more slot of the grid-stride walk (k_air_round): when the active pairs fill every thread's
     // iterations exactly and those are few, add workgroups so that it lands on an idle thread
     if (prefix && n_pairs % ((u64)blocks * 256) == 0 && n_pairs / ((u64)blocks * 256) < 4 && blocks < AIR_MAX_BLOCKS)

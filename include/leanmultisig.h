@@ -109,6 +109,18 @@ int lm_execution_table_trace(lm_ctx* ctx, const uint32_t* d_pcs, const uint32_t*
                              const uint32_t* d_bytecode, uint64_t bytecode_rows, const uint32_t* d_memory, uint64_t memory_len,
                              uint32_t* const* d_cols);
 
+/* The precompile tables from the VM runner's call records (lmh_execute_bytecode, leanmultisig_host.h):
+ * lm_poseidon_table_from_calls: Poseidon16Precompile::execute's pushes (crates/lean_vm/src/tables/poseidon_16/mod.rs:262-286) —
+ *   columns 0..8 (flag, index_b, index_res, half_output, hardcoded_left, offset, effective left indices, permute), the 16 input
+ *   columns 9..24 (read from the final memory image: memory is write-once, so it holds what the call read) and the virtual bus
+ *   columns 109 (index_input_left) and 110 (precompile_data).  d_calls = n_calls x 9 canonical words (LM_VM_POSEIDON_CALL_WORDS);
+ *   d_cols = host array of 111 device column pointers (25..108 are left to lm_poseidon_trace).
+ * lm_extension_table_from_rows: exec_multi_row's pushes (extension_op/exec.rs:149-186): every column of the ExtensionOp table except
+ *   VALUE_A (lm_extension_op_trace) from n_rows x 24-word records (LM_VM_EXTENSION_ROW_WORDS); d_cols = 31 device column pointers. */
+int lm_poseidon_table_from_calls(lm_ctx* ctx, const uint32_t* d_calls, uint64_t n_calls, const uint32_t* d_memory, uint64_t memory_len,
+                                 uint32_t* const* d_cols);
+int lm_extension_table_from_rows(lm_ctx* ctx, const uint32_t* d_rows, uint64_t n_rows, uint32_t* const* d_cols);
+
 /* ---- WHIR commitment: LDE + Merkle tree -------------------------------------------------------------------------
  * lm_commit replaces reorder_and_dft (crates/whir/src/utils.rs:69-98: prepare_evals_for_fft_unpacked :128-150 +
  * EvalsDft::dft_algebra_batch_by_evals crates/whir/src/dft.rs:79-155) followed by MerkleData::build

@@ -233,6 +233,111 @@ const char* lmh_poseidon_backend(void);
 void lmh_poseidon16_permute(uint32_t state[16]);        /* the backend in use */
 void lmh_poseidon16_permute_scalar(uint32_t state[16]); /* always the scalar code */
 
+/* ---- leanVM: bytecode, runner, witness generation ------------------------------------------------
+ * The reference's prove_execution starts from (bytecode, public input, witness hints) and runs the VM itself
+ * (crates/lean_prover/src/prove_execution.rs:20-39: try_execute_bytecode + get_execution_trace are inside the timed region
+ * of the benchmark, rec_aggregation/src/benchmark.rs:397-410).  This section is that part:
+ *   lmh_bytecode_*            `Bytecode` (crates/lean_vm/src/isa/bytecode.rs:17-31) as an opaque object built from the same two
+ *                             things the reference's compiler emits: instructions_multilinear (the field representation of every
+ *                             instruction, lean_compiler/src/instruction_encoder.rs:4-113 — injective, so the runner decodes
+ *                             its instructions from it) and the hints attached to each pc (lean_vm/src/isa/hint.rs:17-81);
+ *   lmh_execute_bytecode      try_execute_bytecode / execute_bytecode_helper (lean_vm/src/execution/runner.rs:27-343) including
+ *                             the parallel loop batches (handle_parallel_batch :361-482, SegmentMemory memory.rs:118-189) on a
+ *                             host thread pool and resolve_deref_hints (:206-236);
+ *   lmh_get_execution_trace   get_execution_trace (lean_prover/src/trace_gen.rs:14-168): upload of the VM log and construction of
+ *                             every table column on the device;
+ *   lmh_prove_execution_vm    prove_execution (prove_execution.rs:20-274) whole.
+ * All addresses, offsets, pcs and fps are plain (canonical) integers; field VALUES (memory words, hint data, constants of
+ * instructions_multilinear) are Montgomery words like everywhere else. */
+#define LM_VM_ARG_CONST 0 /* MemOrConstant::Constant / MemOrFpOrConstant::Constant: canonical value */
+#define LM_VM_ARG_MEM 1   /* MemoryAfterFp { offset }: m[fp + value] */
+#define LM_VM_ARG_FP 2    /* FpRelative { offset }: fp + value */
+/* Hint kinds (lean_vm/src/isa/hint.rs:17-81).  Print / LocationReport / Label / Panic have no effect on the execution
+ * result and are not represented. */
+#define LM_VM_HINT_INVERSE 1                    /* args: arg, res_offset */
+#define LM_VM_HINT_REQUEST_MEMORY 2             /* args: offset, size */
+#define LM_VM_HINT_DEREF 3                      /* DerefHint: args: offset_src, offset_target */
+#define LM_VM_HINT_DECOMPOSE_BITS_XMSS 4        /* CustomHint (hint.rs:137-203), args as in the reference */
+#define LM_VM_HINT_DECOMPOSE_BITS_MERKLE_WHIR 5
+#define LM_VM_HINT_DECOMPOSE_BITS 6
+#define LM_VM_HINT_LESS_THAN 7
+#define LM_VM_HINT_LOG2_CEIL 8
+#define LM_VM_HINT_WITNESS_INLINE 9             /* HintWitness, destination Inline: args: name id, offset */
+#define LM_VM_HINT_WITNESS_INDIRECT 10          /* destination Indirect: args: name id, ptr_offset */
+#define LM_VM_HINT_PARALLEL_BATCH_START 11      /* args: n_args, end_value */
+#define LM_VM_HINT_DEBUG_ASSERT 12              /* args: left, right, kind (0 ==, 1 !=, 2 <, 3 <=), preceds_runtime_inequality */
+typedef struct {
+    uint32_t pc;      /* executed before the instruction at pc; hints of one pc run in array order */
+    uint32_t kind;    /* LM_VM_HINT_* */
+    uint32_t args[4];
+    uint8_t mode[4];  /* LM_VM_ARG_* of each argument that is an operand in the reference; 0 for plain integers */
+} lm_vm_hint;
+
+typedef struct lmh_bytecode lmh_bytecode;
+/* instructions_multilinear: 2^log_size rows x 16 words (12 used, execution/air.rs:18-30 order: operand_a/b/c, flag_a/b/c,
+ * flag_c_fp, flag_ab_fp, mul, jump, aux, precompile_data); rows [n_instructions, 2^log_size) are zero (code.len() = n_instructions).
+ * hints sorted by pc.  NULL with lm_last_error on an undecodable row. */
+lmh_bytecode* lmh_bytecode_new(const uint32_t* instructions_multilinear, uint32_t log_size, uint64_t n_instructions,
+                               uint32_t ending_pc, uint32_t starting_frame_memory, const lm_vm_hint* hints, uint64_t n_hints,
+                               uint32_t n_hint_names);
+void lmh_bytecode_free(lmh_bytecode* bc);
+/* Bytecode::hash = poseidon_compress_slice(instructions_multilinear, true) (lean_compiler/src/c_compile_final.rs:158,
+ * utils/src/poseidon.rs:41-67); computed once, 2^(log_size + 1) sequential compressions */
+void lmh_bytecode_hash(const lmh_bytecode* bc, uint32_t out[8]);
+uint32_t lmh_bytecode_log_size(const lmh_bytecode* bc);
+uint32_t lmh_bytecode_ending_pc(const lmh_bytecode* bc);
+const uint32_t* lmh_bytecode_multilinear(const lmh_bytecode* bc);
+
+/* ExecutionWitness (runner.rs:17-25): hints: HashMap<String, Vec<Vec<F>>> flattened; names are the ids of the bytecode's
+ * HintWitness hints. */
+typedef struct {
+    uint32_t preamble_memory_len;
+    uint32_t n_names;
+    const uint64_t* name_entry_begin; /* n_names + 1: the entries of name k are [begin[k], begin[k + 1]) */
+    const uint64_t* entry_offset;     /* n_entries + 1: the words of entry e are data[offset[e] .. offset[e + 1]) */
+    const uint32_t* data;             /* Montgomery words */
+} lm_vm_witness;
+
+#define LM_VM_POSEIDON_CALL_WORDS 9  /* arg_a, arg_b, res, half_output, hardcoded_left, offset, left_first, left_second, permute */
+#define LM_VM_EXTENSION_ROW_WORDS 24 /* is_be, start, add, mul, poly_eq, len, idx_a, idx_b, idx_res (canonical) | VB(5) VRES(5) COMP(5) (Montgomery) */
+typedef struct lmh_execution lmh_execution; /* ExecutionResult (lean_vm/src/diagnostics/exec_result.rs) */
+typedef struct {
+    uint64_t n_cycles;            /* pcs.len(), the final ending_pc row included */
+    const uint32_t* pcs;
+    const uint32_t* fps;
+    uint64_t memory_len;          /* memory.0.len() */
+    const uint32_t* memory;       /* Montgomery words, undefined cells read 0 */
+    const uint8_t* memory_defined; /* 1 = Some(_) */
+    uint64_t public_memory_size, runtime_memory_size;
+    uint64_t n_poseidon_calls;
+    const uint32_t* poseidon_calls;  /* n x LM_VM_POSEIDON_CALL_WORDS: Poseidon16Precompile::execute's pushes (poseidon_16/mod.rs:262-286) */
+    uint64_t n_extension_rows;
+    const uint32_t* extension_rows;  /* n x LM_VM_EXTENSION_ROW_WORDS: exec_multi_row's pushes (extension_op/exec.rs:149-186) */
+    uint64_t n_add, n_mul, n_deref, n_jump; /* InstructionCounts */
+} lm_vm_execution_view;
+/* n_threads = 0: all hardware threads (capped at 64).  LM_E_INVALID + lm_last_error = the RunnerError and its pc. */
+int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
+                         uint32_t n_threads, lmh_execution** out);
+void lmh_execution_free(lmh_execution* e);
+void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* out);
+
+/* get_execution_trace on the device: every column of the three tables (padding rows included), the padded memory image
+ * (+ zero vector and poseidon16(0) behind the VM's memory, trace_gen.rs:103-113, grown to >= 2^16 and >= the bytecode as
+ * prove_execution.rs:41-46 does), the bytecode table.  The result owns its device buffers. */
+typedef struct lmh_vm_trace lmh_vm_trace;
+int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execution* e, const uint32_t* public_input,
+                            uint32_t n_public_input, uint32_t log_inv_rate, lmh_vm_trace** out);
+const lm_execution_trace* lmh_vm_trace_view(const lmh_vm_trace* t);
+void lmh_vm_trace_free(lm_ctx* ctx, lmh_vm_trace* t);
+
+/* prove_execution(bytecode, public_input, witness, whir_config) -> proof in `p`.  times_ms (nullable): [0] VM run, [1] trace
+ * upload + column construction (until the device work is enqueued), [2] proving. */
+int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
+                           const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3]);
+
+/* n independent Poseidon1-16 compressions perm(x) + x of 16-word states on the host thread pool (signers, hint builders) */
+void lmh_poseidon16_compress_many(uint32_t* states, uint64_t n, uint32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

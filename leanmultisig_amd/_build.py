@@ -1,34 +1,79 @@
-"""Build the HIP shared library in-tree (gfx950 only)."""
+"""Build the HIP shared library in-tree (gfx950 only).
+
+Every source is compiled to its own object under leanmultisig_amd/_obj/ (git-ignored) and only re-compiled when it or a
+header it may include has changed; objects are compiled in parallel and linked into libleanmultisig_hip.so."""
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libleanmultisig_hip.so")
-SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_air.hip", "lm_logup.hip", "host/lm_host.cpp", "host/lm_whir_config.cpp", "host/lm_wire.cpp", "host/lm_verify.cpp", "host/lm_poseidon_x86.cpp"]
+SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_air.hip", "lm_logup.hip", "host/lm_host.cpp",
+           "host/lm_whir_config.cpp", "host/lm_wire.cpp", "host/lm_verify.cpp", "host/lm_poseidon_x86.cpp", "host/lm_vm.cpp",
+           "host/lm_node.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _sources():
-    return [os.path.join(CSRC, s) for s in SOURCES]
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def _deps():
-    deps = _sources()
+def _headers():
+    deps = []
     for root, _, files in os.walk(CSRC):
         for f in files:
             if f.endswith((".h", ".inc", ".hpp")):
                 deps.append(os.path.join(root, f))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "leanmultisig.h"))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "leanmultisig_host.h"))
-    return deps
+    return sorted(deps)
+
+
+def _includes(src, headers_by_name, seen):
+    """transitive closure of the quoted includes of `src` among this tree's headers (file names are unique)"""
+    try:
+        text = open(src, errors="replace").read()
+    except OSError:
+        return
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("#include") and '"' in line:
+            name = os.path.basename(line.split('"')[1])
+            h = headers_by_name.get(name)
+            if h and h not in seen:
+                seen.add(h)
+                _includes(h, headers_by_name, seen)
+
+
+def _stamp(src, headers_by_name):
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    seen = set()
+    _includes(src, headers_by_name, seen)
+    for f in [src] + sorted(seen):
+        h.update(f.encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def _obj_path(src):
+    rel = os.path.relpath(src, CSRC).replace(os.sep, "_")
+    return os.path.join(OBJ, rel + ".o")
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    headers_by_name = {os.path.basename(h): h for h in _headers()}
+    for s in _sources():
+        o = _obj_path(s)
+        if not os.path.exists(o) or not os.path.exists(o + ".sha") or open(o + ".sha").read() != _stamp(s, headers_by_name):
+            return True
+    return os.path.getmtime(LIB) < max(os.path.getmtime(_obj_path(s)) for s in _sources())
 
 
 def build(force=False, verbose=True):
@@ -39,9 +84,27 @@ def build(force=False, verbose=True):
         subprocess.check_call([sys.executable, gen])
     if not force and not needs_build():
         return LIB
+    os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-result", *_sources(), "-o", LIB]
+    headers_by_name = {os.path.basename(h): h for h in _headers()}
+    todo = []
+    for s in _sources():
+        o, st = _obj_path(s), _stamp(s, headers_by_name)
+        if force or not os.path.exists(o) or not os.path.exists(o + ".sha") or open(o + ".sha").read() != st:
+            todo.append((s, o, st))
+
+    def compile_one(job):
+        s, o, st = job
+        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(o + ".sha", "w") as f:
+            f.write(st)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj_path(s) for s in _sources()], "-o", LIB, "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -139,6 +139,21 @@ _HOST_SIGS = {
     "lmh_stacked_n_vars": (C.c_uint32, [vp]),
     "lmh_prove_execution": (C.c_int, [vp, vp, vp, vp]),
     "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
+    # leanVM (leanmultisig_amd/vm.py)
+    "lmh_bytecode_new": (vp, [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, C.c_uint32]),
+    "lmh_bytecode_free": (None, [vp]),
+    "lmh_bytecode_hash": (None, [vp, vp]),
+    "lmh_bytecode_log_size": (C.c_uint32, [vp]),
+    "lmh_bytecode_ending_pc": (C.c_uint32, [vp]),
+    "lmh_bytecode_multilinear": (vp, [vp]),
+    "lmh_execute_bytecode": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]),
+    "lmh_execution_free": (None, [vp]),
+    "lmh_execution_view": (None, [vp, vp]),
+    "lmh_get_execution_trace": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+    "lmh_vm_trace_view": (vp, [vp]),
+    "lmh_vm_trace_free": (None, [vp, vp]),
+    "lmh_prove_execution_vm": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp]),
+    "lmh_poseidon16_compress_many": (None, [vp, C.c_uint64, C.c_uint32]),
 }
 
 LM_MAX_WHIR_ROUNDS = 8

@@ -1,0 +1,207 @@
+// Witness generation on the device and the whole-node entry point (SURVEY.md §8(f) rank 1 + 4):
+//   lmh_get_execution_trace   get_execution_trace (crates/lean_prover/src/trace_gen.rs:14-168) from the runner's ExecutionResult
+//   lmh_prove_execution_vm    prove_execution (crates/lean_prover/src/prove_execution.rs:20-274): VM run, trace, proof
+// The VM log crosses PCIe once (pc / fp per cycle, the memory image, 9 words per Poseidon call, 24 per ExtensionOp row); every
+// table column — execution 24, Poseidon 111 (the 84 permutation columns included), ExtensionOp 31, the padding rows — is
+// produced by kernels from that log and the memory image.
+// (the build compiles every source as HIP: this file is host-only, the device pass sees nothing)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "lm_host_internal.h"
+#include "lm_vm_internal.h"
+
+using namespace lmh;
+
+struct lmh_vm_trace {
+    lm_execution_trace view;
+    std::vector<u32*> owned;            // device buffers freed with the trace
+    std::vector<u32*> cols[3];          // device column pointers per table (n_total)
+    std::vector<u32> public_input;
+    u32 bytecode_hash[8];
+};
+
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int fill_words(lm_ctx* ctx, u32* d, u32 canonical, u64 count) {
+    if (count == 0) return LM_OK;
+    if (hipMemsetD32Async((hipDeviceptr_t)d, (int)kb::to_monty(canonical), count, (hipStream_t)lm_ctx_stream(ctx)) != hipSuccess) {
+        lm_set_error("lmh_get_execution_trace: fill failed");
+        return LM_E_DEVICE;
+    }
+    return LM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execution* e, const uint32_t* public_input, uint32_t n_public_input,
+                            uint32_t log_inv_rate, lmh_vm_trace** out) {
+    if (!ctx || !bc || !e || !out || (n_public_input && !public_input)) {
+        lm_set_error("lmh_get_execution_trace: bad arguments");
+        return LM_E_INVALID;
+    }
+    *out = nullptr;
+    lm_vm_execution_view v;
+    lmh_execution_view(e, &v);
+    lmh_vm_trace* t = new lmh_vm_trace();
+    memset(&t->view, 0, sizeof t->view);
+    int rc = LM_OK;
+    auto fail = [&](int code) {
+        lmh_vm_trace_free(ctx, t);
+        return code;
+    };
+    auto dev = [&](u64 n_words, u32** p) {
+        rc = lm_malloc(ctx, n_words, p);
+        if (rc == LM_OK) t->owned.push_back(*p);
+        return rc == LM_OK;
+    };
+    const u32 log_bytecode = lmh_bytecode_log_size(bc), ending_pc = lmh_bytecode_ending_pc(bc);
+    // ---- memory_padded (trace_gen.rs:101-113) grown as prove_execution.rs:41-46 does -----------------------------------------------
+    const u64 L = v.memory_len, zero_vec_ptr = L, null_hash_ptr = L + 16;
+    u64 padded = 1ull << MIN_LOG_N_ROWS_PER_TABLE;
+    while (padded < L + 24 || padded < v.n_cycles) padded <<= 1;
+    while (padded < (1ull << MIN_LOG_MEMORY_SIZE) || padded < (1ull << log_bytecode)) padded <<= 1;
+    if (padded > (1ull << MAX_LOG_MEMORY_SIZE)) {
+        lm_set_error("lmh_get_execution_trace: memory of %llu words exceeds 2^%u", (unsigned long long)padded, MAX_LOG_MEMORY_SIZE);
+        return fail(LM_E_INVALID);
+    }
+    const u32 log_memory = log2_ceil_u64(padded);
+    u32* d_memory;
+    if (!dev(padded, &d_memory)) return fail(rc);
+    if ((rc = lm_upload_async(ctx, d_memory, v.memory, L))) return fail(rc);
+    {
+        alignas(64) u32 tail[24];
+        memset(tail, 0, sizeof tail);
+        u32 st[16];
+        memset(st, 0, sizeof st);
+        host_compress(st);  // get_poseidon_16_of_zero
+        memcpy(tail + 16, st, 32);
+        if ((rc = lm_upload(ctx, d_memory + L, tail, 24))) return fail(rc);
+        if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
+    }
+    // ---- bytecode table: device copy cached in the bytecode object -------------------------------------------------------------
+    BytecodeDeviceSlot& slot = vm_bytecode_device_slot(bc);
+    if (slot.ctx != (void*)ctx || !slot.d_multilinear) {
+        u32* d;
+        if ((rc = lm_malloc(ctx, 16ull << log_bytecode, &d))) return fail(rc);  // lives as long as the context's pool
+        if ((rc = lm_upload(ctx, d, lmh_bytecode_multilinear(bc), 16ull << log_bytecode))) return fail(rc);
+        slot.ctx = (void*)ctx;
+        slot.d_multilinear = d;
+    }
+    // ---- tables ----------------------------------------------------------------------------------------------------------------
+    const u64 n_rows[3] = {v.n_cycles, v.n_extension_rows, v.n_poseidon_calls};
+    u32 log_rows[3];
+    for (int tb = 0; tb < 3; tb++) {
+        log_rows[tb] = lmh_table_log_rows(n_rows[tb]);
+        if (log_rows[tb] > max_log_n_rows_per_table(tb)) {
+            lm_set_error("TooBigTableError: table %d has 2^%u rows (limit 2^%u)", tb, log_rows[tb], max_log_n_rows_per_table(tb));
+            return fail(LM_E_INVALID);
+        }
+        const u32 n_total = kVmTables[tb].n_total;
+        t->cols[tb].resize(n_total);
+        for (u32 c = 0; c < n_total; c++)
+            if (!dev(1ull << log_rows[tb], &t->cols[tb][c])) return fail(rc);
+    }
+    // execution table (trace_gen.rs:27-100) + its padding row (execution/mod.rs:59-74, the 4 temporary columns included)
+    {
+        u32 *d_pcs, *d_fps;
+        if (!dev(v.n_cycles, &d_pcs) || !dev(v.n_cycles, &d_fps)) return fail(rc);
+        if ((rc = lm_upload_async(ctx, d_pcs, v.pcs, v.n_cycles)) || (rc = lm_upload_async(ctx, d_fps, v.fps, v.n_cycles))) return fail(rc);
+        if ((rc = lm_execution_table_trace(ctx, d_pcs, d_fps, v.n_cycles, slot.d_multilinear, 1ull << log_bytecode, d_memory, padded,
+                                           t->cols[0].data())))
+            return fail(rc);
+        if ((rc = lmh_pad_table(ctx, 0, t->cols[0].data(), v.n_cycles, log_rows[0], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
+        const u64 pad = (1ull << log_rows[0]) - v.n_cycles;
+        if ((rc = fill_words(ctx, t->cols[0][20] + v.n_cycles, 0, pad)) || (rc = fill_words(ctx, t->cols[0][21] + v.n_cycles, 1, pad)) ||
+            (rc = fill_words(ctx, t->cols[0][22] + v.n_cycles, ending_pc, pad)) || (rc = fill_words(ctx, t->cols[0][23] + v.n_cycles, 0, pad)))
+            return fail(rc);
+    }
+    // Poseidon16 table: call records -> flag / index / input columns, padding rows, then the permutation columns of every row
+    {
+        const u64 n = v.n_poseidon_calls, rows = 1ull << log_rows[2];
+        u32* d_calls = nullptr;
+        if (n) {
+            if (!dev(n * LM_VM_POSEIDON_CALL_WORDS, &d_calls)) return fail(rc);
+            if ((rc = lm_upload_async(ctx, d_calls, v.poseidon_calls, n * LM_VM_POSEIDON_CALL_WORDS))) return fail(rc);
+        }
+        if ((rc = lm_poseidon_table_from_calls(ctx, d_calls, n, d_memory, padded, t->cols[2].data()))) return fail(rc);
+        if ((rc = lmh_pad_table(ctx, 2, t->cols[2].data(), n, log_rows[2], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
+        if ((rc = fill_words(ctx, t->cols[2][109] + n, (u32)zero_vec_ptr, rows - n)) || (rc = fill_words(ctx, t->cols[2][110] + n, 1, rows - n)))
+            return fail(rc);
+        if ((rc = lm_poseidon_trace(ctx, t->cols[2].data(), rows))) return fail(rc);
+        if ((rc = lm_poseidon_trace_outputs_from_memory(ctx, t->cols[2].data(), n, d_memory, padded))) return fail(rc);
+    }
+    // ExtensionOp table
+    {
+        const u64 n = v.n_extension_rows, rows = 1ull << log_rows[1];
+        u32* d_rows = nullptr;
+        if (n) {
+            if (!dev(n * LM_VM_EXTENSION_ROW_WORDS, &d_rows)) return fail(rc);
+            if ((rc = lm_upload_async(ctx, d_rows, v.extension_rows, n * LM_VM_EXTENSION_ROW_WORDS))) return fail(rc);
+        }
+        if ((rc = lm_extension_table_from_rows(ctx, d_rows, n, t->cols[1].data()))) return fail(rc);
+        if ((rc = lm_extension_op_trace(ctx, d_memory, padded, t->cols[1][6], t->cols[1].data() + 14, n))) return fail(rc);
+        if ((rc = lmh_pad_table(ctx, 1, t->cols[1].data(), n, log_rows[1], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
+        if ((rc = fill_words(ctx, t->cols[1][29] + n, 0, rows - n)) || (rc = fill_words(ctx, t->cols[1][30] + n, 64, rows - n))) return fail(rc);
+    }
+    // the uploads above read the runner's host buffers asynchronously: they are consumed before this returns
+    if ((rc = lm_sync(ctx))) return fail(rc);
+    t->public_input.assign(public_input, public_input + n_public_input);
+    lmh_bytecode_hash(bc, t->bytecode_hash);
+    lm_execution_trace& w = t->view;
+    w.log_inv_rate = log_inv_rate, w.log_memory = log_memory, w.log_bytecode = log_bytecode, w.ending_pc = ending_pc;
+    w.public_memory_size = (u32)v.public_memory_size, w.n_public_input = n_public_input;
+    w.public_input = t->public_input.data(), w.bytecode_hash = t->bytecode_hash;
+    w.d_bytecode = slot.d_multilinear, w.d_bytecode_acc = nullptr, w.d_memory = d_memory, w.d_memory_acc = nullptr;
+    for (int tb = 0; tb < 3; tb++) {
+        w.tables[tb].log_rows = log_rows[tb];
+        w.tables[tb].non_padded_n_rows = (u32)n_rows[tb];
+        w.tables[tb].d_cols = t->cols[tb].data();
+    }
+    *out = t;
+    return LM_OK;
+}
+const lm_execution_trace* lmh_vm_trace_view(const lmh_vm_trace* t) { return &t->view; }
+void lmh_vm_trace_free(lm_ctx* ctx, lmh_vm_trace* t) {
+    if (!t) return;
+    for (u32* p : t->owned) lm_free(ctx, p);
+    delete t;
+}
+
+int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
+                           const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3]) {
+    if (!ctx || !p || !bc || !builder) {
+        lm_set_error("lmh_prove_execution_vm: bad arguments");
+        return LM_E_INVALID;
+    }
+    if (!rate_ok(builder->starting_log_inv_rate)) {
+        lm_set_error("lmh_prove_execution_vm: log_inv_rate outside [1, 4] (check_rate)");
+        return LM_E_INVALID;
+    }
+    const double t0 = now_ms();
+    lmh_execution* ex = nullptr;
+    int rc = lmh_execute_bytecode(bc, public_input, n_public_input, witness, n_threads, &ex);
+    if (rc) return rc;
+    const double t1 = now_ms();
+    lmh_vm_trace* tr = nullptr;
+    rc = lmh_get_execution_trace(ctx, bc, ex, public_input, n_public_input, builder->starting_log_inv_rate, &tr);
+    lmh_execution_free(ex);
+    if (rc) return rc;
+    const double t2 = now_ms();
+    lm_whir_config cfg;
+    rc = lmh_whir_config_new(builder, lmh_stacked_n_vars(&tr->view), &cfg);
+    if (rc == LM_OK) rc = lmh_prove_execution(ctx, p, &tr->view, &cfg);
+    lmh_vm_trace_free(ctx, tr);
+    const double t3 = now_ms();
+    if (times_ms) times_ms[0] = t1 - t0, times_ms[1] = t2 - t1, times_ms[2] = t3 - t2;
+    return rc;
+}
+
+}  // extern "C"
+#endif

@@ -1,0 +1,1122 @@
+// leanVM on the host: Bytecode object, the runner and its thread pool.
+//
+// Reference: crates/lean_vm/src/execution/runner.rs (execute_bytecode_helper, run_loop, handle_parallel_batch,
+// resolve_deref_hints), execution/memory.rs (Memory, SegmentMemory), isa/instruction.rs (execute_instruction), isa/hint.rs
+// (execute_hint, CustomHint::execute), tables/poseidon_16/mod.rs:209-289 and tables/extension_op/exec.rs (precompile
+// execution).  Written for this machine rather than transcribed:
+//   * instructions are decoded once from instructions_multilinear (the reference keeps an enum per pc next to it) into a flat
+//     32-byte record with canonical AND Montgomery operand forms, hints in one array indexed by [begin, end) per pc;
+//   * memory is a u32 array with a sentinel for "undefined" (the reference: Vec<Option<F>>);
+//   * a parallel loop batch runs its segments on a persistent pool of host threads (the reference: rayon), every segment
+//     logging into its own buffers which are spliced in iteration order afterwards; the precompile tables are kept as compact
+//     call records (9 / 24 words) — the 109 / 31 table columns are built on the device from them and from the final memory
+//     image (lm_node.cpp), so only ~30 MB cross PCIe for a 1550-signature run;
+//   * Poseidon is the AVX-512 permutation of lm_poseidon_x86.cpp.
+// (the build compiles every source as HIP: this file is host-only, the device pass sees nothing)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lm_host_internal.h"
+#include "lm_vm_internal.h"
+
+namespace lmh {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// thread pool: parallel_for(n, f) runs f(i) for i < n on the calling thread + the workers, dynamic scheduling
+// ---------------------------------------------------------------------------------------------------------------------
+class Pool {
+   public:
+    static Pool& get() {
+        static Pool p;
+        return p;
+    }
+    void parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) {
+        if (n == 0) return;
+        u32 want = n_threads ? n_threads : default_threads();
+        if (want > n) want = (u32)n;
+        if (want <= 1) {
+            for (u64 i = 0; i < n; i++) f(i);
+            return;
+        }
+        std::lock_guard<std::mutex> user(user_mu_);  // one batch at a time
+        ensure(want - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            next_.store(0, std::memory_order_relaxed);
+            total_ = n;
+            active_ = want - 1;
+            pending_ = want - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    static u32 default_threads() {
+        u32 hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        return hw > 64 ? 64 : hw;
+    }
+
+   private:
+    Pool() {}
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void ensure(u32 n) {
+        while (workers_.size() < n) {
+            const u32 id = (u32)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void work() {
+        const std::function<void(u64)>& f = *job_;
+        for (;;) {
+            const u64 i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= total_) break;
+            f(i);
+        }
+    }
+    void loop(u32 id) {
+        u64 seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || (generation_ != seen && id < active_); });
+            if (stop_) return;
+            seen = generation_;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_, user_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(u64)>* job_ = nullptr;
+    std::atomic<u64> next_{0};
+    u64 total_ = 0, generation_ = 0;
+    u32 active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) { Pool::get().parallel_for(n, n_threads, f); }
+
+namespace {
+typedef uint8_t u8;
+
+constexpr u32 UNDEF = 0xFFFFFFFFu;  // not a field element (values are < p < 2^31)
+constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// errors (lean_vm/src/diagnostics/error.rs)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Err {
+    bool set = false;
+    std::string msg;
+    void raise(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+        if (set) return;
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        msg = buf;
+        set = true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// memory (execution/memory.rs)
+// ---------------------------------------------------------------------------------------------------------------------
+struct MainMem {  // Memory: grows on write, write-once cells
+    std::vector<u32>& m;
+    u32 peek(u64 i) const { return i < m.size() ? m[i] : UNDEF; }
+    bool set(u64 i, u32 v, Err& e) {
+        if (i >= m.size()) {
+            if (i >= MAX_MEMORY) {
+                e.raise("OutOfMemory");
+                return false;
+            }
+            m.resize(i + 1, UNDEF);
+        }
+        u32& c = m[i];
+        if (c == UNDEF)
+            c = v;
+        else if (c != v) {
+            e.raise("MemoryAlreadySet { address: %llu, prev_value: %u, new_value: %u }", (unsigned long long)i, kb::from_monty(c),
+                    kb::from_monty(v));
+            return false;
+        }
+        return true;
+    }
+};
+struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, own slice writable, other writes deferred
+    const u32* shared;
+    u64 shared_len;
+    u32* seg;
+    u64 seg_start, seg_len;
+    std::vector<std::pair<u64, u32>> deferred;
+    u32 peek(u64 i) const {
+        if (i < seg_start) return i < shared_len ? shared[i] : UNDEF;
+        const u64 o = i - seg_start;
+        return o < seg_len ? seg[o] : UNDEF;
+    }
+    bool set(u64 i, u32 v, Err& e) {
+        if (i < seg_start || i - seg_start >= seg_len) {
+            deferred.emplace_back(i, v);
+            return true;
+        }
+        u32& c = seg[i - seg_start];
+        if (c == UNDEF)
+            c = v;
+        else if (c != v) {
+            e.raise("MemoryAlreadySet { address: %llu, prev_value: %u, new_value: %u }", (unsigned long long)i, kb::from_monty(c),
+                    kb::from_monty(v));
+            return false;
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// decoded program
+// ---------------------------------------------------------------------------------------------------------------------
+enum : u8 { K_ADD = 0, K_MUL, K_DEREF, K_JUMP, K_POSEIDON, K_EXTOP };
+struct Instr {
+    u8 kind, ma, mb, mc;  // LM_VM_ARG_* of the three operands (nu_a, nu_b, nu_c)
+    u32 a, b, c;          // canonical: offset, or the constant
+    u32 am, bm, cm;       // the constant as a Montgomery word
+    u32 x0, x1;           // poseidon: flags (1 permute, 2 half_output, 4 hardcoded_left), offset; extension op: mode flags, size
+};
+struct HintRec {
+    u32 kind;
+    u32 args[4];
+    u8 mode[4];
+};
+
+struct Trace {  // runner.rs:70-76
+    std::vector<u32> pcs, fps;
+    std::vector<u32> pos;  // LM_VM_POSEIDON_CALL_WORDS per call
+    std::vector<u32> ext;  // LM_VM_EXTENSION_ROW_WORDS per row
+    std::vector<std::pair<u64, u64>> pending;  // (target_addr, src_addr)
+    u64 n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
+};
+
+struct Cursors {  // named hint cursors
+    std::vector<u64> index;
+};
+
+}  // namespace
+}  // namespace lmh
+
+using namespace lmh;
+
+struct lmh_bytecode {
+    std::vector<u32> multilinear;
+    u32 log_size = 0, ending_pc = 0, starting_frame_memory = 0, n_names = 0;
+    u64 n_instructions = 0;
+    std::vector<Instr> code;
+    std::vector<u32> hint_begin;  // n_instructions + 1
+    std::vector<HintRec> hints;
+    mutable std::mutex hash_mu;
+    mutable bool hash_done = false;
+    mutable u32 hash[8];
+    mutable BytecodeDeviceSlot device;  // device copy of `multilinear` (lm_node.cpp)
+};
+namespace lmh {
+BytecodeDeviceSlot& vm_bytecode_device_slot(const lmh_bytecode* bc) { return bc->device; }
+}  // namespace lmh
+
+struct lmh_execution {
+    Trace tr;
+    std::vector<u32> memory;       // UNDEF -> 0 after the run
+    std::vector<uint8_t> defined;
+    u64 public_memory_size = 0, runtime_memory_size = 0;
+};
+
+namespace lmh {
+namespace {
+typedef uint8_t u8;
+
+struct Witness {
+    u32 preamble_memory_len;
+    const u64* name_begin;
+    const u64* entry_offset;
+    const u32* data;
+};
+
+template <class Mem>
+struct Machine {
+    const lmh_bytecode& bc;
+    const Witness& w;
+    Mem& mem;
+    Trace& tr;
+    Cursors& cur;
+    u64 pc, fp, ap;
+    Err err;
+
+    Machine(const lmh_bytecode& b, const Witness& wi, Mem& m, Trace& t, Cursors& c) : bc(b), w(wi), mem(m), tr(t), cur(c), pc(0), fp(0), ap(0) {}
+
+    // MemOrConstant / MemOrFpOrConstant::read_value: UNDEF when the value is unknown
+    u32 read(u8 mode, u32 canon, u32 monty) const {
+        if (mode == LM_VM_ARG_CONST) return monty;
+        if (mode == LM_VM_ARG_MEM) return mem.peek(fp + canon);
+        return kb::to_monty((u32)((fp + canon) % kb::P));  // F::from_usize(fp + offset)
+    }
+    u32 need(u8 mode, u32 canon, u32 monty) {  // read_value(..)?
+        const u32 v = read(mode, canon, monty);
+        if (v == UNDEF) err.raise("UndefinedMemory(%llu)", (unsigned long long)(fp + canon));
+        return v;
+    }
+    u32 need_mem(u64 addr) {
+        const u32 v = mem.peek(addr);
+        if (v == UNDEF) err.raise("UndefinedMemory(%llu)", (unsigned long long)addr);
+        return v;
+    }
+    static u64 usize(u32 monty) { return kb::from_monty(monty); }
+
+    u32 hint_arg(const HintRec& h, int k) {  // operand of a hint: value (Montgomery)
+        const u8 mode = h.mode[k];
+        if (mode == LM_VM_ARG_CONST) return kb::to_monty(h.args[k]);
+        if (mode == LM_VM_ARG_MEM) return need_mem(fp + h.args[k]);
+        return kb::to_monty((u32)((fp + h.args[k]) % kb::P));
+    }
+    bool hint_arg_address(const HintRec& h, int k, u64& addr) {  // memory_address(fp)?
+        if (h.mode[k] != LM_VM_ARG_MEM) {
+            err.raise("NotAPointer");
+            return false;
+        }
+        addr = fp + h.args[k];
+        return true;
+    }
+
+    // ---- hints (isa/hint.rs:270-386, CustomHint::execute :137-203).  ParallelBatchStart is the run loop's business. -----
+    void run_hint(const HintRec& h) {
+        switch (h.kind) {
+            case LM_VM_HINT_REQUEST_MEMORY: {
+                const u32 size = hint_arg(h, 1);
+                if (err.set) return;
+                mem.set(fp + h.args[0], kb::to_monty((u32)(ap % kb::P)), err);
+                ap += usize(size);
+                break;
+            }
+            case LM_VM_HINT_INVERSE: {
+                const u32 v = hint_arg(h, 0);
+                if (err.set) return;
+                mem.set(fp + h.args[1], v ? kb::inv(v) : 0u, err);  // try_inverse().unwrap_or(ZERO)
+                break;
+            }
+            case LM_VM_HINT_DEREF:
+                tr.pending.emplace_back(fp + h.args[1], fp + h.args[0]);  // (target_addr, src_addr)
+                break;
+            case LM_VM_HINT_DECOMPOSE_BITS_XMSS: {
+                const u32 dp = hint_arg(h, 0), sp = hint_arg(h, 1), nn = hint_arg(h, 2), cs = hint_arg(h, 3);
+                if (err.set) return;
+                const u64 chunk = usize(cs);
+                if (chunk == 0 || 24 % chunk) {
+                    err.raise("Panic: hint_decompose_bits_xmss: 24 is not a multiple of the chunk size");
+                    return;
+                }
+                u64 out = usize(dp);
+                const u64 src = usize(sp), num = usize(nn);
+                for (u64 i = 0; i < num && !err.set; i++) {
+                    const u32 v = need_mem(src + i);
+                    if (err.set) return;
+                    const u64 x = usize(v);
+                    for (u64 j = 0; j < 24 / chunk; j++)
+                        if (!mem.set(out++, kb::to_monty((u32)((x >> (chunk * j)) & ((1ull << chunk) - 1))), err)) return;
+                }
+                break;
+            }
+            case LM_VM_HINT_DECOMPOSE_BITS_MERKLE_WHIR: {
+                const u32 dp = hint_arg(h, 0), vv = hint_arg(h, 1), cs = hint_arg(h, 2);
+                if (err.set) return;
+                const u64 chunk = usize(cs), x = usize(vv);
+                if (chunk == 0 || 24 % chunk) {
+                    err.raise("Panic: hint_decompose_bits_merkle_whir: 24 is not a multiple of the chunk size");
+                    return;
+                }
+                u64 out = usize(dp);
+                for (u64 j = 0; j < 24 / chunk; j++)
+                    if (!mem.set(out++, kb::to_monty((u32)((x >> (chunk * j)) & ((1ull << chunk) - 1))), err)) return;
+                break;
+            }
+            case LM_VM_HINT_DECOMPOSE_BITS: {  // to_big_endian_in_field(to_decompose, num_bits)
+                const u32 vv = hint_arg(h, 0), mi = hint_arg(h, 1), nb = hint_arg(h, 2);
+                if (err.set) return;
+                const u64 x = usize(vv), at = usize(mi), bits = usize(nb);
+                if (bits > 31) {
+                    err.raise("Panic: hint_decompose_bits: num_bits > F::bits()");
+                    return;
+                }
+                for (u64 j = 0; j < bits; j++)
+                    if (!mem.set(at + j, ((x >> (bits - 1 - j)) & 1) ? kb::ONE : 0u, err)) return;
+                break;
+            }
+            case LM_VM_HINT_LESS_THAN: {
+                const u32 a = hint_arg(h, 0), b = hint_arg(h, 1);
+                u64 at;
+                if (err.set || !hint_arg_address(h, 2, at)) return;
+                mem.set(at, usize(a) < usize(b) ? kb::ONE : 0u, err);
+                break;
+            }
+            case LM_VM_HINT_LOG2_CEIL: {
+                const u32 n = hint_arg(h, 0);
+                u64 at;
+                if (err.set || !hint_arg_address(h, 1, at)) return;
+                mem.set(at, kb::to_monty(log2_ceil_u64(usize(n))), err);
+                break;
+            }
+            case LM_VM_HINT_WITNESS_INLINE:
+            case LM_VM_HINT_WITNESS_INDIRECT: {
+                const u32 name = h.args[0];
+                const u64 e = w.name_begin[name] + cur.index[name];
+                if (e >= w.name_begin[name + 1]) {
+                    err.raise("Panic: hint_witness: exhausted entries for name %u (index=%llu)", name, (unsigned long long)cur.index[name]);
+                    return;
+                }
+                cur.index[name]++;
+                u64 dest;
+                if (h.kind == LM_VM_HINT_WITNESS_INLINE)
+                    dest = fp + h.args[1];
+                else {
+                    const u32 p = need_mem(fp + h.args[1]);
+                    if (err.set) return;
+                    dest = usize(p);
+                }
+                for (u64 k = w.entry_offset[e]; k < w.entry_offset[e + 1]; k++)
+                    if (!mem.set(dest++, w.data[k], err)) return;
+                break;
+            }
+            case LM_VM_HINT_DEBUG_ASSERT: {
+                const u32 l = hint_arg(h, 0), r = hint_arg(h, 1);
+                if (err.set) return;
+                const u64 lv = usize(l), rv = usize(r);
+                if (h.args[3] && rv >= (1ull << MIN_LOG_MEMORY_SIZE)) {
+                    err.raise("RangeCheckWithTooBigRange { range: %llu }", (unsigned long long)rv);
+                    return;
+                }
+                bool ok = true;
+                switch (h.args[2]) {
+                    case 0: ok = lv == rv; break;
+                    case 1: ok = lv != rv; break;
+                    case 2: ok = lv < rv; break;
+                    default: ok = lv <= rv; break;
+                }
+                if (!ok) err.raise("DebugAssertFailed(%llu ? %llu, kind %u)", (unsigned long long)lv, (unsigned long long)rv, h.args[2]);
+                break;
+            }
+            default:
+                break;
+        }
+    }
+
+    // ---- precompiles -----------------------------------------------------------------------------------------------------
+    bool get_slice(u64 at, u32 n, u32* out) {
+        for (u32 i = 0; i < n; i++) {
+            out[i] = need_mem(at + i);
+            if (err.set) return false;
+        }
+        return true;
+    }
+    bool set_slice(u64 at, u32 n, const u32* v) {
+        for (u32 i = 0; i < n; i++)
+            if (!mem.set(at + i, v[i], err)) return false;
+        return true;
+    }
+    void poseidon(const Instr& in, u32 va, u32 vb, u32 vc) {  // Poseidon16Precompile::execute (poseidon_16/mod.rs:209-289)
+        const bool permute = in.x0 & 1, half = in.x0 & 2, hard = in.x0 & 4;
+        const u64 arg_a = usize(va), arg_b = usize(vb), res = usize(vc);
+        const u64 left_first = hard ? in.x1 : arg_a;
+        const u64 left_second = hard ? arg_a : arg_a + 4;
+        alignas(64) u32 st[16];
+        if (!get_slice(left_first, 4, st) || !get_slice(left_second, 4, st + 4) || !get_slice(arg_b, 8, st + 8)) return;
+        if (permute) {
+            host_permute(st);
+            if (!set_slice(res, 16, st)) return;
+        } else {
+            host_compress(st);
+            if (!set_slice(res, half ? 4 : 8, st)) return;
+        }
+        const u32 rec[LM_VM_POSEIDON_CALL_WORDS] = {(u32)arg_a, (u32)arg_b, (u32)res, half ? 1u : 0u, hard ? 1u : 0u, hard ? in.x1 : 0u,
+                                                    (u32)left_first, (u32)left_second, permute ? 1u : 0u};
+        tr.pos.insert(tr.pos.end(), rec, rec + LM_VM_POSEIDON_CALL_WORDS);
+    }
+
+    // extension_op/exec.rs
+    enum { OP_ADD = 8, OP_MUL = 16, OP_POLY_EQ = 32 };
+    static EF compute_elem(const EF& a, const EF& b, u32 op) {
+        if (op == OP_ADD) return kb::ef_add(a, b);
+        const EF ab = kb::ef_mul(a, b);
+        if (op == OP_MUL) return ab;
+        return kb::ef_add_base(kb::ef_sub(kb::ef_sub(kb::ef_dbl(ab), a), b), kb::ONE);  // 2ab - a - b + 1
+    }
+    bool peek_ef(u64 at, EF& out) const {
+        for (int k = 0; k < 5; k++) {
+            const u32 v = mem.peek(at + k);
+            if (v == UNDEF) return false;
+            out.v[k] = v;
+        }
+        return true;
+    }
+    bool need_ef(u64 at, EF& out) {
+        for (int k = 0; k < 5; k++) {
+            out.v[k] = need_mem(at + k);
+            if (err.set) return false;
+        }
+        return true;
+    }
+    bool set_ef(u64 at, const EF& v) { return set_slice(at, 5, v.v); }
+    bool make_slices_equal_and_defined(u64 p0, u64 p1, u32 len) {  // memory.rs:41-66
+        for (u32 i = 0; i < len; i++) {
+            const u32 v0 = mem.peek(p0 + i), v1 = mem.peek(p1 + i);
+            if (v0 != UNDEF && v1 != UNDEF) {
+                if (v0 != v1) {
+                    err.raise("NotEqual(%u, %u)", kb::from_monty(v0), kb::from_monty(v1));
+                    return false;
+                }
+            } else if (v0 != UNDEF) {
+                if (!mem.set(p1 + i, v0, err)) return false;
+            } else if (v1 != UNDEF) {
+                if (!mem.set(p0 + i, v1, err)) return false;
+            } else {
+                if (!mem.set(p0 + i, 0, err) || !mem.set(p1 + i, 0, err)) return false;
+            }
+        }
+        return true;
+    }
+    bool solve_unknowns(u64 pa, u64 pb, u64 pr, bool is_be, u32 op) {  // exec.rs:29-104
+        EF a, b, c;
+        bool ka, kb_, kc;
+        if (is_be) {
+            const u32 v = mem.peek(pa);
+            ka = v != UNDEF;
+            a = kb::ef_from_base(ka ? v : 0);
+        } else
+            ka = peek_ef(pa, a);
+        kb_ = peek_ef(pb, b);
+        kc = peek_ef(pr, c);
+        if (op == OP_MUL && !is_be) {  // "copy_5"
+            if (kb_ && kb::ef_eq(b, kb::ef_one())) return make_slices_equal_and_defined(pa, pr, 5);
+            if (ka && kb::ef_eq(a, kb::ef_one())) return make_slices_equal_and_defined(pb, pr, 5);
+        }
+        if (ka && kb_ && kc) {
+            if (!kb::ef_eq(compute_elem(a, b, op), c)) {
+                err.raise("InvalidExtensionOp");
+                return false;
+            }
+        } else if (ka && kb_ && !kc) {
+        } else if (!ka && kb_ && kc) {
+            const EF x = op == OP_ADD ? kb::ef_sub(c, b) : kb::ef_mul(c, kb::ef_inv(b));
+            if (is_be) {
+                if (x.v[1] | x.v[2] | x.v[3] | x.v[4]) {
+                    err.raise("Panic: solved A not in base field");
+                    return false;
+                }
+                return mem.set(pa, x.v[0], err);
+            }
+            return set_ef(pa, x);
+        } else if (ka && !kb_ && kc) {
+            const EF x = op == OP_ADD ? kb::ef_sub(c, a) : kb::ef_mul(c, kb::ef_inv(a));
+            return set_ef(pb, x);
+        } else {
+            err.raise("InvalidExtensionOp");
+            return false;
+        }
+        return true;
+    }
+    void extension_op(const Instr& in, u32 va, u32 vb, u32 vc) {  // exec_multi_row (exec.rs:106-190)
+        const u32 op = in.x0 & (OP_ADD | OP_MUL | OP_POLY_EQ);
+        const bool is_be = in.x0 & 4;
+        const u64 size = in.x1, pa = usize(va), pb = usize(vb), pr = usize(vc);
+        if (size == 1 && op != OP_POLY_EQ && !solve_unknowns(pa, pb, pr, is_be, op)) return;
+        const u64 a_stride = is_be ? 1 : 5;
+        std::vector<EF> elems(size), vbs(size), comp(size);
+        for (u64 i = 0; i < size; i++) {
+            EF a, b;
+            if (is_be) {
+                const u32 v = need_mem(pa + i);
+                if (err.set) return;
+                a = kb::ef_from_base(v);
+            } else if (!need_ef(pa + i * a_stride, a))
+                return;
+            if (!need_ef(pb + i * 5, b)) return;
+            elems[i] = compute_elem(a, b, op);
+            vbs[i] = b;
+        }
+        comp[size - 1] = elems[size - 1];
+        for (u64 i = size - 1; i-- > 0;) comp[i] = op == OP_POLY_EQ ? kb::ef_mul(elems[i], comp[i + 1]) : kb::ef_add(elems[i], comp[i + 1]);
+        if (!set_ef(pr, comp[0])) return;
+        const size_t base = tr.ext.size();
+        tr.ext.resize(base + size * LM_VM_EXTENSION_ROW_WORDS);
+        for (u64 i = 0; i < size; i++) {
+            u32* r = &tr.ext[base + i * LM_VM_EXTENSION_ROW_WORDS];
+            r[0] = is_be;
+            r[1] = i == 0;
+            r[2] = op == OP_ADD;
+            r[3] = op == OP_MUL;
+            r[4] = op == OP_POLY_EQ;
+            r[5] = (u32)(size - i);
+            r[6] = (u32)(pa + i * a_stride);
+            r[7] = (u32)(pb + i * 5);
+            r[8] = (u32)pr;
+            memcpy(r + 9, vbs[i].v, 20);
+            memcpy(r + 14, comp[0].v, 20);
+            memcpy(r + 19, comp[i].v, 20);
+        }
+    }
+
+    // ---- one instruction (isa/instruction.rs:146-246) -----------------------------------------------------------------------
+    void step(const Instr& in) {
+        switch (in.kind) {
+            case K_ADD:
+            case K_MUL: {  // nu_a (arg_a) op nu_c (arg_c) = nu_b (res)
+                const bool mul = in.kind == K_MUL;
+                const u32 r = read(in.mb, in.b, in.bm);
+                if (r == UNDEF) {
+                    const u32 a = need(in.ma, in.a, in.am);
+                    if (err.set) return;
+                    const u32 c = need(in.mc, in.c, in.cm);
+                    if (err.set) return;
+                    mem.set(fp + in.b, mul ? kb::mul(a, c) : kb::add(a, c), err);
+                } else {
+                    const u32 a = read(in.ma, in.a, in.am);
+                    if (a == UNDEF) {  // a = res inv_op c
+                        const u32 c = need(in.mc, in.c, in.cm);
+                        if (err.set) return;
+                        if (mul && c == 0) {
+                            err.raise("DivByZero");
+                            return;
+                        }
+                        mem.set(fp + in.a, mul ? kb::mul(r, kb::inv(c)) : kb::sub(r, c), err);
+                    } else {
+                        const u32 c = read(in.mc, in.c, in.cm);
+                        if (c == UNDEF) {
+                            if (in.mc != LM_VM_ARG_MEM) {
+                                err.raise("NotAPointer");
+                                return;
+                            }
+                            if (mul && a == 0) {
+                                err.raise("DivByZero");
+                                return;
+                            }
+                            mem.set(fp + in.c, mul ? kb::mul(r, kb::inv(a)) : kb::sub(r, a), err);
+                        } else {
+                            const u32 v = mul ? kb::mul(a, c) : kb::add(a, c);
+                            if (v != r) {
+                                err.raise("NotEqual(%u, %u)", kb::from_monty(v), kb::from_monty(r));
+                                return;
+                            }
+                        }
+                    }
+                }
+                if (mul)
+                    tr.n_mul++;
+                else
+                    tr.n_add++;
+                pc++;
+                break;
+            }
+            case K_DEREF: {  // res = m[m[fp + shift_0] + shift_1]
+                const u32 r = read(in.mc, in.c, in.cm);
+                if (r == UNDEF) {
+                    if (in.mc != LM_VM_ARG_MEM) {
+                        err.raise("NotAPointer");
+                        return;
+                    }
+                    const u32 p = need_mem(fp + in.a);
+                    if (err.set) return;
+                    const u32 v = mem.peek(usize(p) + in.b);
+                    if (v != UNDEF && !mem.set(fp + in.c, v, err)) return;
+                    // else: a range check, resolved by resolve_deref_hints
+                } else {
+                    const u32 p = need_mem(fp + in.a);
+                    if (err.set) return;
+                    if (!mem.set(usize(p) + in.b, r, err)) return;
+                }
+                tr.n_deref++;
+                pc++;
+                break;
+            }
+            case K_JUMP: {
+                const u32 cond = need(in.ma, in.a, in.am);
+                if (err.set) return;
+                if (cond == 0)
+                    pc++;
+                else if (cond == kb::ONE) {
+                    const u32 d = need(in.mb, in.b, in.bm);
+                    if (err.set) return;
+                    const u32 f = need(in.mc, in.c, in.cm);
+                    if (err.set) return;
+                    pc = usize(d);
+                    fp = usize(f);
+                } else {
+                    err.raise("Panic: jump condition %u is not boolean", kb::from_monty(cond));
+                    return;
+                }
+                tr.n_jump++;
+                break;
+            }
+            default: {
+                const u32 a = need(in.ma, in.a, in.am);
+                if (err.set) return;
+                const u32 b = need(in.mb, in.b, in.bm);
+                if (err.set) return;
+                const u32 c = need(in.mc, in.c, in.cm);
+                if (err.set) return;
+                if (in.kind == K_POSEIDON)
+                    poseidon(in, a, b, c);
+                else
+                    extension_op(in, a, b, c);
+                if (err.set) return;
+                pc++;
+                break;
+            }
+        }
+    }
+
+    // run_loop (runner.rs:121-204).  Returns 0 Halted, 1 LoopBack, 2 ParallelBatch, -1 error.
+    struct Batch {
+        u64 batch_pc = 0, batch_fp = 0, frame_size = 0;
+        u32 n_args = 0, end_mode = 0, end_value = 0;
+        std::vector<u64> hint_indices_at_start;
+        bool armed = false;
+    };
+    int run(bool has_stop, u64 stop_pc, Batch& batch) {
+        batch.armed = false;
+        for (;;) {
+            if (pc == bc.ending_pc) return 0;
+            if (pc >= bc.n_instructions) {
+                err.raise("PCOutOfBounds");
+                return -1;
+            }
+            tr.pcs.push_back((u32)pc);
+            tr.fps.push_back((u32)fp);
+            for (u32 h = bc.hint_begin[pc]; h < bc.hint_begin[pc + 1]; h++) {
+                const HintRec& hr = bc.hints[h];
+                if (hr.kind == LM_VM_HINT_PARALLEL_BATCH_START) {
+                    if (!batch.armed) {
+                        batch.armed = true;
+                        batch.batch_pc = pc;
+                        batch.batch_fp = fp;
+                        batch.frame_size = ap - fp;
+                        batch.n_args = hr.args[0];
+                        batch.end_mode = hr.mode[1];
+                        batch.end_value = hr.args[1];
+                        batch.hint_indices_at_start = cur.index;
+                    }
+                    continue;
+                }
+                run_hint(hr);
+                if (err.set) return -1;
+            }
+            step(bc.code[pc]);
+            if (err.set) return -1;
+            if (has_stop && pc == stop_pc) return 1;
+            if (batch.armed && pc == batch.batch_pc) return 2;
+        }
+    }
+};
+
+// resolve_deref_hints (runner.rs:206-236)
+bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& pending, Err& err) {
+    std::vector<uint8_t> resolved(mem.m.size() + 1, 0);
+    auto is_resolved = [&](u64 t) { return t < resolved.size() && resolved[t]; };
+    auto mark = [&](u64 t) {
+        if (t >= resolved.size()) resolved.resize(t + 1, 0);
+        resolved[t] = 1;
+    };
+    for (;;) {
+        bool progress = false;
+        for (const auto& [target, src] : pending) {
+            if (is_resolved(target)) continue;
+            const u32 a = mem.peek(src);
+            if (a == UNDEF) {
+                err.raise("Panic: deref hint source %llu is undefined", (unsigned long long)src);
+                return false;
+            }
+            const u32 v = mem.peek(kb::from_monty(a));
+            if (v == UNDEF) continue;
+            if (!mem.set(target, v, err)) return false;
+            mark(target);
+            progress = true;
+        }
+        if (!progress) break;
+    }
+    for (const auto& [target, src] : pending) {
+        (void)src;
+        if (!is_resolved(target) && !mem.set(target, 0, err)) return false;
+    }
+    return true;
+}
+
+// handle_parallel_batch (runner.rs:361-482)
+bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector<u32>& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
+                           u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
+    MainMem mm{memory};
+    auto get = [&](u64 at) -> u32 {
+        const u32 v = mm.peek(at);
+        if (v == UNDEF) err.raise("UndefinedMemory(%llu)", (unsigned long long)at);
+        return v;
+    };
+    const u32 sv = get(batch.batch_fp + 2);
+    if (err.set) return false;
+    const u64 start_value = kb::from_monty(sv);
+    u64 end_value;
+    if (batch.end_mode == LM_VM_ARG_CONST)
+        end_value = batch.end_value;
+    else {
+        const u32 ev = get(batch.batch_fp + batch.end_value);
+        if (err.set) return false;
+        end_value = kb::from_monty(ev);
+    }
+    if (end_value < start_value) {
+        err.raise("Panic: parallel batch: end value below the start value");
+        return false;
+    }
+    const u64 n_iters = end_value - start_value;
+    if (n_iters == 1) return true;
+    if (n_iters == 0) {
+        err.raise("Panic: parallel batch with zero iterations ran one");
+        return false;
+    }
+    const u64 stride = fp - batch.batch_fp;
+    const u32 return_pc = get(fp), saved_fp = get(fp + 1);
+    if (err.set) return false;
+    std::vector<u32> args(batch.n_args);
+    for (u32 i = 0; i < batch.n_args; i++) {
+        args[i] = get(batch.batch_fp + 2 + i);
+        if (err.set) return false;
+    }
+    std::vector<u64> per_iter(cur.index.size());
+    for (size_t k = 0; k < per_iter.size(); k++) per_iter[k] = cur.index[k] - batch.hint_indices_at_start[k];
+    for (u64 i = 1; i <= n_iters; i++) {  // write_call_frame
+        const u64 f = batch.batch_fp + i * stride;
+        const u64 iter_val = i < n_iters ? start_value + i : end_value;
+        if (!mm.set(f, return_pc, err) || !mm.set(f + 1, saved_fp, err) || !mm.set(f + 2, kb::to_monty((u32)(iter_val % kb::P)), err)) return false;
+        for (u32 j = 1; j < batch.n_args; j++)
+            if (!mm.set(f + 2 + j, args[j], err)) return false;
+    }
+    const u64 max_addr = batch.batch_fp + (n_iters + 1) * stride;
+    if (max_addr > MAX_MEMORY) {
+        err.raise("OutOfMemory");
+        return false;
+    }
+    if (max_addr > memory.size()) memory.resize(max_addr, UNDEF);
+    const u64 n_par = n_iters - 1;
+    const u64 split_at = batch.batch_fp + stride;
+
+    struct Seg {
+        Trace tr;
+        std::vector<std::pair<u64, u32>> deferred;
+        Err err;
+    };
+    std::vector<Seg> segs(n_par);
+    u32* base = memory.data();
+    vm_parallel_for(n_par, n_threads, [&](u64 i) {
+        Seg& s = segs[i];
+        const u64 seg_start = split_at + i * stride;
+        SegMem sm{base, split_at, base + seg_start, seg_start, stride, {}};
+        Cursors c = cur;
+        for (size_t k = 0; k < c.index.size(); k++) c.index[k] += i * per_iter[k];
+        Machine<SegMem> m(bc, w, sm, s.tr, c);
+        m.pc = batch.batch_pc;
+        m.fp = batch.batch_fp + (i + 1) * stride;
+        m.ap = m.fp + batch.frame_size;
+        Machine<SegMem>::Batch inner;
+        const int rc = m.run(true, batch.batch_pc, inner);
+        if (rc != 1 && !m.err.set) m.err.raise(rc == 0 ? "Panic: a parallel segment reached the end of the program" : "Panic: nested parallel batch");
+        s.err = m.err;
+        s.deferred = std::move(sm.deferred);
+    });
+    for (u64 i = 0; i < n_par; i++)
+        if (segs[i].err.set) {
+            err.raise("ParallelSegmentFailed(%llu, %s)", (unsigned long long)(i + 1), segs[i].err.msg.c_str());
+            return false;
+        }
+    // Trace::merge in iteration order, then the deferred writes
+    size_t n_cyc = trace.pcs.size(), n_pos = trace.pos.size(), n_ext = trace.ext.size(), n_pend = trace.pending.size();
+    std::vector<size_t> o_cyc(n_par), o_pos(n_par), o_ext(n_par), o_pend(n_par);
+    for (u64 i = 0; i < n_par; i++) {
+        o_cyc[i] = n_cyc, o_pos[i] = n_pos, o_ext[i] = n_ext, o_pend[i] = n_pend;
+        n_cyc += segs[i].tr.pcs.size(), n_pos += segs[i].tr.pos.size(), n_ext += segs[i].tr.ext.size(), n_pend += segs[i].tr.pending.size();
+        trace.n_add += segs[i].tr.n_add, trace.n_mul += segs[i].tr.n_mul, trace.n_deref += segs[i].tr.n_deref, trace.n_jump += segs[i].tr.n_jump;
+    }
+    trace.pcs.resize(n_cyc), trace.fps.resize(n_cyc), trace.pos.resize(n_pos), trace.ext.resize(n_ext), trace.pending.resize(n_pend);
+    vm_parallel_for(n_par, n_threads, [&](u64 i) {
+        const Trace& t = segs[i].tr;
+        if (!t.pcs.empty()) memcpy(&trace.pcs[o_cyc[i]], t.pcs.data(), t.pcs.size() * 4), memcpy(&trace.fps[o_cyc[i]], t.fps.data(), t.fps.size() * 4);
+        if (!t.pos.empty()) memcpy(&trace.pos[o_pos[i]], t.pos.data(), t.pos.size() * 4);
+        if (!t.ext.empty()) memcpy(&trace.ext[o_ext[i]], t.ext.data(), t.ext.size() * 4);
+        for (size_t k = 0; k < t.pending.size(); k++) trace.pending[o_pend[i] + k] = t.pending[k];
+    });
+    for (u64 i = 0; i < n_par; i++)
+        for (const auto& [addr, val] : segs[i].deferred)
+            if (!mm.set(addr, val, err)) return false;
+    for (size_t k = 0; k < cur.index.size(); k++) cur.index[k] += n_par * per_iter[k];
+    pc = batch.batch_pc;
+    fp = batch.batch_fp + n_iters * stride;
+    ap = fp + batch.frame_size;
+    return true;
+}
+
+bool decode_instruction(const u32* row, Instr& in, std::string& why) {
+    u32 c[12];
+    for (int k = 0; k < 12; k++) c[k] = kb::from_monty(row[k]);
+    const u32 fa = c[3], fb = c[4], fc = c[5], fcfp = c[6], fabfp = c[7], mul = c[8], jump = c[9], aux = c[10], pd = c[11];
+    if (fa > 1 || fb > 1 || fc > 1 || fcfp > 1 || fabfp > 1 || mul > 1 || jump > 1 || aux > 2 || (fc && fcfp) || (fabfp && (fa || fb))) {
+        why = "flag columns out of range";
+        return false;
+    }
+    memset(&in, 0, sizeof in);
+    in.a = c[0], in.b = c[1], in.c = c[2];
+    in.am = row[0], in.bm = row[1], in.cm = row[2];
+    in.ma = fa ? LM_VM_ARG_CONST : (fabfp ? LM_VM_ARG_FP : LM_VM_ARG_MEM);
+    in.mb = fb ? LM_VM_ARG_CONST : (fabfp ? LM_VM_ARG_FP : LM_VM_ARG_MEM);
+    in.mc = fc ? LM_VM_ARG_CONST : (fcfp ? LM_VM_ARG_FP : LM_VM_ARG_MEM);
+    const int n_kinds = (pd != 0) + (jump != 0) + (mul != 0) + (aux != 0);
+    if (n_kinds != 1) {
+        why = "not exactly one of precompile_data / jump / mul / aux";
+        return false;
+    }
+    if (pd) {
+        if (pd & 1) {  // POSEIDON_PRECOMPILE_DATA + 2 permute + 4 half_output + 8 hardcoded_left + 16 offset
+            in.kind = K_POSEIDON;
+            in.x0 = ((pd >> 1) & 1) | (((pd >> 2) & 1) << 1) | (((pd >> 3) & 1) << 2);
+            in.x1 = pd >> 4;
+            if ((in.x0 & 1) && (in.x0 & 6)) {
+                why = "poseidon16: permute excludes half_output / hardcoded_left";
+                return false;
+            }
+            if (!(in.x0 & 4) && in.x1) {
+                why = "poseidon16: offset without the hardcoded_left flag";
+                return false;
+            }
+        } else {  // mode flags (4 is_be, 8 add, 16 mul, 32 poly_eq) + 64 size
+            in.kind = K_EXTOP;
+            in.x0 = pd & 63;
+            in.x1 = pd >> 6;
+            const u32 op = in.x0 & 56;
+            if ((in.x0 & 3) || (op != 8 && op != 16 && op != 32) || in.x1 == 0) {
+                why = "extension_op: bad mode / size";
+                return false;
+            }
+        }
+    } else if (jump)
+        in.kind = K_JUMP;
+    else if (mul)
+        in.kind = K_MUL;
+    else if (aux == 1)
+        in.kind = K_ADD;
+    else {
+        in.kind = K_DEREF;
+        if (in.ma != LM_VM_ARG_MEM || in.mb != LM_VM_ARG_CONST) {
+            why = "deref: operand a must be m[fp + shift_0] and operand b the constant shift_1";
+            return false;
+        }
+    }
+    if ((in.kind == K_ADD || in.kind == K_MUL || in.kind == K_JUMP || in.kind == K_DEREF) && fabfp) {
+        why = "flag_ab_fp outside a precompile";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+}  // namespace lmh
+
+extern "C" {
+
+lmh_bytecode* lmh_bytecode_new(const uint32_t* ml, uint32_t log_size, uint64_t n_instructions, uint32_t ending_pc, uint32_t starting_frame_memory,
+                               const lm_vm_hint* hints, uint64_t n_hints, uint32_t n_hint_names) {
+    if (!ml || log_size > 24 || n_instructions > (1ull << log_size) || ending_pc >= n_instructions || (n_hints && !hints)) {
+        lm_set_error("lmh_bytecode_new: bad arguments");
+        return nullptr;
+    }
+    lmh_bytecode* bc = nullptr;
+    try {
+        bc = new lmh_bytecode();
+        bc->log_size = log_size, bc->ending_pc = ending_pc, bc->starting_frame_memory = starting_frame_memory;
+        bc->n_instructions = n_instructions, bc->n_names = n_hint_names;
+        bc->multilinear.assign(ml, ml + (16ull << log_size));
+        bc->code.resize(n_instructions);
+        for (u64 pc = 0; pc < n_instructions; pc++) {
+            std::string why;
+            if (!decode_instruction(ml + 16 * pc, bc->code[pc], why)) {
+                lm_set_error("lmh_bytecode_new: instruction %llu: %s", (unsigned long long)pc, why.c_str());
+                delete bc;
+                return nullptr;
+            }
+        }
+        bc->hint_begin.assign(n_instructions + 1, 0);
+        bc->hints.resize(n_hints);
+        u64 prev_pc = 0;
+        for (u64 h = 0; h < n_hints; h++) {
+            const lm_vm_hint& s = hints[h];
+            if (s.pc >= n_instructions || s.pc < prev_pc || s.kind == 0 || s.kind > LM_VM_HINT_DEBUG_ASSERT ||
+                ((s.kind == LM_VM_HINT_WITNESS_INLINE || s.kind == LM_VM_HINT_WITNESS_INDIRECT) && s.args[0] >= n_hint_names)) {
+                lm_set_error("lmh_bytecode_new: hint %llu is malformed (pcs must ascend, names < n_hint_names)", (unsigned long long)h);
+                delete bc;
+                return nullptr;
+            }
+            prev_pc = s.pc;
+            HintRec& r = bc->hints[h];
+            r.kind = s.kind;
+            memcpy(r.args, s.args, sizeof r.args);
+            memcpy(r.mode, s.mode, sizeof r.mode);
+            bc->hint_begin[s.pc + 1]++;
+        }
+        for (u64 pc = 0; pc < n_instructions; pc++) bc->hint_begin[pc + 1] += bc->hint_begin[pc];
+    } catch (...) {
+        delete bc;
+        lm_set_error("lmh_bytecode_new: out of memory");
+        return nullptr;
+    }
+    return bc;
+}
+void lmh_bytecode_free(lmh_bytecode* bc) { delete bc; }
+uint32_t lmh_bytecode_log_size(const lmh_bytecode* bc) { return bc->log_size; }
+uint32_t lmh_bytecode_ending_pc(const lmh_bytecode* bc) { return bc->ending_pc; }
+const uint32_t* lmh_bytecode_multilinear(const lmh_bytecode* bc) { return bc->multilinear.data(); }
+void lmh_bytecode_hash(const lmh_bytecode* bc, uint32_t out[8]) {
+    std::lock_guard<std::mutex> lk(bc->hash_mu);
+    if (!bc->hash_done) {  // poseidon_compress_slice(.., use_iv = true): hash = compress(hash || chunk) from the zero IV
+        alignas(64) u32 st[16];
+        memset(st, 0, sizeof st);
+        const u32* d = bc->multilinear.data();
+        const u64 n = bc->multilinear.size();
+        for (u64 off = 0; off < n; off += 8) {
+            memcpy(st + 8, d + off, 32);
+            host_compress(st);
+        }
+        memcpy(bc->hash, st, 32);
+        bc->hash_done = true;
+    }
+    memcpy(out, bc->hash, 32);
+}
+
+int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
+                         uint32_t n_threads, lmh_execution** out) {
+    if (!bc || !out || (n_public_input && !public_input) || !witness || witness->n_names != bc->n_names ||
+        (bc->n_names && (!witness->name_entry_begin || !witness->entry_offset))) {
+        lm_set_error("lmh_execute_bytecode: bad arguments (the witness must carry one hint stream per name of the bytecode)");
+        return LM_E_INVALID;
+    }
+    *out = nullptr;
+    lmh_execution* ex = nullptr;
+    try {
+        ex = new lmh_execution();
+        Witness w{witness->preamble_memory_len, witness->name_entry_begin, witness->entry_offset, witness->data};
+        // execute_bytecode_helper (runner.rs:238-343)
+        u64 pub = 1;
+        while (pub < n_public_input) pub <<= 1;  // padd_with_zero_to_next_power_of_two
+        if (n_public_input == 0) pub = 0;
+        std::vector<u32>& memory = ex->memory;
+        memory.reserve(1u << 20);
+        memory.assign(pub, 0);
+        if (n_public_input) memcpy(memory.data(), public_input, 4ull * n_public_input);
+        u64 fp = pub + w.preamble_memory_len;
+        fp = (fp + 4) / 5 * 5;  // next_multiple_of(DIMENSION)
+        const u64 initial_ap = fp + bc->starting_frame_memory;
+        Cursors cur;
+        cur.index.assign(bc->n_names, 0);
+        MainMem mm{memory};
+        Machine<MainMem> m(*bc, w, mm, ex->tr, cur);
+        m.fp = fp, m.ap = initial_ap, m.pc = 0;
+        for (;;) {
+            Machine<MainMem>::Batch batch;
+            const int rc = m.run(false, 0, batch);
+            if (rc == 0) break;
+            if (rc < 0) break;
+            if (!handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err)) break;
+        }
+        if (!m.err.set) resolve_deref_hints(mm, ex->tr.pending, m.err);
+        if (!m.err.set)
+            for (u32 k = 0; k < bc->n_names; k++)
+                if (cur.index[k] != witness->name_entry_begin[k + 1] - witness->name_entry_begin[k]) {
+                    m.err.raise("Panic: not all entries of named hint %u were consumed (%llu of %llu used)", k, (unsigned long long)cur.index[k],
+                                (unsigned long long)(witness->name_entry_begin[k + 1] - witness->name_entry_begin[k]));
+                    break;
+                }
+        if (m.err.set) {
+            lm_set_error("lmh_execute_bytecode: pc %llu: %s", (unsigned long long)m.pc, m.err.msg.c_str());
+            delete ex;
+            return LM_E_INVALID;
+        }
+        ex->tr.pcs.push_back((u32)m.pc);
+        ex->tr.fps.push_back((u32)m.fp);
+        ex->public_memory_size = pub;
+        ex->runtime_memory_size = m.ap - initial_ap;
+        const u64 n = memory.size();
+        ex->defined.resize(n);
+        uint8_t* def = ex->defined.data();
+        u32* mem = memory.data();
+        const u64 chunk = 1u << 16;
+        vm_parallel_for((n + chunk - 1) / chunk, n_threads, [&](u64 c) {
+            const u64 e = std::min(n, (c + 1) * chunk);
+            for (u64 i = c * chunk; i < e; i++) {
+                const bool d = mem[i] != UNDEF;
+                def[i] = d;
+                if (!d) mem[i] = 0;
+            }
+        });
+    } catch (const std::bad_alloc&) {
+        delete ex;
+        lm_set_error("lmh_execute_bytecode: out of memory");
+        return LM_E_NOMEM;
+    }
+    *out = ex;
+    return LM_OK;
+}
+void lmh_execution_free(lmh_execution* e) { delete e; }
+void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* v) {
+    memset(v, 0, sizeof *v);
+    v->n_cycles = e->tr.pcs.size();
+    v->pcs = e->tr.pcs.data();
+    v->fps = e->tr.fps.data();
+    v->memory_len = e->memory.size();
+    v->memory = e->memory.data();
+    v->memory_defined = e->defined.data();
+    v->public_memory_size = e->public_memory_size;
+    v->runtime_memory_size = e->runtime_memory_size;
+    v->n_poseidon_calls = e->tr.pos.size() / LM_VM_POSEIDON_CALL_WORDS;
+    v->poseidon_calls = e->tr.pos.data();
+    v->n_extension_rows = e->tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS;
+    v->extension_rows = e->tr.ext.data();
+    v->n_add = e->tr.n_add, v->n_mul = e->tr.n_mul, v->n_deref = e->tr.n_deref, v->n_jump = e->tr.n_jump;
+}
+
+void lmh_poseidon16_compress_many(uint32_t* states, uint64_t n, uint32_t n_threads) {
+    const u64 chunk = 256;
+    vm_parallel_for((n + chunk - 1) / chunk, n_threads, [&](u64 c) {
+        const u64 e = std::min(n, (c + 1) * chunk);
+        for (u64 i = c * chunk; i < e; i++) {
+            alignas(64) u32 st[16];
+            memcpy(st, states + 16 * i, 64);
+            host_compress(st);
+            memcpy(states + 16 * i, st, 64);
+        }
+    });
+}
+
+}  // extern "C"
+#endif

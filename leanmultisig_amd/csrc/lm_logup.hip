@@ -426,6 +426,99 @@ extern "C" int lm_poseidon_trace_outputs_from_memory(lm_ctx* ctx, uint32_t* cons
     return LM_OK;
 }
 
+// ---- precompile tables from the VM runner's call records ------------------------------------------------------
+// Poseidon16Precompile::execute pushes the flag / index columns and the 16 input words per call (poseidon_16/mod.rs:262-286); the
+// runner keeps 9 canonical words per call and the inputs are read here from the final (write-once) memory image.
+struct PosCallCols {
+    u32* c[27];  // columns 0..24, then 109 (index_input_left), 110 (precompile_data)
+};
+__global__ __launch_bounds__(256) void k_poseidon_table_from_calls(const u32* __restrict__ calls, u64 n_calls, const u32* __restrict__ memory,
+                                                                   u64 mem_len, PosCallCols out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_calls; i += (u64)gridDim.x * 256) {
+        const u32* r = calls + i * 9;
+        const u32 arg_a = r[0], arg_b = r[1], res = r[2], half = r[3], hard = r[4], off = r[5], lf = r[6], ls = r[7], perm = r[8];
+        out.c[0][i] = ONE;
+        out.c[1][i] = to_monty(arg_b);
+        out.c[2][i] = to_monty(res);
+        out.c[3][i] = half ? ONE : 0u;
+        out.c[4][i] = hard ? ONE : 0u;
+        out.c[5][i] = to_monty(off);
+        out.c[6][i] = to_monty(lf);
+        out.c[7][i] = to_monty(ls);
+        out.c[8][i] = perm ? ONE : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) out.c[9 + j][i] = (u64)lf + j < mem_len ? memory[(u64)lf + j] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) out.c[13 + j][i] = (u64)ls + j < mem_len ? memory[(u64)ls + j] : 0u;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) out.c[17 + j][i] = (u64)arg_b + j < mem_len ? memory[(u64)arg_b + j] : 0u;
+        out.c[25][i] = to_monty(arg_a);
+        out.c[26][i] = to_monty(1u + 2u * perm + 4u * half + 8u * hard + 16u * off);
+    }
+}
+extern "C" int lm_poseidon_table_from_calls(lm_ctx* ctx, const uint32_t* d_calls, uint64_t n_calls, const uint32_t* d_memory, uint64_t memory_len,
+                                            uint32_t* const* d_cols) {
+    LM_REQUIRE(ctx && d_cols && d_memory);
+    if (n_calls == 0) return LM_OK;
+    LM_REQUIRE(d_calls);
+    PosCallCols o;
+    for (int c = 0; c < 25; c++) {
+        LM_REQUIRE(d_cols[c]);
+        o.c[c] = d_cols[c];
+    }
+    LM_REQUIRE(d_cols[109] && d_cols[110]);
+    o.c[25] = d_cols[109], o.c[26] = d_cols[110];
+    LM_LAUNCH(ctx, k_poseidon_table_from_calls, dim3((unsigned)std::min<u64>((n_calls + 255) / 256, 4096)), dim3(256), 0, d_calls, n_calls,
+              d_memory, memory_len, o);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+// exec_multi_row's pushes (extension_op/exec.rs:149-186) from the runner's 24-word row records; VALUE_A stays with
+// lm_extension_op_trace (fill_trace_extension_op).
+struct ExtRowCols {
+    u32* c[31];
+};
+__global__ __launch_bounds__(256) void k_extension_table_from_rows(const u32* __restrict__ rows, u64 n_rows, ExtRowCols out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (u64)gridDim.x * 256) {
+        const u32* r = rows + i * 24;
+        const u32 is_be = r[0], start = r[1], fadd = r[2], fmul = r[3], fpe = r[4], len = r[5];
+        out.c[0][i] = is_be ? ONE : 0u;
+        out.c[1][i] = start ? ONE : 0u;
+        out.c[2][i] = to_monty(len);
+        out.c[3][i] = fadd ? ONE : 0u;
+        out.c[4][i] = fmul ? ONE : 0u;
+        out.c[5][i] = fpe ? ONE : 0u;
+        out.c[6][i] = to_monty(r[6]);
+        out.c[7][i] = to_monty(r[7]);
+        out.c[13][i] = to_monty(r[8]);
+#pragma unroll
+        for (u32 k = 0; k < 5; k++) {
+            out.c[19 + k][i] = r[9 + k];   // VB
+            out.c[24 + k][i] = r[14 + k];  // VRES
+            out.c[8 + k][i] = r[19 + k];   // COMP
+        }
+        out.c[29][i] = start ? ONE : 0u;  // activation flag
+        out.c[30][i] = to_monty(4u * is_be + 8u * fadd + 16u * fmul + 32u * fpe + 64u * len);
+    }
+}
+extern "C" int lm_extension_table_from_rows(lm_ctx* ctx, const uint32_t* d_rows, uint64_t n_rows, uint32_t* const* d_cols) {
+    LM_REQUIRE(ctx && d_cols);
+    if (n_rows == 0) return LM_OK;
+    LM_REQUIRE(d_rows);
+    ExtRowCols o;
+    for (int c = 0; c < 31; c++) {
+        if (c >= 14 && c < 19) {
+            o.c[c] = nullptr;
+            continue;
+        }
+        LM_REQUIRE(d_cols[c]);
+        o.c[c] = d_cols[c];
+    }
+    LM_LAUNCH(ctx, k_extension_table_from_rows, dim3((unsigned)std::min<u64>((n_rows + 255) / 256, 4096)), dim3(256), 0, d_rows, n_rows, o);
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
+
 static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5], const uint32_t* alphas_eq16,
                        uint32_t n_vars, uint32_t* d_nums, uint32_t* d_dens, uint64_t* out_active_len);
 extern "C" int lm_logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n_sections, const uint32_t c[5],

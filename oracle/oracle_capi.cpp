@@ -614,3 +614,98 @@ int orc_set_threads(int n) {
 #endif
 }
 }
+
+// ================================================================================================
+// leanVM runner + get_execution_trace (vm_oracle.hpp)
+// ================================================================================================
+#include "vm_oracle.hpp"
+namespace {
+struct OrcVmHint {  // layout of lm_vm_hint (include/leanmultisig_host.h)
+    uint32_t pc, kind, args[4];
+    uint8_t mode[4];
+};
+struct OrcVmRun {
+    orc::vm::Bytecode bc;
+    orc::vm::ExecutionResult er;
+    orc::vm::ExecutionTrace tr;
+    std::vector<uint32_t> pcs, fps;
+    bool have_trace = false;
+};
+std::string g_vm_err;
+}  // namespace
+extern "C" {
+const char* orc_vm_last_error() { return g_vm_err.c_str(); }
+// Runs the program; returns a handle (NULL + orc_vm_last_error on a RunnerError).  Inputs as lmh_bytecode_new / lm_vm_witness.
+void* orc_vm_execute(const uint32_t* instructions_multilinear, uint32_t log_size, uint64_t n_instructions, uint32_t ending_pc,
+                     uint32_t starting_frame_memory, const void* hints_raw, uint64_t n_hints, uint32_t n_names, const uint32_t* public_input,
+                     uint32_t n_public_input, uint32_t preamble_memory_len, const uint64_t* name_entry_begin, const uint64_t* entry_offset,
+                     const uint32_t* data) {
+    using namespace orc::vm;
+    auto* run = new OrcVmRun();
+    try {
+        Bytecode& bc = run->bc;
+        bc.instructions_multilinear = instructions_multilinear;
+        bc.log_size = log_size, bc.ending_pc = ending_pc, bc.starting_frame_memory = starting_frame_memory, bc.n_names = n_names;
+        for (uint64_t pc = 0; pc < n_instructions; pc++) bc.code.push_back(decode(instructions_multilinear + 16 * pc));
+        bc.hints.resize(n_instructions);
+        const OrcVmHint* hs = (const OrcVmHint*)hints_raw;
+        for (uint64_t h = 0; h < n_hints; h++) {
+            Hint x;
+            x.kind = hs[h].kind;
+            std::memcpy(x.args, hs[h].args, 16);
+            std::memcpy(x.mode, hs[h].mode, 4);
+            bc.hints.at(hs[h].pc).push_back(x);
+        }
+        WitnessHints w{preamble_memory_len, name_entry_begin, entry_offset, data};
+        run->er = execute_bytecode(bc, public_input, n_public_input, w);
+        for (size_t x : run->er.trace.pcs) run->pcs.push_back((uint32_t)x);
+        for (size_t x : run->er.trace.fps) run->fps.push_back((uint32_t)x);
+    } catch (const std::exception& e) {
+        g_vm_err = e.what();
+        delete run;
+        return nullptr;
+    }
+    return run;
+}
+void orc_vm_free(void* h) { delete (OrcVmRun*)h; }
+// sizes: [n_cycles, memory_len, n_poseidon, n_extension_rows, public_memory_size, runtime_memory_size, add, mul, deref, jump]
+void orc_vm_sizes(void* h, uint64_t* out) {
+    auto* r = (OrcVmRun*)h;
+    out[0] = r->pcs.size(), out[1] = r->er.memory.cells.size(), out[2] = r->er.trace.poseidon[0].size(), out[3] = r->er.trace.extension[0].size();
+    out[4] = r->er.public_memory_size, out[5] = r->er.runtime_memory_size;
+    out[6] = r->er.trace.add, out[7] = r->er.trace.mul, out[8] = r->er.trace.deref, out[9] = r->er.trace.jump;
+}
+void orc_vm_log(void* h, uint32_t* pcs, uint32_t* fps, uint32_t* memory, uint8_t* defined) {
+    auto* r = (OrcVmRun*)h;
+    std::memcpy(pcs, r->pcs.data(), r->pcs.size() * 4);
+    std::memcpy(fps, r->fps.data(), r->fps.size() * 4);
+    for (size_t i = 0; i < r->er.memory.cells.size(); i++) {
+        defined[i] = r->er.memory.cells[i].has_value();
+        memory[i] = r->er.memory.cells[i].value_or(0);
+    }
+}
+// get_execution_trace: sizes out = [log_memory, log_rows x 3, non_padded x 3, zero_vec_ptr, null_hash_ptr]
+void orc_vm_trace(void* h, uint64_t* out) {
+    auto* r = (OrcVmRun*)h;
+    if (!r->have_trace) {
+        r->tr = orc::vm::get_execution_trace(r->bc, r->er);
+        r->have_trace = true;
+    }
+    size_t lm = 0;
+    while (((size_t)1 << lm) < r->tr.memory.size()) lm++;
+    out[0] = lm;
+    for (int t = 0; t < 3; t++) out[1 + t] = r->tr.log_n_rows[t], out[4 + t] = r->tr.non_padded_n_rows[t];
+    out[7] = r->tr.zero_vec_ptr, out[8] = r->tr.null_hash_ptr;
+}
+void orc_vm_trace_memory(void* h, uint32_t* out) {
+    auto* r = (OrcVmRun*)h;
+    std::memcpy(out, r->tr.memory.data(), r->tr.memory.size() * 4);
+}
+// table t as n_columns_total x 2^log_rows, column-major
+void orc_vm_trace_table(void* h, uint32_t t, uint32_t* out) {
+    auto* r = (OrcVmRun*)h;
+    const auto& cols = r->tr.tables[t];
+    const size_t n = (size_t)1 << r->tr.log_n_rows[t];
+    for (size_t c = 0; c < cols.size(); c++) std::memcpy(out + c * n, cols[c].data(), n * 4);
+}
+}

@@ -506,3 +506,76 @@ def execution_table_fill(orc, pcs, fps, bytecode, memory):
     orc.lib.orc_execution_table_fill(_p(pcs), _p(fps), C.c_uint64(pcs.size), _p(bc), C.c_uint64(bc.shape[0]), _p(mem),
                                      C.c_uint64(mem.size), _p(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# leanVM runner + get_execution_trace (oracle/vm_oracle.hpp)
+# ------------------------------------------------------------------------------------------------------------
+class VmRun:
+    """One run of the oracle's runner on a leanmultisig_amd.vm.Bytecode (execute_bytecode, lean_vm/src/execution/runner.rs)."""
+
+    def __init__(self, orc, bc, public_input, witness):
+        lib = orc.lib
+        lib.orc_vm_execute.restype = vp
+        lib.orc_vm_execute.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+        lib.orc_vm_last_error.restype = C.c_char_p
+        for n in ("orc_vm_free", "orc_vm_sizes", "orc_vm_log", "orc_vm_trace", "orc_vm_trace_memory"):
+            getattr(lib, n).restype = None
+        lib.orc_vm_free.argtypes = [vp]
+        lib.orc_vm_sizes.argtypes = [vp, vp]
+        lib.orc_vm_log.argtypes = [vp, vp, vp, vp, vp]
+        lib.orc_vm_trace.argtypes = [vp, vp]
+        lib.orc_vm_trace_memory.argtypes = [vp, vp]
+        lib.orc_vm_trace_table.restype = None
+        lib.orc_vm_trace_table.argtypes = [vp, C.c_uint32, vp]
+        self.orc, self.lib, self.bc = orc, lib, bc
+        self.public_input = np.ascontiguousarray(public_input, dtype=np.uint32)
+        self.hints = bc.hint_array()
+        self.witness = witness  # keeps the flat hint arrays alive
+        self.h = lib.orc_vm_execute(bc.multilinear.ctypes.data, bc.log_size, bc.size, bc.ending_pc, bc.starting_frame_memory,
+                                    C.cast(self.hints, vp), len(bc.hints), len(bc.names), self.public_input.ctypes.data, self.public_input.size,
+                                    witness.preamble_memory_len, witness.name_entry_begin.ctypes.data, witness.entry_offset.ctypes.data,
+                                    witness.data.ctypes.data)
+        if not self.h:
+            raise RuntimeError("oracle VM: " + lib.orc_vm_last_error().decode())
+        s = np.zeros(10, dtype=np.uint64)
+        lib.orc_vm_sizes(self.h, _p(s))
+        (self.n_cycles, self.memory_len, self.n_poseidon_calls, self.n_extension_rows, self.public_memory_size, self.runtime_memory_size) = (int(x) for x in s[:6])
+        self.counts = dict(add=int(s[6]), mul=int(s[7]), deref=int(s[8]), jump=int(s[9]))
+        self.pcs, self.fps = np.empty(self.n_cycles, dtype=np.uint32), np.empty(self.n_cycles, dtype=np.uint32)
+        self.memory, self.defined = np.empty(self.memory_len, dtype=np.uint32), np.empty(self.memory_len, dtype=np.uint8)
+        lib.orc_vm_log(self.h, _p(self.pcs), _p(self.fps), _p(self.memory), _p(self.defined))
+
+    def trace(self, log_inv_rate=1):
+        """get_execution_trace + the memory growth of prove_execution.rs:41-46 -> witness dict in the tests/synth_witness.py layout"""
+        from tests import synth_witness
+        s = np.zeros(9, dtype=np.uint64)
+        self.lib.orc_vm_trace(self.h, _p(s))
+        log_memory, log_rows, non_padded = int(s[0]), {t: int(s[1 + t]) for t in range(3)}, {t: int(s[4 + t]) for t in range(3)}
+        memory = np.empty(1 << log_memory, dtype=np.uint32)
+        self.lib.orc_vm_trace_memory(self.h, _p(memory))
+        want = max(16, self.bc.log_size, log_memory)
+        if want > log_memory:
+            memory = np.concatenate([memory, np.zeros((1 << want) - memory.size, dtype=np.uint32)])
+            log_memory = want
+        tables = {}
+        for t, n_total in ((0, 24), (1, 31), (2, 111)):
+            tab = np.empty((n_total, 1 << log_rows[t]), dtype=np.uint32)
+            self.lib.orc_vm_trace_table(self.h, t, _p(tab))
+            tables[t] = tab
+        memory_acc, bytecode_acc = synth_witness.access_counters(self.orc, tables, memory.size, self.bc.size)
+        return dict(log_inv_rate=log_inv_rate, log_memory=log_memory, log_bytecode=self.bc.log_size, ending_pc=self.bc.ending_pc,
+                    public_memory_size=self.public_memory_size, public_input=self.public_input, bytecode_hash=self.bc.hash(),
+                    bytecode=self.bc.multilinear, bytecode_acc=bytecode_acc, memory=memory, memory_acc=memory_acc, tables=tables,
+                    log_rows=log_rows, non_padded=non_padded, zero_vec_ptr=int(s[7]), null_hash_ptr=int(s[8]))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_vm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

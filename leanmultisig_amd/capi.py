@@ -44,6 +44,8 @@ _SIGS = {
     "lm_poseidon_trace": (C.c_int, [vp, vp, C.c_uint64]),
     "lm_extension_op_trace": (C.c_int, [vp, vp, C.c_uint64, vp, vp, C.c_uint64]),
     "lm_poseidon_trace_outputs_from_memory": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64]),
+    "lm_poseidon_table_from_calls": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp]),
+    "lm_extension_table_from_rows": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "lm_execution_table_trace": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, vp]),
     "lm_commit": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp), vp]),
     "lm_tree_free": (None, [vp, vp]),

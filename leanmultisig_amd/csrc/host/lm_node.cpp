@@ -86,14 +86,14 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
     }
     // ---- bytecode table: device copy cached in the bytecode object -------------------------------------------------------------
-    BytecodeDeviceSlot& slot = vm_bytecode_device_slot(bc);
-    if (slot.ctx != (void*)ctx || !slot.d_multilinear) {
+    u32** slot = vm_bytecode_device_slot(bc, (void*)ctx);
+    if (!*slot) {
         u32* d;
         if ((rc = lm_malloc(ctx, 16ull << log_bytecode, &d))) return fail(rc);  // lives as long as the context's pool
         if ((rc = lm_upload(ctx, d, lmh_bytecode_multilinear(bc), 16ull << log_bytecode))) return fail(rc);
-        slot.ctx = (void*)ctx;
-        slot.d_multilinear = d;
+        *slot = d;
     }
+    u32* const d_bytecode = *slot;
     // ---- tables ----------------------------------------------------------------------------------------------------------------
     const u64 n_rows[3] = {v.n_cycles, v.n_extension_rows, v.n_poseidon_calls};
     u32 log_rows[3];
@@ -113,7 +113,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         u32 *d_pcs, *d_fps;
         if (!dev(v.n_cycles, &d_pcs) || !dev(v.n_cycles, &d_fps)) return fail(rc);
         if ((rc = lm_upload_async(ctx, d_pcs, v.pcs, v.n_cycles)) || (rc = lm_upload_async(ctx, d_fps, v.fps, v.n_cycles))) return fail(rc);
-        if ((rc = lm_execution_table_trace(ctx, d_pcs, d_fps, v.n_cycles, slot.d_multilinear, 1ull << log_bytecode, d_memory, padded,
+        if ((rc = lm_execution_table_trace(ctx, d_pcs, d_fps, v.n_cycles, d_bytecode, 1ull << log_bytecode, d_memory, padded,
                                            t->cols[0].data())))
             return fail(rc);
         if ((rc = lmh_pad_table(ctx, 0, t->cols[0].data(), v.n_cycles, log_rows[0], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
@@ -158,7 +158,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     w.log_inv_rate = log_inv_rate, w.log_memory = log_memory, w.log_bytecode = log_bytecode, w.ending_pc = ending_pc;
     w.public_memory_size = (u32)v.public_memory_size, w.n_public_input = n_public_input;
     w.public_input = t->public_input.data(), w.bytecode_hash = t->bytecode_hash;
-    w.d_bytecode = slot.d_multilinear, w.d_bytecode_acc = nullptr, w.d_memory = d_memory, w.d_memory_acc = nullptr;
+    w.d_bytecode = d_bytecode, w.d_bytecode_acc = nullptr, w.d_memory = d_memory, w.d_memory_acc = nullptr;
     for (int tb = 0; tb < 3; tb++) {
         w.tables[tb].log_rows = log_rows[tb];
         w.tables[tb].non_padded_n_rows = (u32)n_rows[tb];

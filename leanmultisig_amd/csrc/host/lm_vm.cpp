@@ -16,11 +16,14 @@
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -122,6 +125,11 @@ void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) { 
 
 namespace {
 typedef uint8_t u8;
+inline double vm_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool vm_times() {
+    static const bool on = getenv("LM_VM_TIMES") != nullptr;
+    return on;
+}
 
 constexpr u32 UNDEF = 0xFFFFFFFFu;  // not a field element (values are < p < 2^31)
 constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
@@ -240,10 +248,14 @@ struct lmh_bytecode {
     mutable std::mutex hash_mu;
     mutable bool hash_done = false;
     mutable u32 hash[8];
-    mutable BytecodeDeviceSlot device;  // device copy of `multilinear` (lm_node.cpp)
+    mutable std::mutex device_mu;
+    mutable std::map<void*, u32*> device;  // context -> device copy of `multilinear` (lm_node.cpp)
 };
 namespace lmh {
-BytecodeDeviceSlot& vm_bytecode_device_slot(const lmh_bytecode* bc) { return bc->device; }
+u32** vm_bytecode_device_slot(const lmh_bytecode* bc, void* ctx) {
+    std::lock_guard<std::mutex> lk(bc->device_mu);
+    return &bc->device[ctx];  // (map nodes are stable)
+}
 }  // namespace lmh
 
 struct lmh_execution {
@@ -830,6 +842,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector
         std::vector<std::pair<u64, u32>> deferred;
         Err err;
     };
+    const double tb0 = vm_now_ms();
     std::vector<Seg> segs(n_par);
     u32* base = memory.data();
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
@@ -853,6 +866,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector
             err.raise("ParallelSegmentFailed(%llu, %s)", (unsigned long long)(i + 1), segs[i].err.msg.c_str());
             return false;
         }
+    const double tb1 = vm_now_ms();
     // Trace::merge in iteration order, then the deferred writes
     size_t n_cyc = trace.pcs.size(), n_pos = trace.pos.size(), n_ext = trace.ext.size(), n_pend = trace.pending.size();
     std::vector<size_t> o_cyc(n_par), o_pos(n_par), o_ext(n_par), o_pend(n_par);
@@ -876,6 +890,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
+    if (vm_times()) fprintf(stderr, "[vm] batch of %llu segments: run %.2f ms, merge + deferred writes %.2f ms\n", (unsigned long long)n_par, tb1 - tb0, vm_now_ms() - tb1);
     return true;
 }
 
@@ -1042,14 +1057,21 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         MainMem mm{memory};
         Machine<MainMem> m(*bc, w, mm, ex->tr, cur);
         m.fp = fp, m.ap = initial_ap, m.pc = 0;
+        const double t_start = vm_now_ms();
+        double t_batches = 0;
         for (;;) {
             Machine<MainMem>::Batch batch;
             const int rc = m.run(false, 0, batch);
             if (rc == 0) break;
             if (rc < 0) break;
-            if (!handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err)) break;
+            const double tb = vm_now_ms();
+            const bool ok = handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
+            t_batches += vm_now_ms() - tb;
+            if (!ok) break;
         }
+        const double t_loop = vm_now_ms();
         if (!m.err.set) resolve_deref_hints(mm, ex->tr.pending, m.err);
+        const double t_resolve = vm_now_ms();
         if (!m.err.set)
             for (u32 k = 0; k < bc->n_names; k++)
                 if (cur.index[k] != witness->name_entry_begin[k + 1] - witness->name_entry_begin[k]) {
@@ -1079,6 +1101,9 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
                 if (!d) mem[i] = 0;
             }
         });
+        if (vm_times())
+            fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, resolve_deref_hints %.2f ms, defined mask %.2f ms\n",
+                    t_loop - t_start - t_batches, t_batches, t_resolve - t_loop, vm_now_ms() - t_resolve);
     } catch (const std::bad_alloc&) {
         delete ex;
         lm_set_error("lmh_execute_bytecode: out of memory");

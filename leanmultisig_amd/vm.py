@@ -36,9 +36,7 @@ def to_monty(x):
 def from_monty(x):
     """Montgomery -> canonical: x * 2^-32 mod p"""
     rinv = pow(1 << 32, P - 2, P)
-    x = np.asarray(x, dtype=np.uint64)
-    lo, hi = x & np.uint64(0xFFFF), x >> np.uint64(16)
-    return (lo * np.uint64(rinv) % np.uint64(P) + (hi * np.uint64(rinv) % np.uint64(P)) * np.uint64(1 << 16)) % np.uint64(P)
+    return (np.asarray(x, dtype=np.uint64) * np.uint64(rinv)) % np.uint64(P)  # x < 2^32, rinv < 2^31
 
 
 class Label:
@@ -105,6 +103,7 @@ class Program:
         self.rows = []     # per instruction: [op_a, op_b, op_c, flag_a, flag_b, flag_c, flag_c_fp, flag_ab_fp, mul, jump, aux, pdata]
         self.fix = []      # (pc, column, Label)
         self.hints = []    # (pc, kind, args, modes)
+        self.hint_fix = [] # (hint index, argument, Label)
         self.labels = {}
         self.names = {}    # hint-witness name -> id
         self.starting_frame_memory = 0
@@ -212,12 +211,21 @@ class Program:
         """IntermediateInstruction::Panic: 0 x fp = 1 (c_compile_final.rs:269-277)"""
         return self.mul(K(0), FP(0), K(1))
 
+    def return_from_main(self, zero_cell):
+        """`return` of main (b_compile_intermediate.rs:567-584): pc -> ending_pc, fp -> 0 — the rows behind the last cycle are the
+        execution table's padding row, whose fp is 0, and the jump constraint ties fp_next to the jump's updated_fp"""
+        self.add(K(0), K(0), M(zero_cell))
+        return self.jump(K(1), K(Label("@end_program")), M(zero_cell))
+
     # ---- hints (attach to the next instruction) ------------------------------------------------------------------------------------
     def _hint(self, kind, ops):
         args, modes = [0] * 4, [0] * 4
         for i, o in enumerate(ops):
             if isinstance(o, Operand):
-                args[i], modes[i] = int(o.value), o.mode
+                modes[i] = o.mode
+                o = o.value
+            if isinstance(o, Label):
+                self.hint_fix.append((len(self.hints), i, o))
             else:
                 args[i] = int(o)
         self.hints.append((self.here(), kind, args, modes))
@@ -282,6 +290,8 @@ class Program:
             rows[pc, col] = self.labels[lab.name] + lab.offset
         ml = np.zeros((size, 16), dtype=np.uint32)
         ml[:, :12] = to_monty(rows).astype(np.uint32)
+        for hi, ai, lab in self.hint_fix:
+            self.hints[hi][2][ai] = self.labels[lab.name] + lab.offset
         hints = sorted(self.hints, key=lambda h: h[0])  # stable: hints of one pc keep their order
         return Bytecode(ml, ending_pc, self.starting_frame_memory, hints, dict(self.names), dict(self.labels))
 
@@ -425,3 +435,56 @@ def poseidon16_compress_many(states, n_threads=0):
     s = np.ascontiguousarray(states, dtype=np.uint32).reshape(-1, 16).copy()
     capi.load().lmh_poseidon16_compress_many(s.ctypes.data, s.shape[0], n_threads)
     return s
+
+
+class DeviceTrace:
+    """lmh_vm_trace: get_execution_trace on the device (every table column, the padded memory image) from an Execution."""
+
+    def __init__(self, ctx, bytecode, execution, public_input, log_inv_rate=1):
+        self.ctx, self.lib = ctx, ctx.lib
+        pi = np.ascontiguousarray(public_input, dtype=np.uint32)
+        out = C.c_void_p()
+        rc = self.lib.lmh_get_execution_trace(ctx.h, bytecode.handle(), execution.h, pi.ctypes.data, pi.size, log_inv_rate, C.byref(out))
+        if rc != 0:
+            raise LmError(self.lib.lm_last_error().decode())
+        self.h = out.value
+        self.bytecode = bytecode  # owns the device copy of the bytecode table
+        self.view = C.cast(self.lib.lmh_vm_trace_view(self.h), C.POINTER(capi.ExecutionTrace)).contents
+
+    def table(self, t):
+        """table t as (n_columns_total, 2^log_rows) host array"""
+        n_total = {0: 24, 1: 31, 2: 111}[t]
+        tb = self.view.tables[t]
+        ptrs = np.ctypeslib.as_array(C.cast(tb.d_cols, C.POINTER(C.c_uint64)), shape=(n_total,))
+        out = np.empty((n_total, 1 << tb.log_rows), dtype=np.uint32)
+        for c in range(n_total):
+            self.ctx._check(self.lib.lm_download(self.ctx.h, out[c].ctypes.data, int(ptrs[c]), out.shape[1]))
+        return out
+
+    def memory(self):
+        out = np.empty(1 << self.view.log_memory, dtype=np.uint32)
+        self.ctx._check(self.lib.lm_download(self.ctx.h, out.ctypes.data, self.view.d_memory, out.size))
+        return out
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.lib.lmh_vm_trace_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_execution_vm(ctx, prover, bytecode, public_input, witness, builder, n_threads=0):
+    """prove_execution(bytecode, public_input, witness, whir_config) (lean_prover/src/prove_execution.rs:20-274), whole: the VM run,
+    the trace on the device, the proof (left in `prover`).  Returns [vm_ms, trace_ms, prove_ms]."""
+    pi = np.ascontiguousarray(public_input, dtype=np.uint32)
+    times = (C.c_double * 3)()
+    rc = ctx.lib.lmh_prove_execution_vm(ctx.h, prover.h, bytecode.handle(), pi.ctypes.data, pi.size, C.byref(witness.c), C.byref(builder),
+                                        n_threads, times)
+    if rc != 0:
+        raise LmError(ctx.lib.lm_last_error().decode())
+    return list(times)

@@ -1,0 +1,62 @@
+"""SURVEY.md §8(f) rank 4 on the device: the tables lmh_get_execution_trace builds from the runner's log equal the oracle's
+get_execution_trace column for column, and lmh_prove_execution_vm (VM run + trace + proof) equals the oracle's proof of the
+oracle's trace word for word — on the hand-assembled XMSS aggregation program with real signatures."""
+import numpy as np
+import pytest
+
+import leanmultisig_amd as lm
+from leanmultisig_amd import vm
+from leanmultisig_amd.programs import xmss_aggregate as xa
+from tests import oracle_binding as ob
+from tests import synth_witness
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def program():
+    return xa.build_program()
+
+
+def test_device_trace_equals_oracle_trace(ctx, orc, program):
+    pi, w, _ = xa.build_witness(program, 7, np.random.default_rng(11), slot=0x0BADCAFE)
+    ex = vm.execute(program, pi, w)
+    run = ob.VmRun(orc, program, pi, w)
+    ref = run.trace()
+    dt = vm.DeviceTrace(ctx, program, ex, pi)
+    assert dt.view.log_memory == ref["log_memory"] and dt.view.ending_pc == program.ending_pc
+    assert np.array_equal(dt.memory(), ref["memory"])
+    for t in range(3):
+        assert dt.view.tables[t].log_rows == ref["log_rows"][t] and dt.view.tables[t].non_padded_n_rows == ref["non_padded"][t]
+        got, want = dt.table(t), ref["tables"][t]
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, f"table {t}: columns {bad[:10]} differ"
+    dt.close()
+
+
+@pytest.mark.parametrize("n_sigs", [3, 33])
+def test_prove_execution_vm_equals_oracle(ctx, orc, program, n_sigs):
+    pi, w, _ = xa.build_witness(program, n_sigs, np.random.default_rng(5 + n_sigs))
+    builder = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    lm_builder = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    pr = lm.Prover(ctx)
+    times = vm.prove_execution_vm(ctx, pr, program, pi, w, lm_builder)
+    assert len(times) == 3
+    proof = pr.proof()
+    ww = ob.VmRun(orc, program, pi, w).trace()
+    ok, err = lm.verify_execution(ww, pr.proof_bytes(compressed=True), lm_builder, compressed=True)
+    assert ok, err
+    ok, err = ob.verify_execution(orc, ww, proof, builder)
+    assert ok, err
+    ob.set_threads(orc, 8)
+    ref = ob.prove_execution(orc, ww, synth_witness.header(ww), builder)
+    assert np.array_equal(proof, ref)
+
+
+def test_runner_error_surfaces(ctx, program):
+    pi, w, info = xa.build_witness(program, 3, np.random.default_rng(2))
+    bad = pi.copy()
+    bad[0] ^= 1     # the hash of the input buffer no longer lands on the public input
+    pr = lm.Prover(ctx)
+    with pytest.raises(lm.LmError, match="MemoryAlreadySet"):
+        vm.prove_execution_vm(ctx, pr, program, bad, w, lm.WhirBuilder.default(1, security_level=60, pow_bits=6))

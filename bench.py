@@ -129,6 +129,9 @@ def time_whole_node(ctx, lm, w, steps, warmup, n_threads=0):
         t0 = time.perf_counter()
         times = vm.prove_execution_vm(ctx, pr, v["bc"], v["pi"], v["wit"], w["lm_builder"], n_threads=n_threads)
         dt = time.perf_counter() - t0
+        if os.environ.get("LM_BENCH_DEBUG"):
+            import ctypes
+            print(f"# whole node step {i}: {1e3 * dt:.2f} ms = " + " + ".join(f"{x:.2f}" for x in times) + f" (cpu {ctypes.CDLL(None).sched_getcpu()})", file=sys.stderr)
         if i >= warmup:
             acc += np.asarray(times)
             t_tot += dt
@@ -354,6 +357,9 @@ def main():
     for _ in range(args.steps):
         pr = run_step(ctx, lm, w)
         gathered = exchange_step(step_root(pr), pr.proof_pruned(), device)
+        if os.environ.get("LM_BENCH_DEBUG"):
+            import ctypes
+            print(f"# hot path step on cpu {ctypes.CDLL(None).sched_getcpu()}", file=sys.stderr)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:

@@ -22,9 +22,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <functional>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -134,6 +136,90 @@ inline bool vm_times() {
 constexpr u32 UNDEF = 0xFFFFFFFFu;  // not a field element (values are < p < 2^31)
 constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
 
+// The VM memory: 2^26 words of address space reserved up front (untouched pages cost nothing), so that growing never moves
+// the image and the segments of a parallel batch can fill and first-touch their own frames concurrently.
+struct MemBuf {
+    u32* p = nullptr;
+    u64 len = 0;
+    MemBuf() {
+        {  // an arena released by an earlier run: its pages are already resident
+            std::lock_guard<std::mutex> lk(cache_mu());
+            auto& c = cache();
+            if (!c.empty()) {
+                p = c.back();
+                c.pop_back();
+                return;
+            }
+        }
+        void* q = mmap(nullptr, MAX_MEMORY * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(q, MAX_MEMORY * 4, MADV_HUGEPAGE);  // 2 MB first-touch faults where the kernel allows them
+        p = (u32*)q;
+    }
+    ~MemBuf() {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(cache_mu());
+            if (cache().size() < 4) {
+                cache().push_back(p);
+                return;
+            }
+        }
+        munmap(p, MAX_MEMORY * 4);
+    }
+    MemBuf(const MemBuf&) = delete;
+    MemBuf& operator=(const MemBuf&) = delete;
+    u64 size() const { return len; }
+    u32* data() { return p; }
+    const u32* data() const { return p; }
+    void grow(u64 n) {  // [len, n) becomes undefined
+        for (u64 i = len; i < n; i++) p[i] = UNDEF;
+        if (n > len) len = n;
+    }
+    static std::mutex& cache_mu() {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<u32*>& cache() {
+        static std::vector<u32*> c;
+        return c;
+    }
+};
+// growable array without value-initialisation (the logs are written exactly once)
+template <class T>
+struct UVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    UVec() {}
+    ~UVec() { free(p); }
+    UVec(const UVec&) = delete;
+    UVec& operator=(const UVec&) = delete;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 256;
+        while (nc < c) nc *= 2;
+        T* q = (T*)realloc(p, nc * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        p = q, cap = nc;
+    }
+    void push_back(const T& v) {
+        if (n == cap) reserve(n + 1);
+        p[n++] = v;
+    }
+    T* extend(size_t k) {  // k uninitialised elements at the end
+        reserve(n + k);
+        T* r = p + n;
+        n += k;
+        return r;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // errors (lean_vm/src/diagnostics/error.rs)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -156,17 +242,17 @@ struct Err {
 // memory (execution/memory.rs)
 // ---------------------------------------------------------------------------------------------------------------------
 struct MainMem {  // Memory: grows on write, write-once cells
-    std::vector<u32>& m;
-    u32 peek(u64 i) const { return i < m.size() ? m[i] : UNDEF; }
+    MemBuf& m;
+    u32 peek(u64 i) const { return i < m.len ? m.p[i] : UNDEF; }
     bool set(u64 i, u32 v, Err& e) {
-        if (i >= m.size()) {
+        if (i >= m.len) {
             if (i >= MAX_MEMORY) {
                 e.raise("OutOfMemory");
                 return false;
             }
-            m.resize(i + 1, UNDEF);
+            m.grow(i + 1);
         }
-        u32& c = m[i];
+        u32& c = m.p[i];
         if (c == UNDEF)
             c = v;
         else if (c != v) {
@@ -222,9 +308,9 @@ struct HintRec {
 };
 
 struct Trace {  // runner.rs:70-76
-    std::vector<u32> pcs, fps;
-    std::vector<u32> pos;  // LM_VM_POSEIDON_CALL_WORDS per call
-    std::vector<u32> ext;  // LM_VM_EXTENSION_ROW_WORDS per row
+    UVec<u32> pcs, fps;
+    UVec<u32> pos;  // LM_VM_POSEIDON_CALL_WORDS per call
+    UVec<u32> ext;  // LM_VM_EXTENSION_ROW_WORDS per row
     std::vector<std::pair<u64, u64>> pending;  // (target_addr, src_addr)
     u64 n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
 };
@@ -260,8 +346,8 @@ u32** vm_bytecode_device_slot(const lmh_bytecode* bc, void* ctx) {
 
 struct lmh_execution {
     Trace tr;
-    std::vector<u32> memory;       // UNDEF -> 0 after the run
-    std::vector<uint8_t> defined;
+    MemBuf memory;                 // UNDEF -> 0 after the run
+    UVec<uint8_t> defined;
     u64 public_memory_size = 0, runtime_memory_size = 0;
 };
 
@@ -471,7 +557,7 @@ struct Machine {
         }
         const u32 rec[LM_VM_POSEIDON_CALL_WORDS] = {(u32)arg_a, (u32)arg_b, (u32)res, half ? 1u : 0u, hard ? 1u : 0u, hard ? in.x1 : 0u,
                                                     (u32)left_first, (u32)left_second, permute ? 1u : 0u};
-        tr.pos.insert(tr.pos.end(), rec, rec + LM_VM_POSEIDON_CALL_WORDS);
+        memcpy(tr.pos.extend(LM_VM_POSEIDON_CALL_WORDS), rec, sizeof rec);
     }
 
     // extension_op/exec.rs
@@ -578,10 +664,9 @@ struct Machine {
         comp[size - 1] = elems[size - 1];
         for (u64 i = size - 1; i-- > 0;) comp[i] = op == OP_POLY_EQ ? kb::ef_mul(elems[i], comp[i + 1]) : kb::ef_add(elems[i], comp[i + 1]);
         if (!set_ef(pr, comp[0])) return;
-        const size_t base = tr.ext.size();
-        tr.ext.resize(base + size * LM_VM_EXTENSION_ROW_WORDS);
+        u32* rows = tr.ext.extend(size * LM_VM_EXTENSION_ROW_WORDS);
         for (u64 i = 0; i < size; i++) {
-            u32* r = &tr.ext[base + i * LM_VM_EXTENSION_ROW_WORDS];
+            u32* r = rows + i * LM_VM_EXTENSION_ROW_WORDS;
             r[0] = is_be;
             r[1] = i == 0;
             r[2] = op == OP_ADD;
@@ -749,18 +834,37 @@ struct Machine {
     }
 };
 
-// resolve_deref_hints (runner.rs:206-236)
-bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& pending, Err& err) {
-    std::vector<uint8_t> resolved(mem.m.size() + 1, 0);
-    auto is_resolved = [&](u64 t) { return t < resolved.size() && resolved[t]; };
-    auto mark = [&](u64 t) {
-        if (t >= resolved.size()) resolved.resize(t + 1, 0);
-        resolved[t] = 1;
-    };
+// resolve_deref_hints (runner.rs:206-236): memory[target] = memory[memory[src]] for every recorded deref, repeated until no more
+// progress, the rest zero-filled.  Almost every entry is a no-op (the DEREF instruction itself found its value): those are
+// recognised by a read-only pass on the pool; the reference's sequential loop then runs over what is left, with its `resolved`
+// set (targets already written are skipped) seeded by the no-op entries that share a target with a remaining one.
+bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& pending, u32 n_threads, Err& err) {
+    const u64 n = pending.size();
+    if (n == 0) return true;
+    std::vector<uint8_t> noop(n, 0);
+    const u64 chunk = 4096;
+    vm_parallel_for((n + chunk - 1) / chunk, n_threads, [&](u64 c) {
+        const u64 e = std::min(n, (c + 1) * chunk);
+        for (u64 i = c * chunk; i < e; i++) {
+            const u32 a = mem.peek(pending[i].second);
+            if (a == UNDEF) continue;
+            const u32 v = mem.peek(kb::from_monty(a));
+            noop[i] = v != UNDEF && mem.peek(pending[i].first) == v;
+        }
+    });
+    std::vector<u64> rest;
+    for (u64 i = 0; i < n; i++)
+        if (!noop[i]) rest.push_back(i);
+    if (rest.empty()) return true;
+    std::set<u64> rest_targets, resolved;
+    for (u64 i : rest) rest_targets.insert(pending[i].first);
+    for (u64 i = 0; i < n; i++)
+        if (noop[i] && rest_targets.count(pending[i].first)) resolved.insert(pending[i].first);
     for (;;) {
         bool progress = false;
-        for (const auto& [target, src] : pending) {
-            if (is_resolved(target)) continue;
+        for (u64 i : rest) {
+            const auto& [target, src] = pending[i];
+            if (resolved.count(target)) continue;
             const u32 a = mem.peek(src);
             if (a == UNDEF) {
                 err.raise("Panic: deref hint source %llu is undefined", (unsigned long long)src);
@@ -769,20 +873,18 @@ bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& p
             const u32 v = mem.peek(kb::from_monty(a));
             if (v == UNDEF) continue;
             if (!mem.set(target, v, err)) return false;
-            mark(target);
+            resolved.insert(target);
             progress = true;
         }
         if (!progress) break;
     }
-    for (const auto& [target, src] : pending) {
-        (void)src;
-        if (!is_resolved(target) && !mem.set(target, 0, err)) return false;
-    }
+    for (u64 i : rest)
+        if (!resolved.count(pending[i].first) && !mem.set(pending[i].first, 0, err)) return false;
     return true;
 }
 
 // handle_parallel_batch (runner.rs:361-482)
-bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector<u32>& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
+bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
                            u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
     MainMem mm{memory};
     auto get = [&](u64 at) -> u32 {
@@ -833,7 +935,15 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector
         err.raise("OutOfMemory");
         return false;
     }
-    if (max_addr > memory.size()) memory.resize(max_addr, UNDEF);
+    if (max_addr > memory.len) {  // memory.0.resize(max_addr, None): filled (and first touched) by the pool
+        const u64 from = memory.len, chunk = 1u << 15;
+        u32* mp = memory.p;
+        vm_parallel_for((max_addr - from + chunk - 1) / chunk, n_threads, [&](u64 c) {
+            const u64 e = std::min(max_addr, from + (c + 1) * chunk);
+            for (u64 i = from + c * chunk; i < e; i++) mp[i] = UNDEF;
+        });
+        memory.len = max_addr;
+    }
     const u64 n_par = n_iters - 1;
     const u64 split_at = batch.batch_fp + stride;
 
@@ -875,7 +985,8 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, std::vector
         n_cyc += segs[i].tr.pcs.size(), n_pos += segs[i].tr.pos.size(), n_ext += segs[i].tr.ext.size(), n_pend += segs[i].tr.pending.size();
         trace.n_add += segs[i].tr.n_add, trace.n_mul += segs[i].tr.n_mul, trace.n_deref += segs[i].tr.n_deref, trace.n_jump += segs[i].tr.n_jump;
     }
-    trace.pcs.resize(n_cyc), trace.fps.resize(n_cyc), trace.pos.resize(n_pos), trace.ext.resize(n_ext), trace.pending.resize(n_pend);
+    trace.pcs.extend(n_cyc - trace.pcs.size()), trace.fps.extend(n_cyc - trace.fps.size()), trace.pos.extend(n_pos - trace.pos.size());
+    trace.ext.extend(n_ext - trace.ext.size()), trace.pending.resize(n_pend);
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
         const Trace& t = segs[i].tr;
         if (!t.pcs.empty()) memcpy(&trace.pcs[o_cyc[i]], t.pcs.data(), t.pcs.size() * 4), memcpy(&trace.fps[o_cyc[i]], t.fps.data(), t.fps.size() * 4);
@@ -1045,10 +1156,10 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         u64 pub = 1;
         while (pub < n_public_input) pub <<= 1;  // padd_with_zero_to_next_power_of_two
         if (n_public_input == 0) pub = 0;
-        std::vector<u32>& memory = ex->memory;
-        memory.reserve(1u << 20);
-        memory.assign(pub, 0);
-        if (n_public_input) memcpy(memory.data(), public_input, 4ull * n_public_input);
+        MemBuf& memory = ex->memory;
+        memory.len = pub;
+        memset(memory.p, 0, 4 * pub);
+        if (n_public_input) memcpy(memory.p, public_input, 4ull * n_public_input);
         u64 fp = pub + w.preamble_memory_len;
         fp = (fp + 4) / 5 * 5;  // next_multiple_of(DIMENSION)
         const u64 initial_ap = fp + bc->starting_frame_memory;
@@ -1070,7 +1181,7 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
             if (!ok) break;
         }
         const double t_loop = vm_now_ms();
-        if (!m.err.set) resolve_deref_hints(mm, ex->tr.pending, m.err);
+        if (!m.err.set) resolve_deref_hints(mm, ex->tr.pending, n_threads, m.err);
         const double t_resolve = vm_now_ms();
         if (!m.err.set)
             for (u32 k = 0; k < bc->n_names; k++)
@@ -1089,7 +1200,7 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         ex->public_memory_size = pub;
         ex->runtime_memory_size = m.ap - initial_ap;
         const u64 n = memory.size();
-        ex->defined.resize(n);
+        ex->defined.extend(n);
         uint8_t* def = ex->defined.data();
         u32* mem = memory.data();
         const u64 chunk = 1u << 16;

@@ -242,16 +242,24 @@ _XBUF = {}
 
 def exchange_step(root, proof_words, device):
     """The exchange of the sharded path, once per step: all-gather of the commitment roots (8 words) and of
-    the pruned proofs (to the rank that would run the 8 -> 1 recursion).  Proof lengths differ by a few words: a length word +
-    zero padding to a fixed capacity.  One rank: nothing to exchange — the packed buffer is returned as it is (no collective,
-    no device round trip; the same code path whether launched directly or through torch.distributed.run with one process)."""
+    the pruned proofs.  Proof lengths differ by a few words: a length word + zero padding to a fixed capacity.  One persistent
+    pinned staging buffer, one persistent send and one persistent receive tensor on `device`; `all_gather_into_tensor` writes the
+    receive tensor in place and NOTHING is downloaded here — the rank that runs the 8 -> 1 recursion step reads it (`.cpu()`),
+    the others never do.  One rank: nothing to exchange — the packed host buffer is returned as it is (no collective, no device
+    round trip; the same code path whether launched directly or through torch.distributed.run with one process).
+    Returns a (world, 9 + capacity) int32 tensor."""
     import torch
     import torch.distributed as dist
     cap = 1 << 17
     assert proof_words.size < cap
-    if "host" not in _XBUF:  # pinned staging buffer, zeroed once; only the words behind a shorter proof are cleared again
-        _XBUF["host"] = torch.zeros(8 + 1 + cap, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros(8 + 1 + cap, dtype=torch.int32)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if "host" not in _XBUF:  # zeroed once; only the words behind a shorter proof are cleared again
+        host = torch.zeros(8 + 1 + cap, dtype=torch.int32)
+        _XBUF["host"] = host.pin_memory() if torch.cuda.is_available() else host
         _XBUF["len"] = 0
+        if world > 1:
+            _XBUF["send"] = torch.zeros(8 + 1 + cap, dtype=torch.int32, device=device)
+            _XBUF["recv"] = torch.zeros(world * (8 + 1 + cap), dtype=torch.int32, device=device)
     t, buf = _XBUF["host"], _XBUF["host"].numpy()
     n = int(proof_words.size)
     buf[:8] = np.asarray(root, dtype=np.uint32).view(np.int32)
@@ -260,13 +268,11 @@ def exchange_step(root, proof_words, device):
     if _XBUF["len"] > n:
         buf[9 + n:9 + _XBUF["len"]] = 0
     _XBUF["len"] = n
-    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
-        return buf.reshape(1, -1)
-    d = t.to(device, non_blocking=True)
-    out = [torch.empty_like(d) for _ in range(world)]
-    dist.all_gather(out, d)
-    return torch.stack(out).cpu().numpy()
+        return t.view(1, -1)
+    _XBUF["send"].copy_(t, non_blocking=True)
+    dist.all_gather_into_tensor(_XBUF["recv"], _XBUF["send"])
+    return _XBUF["recv"].view(world, -1)
 
 
 def main():
@@ -344,11 +350,12 @@ def main():
     # reference's metric times (n_xmss / mean elapsed of one aggregate_type_1, rec_aggregation/src/benchmark.rs:397-431).
     # N ranks prove N independent leaves (weak scaling) and exchange roots + pruned proofs after every step.
     dominant = "k_air_round"
+    hbm_kernels = ("k_fold2_round", "k_prod_round2")  # the HBM-bound passes of the WHIR opening sumcheck: live GB/s line
     for _ in range(args.warmup):
         pr = run_step(ctx, lm, w)
         exchange_step(step_root(pr), pr.proof_pruned(), device)
     ctx.sync()
-    ctx.profile_select(dominant)
+    ctx.profile_select(",".join((dominant,) + hbm_kernels))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -370,8 +377,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     n_launch, k_ms = ctx.profile_read(dominant)
+    hbm_live = {k: ctx.profile_read(k) + (int(ctx.lib.lm_profile_read_bytes(ctx.h, k.encode())),) for k in hbm_kernels}
     ctx.profile_select(None)
-    assert gathered.shape[0] == world and int(gathered[rank, 8]) == pr.proof_pruned().size
+    assert gathered.shape[0] == world
+    if rank == 0:  # the rank that would run the recursion step is the only one that reads the gathered proofs
+        g = gathered.cpu().numpy()
+        assert int(g[0, 8]) == pr.proof_pruned().size and all(int(g[r, 8]) > 0 for r in range(world))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -397,12 +408,12 @@ def main():
         # with the sha of the kernel sources they were taken from)
         traffic, alu, notes = None, None, []
         full = args.scale_log == 0 and args.shape == "xmss" and args.log_inv_rate == 1 and not capacity
-        pmc, why = load_profile("r02_pmc_bench.json", sha) if full else (None, "counter profiles are of the default workload")
+        pmc, why = load_profile("r03_pmc_bench.json", sha) if full else (None, "counter profiles are of the default workload")
         if pmc and dominant in pmc["per_step"] and n_launch:
             traffic = pmc["per_step"][dominant]["hbm_bytes"] / pmc["per_step"][dominant]["launches"]
         elif why:
             notes.append(why)
-        valu, why = load_profile("r02_valu_bench.json", sha) if full else (None, None)
+        valu, why = load_profile("r03_valu_bench.json", sha) if full else (None, None)
         if valu and dominant in valu["per_proof"] and k_ms > 0:
             jv = valu["per_proof"][dominant]
             lane_ops = jv["valu_wave_insts"] * 64
@@ -410,10 +421,10 @@ def main():
             wf = jv.get("issue_cycle_weight")  # issue cycles per instruction / 2, from the kernel's ISA mix (tools/isa_mix.py)
             alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": VALU_PEAK_T, "frac": ach / VALU_PEAK_T,
                    "issue_cycle_weight": wf, "frac_issue_weighted": ach * wf / VALU_PEAK_T if wf else None,
-                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r02_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
+                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r03_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
                              "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
                              "v_mul_lo/hi_u32, v_mad_u64_u32 at 4 cycles per wave64, v_lshl_add_u64 at its measured 7.4, the rest 2 "
-                             "(profiles/r02_int_rates.txt)"}
+                             "(profiles/r03_int_rates.txt)"}
         elif why:
             notes.append(why)
         out = {
@@ -447,19 +458,33 @@ def main():
                 "whir_config": "lmh_whir_config_new (the library's own WhirConfig::new)",
                 "source_sha": sha,
             },
+            # the dominant kernel family is integer-ALU bound: its roofline is the VALU issue rate (256 CUs x 4 SIMD-32 x 2.4 GHz,
+            # every instruction weighted by its issue cycles); `hbm` keeps the same launches priced against HBM for reference
             "roofline": {
-                "kernel": dominant, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": dominant, "bound": "int-alu",
+                "achieved": alu["achieved"] * alu["issue_cycle_weight"] if alu and alu.get("issue_cycle_weight") else None,
+                "peak": VALU_PEAK_T, "unit": "T issue-weighted VALU lane-ops/s",
+                "frac": alu["frac_issue_weighted"] if alu else None,
+                "traffic": traffic,
                 "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
-                "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None,
-                "traffic_source": "profiles/r02_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None},
+                "traffic_source": "profiles/r03_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                   "FETCH x2 per MI355X_MICROARCH.md); refused when recorded for other kernel sources",
-                "note": "live: HIP events on the prover's stream around every k_air_round launch of the timed region (one proof "
-                        "alone on the chip).  The constraint evaluation is integer-ALU bound, so the HBM fraction is small by "
-                        "construction; `alu` is the utilisation that matters — see DESIGN.md §3",
+                "note": "live: HIP events on the prover's streams around every k_air_round launch of the timed region (one proof "
+                        "alone on the chip); instruction counts from profiles/r03_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
+                        "The constraint evaluation is integer-ALU bound — see DESIGN.md §3",
                 "alu": alu,
                 "profile_notes": notes,
             },
+            "roofline_hbm": (lambda n, ms, by: {
+                "kernel": "+".join(hbm_kernels), "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "launches": n, "avg_launch_ms": ms / n if n else None,
+                "algorithmic_bytes_per_step": by / args.steps,
+                "note": "live: HIP events around every launch of the two-rounds-per-pass product sumcheck kernels (WHIR opening) in the "
+                        "timed region; algorithmic bytes = every f and W value read once + the folded tables written once, accumulated by "
+                        "the library at the launch sites (lm_profile_read_bytes)"})(
+                sum(v[0] for v in hbm_live.values()), sum(v[1] for v in hbm_live.values()), sum(v[2] for v in hbm_live.values())),
         }
         if vm_path and world == 1:
             # ---- the reference's metric proper: prove_execution(bytecode, public_input, witness) = VM run + trace + proof per step

@@ -56,6 +56,10 @@ void* lm_ctx_stream(lm_ctx* ctx);
  * lm_profile_read synchronises, returns launch count and summed duration for one kernel and clears its records. */
 int lm_profile_select(lm_ctx* ctx, const char* kernel_name);
 int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms);
+/* the ALGORITHMIC HBM bytes of the recorded launches of an HBM-bound kernel (k_prod_round2 / k_fold2_round: every f and W value
+ * read once, the folded tables written once), for GB/s = bytes / HIP-event time; clears the counter.  lm_profile_select accepts
+ * a comma-separated list of kernel names. */
+uint64_t lm_profile_read_bytes(lm_ctx* ctx, const char* kernel_name);
 /* names of the kernels with recorded launches, '\n'-separated; returns the buffer size needed (buf may be NULL) */
 uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap);
 

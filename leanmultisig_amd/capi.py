@@ -30,6 +30,7 @@ _SIGS = {
     "lm_profile_select": (C.c_int, [vp, C.c_char_p]),
     "lm_profile_names": (C.c_uint64, [vp, vp, C.c_uint64]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
+    "lm_profile_read_bytes": (C.c_uint64, [vp, C.c_char_p]),
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lm_free": (C.c_int, [vp, vp]),
     "lm_upload": (C.c_int, [vp, vp, vp, C.c_uint64]),

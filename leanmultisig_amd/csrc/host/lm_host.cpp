@@ -413,6 +413,11 @@ uint64_t lmh_proof_pruned_words(const lmh_prover* p) { return p ? pruned_blob(p)
 void lmh_proof_pruned_copy(const lmh_prover* p, uint32_t* out) {
     const std::vector<u32>& b = pruned_blob(p);
     memcpy(out, b.data(), b.size() * 4);
+    // the cache only bridges the size query and this copy (its key is the three sizes, which every mutation of a prover changes:
+    // transcript and openings are append-only; lmh_prover_load_raw resets it): released here, rebuilt by the next query.
+    // A prover object is not thread-safe, const calls included.
+    p->pruned_key[0] = ~(size_t)0;
+    std::vector<u32>().swap(p->pruned_cache);
 }
 // Proof::proof_size_fe (fiat-shamir/src/transcript.rs:39-53): transcript + pruned leaf data + 8 words per kept sibling
 uint64_t lmh_proof_size_fe(const lmh_prover* p) {
@@ -887,6 +892,18 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
                                    const uint32_t eta[5], uint32_t* out_point, uint32_t* out_col_evals) {
     if (!ctx || !p || !tables || !n_tables || !alpha || !logup_eq16 || !bus_beta || !eta || !out_point || !out_col_evals)
         return LM_E_INVALID;
+    // a session's slice of the pinned result buffer, its flag word and its side stream are keyed by the TABLE id (lm_air_new): the
+    // sessions of one batch are launched back to back, so two sessions of the same table would overwrite each other's round sums
+    {
+        bool seen[3] = {false, false, false};
+        for (u32 i = 0; i < n_tables; i++) {
+            if (n_tables > 3 || tables[i].table > 2 || seen[tables[i].table]) {
+                lm_set_error("lmh_prove_batched_air_sumcheck: at most one session per table (execution, extension_op, poseidon16) in a batch");
+                return LM_E_INVALID;
+            }
+            seen[tables[i].table] = true;
+        }
+    }
     struct Session {
         lm_air* h = nullptr;
         u32 n_vars = 0, deg = 0;

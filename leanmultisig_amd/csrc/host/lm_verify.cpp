@@ -179,6 +179,9 @@ std::vector<Opening> restore(const PrunedBatch& b) {
     require(h < 32, "restore: tree height");
     require(b.n_trailing_zeros <= 1024, "restore: trailing zeros");
     require(n > 0, "restore: empty batch");
+    // every entry of original_order copies a whole opening: bound it by what a query set can be (the largest schedules of
+    // WhirConfig::new stay below 2^10 queries) and by the paths it can refer to — no quadratic amplification from a forged proof
+    require(b.original_order.size() <= (1u << 12) && n <= b.original_order.size(), "restore: original_order length");
     std::vector<std::vector<u32>> leaves(n);
     for (size_t i = 0; i < n; i++) {
         leaves[i] = b.paths[i].leaf;

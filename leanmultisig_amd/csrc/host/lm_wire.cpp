@@ -71,6 +71,7 @@ struct Reader {
         for (unsigned i = 0; i < max_bytes; i++) {
             if (p >= end) return ok = false, 0;
             const uint8_t b = *p++;
+            if (7 * i + 7 > 64 && ((b & 0x7f) >> (64 - 7 * i))) return ok = false, 0;  // bits beyond the 64th (postcard: "bad varint")
             v |= (u64)(b & 0x7f) << (7 * i);
             if (!(b & 0x80)) {
                 if (max_bits < 64 && (v >> max_bits)) ok = false;
@@ -234,7 +235,16 @@ void lmh_proof_compressed(const lmh_prover* p, uint8_t* out) {
 
 // postcard::from_bytes::<Proof<F>>: NULL (with lm_last_error) on truncated input, over-long varints, lengths the input
 // cannot hold, non-canonical field words or trailing bytes.
+static lmh_proof* proof_from_postcard(const uint8_t* bytes, uint64_t n);
 lmh_proof* lmh_proof_from_postcard(const uint8_t* bytes, uint64_t n) {
+    try {  // nothing unwinds across the ABI
+        return proof_from_postcard(bytes, n);
+    } catch (...) {
+        lm_set_error("lmh_proof_from_postcard: out of memory");
+        return nullptr;
+    }
+}
+static lmh_proof* proof_from_postcard(const uint8_t* bytes, uint64_t n) {
     if (!bytes) return nullptr;
     Reader r{bytes, bytes + n};
     lmh_proof* pf = new lmh_proof();
@@ -292,16 +302,23 @@ lmh_proof* lmh_proof_from_postcard(const uint8_t* bytes, uint64_t n) {
 }
 lmh_proof* lmh_proof_decompress(const uint8_t* bytes, uint64_t n) {
     const int64_t size = lmh_lz4_decompress_size_prepended(bytes, n, nullptr, 0);
-    if (size < 0 || size > (1ll << 30)) {
+    // an LZ4 block expands by at most 255x (one length byte per 255 output bytes): a larger size prefix cannot be honest, and
+    // nothing is allocated for it
+    if (size < 0 || size > (1ll << 30) || (u64)size > 255 * n + 64) {
         lm_set_error("lmh_proof_decompress: bad size prefix");
         return nullptr;
     }
-    Bytes raw((size_t)size);
-    if (lmh_lz4_decompress_size_prepended(bytes, n, raw.data(), raw.size()) != size) {
-        lm_set_error("lmh_proof_decompress: malformed LZ4 block");
+    try {
+        Bytes raw((size_t)size);
+        if (lmh_lz4_decompress_size_prepended(bytes, n, raw.data(), raw.size()) != size) {
+            lm_set_error("lmh_proof_decompress: malformed LZ4 block");
+            return nullptr;
+        }
+        return lmh_proof_from_postcard(raw.data(), raw.size());
+    } catch (...) {
+        lm_set_error("lmh_proof_decompress: out of memory");
         return nullptr;
     }
-    return lmh_proof_from_postcard(raw.data(), raw.size());
 }
 void lmh_proof_free(lmh_proof* p) { delete p; }
 // Proof::proof_size_fe (transcript.rs:39-53)

@@ -79,6 +79,7 @@ struct lm_ctx {
     // optional per-kernel HIP-event timing (bench.py roofline leg): only launches whose kernel name is selected
     std::string prof_select;    // empty = profiling off; "*" = every kernel
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::map<std::string, u64> prof_bytes;  // algorithmic bytes of the recorded launches of a kernel (LM_PROF_BYTES at its launch sites)
 };
 
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)
@@ -111,15 +112,34 @@ struct lm_ctx {
 // blocks are instead written with agent-scope relaxed atomic stores (write-through, sc1), the wave waits until they are
 // acknowledged (s_waitcnt vmcnt(0): what the memory model's release sequence does after its write-back), and the consumer
 // reads them with agent-scope atomic loads (served past the non-coherent L2s).
+// This hand-over is outside the HIP memory model: it relies on gfx9 behaviour (vmcnt counts stores and no-return atomics;
+// sc1 write-through stores to fine-grained memory travel one posted-write path in order).  It is therefore tied to the targets
+// it was validated on — gfx942 / gfx950 (on gfx10+ stores are counted by vscnt, which s_waitcnt(0) does not cover) — and can be
+// switched off at build time: -DLM_PUBLISH_FENCES=1 restores release fences before every flag / ticket (the memory-model
+// version: ~+4 ms per proof).  tools/stress_inflight.py checks every proof of concurrent provers with
+// lmh_verify_execution, so a reordering would show up as a rejected proof.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LM_PUBLISH_FENCES) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "fence-free publish path validated on gfx942 / gfx950 only: build with -DLM_PUBLISH_FENCES=1 for other targets"
+#endif
 __device__ __forceinline__ void lm_store_agent(kb::u32* p, kb::u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ kb::u32 lm_load_agent(const kb::u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lm_store_system(kb::u32* p, kb::u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void lm_wait_stores() {
+#if defined(LM_PUBLISH_FENCES)
+    __threadfence_system();  // conservative build: a real release of everything this wave wrote
+#else
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#endif
 }
-__device__ __forceinline__ kb::u32 lm_ticket(kb::u32* counter) { return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ kb::u32 lm_ticket(kb::u32* counter) {
+#if defined(LM_PUBLISH_FENCES)
+    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 
 // Multi-block reduction without a second launch and without a pass over per-block partials: every block adds its N field
 // words (< 2^31 each: 2^33 blocks fit) into 64-bit accumulators with agent-scope integer atomics, waits until they are
@@ -154,7 +174,11 @@ __device__ __forceinline__ bool lm_grid_sum(const kb::u32* vals_lds, unsigned lo
 // precedes this call, and ONE thread then stores the sequence number.  Payload and flag travel the same posted-write path.
 __device__ __forceinline__ void lm_publish_flag_word(kb::u32* flag_word, kb::u32 seq) {
     lm_wait_stores();
+#if defined(LM_PUBLISH_FENCES)
+    __hip_atomic_store(flag_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
     __hip_atomic_store(flag_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 __device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) { lm_publish_flag_word(h_res + lm_ctx::RES_FLAG, seq); }
 #endif
@@ -163,11 +187,24 @@ int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 int lm_wait_result_aux(lm_ctx* ctx, int aux, kb::u32 seq);
 int lm_aux_stream(lm_ctx* ctx, int aux, hipStream_t* out);  // created on first use
 
-static inline bool lm_prof_match(const char* want, const char* name) {
+static inline bool lm_prof_match(const char* want, const char* name) {  // `want`: one kernel name or a comma-separated list
     if (name[0] == '(') name++;  // template kernels are launched as (k<...>)
-    size_t n = strlen(want);
-    return strncmp(want, name, n) == 0 && (name[n] == 0 || name[n] == '<');
+    for (const char* w = want; *w;) {
+        const char* e = strchr(w, ',');
+        const size_t n = e ? (size_t)(e - w) : strlen(w);
+        if (n && strncmp(w, name, n) == 0 && (name[n] == 0 || name[n] == '<')) return true;
+        if (!e) break;
+        w = e + 1;
+    }
+    return false;
 }
+// algorithmic HBM bytes of a launch that is being profiled (the roofline leg of bench.py divides them by the HIP-event time)
+#define LM_PROF_BYTES(ctx, kernel, bytes)                                                                                    \
+    do {                                                                                                                     \
+        lm_ctx* cb__ = (ctx);                                                                                                \
+        if (!cb__->prof_select.empty() && (cb__->prof_select == "*" || lm_prof_match(cb__->prof_select.c_str(), #kernel)))    \
+            cb__->prof_bytes[#kernel] += (u64)(bytes);                                                                       \
+    } while (0)
 
 struct lm_tree {
     u32* d_matrix = nullptr;   // column-major: stored_cols x h words

@@ -1,7 +1,5 @@
 // Context, memory helpers, twiddle tables, multilinear evaluation.
 #include <stdarg.h>
-#include <ctype.h>
-#include <sched.h>
 #include <stdlib.h>
 #include <algorithm>
 #include "lm_common.h"
@@ -409,58 +407,9 @@ extern "C" {
 const char* lm_last_error(void) { return g_err; }
 
 static int ctx_create_impl(int device, lm_ctx* c);
-// Host thread placement: the prover thread polls pinned result words and rings doorbells ~800 times per proof, and the VM
-// runner's pool streams the memory image the GPU then reads — on a two-socket host all of this is ~2x slower from the socket
-// the GPU is NOT attached to (measured on the 2 x EPYC 9575F box: proof 23 -> 46 ms, VM run 8.5 -> 15 ms after the scheduler
-// had moved the thread).  The calling thread is restricted to the CPUs of the GPU's NUMA node (sysfs: the PCI device's
-// numa_node and that node's cpulist), intersected with its current mask; threads it creates later (the runner's pool) inherit
-// it.  LM_NO_NUMA_PIN=1 turns this off; unknown topology = no change.
-static void lm_pin_thread_to_device_node(int device) {
-#if defined(__linux__)
-    if (getenv("LM_NO_NUMA_PIN")) return;
-    char bdf[64] = {0};
-    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return;
-    for (char* q = bdf; *q; q++) *q = (char)tolower(*q);
-    char path[256];
-    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
-    FILE* f = fopen(path, "r");
-    if (!f) return;
-    int node = -1;
-    const int got = fscanf(f, "%d", &node);
-    fclose(f);
-    if (got != 1 || node < 0) return;
-    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    f = fopen(path, "r");
-    if (!f) return;
-    char list[4096] = {0};
-    const bool ok = fgets(list, sizeof list, f) != nullptr;
-    fclose(f);
-    if (!ok) return;
-    cpu_set_t cur, want;
-    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return;
-    CPU_ZERO(&want);
-    int n_set = 0;
-    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k < 1) continue;
-        if (k == 1) b = a;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
-            if (CPU_ISSET(c, &cur)) {
-                CPU_SET(c, &want);
-                n_set++;
-            }
-    }
-    if (n_set > 0) (void)sched_setaffinity(0, sizeof want, &want);
-#else
-    (void)device;
-#endif
-}
-
 int lm_ctx_create(int device, lm_ctx** out) {
     LM_REQUIRE(out);
     LM_HIP(hipSetDevice(device));
-    lm_pin_thread_to_device_node(device);
     lm_ctx* c = new lm_ctx();
     const int rc = ctx_create_impl(device, c);
     if (rc) {
@@ -539,7 +488,6 @@ void lm_ctx_destroy(lm_ctx* c) {
 int lm_bind_thread(lm_ctx* ctx) {
     LM_REQUIRE(ctx);
     LM_HIP(hipSetDevice(ctx->device));
-    lm_pin_thread_to_device_node(ctx->device);
     return LM_OK;
 }
 // rows of lm_access_counts jobs whose address range fell outside the image since the last reset (the reference panics on
@@ -585,6 +533,16 @@ uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap) {
         buf[n] = 0;
     }
     return all.size() + 1;
+}
+// algorithmic HBM bytes recorded for the launches of `kernel_name` since the last call (only kernels whose launch sites carry
+// LM_PROF_BYTES: k_prod_round2, k_fold2_round); clears the counter
+uint64_t lm_profile_read_bytes(lm_ctx* ctx, const char* kernel_name) {
+    if (!ctx || !kernel_name) return 0;
+    auto it = ctx->prof_bytes.find(kernel_name);
+    if (it == ctx->prof_bytes.end()) return 0;
+    const u64 b = it->second;
+    ctx->prof_bytes.erase(it);
+    return b;
 }
 int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms) {
     LM_REQUIRE(ctx && kernel_name && n_launches && total_ms);

@@ -10,7 +10,8 @@ struct LogupSec {
     const u32* data[LM_LOGUP_MAX_DATA];
     u32 stride[LM_LOGUP_MAX_DATA];
     u32 add_m[LM_LOGUP_MAX_DATA];  // Montgomery
-    u32 log_len, num_mode, n_data, neg_den;
+    u32 log_len, num_mode, n_data, neg_den;  // num_mode 4: a hole between sections, filled with the neutral pair (0, 1)
+    u64 len;
     EF contrib;  // alpha_eq[15] * domsep
 };
 
@@ -28,11 +29,18 @@ __global__ __launch_bounds__(256) void k_logup_fill(const LogupSec* __restrict__
             hi = mid - 1;
     }
     const LogupSec& s = secs[lo];
-    const u64 len = 1ull << s.log_len;
+    const u64 len = s.len;
     const u64 base = (b - s.chunk_begin) * LG_CHUNK;
     for (u32 u = 0; u < LG_CHUNK / 256; u++) {
         const u64 i = base + u * 256 + threadIdx.x;
         if (i >= len) break;
+        if (s.num_mode == 4) {  // neutral pair: everything outside the sections (bytecode padding, holes, the tail)
+            nums[s.out_offset + i] = 0;
+            dens[s.out_offset + i] = ONE;
+#pragma unroll
+            for (int k = 1; k < 5; k++) dens[(u64)k * plane + s.out_offset + i] = 0;
+            continue;
+        }
         u32 n;
         if (s.num_mode == 0)
             n = 0;
@@ -55,16 +63,6 @@ __global__ __launch_bounds__(256) void k_logup_fill(const LogupSec* __restrict__
         for (int k = 0; k < 5; k++) dens[(u64)k * plane + s.out_offset + i] = den.v[k];
     }
 }
-// neutral pair (0, 1) everywhere (sections overwrite their ranges afterwards)
-__global__ __launch_bounds__(256) void k_logup_neutral(u64 plane, u64 fill_len, u32* __restrict__ nums, u32* __restrict__ dens) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < fill_len; i += (u64)gridDim.x * 256) {
-        nums[i] = 0;
-        dens[i] = ONE;
-#pragma unroll
-        for (int k = 1; k < 5; k++) dens[(u64)k * plane + i] = 0;
-    }
-}
-
 // ---- access counters (crates/lean_prover/src/prove_execution.rs:90-110) ---------------------------------------------
 // acc[index(row) + j] += 1 for every row of an index column and j < n_values: a histogram of ~12 M word accesses over the
 // memory image.  The reference loops sequentially ("TODO parallelize").  Round 1 used one device-scope atomic per (pair of)
@@ -551,6 +549,7 @@ static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n
         LM_REQUIRE(in.num_mode < 2 || in.d_num_col);
         LogupSec& s = hs[k];
         s.out_offset = in.out_offset;
+        s.len = 1ull << in.log_len;
         s.chunk_begin = chunks;
         chunks += ((1ull << in.log_len) + LG_CHUNK - 1) / LG_CHUNK;
         s.num_col = in.d_num_col;
@@ -565,6 +564,33 @@ static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n
             s.add_m[j] = j < in.n_data ? to_monty(in.add[j]) : 0;
         }
     }
+    // the neutral pair (0, 1) everywhere outside the sections, written by the same launch: the holes between the sections (sorted by
+    // offset; sections are disjoint) and the tail up to fill_len become sections of their own — every word is written exactly once
+    // (round 2 wrote the whole domain with a separate kernel first: 472 MB that the fill largely rewrote)
+    {
+        std::vector<std::pair<u64, u64>> ranges(n_sections);
+        for (u32 k = 0; k < n_sections; k++) ranges[k] = {sections[k].out_offset, sections[k].out_offset + (1ull << sections[k].log_len)};
+        std::sort(ranges.begin(), ranges.end());
+        u64 at = 0;
+        auto hole = [&](u64 from, u64 to) {
+            if (to <= from) return;
+            LogupSec h;
+            memset(&h, 0, sizeof h);
+            h.out_offset = from;
+            h.len = to - from;
+            h.num_mode = 4;
+            h.chunk_begin = chunks;
+            chunks += (h.len + LG_CHUNK - 1) / LG_CHUNK;
+            hs.push_back(h);
+        };
+        for (const auto& r : ranges) {
+            LM_REQUIRE(r.first >= at);  // disjoint
+            hole(at, r.first);
+            at = r.second;
+        }
+        hole(at, fill_len);
+    }
+    n_sections = (uint32_t)hs.size();
     LM_REQUIRE(chunks < (1ull << 31));
     const u64 w_secs = (sizeof(LogupSec) * n_sections + 3) / 4;
     u32* s;
@@ -574,7 +600,6 @@ static int logup_build(lm_ctx* ctx, const lm_logup_section* sections, uint32_t n
     if ((rc = lm_stage_upload(ctx, s, hs.data(), sizeof(LogupSec) * n_sections)) || (rc = lm_stage_upload(ctx, d_al, alphas_eq16, 320))) return rc;
     EF cc;
     memcpy(cc.v, c, 20);
-    LM_LAUNCH(ctx, k_logup_neutral, dim3((unsigned)std::min<u64>((fill_len + 255) / 256, 4096)), dim3(256), 0, plane, fill_len, d_nums, d_dens);
     LM_LAUNCH(ctx, k_logup_fill, dim3((unsigned)chunks), dim3(256), 0, (const LogupSec*)s, n_sections, (const EF*)d_al, cc,
               plane, d_nums, d_dens, to_monty(to_monty(1)));
     LM_HIP(hipGetLastError());

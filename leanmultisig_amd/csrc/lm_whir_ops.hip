@@ -862,6 +862,7 @@ int lm_prod_round2(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_
     const u64 quarter = 1ull << (n_vars - 2);
     const u32 blocks = (u32)std::min<u64>((quarter + 255) / 256, 2048);
     const u32 seq = ++ctx->res_seq;
+    LM_PROF_BYTES(ctx, k_prod_round2, (4 * quarter) * (f_is_ext ? 40ull : 24ull));  // every f and W value once
     if (f_is_ext)
         LM_LAUNCH(ctx, (k_prod_round2<false>), dim3(blocks), dim3(256), 0, d_f, d_W, quarter, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq);
     else
@@ -886,6 +887,7 @@ int lm_fold2_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_
     memcpy(a.v, r0, 20);
     memcpy(b.v, r1, 20);
     const u32 seq = sums ? ++ctx->res_seq : 0;
+    LM_PROF_BYTES(ctx, k_fold2_round, (4 * m) * (f_is_ext ? 40ull : 24ull) + m * 40ull);  // reads f and W once, writes both folded tables
 #define F2(FB, S) LM_LAUNCH(ctx, (k_fold2_round<FB, S>), dim3(blocks), dim3(256), 0, d_f, d_W, m, a, b, d_f_out, d_W_out, ctx->d_acc, ctx->d_sync + 1, ctx->h_res, seq)
     if (f_is_ext) {
         if (sums == 2)

@@ -249,14 +249,14 @@ def test_extension_op_trace_gather(ctx, orc):
 
 @pytest.mark.parametrize("log_inv_rate", [1, 2])
 def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
-    """BASELINE configs[1] (rate 1/2) and configs[2] (rate 1/4) at their FULL size (1550 signatures: Poseidon table 2^18 with 258 850 active rows, execution 2^20,
-    memory 2^20, stacked polynomial 2^26, logup 2^24, production WHIR parameters): size-independent properties — the oracle's
-    VERIFIER accepts the proof (every sumcheck, GKR layer, Merkle path and PoW witness of the real size), proving twice gives
-    the same words, and the pruned wire form restores to the proof.  (Word-for-word equality with the oracle PROVER at this
-    size: test_full_size_proof_equals_oracle_prover, rate 1/2.)"""
+    """BASELINE configs[1] (rate 1/2) and configs[2] (rate 1/4) at their FULL size on the default workload of bench.py (the
+    aggregation program run by lmh_execute_bytecode on 1550 real signatures: Poseidon table 2^18, execution 2^20, memory 2^22,
+    stacked polynomial 2^26, logup 2^25, production WHIR parameters): size-independent properties — the oracle's VERIFIER accepts
+    the proof (every sumcheck, GKR layer, Merkle path and PoW witness of the real size), proving twice gives the same words, and
+    the pruned wire form restores to the proof."""
     import bench
-    w = bench.build_workload(ctx, orc, ob, np.random.default_rng(77), log_inv_rate=log_inv_rate)
-    assert w["n_vars"] == 26
+    w = bench.build_vm_workload(ctx, np.random.default_rng(77), bench.N_SIGS, log_inv_rate, False)
+    assert w["n_vars"] == 26 and w["w"]["log_bytecode"] == 19 and w["w"]["log_rows"] == {0: 20, 1: 15, 2: 18}
     p1 = bench.run_step(ctx, lm, w)
     proof = p1.proof()
     ok, err = ob.verify_execution(orc, w["w"], proof, None)
@@ -273,19 +273,28 @@ def test_full_size_proof_verifies_and_is_deterministic(ctx, orc, log_inv_rate):
     pruned = p1.proof_pruned()
     assert np.array_equal(ob.restore_proof(orc, pruned), proof)
     assert p1.proof_size_fe() == ob.pruned_size_fe(orc, pruned) < proof.size
+    # the whole node (VM run + trace + proof in one call) produces the same proof
+    from leanmultisig_amd import vm
+    p3 = lm.Prover(ctx)
+    vm.prove_execution_vm(ctx, p3, w["vm"]["bc"], w["vm"]["pi"], w["vm"]["wit"], w["lm_builder"])
+    assert np.array_equal(p3.proof(), proof)
 
 
-def test_full_size_proof_equals_oracle_prover(ctx, orc):
-    """BASELINE configs[1] at its FULL size and on the default workload of bench.py (1550 real XMSS signatures, stacked 2^26,
-    logup domain 2^25, memory 2^22, production WHIR parameters): the device proof equals the proof of the oracle PROVER word
-    for word — every root, round polynomial, PoW witness, query answer and sibling of the full-size schedule (~1 minute of
-    oracle time on 16 OpenMP threads)."""
+@pytest.mark.parametrize("log_inv_rate,capacity", [(1, False), (2, False), (1, True)])
+def test_full_size_proof_equals_oracle_prover(ctx, orc, log_inv_rate, capacity):
+    """BASELINE configs[1] (rate 1/2), configs[2] (rate 1/4) and the `prox-gaps-conjecture` regime (CapacityBound, the README's
+    176 KiB row) at FULL size on the default workload of bench.py (1550 real XMSS signatures, stacked 2^26, logup domain 2^25,
+    memory 2^22, production WHIR parameters): the device proof — of the trace the library's own runner and device trace builder
+    produced — equals, word for word, the proof of the oracle PROVER on the trace of the oracle's runner + get_execution_trace:
+    every root, round polynomial, PoW witness, query answer and sibling of the full-size schedule (~1-2 minutes of oracle time
+    on 16 OpenMP threads each)."""
     import bench
-    w = bench.build_workload(ctx, orc, ob, np.random.default_rng(5), log_inv_rate=1)
+    w = bench.build_vm_workload(ctx, np.random.default_rng(5), bench.N_SIGS, log_inv_rate, capacity)
     assert w["n_vars"] == 26
     proof = bench.run_step(ctx, lm, w).proof()
     ob.set_threads(orc, 16)
-    ref = ob.prove_execution(orc, w["w"], synth_witness.header(w["w"]), ob.whir_builder(log_inv_rate=1))
+    full = bench.oracle_witness(orc, ob, w)
+    ref = ob.prove_execution(orc, full, synth_witness.header(full), bench.oracle_builder(ob, w))
     assert proof.size == ref.size and np.array_equal(proof, ref)
 
 

@@ -17,7 +17,7 @@ ranges = bench.signer_ranges(2 * 1550 + 1, world)
 assert ranges[0][0] == 0 and ranges[-1][1] == 2 * 1550 + 1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
 root = np.arange(8, dtype=np.uint32) + 100 * rank + 0x7E000000      # words near p: the int32 transport must be lossless
 proof = (np.arange(5000 + 37 * rank, dtype=np.uint32) * 2654435761 % 0x7F000001).astype(np.uint32)  # ranks send different lengths
-allg = bench.exchange_step(root, proof, torch.device("cpu"))
+allg = bench.exchange_step(root, proof, torch.device("cpu")).cpu().numpy()
 assert allg.shape[0] == world
 for r in range(world):
     assert list(allg[r, :8]) == list(np.arange(8) + 100 * r + 0x7E000000), allg[r, :8]

@@ -126,3 +126,18 @@ def test_external_pin_fixture_is_current(orc, tmp_path):
              bytecode=inst[11 + n_pub:].reshape(-1, 16))
     ok, err = lm.verify_execution(w, open(os.path.join(pin, "proof.bin"), "rb").read())
     assert ok, err
+
+
+def test_decoder_rejects_overlong_varint_and_dishonest_size_prefix():
+    """a 10-byte varint whose last byte carries bits beyond the 64th is malformed (postcard rejects it, it is not
+    truncated); an LZ4 size prefix larger than any block of that length can expand to is refused before anything is allocated."""
+    import leanmultisig_amd as lm
+    bad = bytes([0xFF] * 9 + [0x02])          # 2^64: does not fit a u64
+    with pytest.raises(lm.LmError):
+        lm.DecodedProof(bad)
+    ok_max = bytes([0xFF] * 9 + [0x01])       # 2^64 - 1 is a well-formed varint (then fails as a LENGTH the input cannot hold)
+    with pytest.raises(lm.LmError, match="length"):
+        lm.DecodedProof(ok_max)
+    frame = (1 << 29).to_bytes(4, "little") + bytes(16)
+    with pytest.raises(lm.LmError, match="size prefix"):
+        lm.DecodedProof(frame, compressed=True)

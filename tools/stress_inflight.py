@@ -1,6 +1,7 @@
 """Race detector for the latency machinery (fence-free publishes, side streams, staging ring, pooled memory): C provers on one
 GPU prove the SAME leaf over and over from C host threads; proofs are deterministic, so every proof of a prover must equal
-its first one word for word (and the first one verifies).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log]"""
+its first one word for word, and EVERY proof is checked by lmh_verify_execution (a reordered publish would corrupt the
+transcript: the proof is rejected).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log]"""
 import os
 import sys
 import threading
@@ -12,14 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import bench  # noqa: E402
 import leanmultisig_amd as lm  # noqa: E402
-from tests import oracle_binding as ob  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-orc = ob.load()
 ctxs = [lm.Context(0) for _ in range(C)]
-ws = [bench.build_workload(ctxs[c], orc, ob, np.random.default_rng(900 + c), SCALE, 1, "xmss", False, "xmss" if SCALE == 0 else "synthetic")
+ws = [bench.build_vm_workload(ctxs[c], np.random.default_rng(900 + c), max(2, bench.N_SIGS >> SCALE), 1, False, log_bytecode=19 if SCALE == 0 else None)
       for c in range(C)]
 first = []
 for c in range(C):
@@ -36,7 +35,11 @@ def worker(c):
         ctxs[c]._check(ctxs[c].lib.lm_bind_thread(ctxs[c].h))   # the HIP device is per host thread
         start.wait()
         for i in range(N):
-            p = bench.run_step(ctxs[c], lm, ws[c]).proof()
+            pr = bench.run_step(ctxs[c], lm, ws[c])
+            p = pr.proof()
+            ok, err = lm.verify_execution(ws[c]["w"], pr, ws[c]["lm_builder"])   # every proof goes through lmh_verify_execution
+            if not ok:
+                bad.append((c, i, "rejected: " + err))
             if p.size != first[c].size or not np.array_equal(p, first[c]):
                 bad.append((c, i, int(np.argmax(p[:min(p.size, first[c].size)] != first[c][:min(p.size, first[c].size)]))))
     except Exception as e:  # noqa: BLE001

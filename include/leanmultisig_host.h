@@ -190,6 +190,13 @@ typedef struct {
     const uint32_t* d_memory;
     const uint32_t* d_memory_acc;   /* NULL = computed on the device */
     lm_vm_table tables[3]; /* indexed by table id: execution, extension_op, poseidon16 */
+    /* Optional (NULL = absent): the trace already lives in its committed layout.  d_stacked = 2^lmh_stacked_n_vars(trace) words
+     * laid out as stack_polynomials does (stacked_pcs.rs:118-136: memory | memory_acc | bytecode_acc (region padded) | the
+     * committed columns of the tables by descending height | zero tail), d_memory and every committed column pointer above point
+     * INTO it at their stacked offsets, and everything outside memory, the access counters and the columns is zero.  The prover
+     * then commits this buffer as it is — no 2^n_vars-word copy ("TODO avoid cloning", stacked_pcs.rs:115) — and writes the
+     * access counters it computes into their slots.  lmh_get_execution_trace builds its traces this way. */
+    uint32_t* d_stacked;
 } lm_execution_trace;
 uint32_t lmh_stacked_n_vars(const lm_execution_trace* trace); /* compute_stacked_n_vars, stacked_pcs.rs:183-196 */
 /* returns LM_E_INVALID with lm_last_error "logup sum != 0" when the witness is inconsistent (prove_generic_logup asserts) */
@@ -306,7 +313,8 @@ typedef struct {
     const uint32_t* pcs;
     const uint32_t* fps;
     uint64_t memory_len;          /* memory.0.len() */
-    const uint32_t* memory;       /* Montgomery words, undefined cells read 0 */
+    const uint32_t* memory;       /* Montgomery words, undefined cells read 0; the 24 words behind memory_len hold the zero vector and
+                                     poseidon16(0) that get_execution_trace appends (trace_gen.rs:106-110) */
     const uint8_t* memory_defined; /* 1 = Some(_) */
     uint64_t public_memory_size, runtime_memory_size;
     uint64_t n_poseidon_calls;

@@ -362,7 +362,8 @@ class ExecutionTrace(C.Structure):
     """lm_execution_trace"""
     _fields_ = [("log_inv_rate", C.c_uint32), ("log_memory", C.c_uint32), ("log_bytecode", C.c_uint32), ("ending_pc", C.c_uint32),
                 ("public_memory_size", C.c_uint32), ("n_public_input", C.c_uint32), ("public_input", vp), ("bytecode_hash", vp),
-                ("d_bytecode", vp), ("d_bytecode_acc", vp), ("d_memory", vp), ("d_memory_acc", vp), ("tables", VmTable * 3)]
+                ("d_bytecode", vp), ("d_bytecode_acc", vp), ("d_memory", vp), ("d_memory_acc", vp), ("tables", VmTable * 3),
+                ("d_stacked", vp)]
 
 
 class WeightItem(C.Structure):

@@ -1099,7 +1099,18 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     // ---- stack_polynomials_and_commit (stacked_pcs.rs:99-157) ----
     const u64 mem = 1ull << log_mem;
     DevBuf poly(ctx);
-    if ((rc = lm_malloc(ctx, 1ull << stacked_n_vars, &poly.p))) return rc;
+    u32* const in_place = tr->d_stacked;  // the trace already lives in its committed layout (leanmultisig_host.h)
+    if (in_place) {
+        u64 at = 2 * mem + std::max(1ull << tr->tables[order[0]].log_rows, 1ull << log_bc);
+        bool ok = tr->d_memory == in_place && !tr->d_memory_acc && !tr->d_bytecode_acc;
+        for (int k = 0; k < 3 && ok; k++) {
+            const int t = order[k];
+            for (u32 c = 0; c < kVmTables[t].n_columns; c++, at += 1ull << tr->tables[t].log_rows) ok = ok && tr->tables[t].d_cols[c] == in_place + at;
+        }
+        if (!ok) return invalid("d_stacked: memory / committed columns are not at their stacked offsets (or access counters were supplied)");
+    } else if ((rc = lm_malloc(ctx, 1ull << stacked_n_vars, &poly.p)))
+        return rc;
+    u32* const d_poly = in_place ? in_place : poly.p;
     std::vector<const u32*> srcs;
     std::vector<u64> offs, lens;
     auto place = [&](const u32* src, u64 at, u64 n) {
@@ -1122,17 +1133,25 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
                 rows.push_back(1ull << tr->tables[t].log_rows);
                 nv.push_back(kVmTables[t].lookups[l].n_values);
             }
-        if ((rc = lm_malloc(ctx, mem, &mem_acc.p))) return rc;
-        if ((rc = lm_access_counts(ctx, mem_acc.p, mem, (u32)idx.size(), idx.data(), rows.data(), nv.data()))) return rc;
-        d_memory_acc = mem_acc.p;
+        u32* dst = in_place ? in_place + mem : nullptr;
+        if (!dst) {
+            if ((rc = lm_malloc(ctx, mem, &mem_acc.p))) return rc;
+            dst = mem_acc.p;
+        }
+        if ((rc = lm_access_counts(ctx, dst, mem, (u32)idx.size(), idx.data(), rows.data(), nv.data()))) return rc;
+        d_memory_acc = dst;
     }
     if (!d_bytecode_acc) {
         const u32* pc = tr->tables[0].d_cols[0];  // COL_PC
         const u64 rows = 1ull << tr->tables[0].log_rows;
         const u32 one = 1;
-        if ((rc = lm_malloc(ctx, 1ull << log_bc, &bc_acc.p))) return rc;
-        if ((rc = lm_access_counts(ctx, bc_acc.p, 1ull << log_bc, 1, &pc, &rows, &one))) return rc;
-        d_bytecode_acc = bc_acc.p;
+        u32* dst = in_place ? in_place + 2 * mem : nullptr;
+        if (!dst) {
+            if ((rc = lm_malloc(ctx, 1ull << log_bc, &bc_acc.p))) return rc;
+            dst = bc_acc.p;
+        }
+        if ((rc = lm_access_counts(ctx, dst, 1ull << log_bc, 1, &pc, &rows, &one))) return rc;
+        d_bytecode_acc = dst;
     }
     place(tr->d_memory, 0, mem);
     place(d_memory_acc, mem, mem);
@@ -1146,10 +1165,10 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
             off += 1ull << tr->tables[t].log_rows;
         }
     }
-    if ((rc = lm_stack_columns(ctx, poly.p, 1ull << stacked_n_vars, (u32)srcs.size(), srcs.data(), offs.data(), lens.data()))) return rc;
+    if (!in_place && (rc = lm_stack_columns(ctx, poly.p, 1ull << stacked_n_vars, (u32)srcs.size(), srcs.data(), offs.data(), lens.data()))) return rc;
     lmh_witness* wit = nullptr;
     clk.mark("stack");
-    if ((rc = lmh_whir_commit(ctx, p, cfg, poly.p, off, &wit))) return rc;
+    if ((rc = lmh_whir_commit(ctx, p, cfg, d_poly, off, &wit))) return rc;
     clk.mark("whir_commit");
     // (the root has been published behind the counting kernels on the same stream: the stream is idle, the count final)
     if (const u32 n_bad = lm_access_errors(ctx, 0)) {
@@ -1340,7 +1359,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     lmh_witness* w = wit;
     wit = nullptr;  // consumed by lmh_whir_prove
     rc = lmh_whir_prove(ctx, p, cfg, S.sts.data(), (u32)S.sts.size(), S.pts.data(), S.pts.size() / 5, S.sels.data(), S.vals.data(),
-                        S.sels.size(), w, poly.p, out_point.data());
+                        S.sels.size(), w, d_poly, out_point.data());
     clk.mark("whir_open");
     return rc;
 }

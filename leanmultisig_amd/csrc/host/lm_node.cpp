@@ -72,19 +72,42 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         return fail(LM_E_INVALID);
     }
     const u32 log_memory = log2_ceil_u64(padded);
-    u32* d_memory;
-    if (!dev(padded, &d_memory)) return fail(rc);
-    if ((rc = lm_upload_async(ctx, d_memory, v.memory, L))) return fail(rc);
-    {
-        alignas(64) u32 tail[24];
-        memset(tail, 0, sizeof tail);
-        u32 st[16];
-        memset(st, 0, sizeof st);
-        host_compress(st);  // get_poseidon_16_of_zero
-        memcpy(tail + 16, st, 32);
-        if ((rc = lm_upload(ctx, d_memory + L, tail, 24))) return fail(rc);
-        if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
+    // ---- the committed layout (stack_polynomials, stacked_pcs.rs:118-136): ONE buffer; memory, the access-counter slots and every
+    // committed column are slices of it, so the prover commits it without the 2^n_vars-word copy (lm_execution_trace::d_stacked) ----
+    const u64 n_rows[3] = {v.n_cycles, v.n_extension_rows, v.n_poseidon_calls};
+    u32 log_rows[3];
+    for (int tb = 0; tb < 3; tb++) {
+        log_rows[tb] = lmh_table_log_rows(n_rows[tb]);
+        if (log_rows[tb] > max_log_n_rows_per_table(tb)) {
+            lm_set_error("TooBigTableError: table %d has 2^%u rows (limit 2^%u)", tb, log_rows[tb], max_log_n_rows_per_table(tb));
+            return fail(LM_E_INVALID);
+        }
     }
+    if (log_rows[0] < log_rows[1] || log_rows[0] < log_rows[2] || log_memory < log_rows[0]) {
+        lm_set_error("lmh_get_execution_trace: the execution table must be the tallest table and the memory at least as tall (stacked_pcs.rs:108-112)");
+        return fail(LM_E_INVALID);
+    }
+    int order[3];
+    sorted_tables(log_rows, order);
+    u64 col_base[3];
+    u64 total = 2 * padded + std::max(1ull << log_rows[order[0]], 1ull << log_bytecode);
+    const u64 hole_from = 2 * padded + (1ull << log_bytecode), hole_to = total;
+    for (int k = 0; k < 3; k++) {
+        col_base[order[k]] = total;
+        total += (u64)kVmTables[order[k]].n_columns << log_rows[order[k]];
+    }
+    const u32 stacked_n_vars = log2_ceil_u64(total);
+    u32* d_stacked;
+    if (!dev(1ull << stacked_n_vars, &d_stacked)) return fail(rc);
+    if ((rc = lm_memset_zero(ctx, d_stacked + hole_from, hole_to - hole_from)) || (rc = lm_memset_zero(ctx, d_stacked + total, (1ull << stacked_n_vars) - total)))
+        return fail(rc);
+    u32* d_memory = d_stacked;
+    if (L + 24 > (1ull << MAX_LOG_MEMORY_SIZE)) {
+        lm_set_error("lmh_get_execution_trace: no room for the zero vector behind the memory");
+        return fail(LM_E_INVALID);
+    }
+    if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24))) return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
+    if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
     // ---- bytecode table: device copy cached in the bytecode object -------------------------------------------------------------
     u32** slot = vm_bytecode_device_slot(bc, (void*)ctx);
     if (!*slot) {
@@ -95,17 +118,11 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     }
     u32* const d_bytecode = *slot;
     // ---- tables ----------------------------------------------------------------------------------------------------------------
-    const u64 n_rows[3] = {v.n_cycles, v.n_extension_rows, v.n_poseidon_calls};
-    u32 log_rows[3];
     for (int tb = 0; tb < 3; tb++) {
-        log_rows[tb] = lmh_table_log_rows(n_rows[tb]);
-        if (log_rows[tb] > max_log_n_rows_per_table(tb)) {
-            lm_set_error("TooBigTableError: table %d has 2^%u rows (limit 2^%u)", tb, log_rows[tb], max_log_n_rows_per_table(tb));
-            return fail(LM_E_INVALID);
-        }
-        const u32 n_total = kVmTables[tb].n_total;
+        const u32 n_total = kVmTables[tb].n_total, n_com = kVmTables[tb].n_columns;
         t->cols[tb].resize(n_total);
-        for (u32 c = 0; c < n_total; c++)
+        for (u32 c = 0; c < n_com; c++) t->cols[tb][c] = d_stacked + col_base[tb] + ((u64)c << log_rows[tb]);
+        for (u32 c = n_com; c < n_total; c++)  // the virtual bus columns are not committed
             if (!dev(1ull << log_rows[tb], &t->cols[tb][c])) return fail(rc);
     }
     // execution table (trace_gen.rs:27-100) + its padding row (execution/mod.rs:59-74, the 4 temporary columns included)
@@ -159,6 +176,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     w.public_memory_size = (u32)v.public_memory_size, w.n_public_input = n_public_input;
     w.public_input = t->public_input.data(), w.bytecode_hash = t->bytecode_hash;
     w.d_bytecode = d_bytecode, w.d_bytecode_acc = nullptr, w.d_memory = d_memory, w.d_memory_acc = nullptr;
+    w.d_stacked = d_stacked;
     for (int tb = 0; tb < 3; tb++) {
         w.tables[tb].log_rows = log_rows[tb];
         w.tables[tb].non_padded_n_rows = (u32)n_rows[tb];

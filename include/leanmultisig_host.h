@@ -323,7 +323,7 @@ typedef struct {
     const uint32_t* extension_rows;  /* n x LM_VM_EXTENSION_ROW_WORDS: exec_multi_row's pushes (extension_op/exec.rs:149-186) */
     uint64_t n_add, n_mul, n_deref, n_jump; /* InstructionCounts */
 } lm_vm_execution_view;
-/* n_threads = 0: all hardware threads (capped at 64).  LM_E_INVALID + lm_last_error = the RunnerError and its pc. */
+/* n_threads = 0: all hardware threads (capped at 128).  LM_E_INVALID + lm_last_error = the RunnerError and its pc. */
 int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
                          uint32_t n_threads, lmh_execution** out);
 void lmh_execution_free(lmh_execution* e);

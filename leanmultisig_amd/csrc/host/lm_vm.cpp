@@ -45,9 +45,22 @@ class Pool {
         static Pool p;
         return p;
     }
+    // A session keeps the workers SPINNING between jobs instead of sleeping on the condition variable: a VM run issues five
+    // parallel_for's a few hundred microseconds apart, and waking 127 sleeping threads costs ~0.7 ms each time on the 2 x 64-core
+    // host (measured: 3.5 of a 7 ms run).  Sessions nest; outside of one the workers sleep.
+    void begin_session(u32 n_threads) {
+        std::lock_guard<std::mutex> user(user_mu_);
+        ensure(resolve(n_threads) - 1);
+        spin_.fetch_add(1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+        }
+        cv_.notify_all();
+    }
+    void end_session() { spin_.fetch_sub(1, std::memory_order_release); }
     void parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) {
         if (n == 0) return;
-        u32 want = n_threads ? n_threads : default_threads();
+        u32 want = resolve(n_threads);
         if (want > n) want = (u32)n;
         if (want <= 1) {
             for (u64 i = 0; i < n; i++) f(i);
@@ -55,25 +68,24 @@ class Pool {
         }
         std::lock_guard<std::mutex> user(user_mu_);  // one batch at a time
         ensure(want - 1);
+        job_ = &f;
+        total_ = n;
+        active_ = want - 1;
+        next_.store(0, std::memory_order_relaxed);
+        pending_.store(want - 1, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            job_ = &f;
-            next_.store(0, std::memory_order_relaxed);
-            total_ = n;
-            active_ = want - 1;
-            pending_ = want - 1;
-            generation_++;
+            std::lock_guard<std::mutex> lk(mu_);  // (orders the generation change with sleepers that are about to wait)
+            gen_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_all();
+        if (spin_.load(std::memory_order_relaxed) == 0 || sleepers_.load(std::memory_order_relaxed)) cv_.notify_all();
         work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         job_ = nullptr;
     }
     static u32 default_threads() {
         u32 hw = std::thread::hardware_concurrency();
         if (hw == 0) hw = 1;
-        return hw > 64 ? 64 : hw;
+        return hw > 128 ? 128 : hw;  // (2 x 64-core EPYC host of the GPU box: 64 threads 2.9 ms, 128 threads 1.7 ms for the 1549 segments)
     }
 
    private:
@@ -81,10 +93,21 @@ class Pool {
     ~Pool() {
         {
             std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_release);
         }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
+    }
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    static u32 resolve(u32 n_threads) {
+        u32 hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        const u32 want = n_threads ? n_threads : default_threads();
+        return want > hw ? hw : want;  // never more threads than hardware threads: spinning workers must not compete for cores
     }
     void ensure(u32 n) {
         while (workers_.size() < n) {
@@ -103,27 +126,43 @@ class Pool {
     void loop(u32 id) {
         u64 seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || (generation_ != seen && id < active_); });
-            if (stop_) return;
-            seen = generation_;
-            lk.unlock();
-            work();
-            lk.lock();
-            if (--pending_ == 0) done_cv_.notify_all();
+            u64 g;
+            for (;;) {
+                g = gen_.load(std::memory_order_acquire);
+                if (g != seen) break;
+                if (stop_.load(std::memory_order_acquire)) return;
+                if (spin_.load(std::memory_order_acquire)) {
+                    cpu_relax();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1, std::memory_order_relaxed);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire) || spin_.load(std::memory_order_acquire); });
+                sleepers_.fetch_sub(1, std::memory_order_relaxed);
+            }
+            seen = g;
+            if (id < active_) {  // (job_, total_, active_ were written before the generation was released)
+                work();
+                pending_.fetch_sub(1, std::memory_order_release);
+            }
         }
     }
     std::mutex mu_, user_mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     std::vector<std::thread> workers_;
     const std::function<void(u64)>* job_ = nullptr;
-    std::atomic<u64> next_{0};
-    u64 total_ = 0, generation_ = 0;
-    u32 active_ = 0, pending_ = 0;
-    bool stop_ = false;
+    std::atomic<u64> next_{0}, gen_{0};
+    std::atomic<u32> pending_{0}, spin_{0}, sleepers_{0};
+    std::atomic<bool> stop_{false};
+    u64 total_ = 0;
+    u32 active_ = 0;
 };
 
 void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) { Pool::get().parallel_for(n, n_threads, f); }
+struct PoolSession {
+    explicit PoolSession(u32 n_threads) { Pool::get().begin_session(n_threads); }
+    ~PoolSession() { Pool::get().end_session(); }
+};
 
 namespace {
 typedef uint8_t u8;
@@ -211,6 +250,11 @@ struct UVec {
     void push_back(const T& v) {
         if (n == cap) reserve(n + 1);
         p[n++] = v;
+    }
+    void release() {
+        free(p);
+        p = nullptr;
+        n = cap = 0;
     }
     void swap(UVec& o) {
         std::swap(p, o.p), std::swap(n, o.n), std::swap(cap, o.cap);
@@ -921,6 +965,7 @@ bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& p
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
                            u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
     MainMem mm{memory};
+    const double tp0 = vm_now_ms();
     auto get = [&](u64 at) -> u32 {
         const u32 v = mm.peek(at);
         if (v == UNDEF) err.raise("UndefinedMemory(%llu)", (unsigned long long)at);
@@ -957,19 +1002,14 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     }
     std::vector<u64> per_iter(cur.index.size());
     for (size_t k = 0; k < per_iter.size(); k++) per_iter[k] = cur.index[k] - batch.hint_indices_at_start[k];
-    for (u64 i = 1; i <= n_iters; i++) {  // write_call_frame
-        const u64 f = batch.batch_fp + i * stride;
-        const u64 iter_val = i < n_iters ? start_value + i : end_value;
-        if (!mm.set(f, return_pc, err) || !mm.set(f + 1, saved_fp, err) || !mm.set(f + 2, kb::to_monty((u32)(iter_val % kb::P)), err)) return false;
-        for (u32 j = 1; j < batch.n_args; j++)
-            if (!mm.set(f + 2 + j, args[j], err)) return false;
-    }
     const u64 max_addr = batch.batch_fp + (n_iters + 1) * stride;
     if (max_addr > MAX_MEMORY) {
         err.raise("OutOfMemory");
         return false;
     }
-    if (max_addr > memory.len) {  // memory.0.resize(max_addr, None): filled (and first touched) by the pool
+    // memory.0.resize(max_addr, None), done BEFORE the call frames are written (the reference resizes after; Memory::set grows on demand
+    // either way, so the final length is the same): the new cells are filled — and first touched — by the pool instead of one by one
+    if (max_addr > memory.len) {
         const u64 from = memory.len, chunk = 1u << 15;
         u32* mp = memory.p;
         vm_parallel_for((max_addr - from + chunk - 1) / chunk, n_threads, [&](u64 c) {
@@ -977,6 +1017,14 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
             for (u64 i = from + c * chunk; i < e; i++) mp[i] = UNDEF;
         });
         memory.len = max_addr;
+    }
+    const double tp1 = vm_now_ms();
+    for (u64 i = 1; i <= n_iters; i++) {  // write_call_frame
+        const u64 f = batch.batch_fp + i * stride;
+        const u64 iter_val = i < n_iters ? start_value + i : end_value;
+        if (!mm.set(f, return_pc, err) || !mm.set(f + 1, saved_fp, err) || !mm.set(f + 2, kb::to_monty((u32)(iter_val % kb::P)), err)) return false;
+        for (u32 j = 1; j < batch.n_args; j++)
+            if (!mm.set(f + 2 + j, args[j], err)) return false;
     }
     const u64 n_par = n_iters - 1;
     const u64 split_at = batch.batch_fp + stride;
@@ -1011,31 +1059,41 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
             return false;
         }
     const double tb1 = vm_now_ms();
-    // Trace::merge in iteration order, then the deferred writes
-    size_t n_cyc = trace.pcs.size(), n_pos = trace.pos.size(), n_ext = trace.ext.size(), n_pend = trace.pending.size();
-    std::vector<size_t> o_cyc(n_par), o_pos(n_par), o_ext(n_par), o_pend(n_par);
+    // Trace::merge in iteration order, then the deferred writes.  The segments' buffers are copied AND released by the pool (they
+    // were allocated there: 10^4 frees from the main thread were 1.6 ms of a 6 ms run).
+    size_t n_cyc = trace.pcs.size(), n_pos = trace.pos.size(), n_ext = trace.ext.size(), n_pend = trace.pending.size(), n_def = 0;
+    std::vector<size_t> o_cyc(n_par), o_pos(n_par), o_ext(n_par), o_pend(n_par), o_def(n_par);
     for (u64 i = 0; i < n_par; i++) {
-        o_cyc[i] = n_cyc, o_pos[i] = n_pos, o_ext[i] = n_ext, o_pend[i] = n_pend;
+        o_cyc[i] = n_cyc, o_pos[i] = n_pos, o_ext[i] = n_ext, o_pend[i] = n_pend, o_def[i] = n_def;
         n_cyc += segs[i].tr.pcs.size(), n_pos += segs[i].tr.pos.size(), n_ext += segs[i].tr.ext.size(), n_pend += segs[i].tr.pending.size();
+        n_def += segs[i].deferred.size();
         trace.n_add += segs[i].tr.n_add, trace.n_mul += segs[i].tr.n_mul, trace.n_deref += segs[i].tr.n_deref, trace.n_jump += segs[i].tr.n_jump;
     }
     trace.pcs.extend(n_cyc - trace.pcs.size()), trace.fps.extend(n_cyc - trace.fps.size()), trace.pos.extend(n_pos - trace.pos.size());
     trace.ext.extend(n_ext - trace.ext.size()), trace.pending.resize(n_pend);
+    UVec<std::pair<u64, u32>> all_def;
+    all_def.extend(n_def);
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
-        const Trace& t = segs[i].tr;
+        Seg& sg = segs[i];
+        Trace& t = sg.tr;
         if (!t.pcs.empty()) memcpy(&trace.pcs[o_cyc[i]], t.pcs.data(), t.pcs.size() * 4), memcpy(&trace.fps[o_cyc[i]], t.fps.data(), t.fps.size() * 4);
         if (!t.pos.empty()) memcpy(&trace.pos[o_pos[i]], t.pos.data(), t.pos.size() * 4);
         if (!t.ext.empty()) memcpy(&trace.ext[o_ext[i]], t.ext.data(), t.ext.size() * 4);
         for (size_t k = 0; k < t.pending.size(); k++) trace.pending[o_pend[i] + k] = t.pending[k];
+        for (size_t k = 0; k < sg.deferred.size(); k++) all_def[o_def[i] + k] = sg.deferred[k];
+        t.pcs.release(), t.fps.release(), t.pos.release(), t.ext.release();
+        std::vector<std::pair<u64, u64>>().swap(t.pending);
+        std::vector<std::pair<u64, u32>>().swap(sg.deferred);
     });
-    for (u64 i = 0; i < n_par; i++)
-        for (const auto& [addr, val] : segs[i].deferred)
-            if (!mm.set(addr, val, err)) return false;
+    for (size_t k = 0; k < n_def; k++)
+        if (!mm.set(all_def[k].first, all_def[k].second, err)) return false;
     for (size_t k = 0; k < cur.index.size(); k++) cur.index[k] += n_par * per_iter[k];
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
-    if (vm_times()) fprintf(stderr, "[vm] batch of %llu segments: run %.2f ms, merge + deferred writes %.2f ms\n", (unsigned long long)n_par, tb1 - tb0, vm_now_ms() - tb1);
+    if (vm_times())
+        fprintf(stderr, "[vm] batch of %llu segments: resize %.2f ms, call frames %.2f ms, run %.2f ms, merge + deferred writes %.2f ms\n",
+                (unsigned long long)n_par, tp1 - tp0, tb0 - tp1, tb1 - tb0, vm_now_ms() - tb1);
     return true;
 }
 
@@ -1185,6 +1243,7 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
     lmh_execution* ex = nullptr;
     try {
         ex = new lmh_execution();
+        PoolSession session(n_threads);  // the pool stays hot from here to the end of the run
         Witness w{witness->preamble_memory_len, witness->name_entry_begin, witness->entry_offset, witness->data};
         // execute_bytecode_helper (runner.rs:238-343)
         u64 pub = 1;

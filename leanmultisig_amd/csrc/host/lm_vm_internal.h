@@ -5,7 +5,7 @@
 #include "lm_host_internal.h"
 
 namespace lmh {
-// f(i) for i < n on the persistent host thread pool (the calling thread takes part); n_threads = 0: all hardware threads, <= 64
+// f(i) for i < n on the persistent host thread pool (the calling thread takes part); n_threads = 0: all hardware threads, <= 128
 void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f);
 // device copy of a bytecode's instructions_multilinear for context `ctx` (cached in the bytecode object, one per context):
 // *slot is nullptr until lm_node.cpp fills it

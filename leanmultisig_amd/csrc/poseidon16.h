@@ -79,22 +79,42 @@ KB_HD u32 reduce40(u64 s) {
 // (poseidon1_koalabear_16.rs:22,580-581).  Plain small integers act directly on Montgomery-form values.
 // bias: optional per-lane constants added before the reduction (the round constants of the NEXT round ride along for
 // free in the 64-bit accumulator instead of costing a modular addition each)
+//
+// One CRT split of the cyclic convolution, over the INTEGERS (x^16 - 1 = (x^8 - 1)(x^8 + 1)): with s = (lo, hi), c = (c_lo, c_hi)
+//     P = (c_lo + c_hi) * (lo + hi)  mod x^8 - 1   (8 x 8 cyclic,     64 unsigned multiply-adds)
+//     M = (c_lo - c_hi) * (lo - hi)  mod x^8 + 1   (8 x 8 negacyclic, 64 signed multiply-adds)
+//     out_lo = (P + M) / 2,  out_hi = (P - M) / 2  — exact: P = out_lo + out_hi and M = out_lo - out_hi as integers, so the sums
+//     are even.  128 v_mad_{u,i}64_{u,i}32 + 16 x (64-bit add, shift) instead of 256 multiply-adds: the 4-cycle multiply-adds are
+//     63 % of the permutation's issue cycles.  lo + hi < 2^32 fits a u32, |lo - hi| < 2^31 an i32; every
+//     accumulator stays below 2^43.  The optional bias rides along: (b_lo + b_hi) enters P, (b_lo - b_hi) enters M.
 template <bool WITH_BIAS>
 KB_HD void mds_circ16_impl(u32 s[16], const u32* bias) {
-    const u32 c1 = opaque_const(1), c2 = opaque_const(2), c3 = opaque_const(3), c13 = opaque_const(13);
-    const u32 c22 = opaque_const(22), c67 = opaque_const(67), c15 = opaque_const(15), c63 = opaque_const(63);
-    const u32 c101 = opaque_const(101), c17 = opaque_const(17), c11 = opaque_const(11), c51 = opaque_const(51);
-    const u32 C[16] = {c1, c3, c13, c22, c67, c2, c15, c63, c101, c1, c2, c17, c11, c1, c51, c1};
-    u32 o[16];
+    // c_lo + c_hi and c_lo - c_hi of col = {1,3,13,22,67,2,15,63 | 101,1,2,17,11,1,51,1}
+    const u32 CP[8] = {opaque_const(102), opaque_const(4), opaque_const(15), opaque_const(39), opaque_const(78), opaque_const(3), opaque_const(66), opaque_const(64)};
+    // (both signs as their own scalar constants: the wrap-around terms of the negacyclic product are multiply-adds too)
+    const int32_t CM[8] = {(int32_t)opaque_const((u32)-100), (int32_t)opaque_const(2), (int32_t)opaque_const(11), (int32_t)opaque_const(5),
+                           (int32_t)opaque_const(56), (int32_t)opaque_const(1), (int32_t)opaque_const((u32)-36), (int32_t)opaque_const(62)};
+    const int32_t CN[8] = {(int32_t)opaque_const(100), (int32_t)opaque_const((u32)-2), (int32_t)opaque_const((u32)-11), (int32_t)opaque_const((u32)-5),
+                           (int32_t)opaque_const((u32)-56), (int32_t)opaque_const((u32)-1), (int32_t)opaque_const(36), (int32_t)opaque_const((u32)-62)};
+    u32 sp[8];
+    int32_t sm[8];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        u64 acc = WITH_BIAS ? (u64)bias[i] : 0;
-#pragma unroll
-        for (int j = 0; j < 16; j++) acc += (u64)s[j] * C[(16 + i - j) & 15];
-        o[i] = reduce40(acc);
+    for (int j = 0; j < 8; j++) {
+        sp[j] = s[j] + s[j + 8];
+        sm[j] = (int32_t)(s[j] - s[j + 8]);
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = o[i];
+    for (int i = 0; i < 8; i++) {
+        u64 accp = WITH_BIAS ? (u64)bias[i] + bias[i + 8] : 0;
+        int64_t accm = WITH_BIAS ? (int64_t)bias[i] - (int64_t)bias[i + 8] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            accp += (u64)sp[j] * CP[(8 + i - j) & 7];
+            accm += (int64_t)sm[j] * (j <= i ? CM[i - j] : CN[8 + i - j]);
+        }
+        s[i] = reduce40((u64)((int64_t)accp + accm) >> 1);
+        s[i + 8] = reduce40((u64)((int64_t)accp - accm) >> 1);
+    }
 }
 KB_HD void mds_circ16(u32 s[16]) { mds_circ16_impl<false>(s, nullptr); }
 KB_HD void mds_circ16_bias(u32 s[16], const u32 bias[16]) { mds_circ16_impl<true>(s, bias); }

@@ -709,3 +709,74 @@ void orc_vm_trace_table(void* h, uint32_t t, uint32_t* out) {
     for (size_t c = 0; c < cols.size(); c++) std::memcpy(out + c * n, cols[c].data(), n * 4);
 }
 }
+
+// ================================================================================================
+// transcript primitives and the product sumcheck with fixed challenges, for the second pin (tests/golden/twin_r03.py)
+// ================================================================================================
+extern "C" {
+void* orc_ps_new() { return new orc::ProverState(); }
+void orc_ps_free(void* h) { delete (orc::ProverState*)h; }
+void orc_ps_add_base(void* h, const uint32_t* s, uint64_t n) { ((orc::ProverState*)h)->add_base_scalars(s, n); }
+void orc_ps_duplex(void* h) { ((orc::ProverState*)h)->duplex(); }
+void orc_ps_sample_vec(void* h, uint64_t n, uint32_t* out) {
+    auto v = ((orc::ProverState*)h)->sample_vec(n);
+    for (uint64_t i = 0; i < n; i++) std::memcpy(out + 5 * i, v[i].v, 20);
+}
+void orc_ps_sample_in_range(void* h, uint32_t bits, uint64_t n, uint64_t* out) {
+    auto v = ((orc::ProverState*)h)->sample_in_range(bits, n);
+    for (uint64_t i = 0; i < n; i++) out[i] = v[i];
+}
+void orc_ps_add_sumcheck_polynomial(void* h, const uint32_t* coeffs, uint32_t n, const uint32_t* eq_alpha) {
+    std::vector<orc::EF> c(n);
+    for (uint32_t i = 0; i < n; i++) std::memcpy(c[i].v, coeffs + 5 * i, 20);
+    orc::EF a;
+    if (eq_alpha) std::memcpy(a.v, eq_alpha, 20);
+    ((orc::ProverState*)h)->add_sumcheck_polynomial(c, eq_alpha ? &a : nullptr);
+}
+void orc_ps_pow_grinding(void* h, uint32_t bits) { ((orc::ProverState*)h)->pow_grinding(bits); }
+void orc_ps_state(void* h, uint32_t* out16) { std::memcpy(out16, ((orc::ProverState*)h)->ch.state, 64); }
+uint64_t orc_ps_transcript(void* h, uint32_t* out) {
+    auto& t = ((orc::ProverState*)h)->transcript;
+    if (out) std::memcpy(out, t.data(), t.size() * 4);
+    return t.size();
+}
+// run_product_sumcheck's rounds (product_computation.rs:37-315) with GIVEN challenges: out = n_rounds x (c0, c1, c2); the folded
+// tables are returned in f_out / w_out (2^(n_vars - n_rounds) EF each)
+void orc_product_sumcheck_fixed(const uint32_t* f_base, const uint32_t* w_ef, uint32_t n_vars, const uint32_t* challenges, uint32_t n_rounds,
+                                uint32_t* out, uint32_t* f_out, uint32_t* w_out) {
+    using namespace orc;
+    size_t n = (size_t)1 << n_vars;
+    std::vector<EF> f(n), w(n);
+    EF sum = ef_zero();
+    for (size_t i = 0; i < n; i++) {
+        f[i] = ef_from_base(f_base[i]);
+        std::memcpy(w[i].v, w_ef + 5 * i, 20);
+        sum = ef_add(sum, ef_mul(f[i], w[i]));
+    }
+    for (uint32_t r = 0; r < n_rounds; r++) {
+        const size_t half = f.size() / 2;
+        EF c0 = ef_zero(), c2 = ef_zero();
+        for (size_t i = 0; i < half; i++) {
+            c0 = ef_add(c0, ef_mul(f[i], w[i]));
+            c2 = ef_add(c2, ef_mul(ef_sub(f[i + half], f[i]), ef_sub(w[i + half], w[i])));
+        }
+        const EF c1 = ef_sub(ef_sub(sum, ef_add(c0, c0)), c2);
+        std::memcpy(out + 15 * r, c0.v, 20);
+        std::memcpy(out + 15 * r + 5, c1.v, 20);
+        std::memcpy(out + 15 * r + 10, c2.v, 20);
+        EF ch;
+        std::memcpy(ch.v, challenges + 5 * r, 20);
+        sum = ef_add(c0, ef_mul(ch, ef_add(c1, ef_mul(ch, c2))));
+        for (size_t i = 0; i < half; i++) {
+            f[i] = ef_add(f[i], ef_mul(ch, ef_sub(f[i + half], f[i])));
+            w[i] = ef_add(w[i], ef_mul(ch, ef_sub(w[i + half], w[i])));
+        }
+        f.resize(half);
+        w.resize(half);
+    }
+    for (size_t i = 0; i < f.size(); i++) {
+        std::memcpy(f_out + 5 * i, f[i].v, 20);
+        std::memcpy(w_out + 5 * i, w[i].v, 20);
+    }
+}
+}

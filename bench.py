@@ -529,7 +529,10 @@ def main():
         # host thread) each — the node-level throughput when several leaves are queued
         C = args.inflight if args.inflight > 0 else max(1, min(10, hw // 2))
         if world == 1 and C > 1:
-            out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctx, w, C, max(3, args.steps // 2), args, sigs)
+            ctxs = [ctx] + [lm.Context(local_rank) for _ in range(C - 1)]
+            out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs)
+            if vm_path and "whole_node" in out:
+                out["whole_node"]["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs, whole_node=True)
         if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc, ob, ctx, args.witness)
         print(json.dumps(out), flush=True)
@@ -545,12 +548,14 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_inflight(lm, orc, ob, local_rank, ctx0, w0, C, steps, args, sigs):
-    """C provers (own lm_ctx each) prove `steps` leaves each, concurrently; returns the aggregate rate."""
+def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, whole_node=False):
+    """C provers (own lm_ctx each) prove `steps` leaves each, concurrently; returns the aggregate rate.  whole_node: every step is
+    lmh_prove_execution_vm (VM run + trace + proof): the leaves' VM runs share the host thread pool, their proofs the GPU."""
     import threading
     import torch
-    ctxs = [ctx0] + [lm.Context(local_rank) for _ in range(C - 1)]
-    if "vm" in w0:  # the same leaf on every context: own VM run and device trace each
+    if whole_node:
+        ws = [w0] * C
+    elif "vm" in w0:  # the same leaf on every context: own VM run and device trace each
         from leanmultisig_amd import vm
         ws = [w0]
         for c in range(1, C):
@@ -562,7 +567,11 @@ def measure_inflight(lm, orc, ob, local_rank, ctx0, w0, C, steps, args, sigs):
         ws = [w0] + [build_workload(ctxs[c], orc, ob, np.random.default_rng(2000 + c), args.scale_log, args.log_inv_rate, args.shape,
                                     args.soundness == "capacity", args.witness) for c in range(1, C)]
     for c in range(C):
-        run_step(ctxs[c], lm, ws[c])
+        if whole_node:
+            from leanmultisig_amd import vm
+            vm.prove_execution_vm(ctxs[c], lm.Prover(ctxs[c]), w0["vm"]["bc"], w0["vm"]["pi"], w0["vm"]["wit"], w0["lm_builder"])
+        else:
+            run_step(ctxs[c], lm, ws[c])
         ctxs[c].sync()
     errors = []
     start = threading.Barrier(C + 1)
@@ -572,7 +581,14 @@ def measure_inflight(lm, orc, ob, local_rank, ctx0, w0, C, steps, args, sigs):
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
             start.wait()
             for _ in range(steps):
-                run_step(ctxs[c], lm, ws[c]).proof_pruned()
+                if whole_node:
+                    from leanmultisig_amd import vm
+                    pr = lm.Prover(ctxs[c])
+                    v = w0["vm"]
+                    vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], w0["lm_builder"])
+                    pr.proof_pruned()
+                else:
+                    run_step(ctxs[c], lm, ws[c]).proof_pruned()
             ctxs[c].sync()
         except Exception as e:  # noqa: BLE001 — reported after the join
             errors.append(e)

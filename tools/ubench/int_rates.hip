@@ -16,7 +16,9 @@ __global__ __launch_bounds__(256) void k_rate(u32* out, u32 seed) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (OP == 0) w[i] = (u64)(u32)w[i] * c + w[i];                    // v_mad_u64_u32
-            if (OP == 1) a[i] = a[i] * c;                                      // v_mul_lo_u32
+            // (as C, `a *= c` 4096 times is folded into one multiplication by c^4096 — round 2's "270 T/s"; the instruction is
+            // pinned with inline assembly, one dependent v_mul_lo_u32 per iteration and chain)
+            if (OP == 1) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(c));   // v_mul_lo_u32
             if (OP == 2) a[i] = __umulhi(a[i], c) + 1;                         // v_mul_hi_u32
             if (OP == 3) a[i] = __umul24(a[i], c) + a[i];                      // v_mad_u32_u24
             if (OP == 4) a[i] = kb::mul(a[i] & 0x3fffffff, c & 0x3fffffff);   // Montgomery mul

@@ -489,7 +489,7 @@ def main():
         if vm_path and world == 1:
             # ---- the reference's metric proper: prove_execution(bytecode, public_input, witness) = VM run + trace + proof per step
             hw_threads = min(128, hw)
-            t_step, phases, pr_node = time_whole_node(ctx, lm, w, max(3, args.steps // 2), 2)
+            t_step, phases, pr_node = time_whole_node(ctx, lm, w, max(3, args.steps // 2), 4)
             out["whole_node"] = {"value": sigs / t_step, "unit": "xmss_sigs/s", "ms_per_step": 1e3 * t_step,
                                  "witness_ms": float(phases[0] + phases[1]), "vm_run_ms": float(phases[0]), "trace_ms": float(phases[1]),
                                  "prove_ms": float(phases[2]), "host_threads": hw_threads,

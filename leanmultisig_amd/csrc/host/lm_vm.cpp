@@ -45,17 +45,16 @@ class Pool {
         static Pool p;
         return p;
     }
-    // A session keeps the workers SPINNING between jobs instead of sleeping on the condition variable: a VM run issues five
-    // parallel_for's a few hundred microseconds apart, and waking 127 sleeping threads costs ~0.7 ms each time on the 2 x 64-core
-    // host (measured: 3.5 of a 7 ms run).  Sessions nest; outside of one the workers sleep.
+    // Inside a session a worker that has finished a job keeps polling for the next one for ~100 us before it goes back to sleep on
+    // the condition variable: a VM run issues its parallel_for's in bursts (resize -> segments -> merge, resolve -> mask) a few
+    // microseconds apart, and waking 127 sleeping threads costs ~0.7 ms each time on the 2 x 64-core host.  The poll is BOUNDED:
+    // the GPU box runs under a CPU quota (cgroup cpu.max = 16 CPUs per 100 ms), and 127 threads spinning through the sequential
+    // parts of a run exhausted it — the whole process, prover thread included, was throttled for 20-60 ms every few proofs.
+    static constexpr u32 SPIN_LIMIT = 4000;  // x pause (~25 ns)
     void begin_session(u32 n_threads) {
         std::lock_guard<std::mutex> user(user_mu_);
         ensure(resolve(n_threads) - 1);
         spin_.fetch_add(1, std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-        }
-        cv_.notify_all();
     }
     void end_session() { spin_.fetch_sub(1, std::memory_order_release); }
     void parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) {
@@ -70,14 +69,16 @@ class Pool {
         ensure(want - 1);
         job_ = &f;
         total_ = n;
-        active_ = want - 1;
         next_.store(0, std::memory_order_relaxed);
         pending_.store(want - 1, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(mu_);  // (orders the generation change with sleepers that are about to wait)
-            gen_.fetch_add(1, std::memory_order_release);
+            // generation and the number of workers that take part travel in ONE word: a worker that is not part of generation g
+            // may read it late, when g + 1 (with more participants) is already being set up — it must not pick up g + 1's count
+            // with g's number and run (and check out) twice
+            gen_.store(((gen_.load(std::memory_order_relaxed) >> 16) + 1) << 16 | (want - 1), std::memory_order_release);
         }
-        if (spin_.load(std::memory_order_relaxed) == 0 || sleepers_.load(std::memory_order_relaxed)) cv_.notify_all();
+        if (sleepers_.load(std::memory_order_acquire)) cv_.notify_all();
         work();
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         job_ = nullptr;
@@ -127,21 +128,23 @@ class Pool {
         u64 seen = 0;
         for (;;) {
             u64 g;
+            u32 spins = 0;
             for (;;) {
                 g = gen_.load(std::memory_order_acquire);
                 if (g != seen) break;
                 if (stop_.load(std::memory_order_acquire)) return;
-                if (spin_.load(std::memory_order_acquire)) {
+                if (spin_.load(std::memory_order_acquire) && spins < SPIN_LIMIT) {  // bounded: see begin_session
+                    spins++;
                     cpu_relax();
                     continue;
                 }
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1, std::memory_order_relaxed);
-                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire) || spin_.load(std::memory_order_acquire); });
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire); });
                 sleepers_.fetch_sub(1, std::memory_order_relaxed);
             }
             seen = g;
-            if (id < active_) {  // (job_, total_, active_ were written before the generation was released)
+            if (id < (u32)(g & 0xffff)) {  // (job_ and total_ were written before the word was released and stay until this worker checks out)
                 work();
                 pending_.fetch_sub(1, std::memory_order_release);
             }
@@ -155,13 +158,17 @@ class Pool {
     std::atomic<u32> pending_{0}, spin_{0}, sleepers_{0};
     std::atomic<bool> stop_{false};
     u64 total_ = 0;
-    u32 active_ = 0;
 };
 
 void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) { Pool::get().parallel_for(n, n_threads, f); }
-struct PoolSession {
-    explicit PoolSession(u32 n_threads) { Pool::get().begin_session(n_threads); }
-    ~PoolSession() { Pool::get().end_session(); }
+struct PoolSession {  // LM_VM_NO_SPIN=1: the workers sleep between the jobs of a run (for A/B measurements)
+    bool on;
+    explicit PoolSession(u32 n_threads) : on(getenv("LM_VM_NO_SPIN") == nullptr) {
+        if (on) Pool::get().begin_session(n_threads);
+    }
+    ~PoolSession() {
+        if (on) Pool::get().end_session();
+    }
 };
 
 namespace {
@@ -192,7 +199,6 @@ struct MemBuf {
         }
         void* q = mmap(nullptr, MAX_MEMORY * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (q == MAP_FAILED) throw std::bad_alloc();
-        (void)madvise(q, MAX_MEMORY * 4, MADV_HUGEPAGE);  // 2 MB first-touch faults where the kernel allows them
         p = (u32*)q;
     }
     ~MemBuf() {
@@ -239,6 +245,8 @@ struct UVec {
     const T* data() const { return p; }
     T& operator[](size_t i) { return p[i]; }
     const T& operator[](size_t i) const { return p[i]; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
     void reserve(size_t c) {
         if (c <= cap) return;
         size_t nc = cap ? cap : 256;
@@ -315,7 +323,7 @@ struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, 
     u64 shared_len;
     u32* seg;
     u64 seg_start, seg_len;
-    std::vector<std::pair<u64, u32>> deferred;
+    UVec<std::pair<u64, u32>>* deferred;  // the running thread's log (ThreadLog)
     u32 peek(u64 i) const {
         if (i < seg_start) return i < shared_len ? shared[i] : UNDEF;
         const u64 o = i - seg_start;
@@ -323,7 +331,7 @@ struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, 
     }
     bool set(u64 i, u32 v, Err& e) {
         if (i < seg_start || i - seg_start >= seg_len) {
-            deferred.emplace_back(i, v);
+            deferred->push_back(std::pair<u64, u32>(i, v));
             return true;
         }
         u32& c = seg[i - seg_start];
@@ -358,7 +366,7 @@ struct Trace {  // runner.rs:70-76
     UVec<u32> pcs, fps;
     UVec<u32> pos;  // LM_VM_POSEIDON_CALL_WORDS per call
     UVec<u32> ext;  // LM_VM_EXTENSION_ROW_WORDS per row
-    std::vector<std::pair<u64, u64>> pending;  // (target_addr, src_addr)
+    UVec<std::pair<u64, u64>> pending;  // (target_addr, src_addr)
     u64 n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
 };
 
@@ -502,7 +510,7 @@ struct Machine {
                 break;
             }
             case LM_VM_HINT_DEREF:
-                tr.pending.emplace_back(fp + h.args[1], fp + h.args[0]);  // (target_addr, src_addr)
+                tr.pending.push_back(std::pair<u64, u64>(fp + h.args[1], fp + h.args[0]));  // (target_addr, src_addr)
                 break;
             case LM_VM_HINT_DECOMPOSE_BITS_XMSS: {
                 const u32 dp = hint_arg(h, 0), sp = hint_arg(h, 1), nn = hint_arg(h, 2), cs = hint_arg(h, 3);
@@ -916,7 +924,7 @@ struct Machine {
 // progress, the rest zero-filled.  Almost every entry is a no-op (the DEREF instruction itself found its value): those are
 // recognised by a read-only pass on the pool; the reference's sequential loop then runs over what is left, with its `resolved`
 // set (targets already written are skipped) seeded by the no-op entries that share a target with a remaining one.
-bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& pending, u32 n_threads, Err& err) {
+bool resolve_deref_hints(MainMem& mem, const UVec<std::pair<u64, u64>>& pending, u32 n_threads, Err& err) {
     const u64 n = pending.size();
     if (n == 0) return true;
     std::vector<uint8_t> noop(n, 0);
@@ -959,6 +967,34 @@ bool resolve_deref_hints(MainMem& mem, const std::vector<std::pair<u64, u64>>& p
     for (u64 i : rest)
         if (!resolved.count(pending[i].first) && !mem.set(pending[i].first, 0, err)) return false;
     return true;
+}
+
+// per pool thread: the logs of the segments it has run in the current batch (persistent, grow-only)
+struct ThreadLog {
+    Trace tr;
+    UVec<std::pair<u64, u32>> deferred;
+};
+std::mutex g_logs_mu;
+std::vector<ThreadLog*> g_logs;
+ThreadLog& thread_log() {
+    static thread_local ThreadLog* mine = nullptr;
+    if (!mine) {
+        mine = new ThreadLog();  // lives as long as the process (pool threads do)
+        std::lock_guard<std::mutex> lk(g_logs_mu);
+        g_logs.push_back(mine);
+    }
+    return *mine;
+}
+void thread_logs_reset() {  // (no batch is running: parallel_for's are serialised)
+    std::lock_guard<std::mutex> lk(g_logs_mu);
+    for (ThreadLog* l : g_logs) {
+        l->tr.pcs.n = l->tr.fps.n = l->tr.pos.n = l->tr.ext.n = l->tr.pending.n = l->deferred.n = 0;
+        l->tr.n_add = l->tr.n_mul = l->tr.n_deref = l->tr.n_jump = 0;
+    }
+}
+UVec<std::pair<u64, u32>>& batch_deferred() {
+    static UVec<std::pair<u64, u32>> v;
+    return v;
 }
 
 // handle_parallel_batch (runner.rs:361-482)
@@ -1029,21 +1065,31 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     const u64 n_par = n_iters - 1;
     const u64 split_at = batch.batch_fp + stride;
 
+    // Every pool thread appends the logs of the segments it runs to its own persistent buffers (ThreadLog: grow-only, reused by the
+    // next run); a segment remembers where its part lies.  No allocation per segment: 10^4 malloc / free pairs per run (and the
+    // page trimming they trigger under 128 threads) were the source of sporadic 10-30 ms stalls.
     struct Seg {
-        Trace tr;
-        std::vector<std::pair<u64, u32>> deferred;
+        ThreadLog* log = nullptr;
+        size_t o_cyc = 0, n_cyc = 0, o_pos = 0, n_pos = 0, o_ext = 0, n_ext = 0, o_pend = 0, n_pend = 0, o_def = 0, n_def = 0;
+        u64 n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
         Err err;
     };
     const double tb0 = vm_now_ms();
+    thread_logs_reset();
     std::vector<Seg> segs(n_par);
     u32* base = memory.data();
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
         Seg& s = segs[i];
+        ThreadLog& L = thread_log();
+        Trace& t = L.tr;
+        s.log = &L;
+        s.o_cyc = t.pcs.size(), s.o_pos = t.pos.size(), s.o_ext = t.ext.size(), s.o_pend = t.pending.size(), s.o_def = L.deferred.size();
+        const u64 a0 = t.n_add, m0 = t.n_mul, d0 = t.n_deref, j0 = t.n_jump;
         const u64 seg_start = split_at + i * stride;
-        SegMem sm{base, split_at, base + seg_start, seg_start, stride, {}};
+        SegMem sm{base, split_at, base + seg_start, seg_start, stride, &L.deferred};
         Cursors c = cur;
         for (size_t k = 0; k < c.index.size(); k++) c.index[k] += i * per_iter[k];
-        Machine<SegMem> m(bc, w, sm, s.tr, c);
+        Machine<SegMem> m(bc, w, sm, t, c);
         m.pc = batch.batch_pc;
         m.fp = batch.batch_fp + (i + 1) * stride;
         m.ap = m.fp + batch.frame_size;
@@ -1051,7 +1097,9 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
         const int rc = m.run(true, batch.batch_pc, inner);
         if (rc != 1 && !m.err.set) m.err.raise(rc == 0 ? "Panic: a parallel segment reached the end of the program" : "Panic: nested parallel batch");
         s.err = m.err;
-        s.deferred = std::move(sm.deferred);
+        s.n_cyc = t.pcs.size() - s.o_cyc, s.n_pos = t.pos.size() - s.o_pos, s.n_ext = t.ext.size() - s.o_ext;
+        s.n_pend = t.pending.size() - s.o_pend, s.n_def = L.deferred.size() - s.o_def;
+        s.n_add = t.n_add - a0, s.n_mul = t.n_mul - m0, s.n_deref = t.n_deref - d0, s.n_jump = t.n_jump - j0;
     });
     for (u64 i = 0; i < n_par; i++)
         if (segs[i].err.set) {
@@ -1059,31 +1107,27 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
             return false;
         }
     const double tb1 = vm_now_ms();
-    // Trace::merge in iteration order, then the deferred writes.  The segments' buffers are copied AND released by the pool (they
-    // were allocated there: 10^4 frees from the main thread were 1.6 ms of a 6 ms run).
+    // Trace::merge in iteration order (a parallel copy out of the thread logs), then the deferred writes
     size_t n_cyc = trace.pcs.size(), n_pos = trace.pos.size(), n_ext = trace.ext.size(), n_pend = trace.pending.size(), n_def = 0;
     std::vector<size_t> o_cyc(n_par), o_pos(n_par), o_ext(n_par), o_pend(n_par), o_def(n_par);
     for (u64 i = 0; i < n_par; i++) {
         o_cyc[i] = n_cyc, o_pos[i] = n_pos, o_ext[i] = n_ext, o_pend[i] = n_pend, o_def[i] = n_def;
-        n_cyc += segs[i].tr.pcs.size(), n_pos += segs[i].tr.pos.size(), n_ext += segs[i].tr.ext.size(), n_pend += segs[i].tr.pending.size();
-        n_def += segs[i].deferred.size();
-        trace.n_add += segs[i].tr.n_add, trace.n_mul += segs[i].tr.n_mul, trace.n_deref += segs[i].tr.n_deref, trace.n_jump += segs[i].tr.n_jump;
+        n_cyc += segs[i].n_cyc, n_pos += segs[i].n_pos, n_ext += segs[i].n_ext, n_pend += segs[i].n_pend, n_def += segs[i].n_def;
+        trace.n_add += segs[i].n_add, trace.n_mul += segs[i].n_mul, trace.n_deref += segs[i].n_deref, trace.n_jump += segs[i].n_jump;
     }
     trace.pcs.extend(n_cyc - trace.pcs.size()), trace.fps.extend(n_cyc - trace.fps.size()), trace.pos.extend(n_pos - trace.pos.size());
-    trace.ext.extend(n_ext - trace.ext.size()), trace.pending.resize(n_pend);
-    UVec<std::pair<u64, u32>> all_def;
+    trace.ext.extend(n_ext - trace.ext.size()), trace.pending.extend(n_pend - trace.pending.size());
+    UVec<std::pair<u64, u32>>& all_def = batch_deferred();
+    all_def.n = 0;
     all_def.extend(n_def);
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
-        Seg& sg = segs[i];
-        Trace& t = sg.tr;
-        if (!t.pcs.empty()) memcpy(&trace.pcs[o_cyc[i]], t.pcs.data(), t.pcs.size() * 4), memcpy(&trace.fps[o_cyc[i]], t.fps.data(), t.fps.size() * 4);
-        if (!t.pos.empty()) memcpy(&trace.pos[o_pos[i]], t.pos.data(), t.pos.size() * 4);
-        if (!t.ext.empty()) memcpy(&trace.ext[o_ext[i]], t.ext.data(), t.ext.size() * 4);
-        for (size_t k = 0; k < t.pending.size(); k++) trace.pending[o_pend[i] + k] = t.pending[k];
-        for (size_t k = 0; k < sg.deferred.size(); k++) all_def[o_def[i] + k] = sg.deferred[k];
-        t.pcs.release(), t.fps.release(), t.pos.release(), t.ext.release();
-        std::vector<std::pair<u64, u64>>().swap(t.pending);
-        std::vector<std::pair<u64, u32>>().swap(sg.deferred);
+        const Seg& sg = segs[i];
+        const Trace& t = sg.log->tr;
+        if (sg.n_cyc) memcpy(&trace.pcs[o_cyc[i]], t.pcs.data() + sg.o_cyc, sg.n_cyc * 4), memcpy(&trace.fps[o_cyc[i]], t.fps.data() + sg.o_cyc, sg.n_cyc * 4);
+        if (sg.n_pos) memcpy(&trace.pos[o_pos[i]], t.pos.data() + sg.o_pos, sg.n_pos * 4);
+        if (sg.n_ext) memcpy(&trace.ext[o_ext[i]], t.ext.data() + sg.o_ext, sg.n_ext * 4);
+        if (sg.n_pend) memcpy((void*)&trace.pending[o_pend[i]], t.pending.data() + sg.o_pend, sg.n_pend * sizeof(std::pair<u64, u64>));
+        if (sg.n_def) memcpy((void*)&all_def[o_def[i]], sg.log->deferred.data() + sg.o_def, sg.n_def * sizeof(std::pair<u64, u32>));
     });
     for (size_t k = 0; k < n_def; k++)
         if (!mm.set(all_def[k].first, all_def[k].second, err)) return false;

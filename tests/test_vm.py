@@ -448,3 +448,16 @@ def test_xmss_program_trace_is_provable(orc, program):
     assert ok, err
     assert int(from_monty(ww["bytecode_acc"])[:-1].max()) == 5              # bytecode_acc > 1: 4 iterations + the terminating call
     assert int(from_monty(ww["bytecode_acc"])[-1]) == (1 << ww["log_rows"][0]) - ww["non_padded"][0] + 1   # ending_pc: the padding rows
+
+
+def test_runner_is_deterministic_under_repeated_parallel_runs(program):
+    """The host pool runs parallel_for's with different participant counts back to back (memory resize: a few chunks; segments:
+    all threads): 40 runs of the same input on 8 threads must all give the first run's log (a worker joining a generation it is
+    not part of would run — and check out — twice)."""
+    pi, w, _ = xa.build_witness(program, 40, np.random.default_rng(77))
+    first = execute(program, pi, w, n_threads=8)
+    ref = (first.pcs().tobytes(), first.fps().tobytes(), first.memory().tobytes(), first.poseidon_calls().tobytes(), first.extension_rows().tobytes())
+    for k in range(40):
+        ex = execute(program, pi, w, n_threads=8 if k % 3 else 5)
+        got = (ex.pcs().tobytes(), ex.fps().tobytes(), ex.memory().tobytes(), ex.poseidon_calls().tobytes(), ex.extension_rows().tobytes())
+        assert got == ref, k

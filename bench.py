@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-whole-node", action="store_true", help="skip the whole_node leg (counter passes: only the timed region's proofs run)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="side measurement after the timed region (N = 1 only): independent proofs in flight on the GPU (one host "
                          "thread + HIP stream each).  0 = default: 10, fewer if the host has less than 2 hardware threads per "
@@ -486,7 +487,7 @@ def main():
                         "the library at the launch sites (lm_profile_read_bytes)"})(
                 sum(v[0] for v in hbm_live.values()), sum(v[1] for v in hbm_live.values()), sum(v[2] for v in hbm_live.values())),
         }
-        if vm_path and world == 1:
+        if vm_path and world == 1 and not args.no_whole_node:
             # ---- the reference's metric proper: prove_execution(bytecode, public_input, witness) = VM run + trace + proof per step
             hw_threads = min(128, hw)
             t_step, phases, pr_node = time_whole_node(ctx, lm, w, max(3, args.steps // 2), 4)

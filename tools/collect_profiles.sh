@@ -6,12 +6,12 @@
 #   pmc_fetch/, pmc_write/, pmc_valu/   FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate)
 #   *.json             plain bench lines for the BASELINE configs and side measurements
 set -u
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B1="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1"
+B1="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 --no-whole-node"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inflight1 -- $B1 > $OUT/bench_under_rocprof.json 2> $OUT/stats1.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B1 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B1 > /dev/null 2> $OUT/pmc_write.err

@@ -58,9 +58,46 @@ pub struct lm_execution_trace {
     pub d_memory: *const u32,
     pub d_memory_acc: *const u32,
     pub tables: [lm_vm_table; 3],
+    pub d_stacked: *mut u32, // optional: the trace already in its committed layout (null = absent)
+}
+#[repr(C)]
+pub struct lmh_bytecode(c_void);
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lm_vm_hint {
+    pub pc: u32,
+    pub kind: u32, // LM_VM_HINT_*
+    pub args: [u32; 4],
+    pub mode: [u8; 4], // LM_VM_ARG_*: 0 constant, 1 m[fp + x], 2 fp + x
+}
+#[repr(C)]
+pub struct lm_vm_witness {
+    pub preamble_memory_len: u32,
+    pub n_names: u32,
+    pub name_entry_begin: *const u64,
+    pub entry_offset: *const u64,
+    pub data: *const u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct lm_whir_builder {
+    pub starting_log_inv_rate: u32,
+    pub max_num_variables_to_send_coeffs: u32,
+    pub rs_domain_initial_reduction_factor: u32,
+    pub folding_factor_first: u32,
+    pub folding_factor_subsequent: u32,
+    pub soundness_type: u32,
+    pub security_level: u32,
+    pub pow_bits: u32,
 }
 
 unsafe extern "C" {
+    pub fn lmh_bytecode_new(instructions_multilinear: *const u32, log_size: u32, n_instructions: u64, ending_pc: u32, starting_frame_memory: u32,
+                            hints: *const lm_vm_hint, n_hints: u64, n_hint_names: u32) -> *mut lmh_bytecode;
+    pub fn lmh_bytecode_free(bc: *mut lmh_bytecode);
+    pub fn lmh_default_whir_builder(starting_log_inv_rate: u32, prox_gaps_conjecture: c_int, out: *mut lm_whir_builder);
+    pub fn lmh_prove_execution_vm(ctx: *mut lm_ctx, p: *mut lmh_prover, bc: *const lmh_bytecode, public_input: *const u32, n_public_input: u32,
+                                  witness: *const lm_vm_witness, builder: *const lm_whir_builder, n_threads: u32, times_ms: *mut f64) -> c_int;
     pub fn lm_ctx_create(device: c_int, out: *mut *mut lm_ctx) -> c_int;
     pub fn lm_ctx_destroy(ctx: *mut lm_ctx);
     pub fn lm_last_error() -> *const c_char;
@@ -100,6 +137,94 @@ pub fn whir_config_ints(c: &backend::WhirConfig<backend::EF>) -> lm_whir_config 
         };
     }
     o
+}
+
+/// `Bytecode` -> the library's object: `instructions_multilinear` as it is (the runner decodes its instructions from it) and the
+/// hints attached to each pc, flattened (crates/lean_vm/src/isa/hint.rs:17-81).  `names` collects the `HintWitness` names in
+/// first-use order: index = the id the witness streams are passed under.  Print / LocationReport / Label / Panic have no effect
+/// on the execution result and are dropped.
+pub fn bytecode_to_hip(bytecode: &lean_vm::Bytecode, names: &mut Vec<String>) -> *mut lmh_bytecode {
+    use lean_vm::{CustomHint, Hint, HintWitnessDestination, MemOrConstant, MemOrFpOrConstant};
+    fn moc(a: &MemOrConstant) -> (u32, u8) {
+        match a {
+            MemOrConstant::Constant(c) => (c.as_canonical_u32(), 0),
+            MemOrConstant::MemoryAfterFp { offset } => (*offset as u32, 1),
+        }
+    }
+    fn mfc(a: &MemOrFpOrConstant) -> (u32, u8) {
+        match a {
+            MemOrFpOrConstant::Constant(c) => (c.as_canonical_u32(), 0),
+            MemOrFpOrConstant::MemoryAfterFp { offset } => (*offset as u32, 1),
+            MemOrFpOrConstant::FpRelative { offset } => (*offset as u32, 2),
+        }
+    }
+    let mut flat: Vec<lm_vm_hint> = Vec::new();
+    for (pc, entry) in bytecode.code.iter().enumerate() {
+        for h in entry.hints.iter() {
+            let mut o = lm_vm_hint { pc: pc as u32, ..Default::default() };
+            let mut set = |k: usize, (v, m): (u32, u8)| {
+                o.args[k] = v;
+                o.mode[k] = m;
+            };
+            match h {
+                Hint::Inverse { arg, res_offset } => { o.kind = 1; set(0, moc(arg)); set(1, (*res_offset as u32, 0)); }
+                Hint::RequestMemory { offset, size } => { o.kind = 2; set(0, (*offset as u32, 0)); set(1, moc(size)); }
+                Hint::DerefHint { offset_src, offset_target } => { o.kind = 3; set(0, (*offset_src as u32, 0)); set(1, (*offset_target as u32, 0)); }
+                Hint::Custom(c, args) => {
+                    o.kind = match c { CustomHint::DecomposeBitsXMSS => 4, CustomHint::DecomposeBitsMerkleWhir => 5, CustomHint::DecomposeBits => 6,
+                                       CustomHint::LessThan => 7, CustomHint::Log2Ceil => 8 };
+                    for (k, a) in args.iter().enumerate() { set(k, mfc(a)); }
+                }
+                Hint::HintWitness { name, destination } => {
+                    let id = names.iter().position(|n| n == name).unwrap_or_else(|| { names.push(name.clone()); names.len() - 1 }) as u32;
+                    match destination {
+                        HintWitnessDestination::Inline { offset } => { o.kind = 9; set(0, (id, 0)); set(1, (*offset as u32, 0)); }
+                        HintWitnessDestination::Indirect { ptr_offset } => { o.kind = 10; set(0, (id, 0)); set(1, (*ptr_offset as u32, 0)); }
+                    }
+                }
+                Hint::ParallelBatchStart { n_args, end_value } => { o.kind = 11; set(0, (*n_args as u32, 0)); set(1, moc(end_value)); }
+                Hint::DebugAssert { expr, preceds_runtime_inequality, .. } => {
+                    o.kind = 12; set(0, moc(&expr.left)); set(1, moc(&expr.right)); set(2, (expr.kind as u32, 0)); set(3, (*preceds_runtime_inequality as u32, 0));
+                }
+                Hint::Print { .. } | Hint::LocationReport { .. } | Hint::Label { .. } | Hint::Panic { .. } => continue,
+            }
+            flat.push(o);
+        }
+    }
+    unsafe {
+        lmh_bytecode_new(bytecode.instructions_multilinear.as_ptr() as *const u32, bytecode.log_size() as u32, bytecode.code.len() as u64,
+                         bytecode.ending_pc as u32, bytecode.starting_frame_memory as u32, flat.as_ptr(), flat.len() as u64, names.len() as u32)
+    }
+}
+
+/// The whole of `lean_prover::prove_execution` on the library: VM run (host thread pool), execution trace (device), proof.
+pub fn prove_execution_vm_hip(ctx: *mut lm_ctx, bc: *const lmh_bytecode, names: &[String], public_input: &[backend::F],
+                              witness: &lean_vm::ExecutionWitness, log_inv_rate: usize) -> Option<backend::Proof<backend::F>> {
+    let (mut begin, mut offs, mut data) = (vec![0u64], vec![0u64], Vec::<u32>::new());
+    for name in names {
+        for entry in witness.hints.get(name).map(|v| v.as_slice()).unwrap_or(&[]) {
+            data.extend(entry.iter().map(|f| f.to_monty_u32())); // the in-memory word of MontyField31
+            offs.push(data.len() as u64);
+        }
+        begin.push(offs.len() as u64 - 1);
+    }
+    let w = lm_vm_witness { preamble_memory_len: witness.preamble_memory_len as u32, n_names: names.len() as u32,
+                            name_entry_begin: begin.as_ptr(), entry_offset: offs.as_ptr(), data: data.as_ptr() };
+    unsafe {
+        let mut b = lm_whir_builder::default();
+        lmh_default_whir_builder(log_inv_rate as u32, cfg!(feature = "prox-gaps-conjecture") as c_int, &mut b);
+        let p = lmh_prover_new();
+        let rc = lmh_prove_execution_vm(ctx, p, bc, public_input.as_ptr() as *const u32, public_input.len() as u32, &w, &b, 0, std::ptr::null_mut());
+        let out = if rc == 0 {
+            let mut bytes = vec![0u8; lmh_proof_postcard_size(p) as usize];
+            lmh_proof_postcard(p, bytes.as_mut_ptr());
+            proof_from_bytes(&bytes)
+        } else {
+            None
+        };
+        lmh_prover_free(p);
+        out
+    }
 }
 
 /// Decode the bytes written by `lmh_proof_postcard` into the reference's `Proof<F>`: same serde derive, same postcard.

@@ -833,6 +833,24 @@ int lmh_prove_gkr_quotient_active(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_
         if (clk_on) t_begin += ms(tb0, now());
         std::vector<EF> q;
         EF r_prev;
+        // 1 / point[j] for every round of the layer with ONE inversion (the per-round inverse sat between two device exchanges)
+        std::vector<EF> inv_pt(K);
+        {
+            std::vector<EF> pre(K + 1);
+            pre[0] = kb::ef_one();
+            for (u32 j = 0; j < K; j++) pre[j + 1] = kb::ef_mul(pre[j], point[j]);
+            bool zero = true;
+            for (int k = 0; k < 5; k++) zero = zero && pre[K].v[k] == 0;
+            if (zero) {
+                for (u32 j = 0; j < K; j++) inv_pt[j] = kb::ef_inv(point[j]);
+            } else {
+                EF run = kb::ef_inv(pre[K]);
+                for (u32 j = K; j-- > 0;) {
+                    inv_pt[j] = kb::ef_mul(run, pre[j]);
+                    run = kb::ef_mul(run, point[j]);
+                }
+            }
+        }
         for (u32 t = 0; t < K; t++) {
             u32 c[10];
             auto tr0 = now();
@@ -841,7 +859,7 @@ int lmh_prove_gkr_quotient_active(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_
             const EF eq_alpha = point[K - 1 - t];
             // build_bare_from_coeffs, sumcheck_utils.rs:491-503
             const EF c0 = kb::ef_mul(ef_load(c), mmf), c2 = kb::ef_mul(ef_load(c + 5), mmf);
-            const EF h1 = kb::ef_mul(kb::ef_sub(sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), c0)), kb::ef_inv(eq_alpha));
+            const EF h1 = kb::ef_mul(kb::ef_sub(sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), c0)), inv_pt[K - 1 - t]);
             const EF c1 = kb::ef_sub(kb::ef_sub(h1, c0), c2);
             add_sumcheck_poly(p, {c0, c1, c2}, &eq_alpha);
             std::vector<EF> rv;

@@ -985,7 +985,7 @@ ThreadLog& thread_log() {
     }
     return *mine;
 }
-void thread_logs_reset() {  // (no batch is running: parallel_for's are serialised)
+void thread_logs_reset() {  // (called by the batch that holds g_batch_mu: no other batch is running)
     std::lock_guard<std::mutex> lk(g_logs_mu);
     for (ThreadLog* l : g_logs) {
         l->tr.pcs.n = l->tr.fps.n = l->tr.pos.n = l->tr.ext.n = l->tr.pending.n = l->deferred.n = 0;
@@ -998,8 +998,13 @@ UVec<std::pair<u64, u32>>& batch_deferred() {
 }
 
 // handle_parallel_batch (runner.rs:361-482)
+// The per-thread logs and the deferred-write list are process-wide (they belong to the pool's threads): ONE batch owns them from
+// its reset to its splice.  Concurrent runs (several provers in one process) take turns here — a batch occupies the whole pool
+// anyway — and overlap everywhere else.
+std::mutex g_batch_mu;
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
                            u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
+    std::lock_guard<std::mutex> batch_owner(g_batch_mu);
     MainMem mm{memory};
     const double tp0 = vm_now_ms();
     auto get = [&](u64 at) -> u32 {

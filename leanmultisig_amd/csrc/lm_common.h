@@ -59,6 +59,10 @@ struct lm_ctx {
     static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
     static constexpr u64 ERR_WORD = 8;          // h_res[RES_FLAG + ERR_WORD]: sticky count of data errors seen by kernels (lm_access_errors)
     u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
+    // pinned, device-visible mailbox lines (host -> resident kernel): line 0 belongs to `stream`, line 1 + k to aux_stream[k].
+    // A resident kernel (k_gkr_tail) polls its line for the next message instead of ending and being relaunched.
+    u32* h_cmd = nullptr;
+    static constexpr u64 CMD_LINE_WORDS = 16;
     // pinned staging ring for small host -> device tables (pointer lists, job lists, evaluation points): the host image is
     // written here and copied with ONE asynchronous command — no synchronisation to keep a caller's vector alive, no
     // pageable-memory staging inside the runtime.  A region stays valid until the ring wraps; wrapping synchronises.

@@ -426,6 +426,8 @@ static int ctx_create_impl(int device, lm_ctx* c) {
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
     LM_HIP(hipHostMalloc((void**)&c->h_res, (lm_ctx::RES_WORDS + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
     for (int i = 0; i < 16; i++) c->h_res[lm_ctx::RES_FLAG + i] = 0;
+    LM_HIP(hipHostMalloc((void**)&c->h_cmd, lm_ctx::CMD_LINE_WORDS * (1 + lm_ctx::N_AUX) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_cmd, 0, lm_ctx::CMD_LINE_WORDS * (1 + lm_ctx::N_AUX) * 4);
     LM_HIP(hipHostMalloc((void**)&c->h_stage, lm_ctx::STAGE_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     LM_HIP(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     const u64 n = 1ull << (LM_TW_LOG - 1);
@@ -480,6 +482,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_cmd) (void)hipHostFree(c->h_cmd);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -39,6 +39,11 @@ struct lm_gkr {
     EF la[6];
     u32 fin_m = 0;            // tail of the layer published by the last launch: fin[array][i], i < fin_m <= 4
     EF fin[4][4];
+    bool tail_live = false;   // a k_gkr_tail workgroup is resident and waiting for the next pair of challenges
+    u32 tail_seq = 0;         // sequence number of its last publication (the next one must be tail_seq + 1)
+    u32 tail_W = 1, tail_S = 0;  // its workgroups and the length of a workgroup's slice (the host mirrors the kernel's schedule)
+    bool tail_solo = true;       // only workgroup 0 is left (always true for tail_W == 1)
+    u32* d_merge = nullptr;      // hand-over scratch of a multi-workgroup tail
 };
 
 // ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
@@ -166,6 +171,113 @@ __device__ __forceinline__ EF fold_n_base(const u32 (&in)[N], const EF& r0, cons
 
 // MODE 0: layer storage with base numerators (the caller's input layer), 1: layer storage with EF numerators, 2: the four
 // SoA work arrays (nl, nr~, dl, dr).  F: number of pending challenges folded in first.  LA: compute the look-ahead sums.
+
+// the four arrays at output index i: inputs (i << F) .. + 2^F folded by (r0, r1)
+template <int MODE, int F>
+__device__ __forceinline__ void gkr_entry(const u32* __restrict__ n_in, const u32* __restrict__ d_in, const u32* __restrict__ arr_in, u64 m_in,
+                                          u64 i, const EF& r0, const EF& r1, const EF& alpha, EF (&x)[4]) {
+    constexpr int NIN = 1 << F;  // inputs per output entry
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            EF in[NIN];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                u32 a[NIN];
+                load_n<NIN>(arr_in + ((u64)q * 5 + k) * m_in + (i << F), a);
+#pragma unroll
+                for (int e = 0; e < NIN; e++) in[e].v[k] = a[e];
+            }
+            x[q] = fold_n<NIN>(in, r0, r1);
+        }
+    } else {
+        // storage: array index y <-> entries 2y (left), 2y + 1 (right); this thread's inputs y = (i << F) .. + NIN
+        const u64 plane = 2 * m_in;
+        const u64 at = i << (F + 1);
+        {
+            EF l[NIN], r[NIN];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                u32 a[NIN], b[NIN];
+                load_lr<NIN>(d_in + (u64)k * plane + at, a, b);
+#pragma unroll
+                for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
+            }
+            x[2] = fold_n<NIN>(l, r0, r1), x[3] = fold_n<NIN>(r, r0, r1);
+        }
+        if constexpr (MODE == 0) {
+            u32 a[NIN], b[NIN];
+            load_lr<NIN>(n_in + at, a, b);
+            x[0] = fold_n_base<NIN>(a, r0, r1), x[1] = fold_n_base<NIN>(b, r0, r1);
+        } else {
+            EF l[NIN], r[NIN];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                u32 a[NIN], b[NIN];
+                load_lr<NIN>(n_in + (u64)k * plane + at, a, b);
+#pragma unroll
+                for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
+            }
+            x[0] = fold_n<NIN>(l, r0, r1), x[1] = fold_n<NIN>(r, r0, r1);
+        }
+        x[1] = ef_add(x[1], ef_mul(alpha, x[3]));  // nr~ = nr + alpha dr
+    }
+}
+
+// sums of one entry: its own bracket e and the quad's difference forms of its lane class (see above); w = eq weight of the quad
+// (LA) or of the pair (!LA).  All four lanes of a quad call this together (idle lanes with x = 0).
+template <bool LA>
+__device__ __forceinline__ void gkr_quad_sums(const EF (&x)[4], const EF& w, u32 cls, EF& acc_e, EF& acc_x, EF& acc_y) {
+    const EF e = ef_add(ef_mul(x[0], x[3]), ef_mul(x[1], x[2]));
+    EF A[4], H[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u32 v = x[q].v[k];
+            const u32 v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v), v3 = quad_bcast<3>(v);
+            const u32 d1 = sub(v1, v0), d3 = sub(v3, v2);
+            if (LA) {
+                const u32 ee = sub(v2, v0), gg = sub(d3, d1);
+                A[q].v[k] = cls == 0 ? gg : cls == 1 ? d1 : cls == 2 ? ee : d3;
+                H[q].v[k] = sub(v3, v1);
+            } else {
+                A[q].v[k] = cls == 1 ? d1 : d3;
+            }
+        }
+    const EF X = ef_add(ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
+    acc_e = ef_add(acc_e, ef_mul(e, w));
+    acc_x = ef_add(acc_x, ef_mul(X, w));
+    if (LA) {
+        const EF Y = ef_add(ef_mul(H[0], H[3]), ef_mul(H[1], H[2]));
+        acc_y = ef_add(acc_y, ef_mul(Y, w));
+    }
+}
+
+// per-class block sums (lanes of equal lane & 3) -> tot[GKR_SUM_WORDS], valid in threads < GKR_SUM_WORDS after the call
+// (lds: (blockDim.x / 64) * GKR_SUM_WORDS words)
+__device__ __forceinline__ void gkr_block_sums(const EF& acc_e, const EF& acc_x, const EF& acc_y, u32* lds, u32* tot) {
+    u32 v[15];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = acc_e.v[k], v[5 + k] = acc_x.v[k], v[10 + k] = acc_y.v[k];
+#pragma unroll
+    for (int s = 0; s < 15; s++)
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) v[s] = add(v[s], (u32)__shfl_down(v[s], off, 64));
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int s = 0; s < 15; s++) lds[wave * GKR_SUM_WORDS + lane * 15 + s] = v[s];
+    }
+    __syncthreads();
+    if (threadIdx.x < GKR_SUM_WORDS) {
+        u32 s = 0;
+        for (u32 wv = 0; wv < (blockDim.x >> 6); wv++) s = add(s, lds[wv * GKR_SUM_WORDS + threadIdx.x]);
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 template <int MODE, int F, bool LA>
 __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
                                                   const u32* __restrict__ arr_in, u64 m_out, u64 n_threads, u64 valid_in, EF r0, EF r1, EF alpha,
@@ -174,7 +286,6 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
                                                   u32* __restrict__ h_res, u32 seq) {
     __shared__ u32 lds[4 * GKR_SUM_WORDS];
     __shared__ u32 tot[GKR_SUM_WORDS];
-    constexpr int NIN = 1 << F;  // inputs per output entry
     const u64 m_in = m_out << F;
     const u32 cls = threadIdx.x & 3;
     EF acc_e = ef_zero(), acc_x = ef_zero(), acc_y = ef_zero();
@@ -189,53 +300,7 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
             x[0] = ef_zero(), x[1] = alpha, x[2] = ef_one(), x[3] = ef_one();
         }
         if (active) {
-          if (!padding) {
-            if constexpr (MODE == 2) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    EF in[NIN];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        u32 a[NIN];
-                        load_n<NIN>(arr_in + ((u64)q * 5 + k) * m_in + (i << F), a);
-#pragma unroll
-                        for (int e = 0; e < NIN; e++) in[e].v[k] = a[e];
-                    }
-                    x[q] = fold_n<NIN>(in, r0, r1);
-                }
-            } else {
-                // storage: array index y <-> entries 2y (left), 2y + 1 (right); this thread's inputs y = (i << F) .. + NIN
-                const u64 plane = 2 * m_in;
-                const u64 at = i << (F + 1);
-                {
-                    EF l[NIN], r[NIN];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        u32 a[NIN], b[NIN];
-                        load_lr<NIN>(d_in + (u64)k * plane + at, a, b);
-#pragma unroll
-                        for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
-                    }
-                    x[2] = fold_n<NIN>(l, r0, r1), x[3] = fold_n<NIN>(r, r0, r1);
-                }
-                if constexpr (MODE == 0) {
-                    u32 a[NIN], b[NIN];
-                    load_lr<NIN>(n_in + at, a, b);
-                    x[0] = fold_n_base<NIN>(a, r0, r1), x[1] = fold_n_base<NIN>(b, r0, r1);
-                } else {
-                    EF l[NIN], r[NIN];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        u32 a[NIN], b[NIN];
-                        load_lr<NIN>(n_in + (u64)k * plane + at, a, b);
-#pragma unroll
-                        for (int e = 0; e < NIN; e++) l[e].v[k] = a[e], r[e].v[k] = b[e];
-                    }
-                    x[0] = fold_n<NIN>(l, r0, r1), x[1] = fold_n<NIN>(r, r0, r1);
-                }
-                x[1] = ef_add(x[1], ef_mul(alpha, x[3]));  // nr~ = nr + alpha dr
-            }
-          }
+            if (!padding) gkr_entry<MODE, F>(n_in, d_in, arr_in, m_in, i, r0, r1, alpha, x);
             if constexpr (F > 0) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -254,53 +319,10 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
             for (int q = 0; q < 4; q++) x[q] = ef_zero();
         }
         // ---- sums: own entry, then the quad's differences ----
-        const EF e = ef_add(ef_mul(x[0], x[3]), ef_mul(x[1], x[2]));
-        EF A[4], H[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const u32 v = x[q].v[k];
-                const u32 v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v), v3 = quad_bcast<3>(v);
-                const u32 d1 = sub(v1, v0), d3 = sub(v3, v2);
-                if (LA) {
-                    const u32 ee = sub(v2, v0), gg = sub(d3, d1);
-                    A[q].v[k] = cls == 0 ? gg : cls == 1 ? d1 : cls == 2 ? ee : d3;
-                    H[q].v[k] = sub(v3, v1);
-                } else {
-                    A[q].v[k] = cls == 1 ? d1 : d3;
-                }
-            }
-        const EF X = ef_add(ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
         const EF w = eq_split_at(eq, active ? (LA ? i >> 2 : i >> 1) : 0);  // (n_threads is a multiple of 4: a quad is all-active or all-idle)
-        acc_e = ef_add(acc_e, ef_mul(e, w));
-        acc_x = ef_add(acc_x, ef_mul(X, w));
-        if (LA) {
-            const EF Y = ef_add(ef_mul(H[0], H[3]), ef_mul(H[1], H[2]));
-            acc_y = ef_add(acc_y, ef_mul(Y, w));
-        }
+        gkr_quad_sums<LA>(x, w, cls, acc_e, acc_x, acc_y);
     }
-    // ---- per-class block sums: lanes of equal (lane & 3) ----
-    u32 v[15];
-#pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = acc_e.v[k], v[5 + k] = acc_x.v[k], v[10 + k] = acc_y.v[k];
-#pragma unroll
-    for (int s = 0; s < 15; s++)
-#pragma unroll
-        for (int off = 32; off >= 4; off >>= 1) v[s] = add(v[s], (u32)__shfl_down(v[s], off, 64));
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < 4) {
-#pragma unroll
-        for (int s = 0; s < 15; s++) lds[wave * GKR_SUM_WORDS + lane * 15 + s] = v[s];
-    }
-    __syncthreads();
-    if (threadIdx.x < GKR_SUM_WORDS) {
-        u32 s = 0;
-#pragma unroll
-        for (int wv = 0; wv < 4; wv++) s = add(s, lds[wv * GKR_SUM_WORDS + threadIdx.x]);
-        tot[threadIdx.x] = s;
-    }
-    __syncthreads();
+    gkr_block_sums(acc_e, acc_x, acc_y, lds, tot);
     if (gridDim.x > 1 && !lm_grid_sum<GKR_SUM_WORDS>(tot, acc, done_counter, tot)) return;
     if (threadIdx.x < GKR_SUM_WORDS) {
         lm_store_system(h_res + threadIdx.x, tot[threadIdx.x]);
@@ -310,11 +332,284 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
     if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
 }
 
+// ---- the resident tail of a layer ------------------------------------------------------------------------------------
+// Once the four arrays have <= GKR_TAIL_MAX entries each, ONE workgroup keeps them in LDS and stays on the device for the
+// rest of the layer: it publishes the sums of a round pair exactly as k_gkr_step does, then polls a mailbox line in pinned
+// host memory for the two challenges, folds in LDS and goes on — no launch and no kernel completion per exchange
+// (tools/ubench/mailbox.hip: 4.3 us per exchange against 8 us for the smallest launch + publish).  What bounds an exchange
+// then is the LATENCY of one wave's instruction stream (a lone wave retires an instruction every ~8 cycles: the 21 extension
+// multiplications k_gkr_step spends per entry are 9 us however few entries there are), so the work of one entry is spread
+// over lanes of different WAVES, each role wave-uniform:
+//   phase A: wave (j, q) folds array q of entries 64 j .. + 64 (3 multiplications), LDS -> LDS;
+//   phase B: wave (j, role) reads its entry's quad of two arrays from LDS and multiplies ONE pair of operands, then the quad's
+//            eq weight: role 0 / 1: (nl, dr) / (nr~, dl) at the entry itself — or, in lane class 3 whose own bracket no round
+//            needs, the H = x3 - x1 forms (T3); role 2 / 3: the same two pairs on the class's difference form (k_gkr_step's A).
+// Five multiplications deep instead of 21.  The sums leave in k_gkr_step's [class][slot][5] order.
+// Mailbox line (16 words, lm_ctx::h_cmd): words 0..9 = r0, r1 with bit 31 (free: field words are < 2^31) carrying the parity
+// of the sequence number the NEXT publication must use, word 10 = that sequence number, word 11 = GKR_TAIL_ABORT to dismiss
+// the kernel.  A message is complete when all conditions hold in ONE wave-wide load of the line: no ordering between the
+// host's stores is assumed.
+// Above 256 entries the tail runs as W = entries / 256 workgroups, each owning a contiguous slice (LSB-first folding keeps a
+// slice's outputs inside it): every workgroup publishes its own partial sums (slot w of the pinned buffer, the host adds
+// them) and polls the same mailbox line; no workgroup talks to another until a slice is down to one quad or two, when the
+// others hand their folded entries to workgroup 0 through device memory (agent-scope stores + a ticket) and leave.
+static constexpr u32 GKR_TAIL_SLICE = 256;                 // entries per workgroup
+static constexpr u32 GKR_TAIL_MAX_W = 16;
+static constexpr u32 GKR_TAIL_MAX = GKR_TAIL_SLICE * GKR_TAIL_MAX_W;
+static constexpr u32 GKR_TAIL_THREADS = 4 * GKR_TAIL_SLICE;
+static constexpr u32 GKR_TAIL_STEPS = 7;  // entries: 4096, 1024, 256, 64, 16, 4  /  2048, 512, 128, 32, 8, 2
+static constexpr u32 GKR_TAIL_SLOT_AT = 1024, GKR_TAIL_SLOT_WORDS = 64;  // h_res: partial sums of workgroup w > 0 (+ 63: its flag)
+static constexpr u32 GKR_TAIL_MERGE_WORDS = GKR_TAIL_MAX_W * 2 * 20;       // device scratch of the hand-over
+static constexpr u32 GKR_TAIL_ABORT = 0xdead0001u;
+static constexpr unsigned long long GKR_TAIL_TIMEOUT = 300000000ull;  // wall_clock64 ticks (100 MHz): 3 s without an answer = abandoned
+struct GkrTailEq {
+    EqSplit e[GKR_TAIL_STEPS];
+};
+
+// array q of the entry at output index i (gkr_entry, one array)
+template <int MODE, int F>
+__device__ __forceinline__ EF gkr_entry_one(u32 q, const u32* __restrict__ n_in, const u32* __restrict__ d_in, const u32* __restrict__ arr_in,
+                                            u64 m_in, u64 i, const EF& r0, const EF& r1, const EF& alpha) {
+    constexpr int NIN = 1 << F;
+    if constexpr (MODE == 2) {
+        EF in[NIN];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            u32 a[NIN];
+            load_n<NIN>(arr_in + ((u64)q * 5 + k) * m_in + (i << F), a);
+#pragma unroll
+            for (int e = 0; e < NIN; e++) in[e].v[k] = a[e];
+        }
+        return fold_n<NIN>(in, r0, r1);
+    } else {
+        const u64 plane = 2 * m_in;
+        const u64 at = i << (F + 1);
+        auto ext = [&](const u32* base, bool right) {
+            EF s[NIN];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                u32 a[NIN], b[NIN];
+                load_lr<NIN>(base + (u64)k * plane + at, a, b);
+#pragma unroll
+                for (int e = 0; e < NIN; e++) s[e].v[k] = right ? b[e] : a[e];
+            }
+            return fold_n<NIN>(s, r0, r1);
+        };
+        auto num = [&](bool right) {
+            if constexpr (MODE == 0) {
+                u32 a[NIN], b[NIN];
+                load_lr<NIN>(n_in + at, a, b);
+                return right ? fold_n_base<NIN>(b, r0, r1) : fold_n_base<NIN>(a, r0, r1);
+            } else {
+                return ext(n_in, right);
+            }
+        };
+        if (q == 0) return num(false);
+        if (q == 1) return ef_add(num(true), ef_mul(alpha, ext(d_in, true)));  // nr~ = nr + alpha dr
+        return ext(d_in, q == 3);
+    }
+}
+
+template <int MODE, int F>
+__global__ __launch_bounds__(GKR_TAIL_THREADS) void k_gkr_tail(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
+                                                               const u32* __restrict__ arr_in, u32 m_out0, u64 valid_in, EF r0, EF r1, EF alpha,
+                                                               GkrTailEq eqs, u32* __restrict__ h_res, u32 seq0, const u32* __restrict__ h_cmd,
+                                                               u32* __restrict__ merge_buf, u32* __restrict__ merge_counter) {
+    __shared__ __attribute__((aligned(16))) u32 arr[20 * GKR_TAIL_SLICE];  // [(array * 5 + k) * stride + i], stride = max(local length, 4)
+    __shared__ u32 red[(GKR_TAIL_THREADS / 64) * 20];                      // per wave: [class][5]
+    __shared__ u32 msg[16];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 role = wv & 3, grp = wv >> 2;  // phase A: array `role`; phase B: operand pair / form `role`
+    const u32 i = grp * 64 + lane;            // local entry
+    const u32 W = gridDim.x;
+    u32 w = blockIdx.x;
+    bool solo = W == 1;
+    u32 S = m_out0 / W;  // local length
+    u32 m_out = m_out0;  // global length
+    u32 seq = seq0;
+    for (u32 step = 0;; step++) {
+        const bool la = m_out >= 4;
+        const EqSplit eq = eqs.e[step];
+        // ---- phase A: array `role` of local entry i ----
+        EF xa = ef_zero();
+        if (step == 0) {
+            const u64 gi = (u64)w * S + i;
+            const u64 m_in = (u64)m_out << F;
+            if (i < S) {
+                if ((MODE == 2 ? (gi << F) : (gi << (F + 1))) >= valid_in)
+                    xa = role == 0 ? ef_zero() : role == 1 ? alpha : ef_one();  // folded padding (0, alpha, 1, 1)
+                else
+                    xa = gkr_entry_one<MODE, F>(role, n_in, d_in, arr_in, m_in, gi, r0, r1, alpha);
+            }
+        } else {
+            // fold the LDS arrays by the two challenges of the message (in place: all reads, barrier, all writes)
+            const u32 Sn = S >> 2;
+            if (i < Sn) {
+                EF c0, c1;
+#pragma unroll
+                for (int k = 0; k < 5; k++) c0.v[k] = msg[k], c1.v[k] = msg[5 + k];
+                EF in[4];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(arr + (role * 5 + k) * S + (i << 2));
+                    in[0].v[k] = v.x, in[1].v[k] = v.y, in[2].v[k] = v.z, in[3].v[k] = v.w;
+                }
+                xa = fold_n<4>(in, c0, c1);
+            }
+            __syncthreads();
+            if (!solo && Sn < 4) {
+                // ---- hand-over: the slices are too short for a quad each; workgroup 0 takes everything ----
+                if (w > 0) {
+                    if (i < Sn) {
+#pragma unroll
+                        for (int k = 0; k < 5; k++) lm_store_agent(merge_buf + ((w * 2 + i) * 4 + role) * 5 + k, xa.v[k]);
+                    }
+                    lm_wait_stores();
+                    __syncthreads();
+                    if (threadIdx.x == 0) (void)lm_ticket(merge_counter);
+                    return;
+                }
+                if (threadIdx.x == 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    bool ok = true;
+                    while (lm_load_agent(merge_counter) != W - 1)
+                        if (wall_clock64() - t0 > GKR_TAIL_TIMEOUT) {
+                            ok = false;
+                            break;
+                        }
+                    lm_store_agent(merge_counter, 0);  // re-armed for the next kernel on the stream
+                    msg[12] = ok ? 0 : GKR_TAIL_ABORT;
+                }
+                __syncthreads();
+                if (msg[12] == GKR_TAIL_ABORT) return;
+                const u32 Sm = W * Sn, stride = Sm < 4 ? 4 : Sm;
+                // own entries, then the others' (thread = (array, plane, entry) of the gathered part), zero above Sm
+                if (i < Sn) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) arr[(role * 5 + k) * stride + i] = xa.v[k];
+                }
+                if (threadIdx.x < 20 * stride) {
+                    const u32 qk = threadIdx.x / stride, e = threadIdx.x % stride;
+                    if (e >= Sn) {
+                        const u32 src_w = e / Sn, src_i = e % Sn;
+                        arr[qk * stride + e] = e < Sm ? lm_load_agent(merge_buf + ((src_w * 2 + src_i) * 4 + qk / 5) * 5 + qk % 5) : 0;
+                    }
+                }
+                solo = true;
+                S = Sm;
+            } else {
+                S = Sn;
+                const u32 stride = S < 4 ? 4 : S;
+                if (i < stride) {  // (entries S .. 4 of a two-entry tail are zero)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) arr[(role * 5 + k) * stride + i] = xa.v[k];
+                }
+            }
+        }
+        const u32 stride = S < 4 ? 4 : S;
+        if (step == 0 && i < stride) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) arr[(role * 5 + k) * stride + i] = xa.v[k];
+        }
+        __syncthreads();
+        if (m_out <= 4 && threadIdx.x < 20 * m_out) {  // the layer's last entries go to the host as well (lm_gkr_layer_end folds them)
+            const u32 qk = threadIdx.x / m_out, e = threadIdx.x % m_out;
+            lm_store_system(h_res + GKR_FIN_AT + qk * 4 + e, arr[qk * stride + e]);
+        }
+        // ---- phase B: one operand pair of one form per thread ----
+        EF acc = ef_zero();
+        if (i < S) {
+            const u32 cls = i & 3;
+            const u32 qa = role & 1 ? 1 : 0, qb = role & 1 ? 2 : 3;
+            EF A, B;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint4 va = *reinterpret_cast<const uint4*>(arr + (qa * 5 + k) * stride + (i & ~3u));
+                const uint4 vb = *reinterpret_cast<const uint4*>(arr + (qb * 5 + k) * stride + (i & ~3u));
+                if (role < 2) {
+                    A.v[k] = cls == 0 ? va.x : cls == 1 ? va.y : cls == 2 ? va.z : sub(va.w, va.y);
+                    B.v[k] = cls == 0 ? vb.x : cls == 1 ? vb.y : cls == 2 ? vb.z : sub(vb.w, vb.y);
+                } else {
+                    const u32 a1 = sub(va.y, va.x), a3 = sub(va.w, va.z), b1 = sub(vb.y, vb.x), b3 = sub(vb.w, vb.z);
+                    A.v[k] = cls == 0 ? sub(a3, a1) : cls == 1 ? a1 : cls == 2 ? sub(va.z, va.x) : a3;
+                    B.v[k] = cls == 0 ? sub(b3, b1) : cls == 1 ? b1 : cls == 2 ? sub(vb.z, vb.x) : b3;
+                }
+            }
+            const EF wgt = eq_split_at(eq, la ? ((u64)(solo ? 0 : w) * S + i) >> 2 : 0);
+            acc = ef_mul(ef_mul(A, B), wgt);
+        }
+        // ---- sums per lane class inside the wave, then across the waves of a role pair ----
+        {
+            u32 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) v[k] = acc.v[k];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int off = 32; off >= 4; off >>= 1) v[k] = add(v[k], (u32)__shfl_down(v[k], off, 64));
+            if (lane < 4) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) red[wv * 20 + lane * 5 + k] = v[k];
+            }
+        }
+        __syncthreads();
+        u32* const out = h_res + (w == 0 ? 0 : GKR_TAIL_SLOT_AT + w * GKR_TAIL_SLOT_WORDS);
+        if (threadIdx.x < GKR_SUM_WORDS) {
+            const u32 cls = threadIdx.x / 15, sl = (threadIdx.x % 15) / 5, k = threadIdx.x % 5;
+            // slot 0 (e): roles 0, 1 of classes 0..2; slot 1 (X): roles 2, 3; slot 2 (Y, class 0 only): roles 0, 1 of class 3
+            const u32 src_cls = sl == 2 ? 3 : cls;
+            const bool used = sl == 0 ? cls < 3 : sl == 1 ? true : cls == 0;
+            u32 t = 0;
+            if (used)
+                for (u32 g4 = 0; g4 < GKR_TAIL_THREADS / 256; g4++)
+                    for (u32 r = 0; r < 2; r++) t = add(t, red[(g4 * 4 + (sl == 1 ? 2 : 0) + r) * 20 + src_cls * 5 + k]);
+            lm_store_system(out + threadIdx.x, t);
+        }
+        lm_wait_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) lm_publish_flag_word(w == 0 ? h_res + lm_ctx::RES_FLAG : out + GKR_TAIL_SLOT_WORDS - 1, seq);
+        if (m_out <= 4) return;  // the layer's last launch-equivalent: lm_gkr_layer_end folds the rest on the host
+        // ---- wait for the two challenges ----
+        seq++;
+        if (threadIdx.x < 64) {
+            const unsigned long long t0 = wall_clock64();
+            u32 v = 0;
+            bool done = false, dismissed = false;
+            while (!done) {
+                v = lane < 16 ? __hip_atomic_load(h_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+                const bool ok = lane < 10 ? (v >> 31) == (seq & 1) : lane == 10 ? v == seq : true;
+                done = __ballot(ok) == ~0ull;
+                dismissed = __ballot(lane == 11 && v == GKR_TAIL_ABORT) != 0 || wall_clock64() - t0 > GKR_TAIL_TIMEOUT;
+                if (dismissed) break;
+            }
+            if (lane < 16) msg[lane] = dismissed ? GKR_TAIL_ABORT : (v & 0x7fffffffu);
+        }
+        __syncthreads();
+        if (msg[11] == GKR_TAIL_ABORT) return;
+        m_out >>= 2;
+    }
+}
+
 namespace {
 EF host_ef(const u32* p) {
     EF r;
     memcpy(r.v, p, 20);
     return r;
+}
+bool gkr_tail_enabled() {
+    static const bool on = getenv("LM_GKR_NO_TAIL") == nullptr;
+    return on;
+}
+// a resident workgroup whose layer is abandoned (error path, early free) is told to leave; it would otherwise poll until its
+// own timeout
+void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
+    if (!g->tail_live) return;
+    ((volatile u32*)ctx->h_cmd)[11] = GKR_TAIL_ABORT;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream);  // the hand-over ticket of an interrupted multi-workgroup tail
+    ctx->h_cmd[11] = 0;
+    g->tail_live = false;
 }
 // a + r (b + r c)
 EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
@@ -324,10 +619,12 @@ extern "C" {
 
 void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
     if (!g) return;
+    gkr_tail_dismiss(ctx, g);
     for (u32* p : g->nums) lm_pool_free(ctx, p);
     for (u32* p : g->dens) lm_pool_free(ctx, p);
     for (int i = 0; i < 2; i++) lm_pool_free(ctx, g->work[i]);
     lm_pool_free(ctx, g->eqt.d_buf);
+    lm_pool_free(ctx, g->d_merge);
     delete g;
 }
 
@@ -373,7 +670,8 @@ int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_d
     const u64 w1 = std::max<u64>(g->work_words / 4, 256);
     if (lm_pool_alloc_t(ctx, &g->work[0], g->work_words * 4) != hipSuccess ||
         lm_pool_alloc_t(ctx, &g->work[1], w1 * 4) != hipSuccess ||
-        lm_pool_alloc_t(ctx, &g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess) {
+        lm_pool_alloc_t(ctx, &g->eqt.d_buf, PrefixEqTables::words_needed(n_vars) * 4) != hipSuccess ||
+        lm_pool_alloc_t(ctx, &g->d_merge, GKR_TAIL_MERGE_WORDS * 4) != hipSuccess) {
         lm_set_error("lm_gkr_build: device allocation failed (work)");
         lm_gkr_free(ctx, g);
         return LM_E_NOMEM;
@@ -406,6 +704,7 @@ int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32)
 // Start the sumcheck of the layer with 2^(K+1) entries (K = number of coordinates of the claim point, 5 <= K < n_vars).
 int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point, const uint32_t alpha[5]) {
     LM_REQUIRE(ctx && g && point && alpha && K >= 5 && K < g->n_vars);
+    gkr_tail_dismiss(ctx, g);
     g->K = K;
     g->round = 0;
     g->cur = -1;
@@ -450,19 +749,79 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const bool input_layer0 = g->K == g->n_vars - 1;
     const u64 valid_in = g->cur < 0 ? (input_layer0 ? g->valid0 : g->valid[g->n_vars - g->K - 2]) : g->arr_valid;
     const u64 arr_in_valid = g->cur < 0 ? valid_in / 2 : valid_in;                      // in array entries
-    const u64 n_threads = round_up8((arr_in_valid + (1ull << F) - 1) >> F, m_out);     // outputs that are computed (rest: closed form)
-    const u32 blocks = (u32)std::min<u64>((n_threads + 255) / 256, 1024);
+    u64 n_threads = round_up8((arr_in_valid + (1ull << F) - 1) >> F, m_out);     // outputs that are computed (rest: closed form)
     int rc;
-    const u32 seq = ++ctx->res_seq;
+    const int dst = g->cur < 0 ? 0 : 1 - g->cur;
     const bool input_layer = input_layer0;
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
     // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
     const u32* n_st = input_layer ? g->d_nums0 : g->nums[g->n_vars - g->K - 2];
     const u32* d_st = input_layer ? g->d_dens0 : g->dens[g->n_vars - g->K - 2];
     const EF r0 = F ? g->pending[0] : ef_zero(), r1 = F ? g->pending[1] : ef_zero();
-    const int dst = g->cur < 0 ? 0 : 1 - g->cur;
-    u32* counter = ctx->d_sync + 1;
     const u32* nul = nullptr;
+    u32 seq;
+    if (g->tail_live) {
+        // the resident workgroup holds the arrays in LDS: hand it the two challenges (bit 31 = parity of the sequence number
+        // of its next publication, see k_gkr_tail) and wait for that publication
+        LM_REQUIRE(F == 2 && ctx->res_seq == g->tail_seq);
+        seq = ++ctx->res_seq;
+        volatile u32* cmd = ctx->h_cmd;
+        const u32 tag = (seq & 1) << 31;
+        for (int k = 0; k < 5; k++) cmd[k] = r0.v[k] | tag, cmd[5 + k] = r1.v[k] | tag;
+        cmd[10] = seq;
+        n_threads = m_out;  // the resident workgroup materialises every entry (padding included)
+        const u32 Sn = g->tail_S >> 2;
+        if (!g->tail_solo && Sn < 4) {
+            g->tail_solo = true;
+            g->tail_S = g->tail_W * Sn;
+        } else {
+            g->tail_S = Sn;
+        }
+    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8) {
+        seq = ++ctx->res_seq;
+        GkrTailEq eqs;
+        {
+            u32 s = 0;
+            for (u64 mo = m_out; s < GKR_TAIL_STEPS; mo >>= 2, s++) {
+                // step s answers round t + 2 s: 2^(p - 2 s) pairs
+                const u32 ps = p - 2 * s;
+                eqs.e[s] = g->eqt.at(mo >= 4 ? ps - 1 : ps);
+                if (mo <= 4) break;
+            }
+            LM_REQUIRE(s < GKR_TAIL_STEPS);
+        }
+        // no stale message, no stale dismissal; the payload words carry the parity the FIRST message will NOT have (that of this
+        // launch's own sequence number), so a poll that sees part of the line before and part after the host's stores is refused
+        for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) ((volatile u32*)ctx->h_cmd)[i] = i < 10 ? (seq & 1) << 31 : 0;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        g->tail_W = (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE);
+        g->tail_S = (u32)(m_out / g->tail_W);
+        g->tail_solo = g->tail_W == 1;
+#define GKR_TAIL(MODE, FF, NI, DI, AI) \
+    LM_LAUNCH(ctx, (k_gkr_tail<MODE, FF>), dim3(g->tail_W), dim3(GKR_TAIL_THREADS), 0, NI, DI, AI, (u32)m_out, valid_in, r0, r1, g->alpha, eqs, ctx->h_res, seq, (const u32*)ctx->h_cmd, g->d_merge, ctx->d_sync + 1)
+        if (g->cur < 0) {
+            if (F == 0) {
+                if (input_layer)
+                    GKR_TAIL(0, 0, n_st, d_st, nul);
+                else
+                    GKR_TAIL(1, 0, n_st, d_st, nul);
+            } else {
+                if (input_layer)
+                    GKR_TAIL(0, 2, n_st, d_st, nul);
+                else
+                    GKR_TAIL(1, 2, n_st, d_st, nul);
+            }
+        } else {
+            LM_REQUIRE(F == 2);
+            GKR_TAIL(2, 2, nul, nul, (const u32*)g->work[g->cur]);
+        }
+#undef GKR_TAIL
+        g->tail_live = true;
+        n_threads = m_out;
+    } else {
+    const u32 blocks = (u32)std::min<u64>((n_threads + 255) / 256, 1024);
+    seq = ++ctx->res_seq;
+    u32* counter = ctx->d_sync + 1;
 #define GKR_STEP(MODE, FF, LL, NI, DI, AI) \
     LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq)
     if (g->cur < 0) {
@@ -486,9 +845,39 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             GKR_STEP(2, 2, false, nul, nul, (const u32*)g->work[g->cur]);
     }
 #undef GKR_STEP
+    }
     LM_HIP(hipGetLastError());
-    if ((rc = lm_wait_result(ctx, seq))) return rc;
+    if ((rc = lm_wait_result(ctx, seq))) {
+        gkr_tail_dismiss(ctx, g);
+        return rc;
+    }
+    u32 h_sum[GKR_SUM_WORDS];
     const u32* h = ctx->h_res;
+    if (g->tail_live) {
+        g->tail_seq = seq;
+        if (m_out <= 4) g->tail_live = false;  // the workgroup returned after this publication
+        if (!g->tail_solo) {
+            // every workgroup published its own partial sums: wait for the other flags, add the slots
+            memcpy(h_sum, ctx->h_res, sizeof h_sum);
+            for (u32 w = 1; w < g->tail_W; w++) {
+                volatile u32* slot = ctx->h_res + GKR_TAIL_SLOT_AT + w * GKR_TAIL_SLOT_WORDS;
+                u64 spins = 0;
+                while (slot[GKR_TAIL_SLOT_WORDS - 1] != seq) {
+                    if (++spins > (1ull << 28)) {
+                        lm_set_error("lm_gkr_round: workgroup %u of the resident tail never published sequence %u", w, seq);
+                        gkr_tail_dismiss(ctx, g);
+                        return LM_E_DEVICE;
+                    }
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                for (u32 t = 0; t < GKR_SUM_WORDS; t++) h_sum[t] = add(h_sum[t], slot[t]);
+            }
+            h = h_sum;
+        }
+    }
     auto S = [&](u32 cls, u32 slot) { return host_ef(h + cls * 15 + slot * 5); };  // slot 0: e, 1: X, 2: Y
     EF c0, c2;
     if (la) {
@@ -534,7 +923,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             g->fin_m = (u32)m_out;
             for (int q = 0; q < 4; q++)
                 for (int k = 0; k < 5; k++)
-                    for (u32 i = 0; i < m_out; i++) g->fin[q][i].v[k] = h[GKR_FIN_AT + (q * 5 + k) * 4 + i];
+                    for (u32 i = 0; i < m_out; i++) g->fin[q][i].v[k] = ctx->h_res[GKR_FIN_AT + (q * 5 + k) * 4 + i];
         }
     }
     memcpy(out_c0_c2, c0.v, 20);

@@ -461,3 +461,25 @@ def test_runner_is_deterministic_under_repeated_parallel_runs(program):
         ex = execute(program, pi, w, n_threads=8 if k % 3 else 5)
         got = (ex.pcs().tobytes(), ex.fps().tobytes(), ex.memory().tobytes(), ex.poseidon_calls().tobytes(), ex.extension_rows().tobytes())
         assert got == ref, k
+
+
+def test_concurrent_runs_from_several_caller_threads(program):
+    """Several provers of one process run the VM at the same time (bench.py --inflight, whole node): the pool's per-thread segment
+    logs belong to ONE parallel batch at a time, so concurrent runs must take turns there and still give the sequential result."""
+    import threading
+    inputs = [xa.build_witness(program, 12 + 3 * t, np.random.default_rng(500 + t))[:2] for t in range(4)]
+    def snapshot(ex):
+        return (ex.pcs().tobytes(), ex.fps().tobytes(), ex.memory().tobytes(), ex.poseidon_calls().tobytes(), ex.extension_rows().tobytes())
+    ref = [snapshot(execute(program, pi, w, n_threads=6)) for pi, w in inputs]
+    bad = []
+    def worker(t):
+        pi, w = inputs[t]
+        for k in range(12):
+            if snapshot(execute(program, pi, w, n_threads=6)) != ref[t]:
+                bad.append((t, k))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad

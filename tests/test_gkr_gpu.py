@@ -55,3 +55,38 @@ def test_gkr_large_verifies_and_claims_match_mle(ctx, orc):
     assert np.array_equal(vq, q) and np.array_equal(vpt, pt) and np.array_equal(vcl, cl)
     assert list(ctx.mle_eval(d_n, False, log_n, pt)[0]) == list(cl[0])
     assert list(ctx.mle_eval(d_d, True, log_n, pt)[0]) == list(cl[1])
+
+
+@pytest.mark.parametrize("log_n,rounds_before_drop", [(14, 1), (14, 3), (14, 7), (9, 1), (12, 5)])
+def test_gkr_abandoned_layer_dismisses_the_resident_tail(ctx, orc, log_n, rounds_before_drop):
+    """The tail of a layer's sumcheck stays resident on the device between challenge pairs (k_gkr_tail: up to 16 workgroups
+    polling a mailbox).  A caller that drops the layer half way — error path, early free — must not leave them polling: lm_gkr_free
+    dismisses them (well inside their own 3 s timeout), the hand-over ticket is re-armed, and the context proves the next
+    instance as if nothing had happened."""
+    import ctypes as C
+    import time
+    rng = np.random.default_rng(4242 + log_n + rounds_before_drop)
+    nums, dens = ob.gkr_instance(orc, rng, log_n, 0.9)
+    d_n, d_d = ctx.to_device(nums), ctx.ef_to_device_soa(dens)
+    lib = ctx.lib
+    g = C.c_void_p()
+    assert lib.lm_gkr_build(ctx.h, d_n.ptr, d_d.ptr, log_n, C.byref(g)) == 0
+    K = log_n - 1  # the input layer: 2^(K+1) entries, K rounds
+    point = ob.rand_field(rng, (K, 5)).astype(np.uint32)
+    alpha = ob.rand_field(rng, (5,)).astype(np.uint32)
+    assert lib.lm_gkr_layer_begin(ctx.h, g, K, point.ctypes.data_as(C.c_void_p), alpha.ctypes.data_as(C.c_void_p)) == 0
+    out = np.zeros(10, dtype=np.uint32)
+    r = None
+    for t in range(rounds_before_drop):
+        assert lib.lm_gkr_round(ctx.h, g, None if r is None else r.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        r = ob.rand_field(rng, (5,)).astype(np.uint32)
+    t0 = time.time()
+    lib.lm_gkr_free(ctx.h, g)
+    assert time.time() - t0 < 1.0
+    # the same context proves a fresh instance correctly afterwards
+    nums2, dens2 = ob.gkr_instance(orc, rng, 13, 0.75)
+    ref_proof, rq, rpt, rcl = ob.gkr_prove(orc, nums2, dens2)
+    pr = lm.Prover(ctx)
+    q, pt, cl = pr.prove_gkr_quotient(ctx.to_device(nums2), ctx.ef_to_device_soa(dens2), 13)
+    assert np.array_equal(q, rq) and np.array_equal(pt, rpt) and np.array_equal(cl, rcl)
+    assert np.array_equal(pr.proof(), ref_proof)

@@ -6,6 +6,8 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include "lm_host_internal.h"
@@ -904,6 +906,36 @@ int lmh_prove_gkr_quotient_active(lm_ctx* ctx, lmh_prover* p, const uint32_t* d_
 }
 
 
+// Coefficients of the Lagrange basis polynomials of the nodes 0..d (row a: L_a = prod_{b != a} (X - b) / (a - b), base field),
+// built once per degree: the batched AIR sumcheck interpolates every table's round polynomial every round, between two
+// device exchanges.
+static const std::vector<u32>& lagrange_basis(u32 d) {
+    static std::mutex mu;
+    static std::map<u32, std::vector<u32>> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(d);
+    if (it != cache.end()) return it->second;
+    std::vector<u32> L((size_t)(d + 1) * (d + 1), 0);
+    for (u32 a = 0; a <= d; a++) {
+        std::vector<u32> num{kb::ONE};  // prod_{b != a} (X - b)
+        u32 den = kb::ONE;
+        for (u32 b = 0; b <= d; b++) {
+            if (b == a) continue;
+            std::vector<u32> nn(num.size() + 1, 0);
+            const u32 mb = kb::neg(kb::to_monty(b));
+            for (size_t c = 0; c < num.size(); c++) {
+                nn[c + 1] = kb::add(nn[c + 1], num[c]);
+                nn[c] = kb::add(nn[c], kb::mul(num[c], mb));
+            }
+            num.swap(nn);
+            den = kb::mul(den, kb::sub(kb::to_monty(a), kb::to_monty(b)));
+        }
+        const u32 inv_den = kb::inv(den);
+        for (size_t c = 0; c < num.size(); c++) L[(size_t)a * (d + 1) + c] = kb::mul(num[c], inv_den);
+    }
+    return cache.emplace(d, std::move(L)).first->second;
+}
+
 // prove_batched_air_sumcheck (air_sumcheck.rs:636-681) + compute_bare_round_poly / process_challenge (:225-292) host side
 int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_table* tables, uint32_t n_tables,
                                    const uint32_t alpha[5], const uint32_t* logup_eq16, const uint32_t bus_beta[5],
@@ -959,15 +991,24 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     std::vector<EF> eta_p(n_tables, kb::ef_one()), k(n_tables, kb::ef_one());
     for (u32 i = 1; i < n_tables; i++) eta_p[i] = kb::ef_mul(eta_p[i - 1], eta_e);
     std::vector<EF> challenges;
+    // LM_STAGE_TIMES: how the wall clock of the round loop splits into waiting for the device and host work between exchanges
+    const bool clk_on = getenv("LM_STAGE_TIMES") != nullptr;
+    double t_wait = 0, t_launch = 0;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     for (u32 round = 0; round < n_rounds; round++) {
         std::vector<EF> combined(max_full_degree + 1, kb::ef_zero());
         std::vector<std::vector<EF>> bare(n_tables);
         // the sessions are independent until the challenge: enqueue every active table's round, then collect
+        const auto tl0 = std::chrono::steady_clock::now();
         for (u32 i = 0; i < n_tables; i++)
             if (round >= n_rounds - ss[i].n_vars) {
                 int rc = lm_air_round_launch(ctx, ss[i].h);
                 if (rc) return cleanup(rc);
             }
+        if (clk_on) t_launch += since(tl0);
         for (u32 i = 0; i < n_tables; i++) {
             Session& s = ss[i];
             const u32 join = n_rounds - s.n_vars;
@@ -978,32 +1019,25 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             }
             // compute_bare_round_poly: raw sums at z = 0, 2, .., deg from the device
             std::vector<u32> raw((size_t)s.deg * 5);
+            const auto tw0 = std::chrono::steady_clock::now();
             int rc = lm_air_round_wait(ctx, s.h, raw.data());
             if (rc) return cleanup(rc);
+            if (clk_on) {
+                t_wait += since(tw0);
+                if (getenv("LM_AIR_DBG")) fprintf(stderr, "#     air round %u table %u: wait %.1f us\n", round, i, since(tw0) * 1e3);
+            }
             const u32 d = s.deg;
             std::vector<EF> ev(d + 1);
             ev[0] = kb::ef_mul(ef_load(&raw[0]), s.mmf);
             for (u32 z = 2; z <= d; z++) ev[z] = kb::ef_mul(ef_load(&raw[(size_t)(z - 1) * 5]), s.mmf);
             const EF eq_alpha = s.eq_factor.back();
             ev[1] = kb::ef_mul(kb::ef_sub(s.sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), ev[0])), kb::ef_inv(eq_alpha));
-            // DensePolynomial::lagrange_interpolation on the points 0..d
+            // DensePolynomial::lagrange_interpolation on the points 0..d: the basis polynomials depend on d only (lagrange_basis)
             std::vector<EF> coeffs(d + 1, kb::ef_zero());
-            for (u32 a = 0; a <= d; a++) {
-                std::vector<u32> num{kb::ONE};  // prod_{b != a} (X - b), base coefficients
-                u32 den = kb::ONE;
-                for (u32 b = 0; b <= d; b++) {
-                    if (b == a) continue;
-                    std::vector<u32> nn(num.size() + 1, 0);
-                    const u32 mb = kb::neg(kb::to_monty(b));
-                    for (size_t c = 0; c < num.size(); c++) {
-                        nn[c + 1] = kb::add(nn[c + 1], num[c]);
-                        nn[c] = kb::add(nn[c], kb::mul(num[c], mb));
-                    }
-                    num.swap(nn);
-                    den = kb::mul(den, kb::sub(kb::to_monty(a), kb::to_monty(b)));
-                }
-                const EF scale = kb::ef_mul_base(ev[a], kb::inv(den));
-                for (size_t c = 0; c < num.size(); c++) coeffs[c] = kb::ef_add(coeffs[c], kb::ef_mul_base(scale, num[c]));
+            {
+                const std::vector<u32>& L = lagrange_basis(d);
+                for (u32 a = 0; a <= d; a++)
+                    for (u32 c = 0; c <= d; c++) coeffs[c] = kb::ef_add(coeffs[c], kb::ef_mul_base(ev[a], L[(size_t)a * (d + 1) + c]));
             }
             bare[i] = coeffs;
             // expand_bare_to_full (fiat-shamir/src/utils.rs:30-41)
@@ -1037,6 +1071,11 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             if (rc) return cleanup(rc);
             s.eq_factor.pop_back();
         }
+    }
+    if (clk_on) {
+        const double total = since(t_loop0);
+        fprintf(stderr, "#   air: %u rounds %.3f ms: waiting for round sums %.3f ms, launch calls %.3f ms, host (interpolation, transcript, bind calls) %.3f ms\n",
+                n_rounds, total, t_wait, t_launch, total - t_wait - t_launch);
     }
     u32* oe = out_col_evals;
     for (u32 i = 0; i < n_tables; i++) {

@@ -7,6 +7,7 @@
 // During a layer's sumcheck the four multilinears (n_l, n_r, d_l, d_r) live as 4 SoA EF arrays that halve every round
 // (LSB-first folding, sumcheck_utils.rs:278-357).
 #include <algorithm>
+#include <atomic>
 #include "lm_common.h"
 #include "lm_eqsplit.h"
 
@@ -601,6 +602,22 @@ bool gkr_tail_enabled() {
     static const bool on = getenv("LM_GKR_NO_TAIL") == nullptr;
     return on;
 }
+// Resident workgroups hold their CU slots while they poll, and a tail makes progress only when ALL its workgroups are
+// resident: the tails of every prover of this process together must fit the chip (256 CUs x 2 workgroups of 1024 threads),
+// or tails could wait for each other's slots until their timeouts.  Above the cap a layer falls back to launches.
+static constexpr int GKR_TAIL_MAX_LIVE_WORKGROUPS = 256;
+std::atomic<int> g_tail_workgroups{0};
+bool gkr_tail_reserve(u32 W) {
+    if (g_tail_workgroups.fetch_add((int)W, std::memory_order_acq_rel) + (int)W > GKR_TAIL_MAX_LIVE_WORKGROUPS) {
+        g_tail_workgroups.fetch_sub((int)W, std::memory_order_acq_rel);
+        return false;
+    }
+    return true;
+}
+void gkr_tail_release(lm_gkr* g) {
+    g_tail_workgroups.fetch_sub((int)g->tail_W, std::memory_order_acq_rel);
+    g->tail_live = false;
+}
 // a resident workgroup whose layer is abandoned (error path, early free) is told to leave; it would otherwise poll until its
 // own timeout
 void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
@@ -609,7 +626,7 @@ void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream);  // the hand-over ticket of an interrupted multi-workgroup tail
     ctx->h_cmd[11] = 0;
-    g->tail_live = false;
+    gkr_tail_release(g);
 }
 // a + r (b + r c)
 EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
@@ -777,7 +794,8 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         } else {
             g->tail_S = Sn;
         }
-    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8) {
+    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8 &&
+               gkr_tail_reserve((u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
         seq = ++ctx->res_seq;
         GkrTailEq eqs;
         {
@@ -855,7 +873,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32* h = ctx->h_res;
     if (g->tail_live) {
         g->tail_seq = seq;
-        if (m_out <= 4) g->tail_live = false;  // the workgroup returned after this publication
+        if (m_out <= 4) gkr_tail_release(g);  // the workgroup returned after this publication
         if (!g->tail_solo) {
             // every workgroup published its own partial sums: wait for the other flags, add the slots
             memcpy(h_sum, ctx->h_res, sizeof h_sum);

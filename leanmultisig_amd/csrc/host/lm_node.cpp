@@ -10,6 +10,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "lm_host_internal.h"
@@ -26,6 +28,53 @@ struct lmh_vm_trace {
 };
 
 namespace {
+// ---- pinned upload sources -----------------------------------------------------------------------------------------------------
+// The runner's buffers (memory arena, logs) are recycled from run to run, so they are registered with the HIP runtime ONCE and
+// uploaded from by plain DMA afterwards (an upload from pageable memory pins and unpins its pages every time, inside the copy
+// call).  The runner reports every free / move of a buffer (vm_set_release_hook) and the registration goes with it.
+// LM_VM_NO_PIN=1 switches this off.
+struct PinRegistry {
+    std::mutex mu;
+    std::map<void*, size_t> pinned;  // base -> registered bytes
+};
+PinRegistry& pins() {
+    static PinRegistry r;
+    return r;
+}
+void unpin_hook(void* base) {
+    PinRegistry& r = pins();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.pinned.find(base);
+    if (it == r.pinned.end()) return;
+    (void)hipHostUnregister(base);
+    r.pinned.erase(it);
+}
+bool pin_enabled() {
+    static const bool on = getenv("LM_VM_NO_PIN") == nullptr;
+    return on;
+}
+// make [base, base + need) registered (need <= capacity); best effort: an upload from an unregistered buffer is still correct
+void ensure_pinned(const VmRegion& reg, size_t need) {
+    if (!pin_enabled() || !reg.base || need == 0 || need > reg.bytes) return;
+    static std::once_flag hook_once;
+    std::call_once(hook_once, [] { vm_set_release_hook(unpin_hook); });
+    const size_t gran = 4u << 20;
+    size_t want = (need + gran - 1) / gran * gran;
+    if (want > reg.bytes) want = reg.bytes;
+    PinRegistry& r = pins();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.pinned.find(reg.base);
+    if (it != r.pinned.end()) {
+        if (it->second >= need) return;
+        (void)hipHostUnregister(reg.base);
+        r.pinned.erase(it);
+    }
+    if (hipHostRegister(reg.base, want, hipHostRegisterDefault) == hipSuccess)
+        r.pinned[reg.base] = want;
+    else
+        (void)hipGetLastError();
+}
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int fill_words(lm_ctx* ctx, u32* d, u32 canonical, u64 count) {
@@ -49,9 +98,29 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     *out = nullptr;
     lm_vm_execution_view v;
     lmh_execution_view(e, &v);
+    {
+        VmRegion reg[5];
+        vm_execution_regions(e, reg);
+        ensure_pinned(reg[0], (size_t)(v.memory_len + 24) * 4);
+        ensure_pinned(reg[1], (size_t)v.n_cycles * 4);
+        ensure_pinned(reg[2], (size_t)v.n_cycles * 4);
+        ensure_pinned(reg[3], (size_t)v.n_poseidon_calls * LM_VM_POSEIDON_CALL_WORDS * 4);
+        ensure_pinned(reg[4], (size_t)v.n_extension_rows * LM_VM_EXTENSION_ROW_WORDS * 4);
+    }
     lmh_vm_trace* t = new lmh_vm_trace();
     memset(&t->view, 0, sizeof t->view);
     int rc = LM_OK;
+    // LM_VM_TIMES=1: wall clock of the steps below (each mark synchronises the stream: the total is pessimistic)
+    const bool clk = getenv("LM_VM_TIMES") != nullptr;
+    double t_mark = now_ms();
+    auto mark = [&](const char* what) {
+        if (!clk) return;
+        (void)lm_sync(ctx);
+        const double t1 = now_ms();
+        fprintf(stderr, "#   trace: %-28s %.3f ms\n", what, t1 - t_mark);
+        t_mark = t1;
+    };
+    mark("pin");
     auto fail = [&](int code) {
         lmh_vm_trace_free(ctx, t);
         return code;
@@ -108,6 +177,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     }
     if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24))) return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
     if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
+    mark("alloc + memory upload");
     // ---- bytecode table: device copy cached in the bytecode object -------------------------------------------------------------
     u32** slot = vm_bytecode_device_slot(bc, (void*)ctx);
     if (!*slot) {
@@ -139,6 +209,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
             (rc = fill_words(ctx, t->cols[0][22] + v.n_cycles, ending_pc, pad)) || (rc = fill_words(ctx, t->cols[0][23] + v.n_cycles, 0, pad)))
             return fail(rc);
     }
+    mark("execution table");
     // Poseidon16 table: call records -> flag / index / input columns, padding rows, then the permutation columns of every row
     {
         const u64 n = v.n_poseidon_calls, rows = 1ull << log_rows[2];
@@ -154,6 +225,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         if ((rc = lm_poseidon_trace(ctx, t->cols[2].data(), rows))) return fail(rc);
         if ((rc = lm_poseidon_trace_outputs_from_memory(ctx, t->cols[2].data(), n, d_memory, padded))) return fail(rc);
     }
+    mark("poseidon table");
     // ExtensionOp table
     {
         const u64 n = v.n_extension_rows, rows = 1ull << log_rows[1];
@@ -167,6 +239,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         if ((rc = lmh_pad_table(ctx, 1, t->cols[1].data(), n, log_rows[1], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
         if ((rc = fill_words(ctx, t->cols[1][29] + n, 0, rows - n)) || (rc = fill_words(ctx, t->cols[1][30] + n, 64, rows - n))) return fail(rc);
     }
+    mark("extension table");
     // the uploads above read the runner's host buffers asynchronously: they are consumed before this returns
     if ((rc = lm_sync(ctx))) return fail(rc);
     t->public_input.assign(public_input, public_input + n_public_input);

@@ -179,6 +179,13 @@ inline bool vm_times() {
     return on;
 }
 
+// lm_node.cpp pins the buffers it uploads from; it must hear about every free / move (vm_set_release_hook)
+std::atomic<void (*)(void*)> g_release_hook{nullptr};
+inline void notify_release(void* base) {
+    if (!base) return;
+    if (auto h = g_release_hook.load(std::memory_order_acquire)) h(base);
+}
+
 constexpr u32 UNDEF = 0xFFFFFFFFu;  // not a field element (values are < p < 2^31)
 constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
 
@@ -210,6 +217,7 @@ struct MemBuf {
                 return;
             }
         }
+        notify_release(p);
         munmap(p, MAX_MEMORY * 4);
     }
     MemBuf(const MemBuf&) = delete;
@@ -236,7 +244,10 @@ struct UVec {
     T* p = nullptr;
     size_t n = 0, cap = 0;
     UVec() {}
-    ~UVec() { free(p); }
+    ~UVec() {
+        notify_release(p);
+        free(p);
+    }
     UVec(const UVec&) = delete;
     UVec& operator=(const UVec&) = delete;
     size_t size() const { return n; }
@@ -251,6 +262,7 @@ struct UVec {
         if (c <= cap) return;
         size_t nc = cap ? cap : 256;
         while (nc < c) nc *= 2;
+        notify_release(p);
         T* q = (T*)realloc(p, nc * sizeof(T));
         if (!q) throw std::bad_alloc();
         p = q, cap = nc;
@@ -260,6 +272,7 @@ struct UVec {
         p[n++] = v;
     }
     void release() {
+        notify_release(p);
         free(p);
         p = nullptr;
         n = cap = 0;
@@ -1209,6 +1222,17 @@ bool decode_instruction(const u32* row, Instr& in, std::string& why) {
 }
 
 }  // namespace
+}  // namespace lmh
+
+namespace lmh {
+void vm_execution_regions(const lmh_execution* e, VmRegion out[5]) {
+    out[0] = {(void*)e->memory.data(), (size_t)MAX_MEMORY * 4};
+    out[1] = {(void*)e->tr.pcs.data(), e->tr.pcs.cap * sizeof(u32)};
+    out[2] = {(void*)e->tr.fps.data(), e->tr.fps.cap * sizeof(u32)};
+    out[3] = {(void*)e->tr.pos.data(), e->tr.pos.cap * sizeof(u32)};
+    out[4] = {(void*)e->tr.ext.data(), e->tr.ext.cap * sizeof(u32)};
+}
+void vm_set_release_hook(void (*hook)(void*)) { g_release_hook.store(hook, std::memory_order_release); }
 }  // namespace lmh
 
 extern "C" {

@@ -1,5 +1,6 @@
 // Internal to the host layer: what lm_node.cpp needs from the VM runner (lm_vm.cpp).  Not part of the ABI.
 #pragma once
+#include <cstddef>
 #include <functional>
 
 #include "lm_host_internal.h"
@@ -10,4 +11,13 @@ void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f);
 // device copy of a bytecode's instructions_multilinear for context `ctx` (cached in the bytecode object, one per context):
 // *slot is nullptr until lm_node.cpp fills it
 u32** vm_bytecode_device_slot(const lmh_bytecode* bc, void* ctx);
+// The host buffers of an execution the device uploads from — [0] the memory arena, [1] pcs, [2] fps, [3] Poseidon call records,
+// [4] ExtensionOp rows — with their CAPACITY in bytes (they are recycled from run to run, so a buffer pinned once stays useful).
+struct VmRegion {
+    void* base;
+    size_t bytes;
+};
+void vm_execution_regions(const lmh_execution* e, VmRegion out[5]);
+// called with a buffer's base address right before the runner frees or moves it (lm_node.cpp unpins it there)
+void vm_set_release_hook(void (*hook)(void* base));
 }  // namespace lmh

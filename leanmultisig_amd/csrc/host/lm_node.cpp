@@ -8,7 +8,9 @@
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -38,15 +40,16 @@ struct PinRegistry {
     std::map<void*, size_t> pinned;  // base -> registered bytes
 };
 PinRegistry& pins() {
-    static PinRegistry r;
-    return r;
+    static PinRegistry* r = new PinRegistry();  // never destroyed: buffers may be released from static destructors at exit
+    return *r;
 }
+std::atomic<bool> g_exiting{false};  // set by an atexit handler: the HIP runtime may be gone, registrations die with the process
 void unpin_hook(void* base) {
     PinRegistry& r = pins();
     std::lock_guard<std::mutex> lk(r.mu);
     auto it = r.pinned.find(base);
     if (it == r.pinned.end()) return;
-    (void)hipHostUnregister(base);
+    if (!g_exiting.load(std::memory_order_acquire)) (void)hipHostUnregister(base);
     r.pinned.erase(it);
 }
 bool pin_enabled() {
@@ -57,7 +60,10 @@ bool pin_enabled() {
 void ensure_pinned(const VmRegion& reg, size_t need) {
     if (!pin_enabled() || !reg.base || need == 0 || need > reg.bytes) return;
     static std::once_flag hook_once;
-    std::call_once(hook_once, [] { vm_set_release_hook(unpin_hook); });
+    std::call_once(hook_once, [] {
+        vm_set_release_hook(unpin_hook);
+        std::atexit([] { g_exiting.store(true, std::memory_order_release); });
+    });
     const size_t gran = 4u << 20;
     size_t want = (need + gran - 1) / gran * gran;
     if (want > reg.bytes) want = reg.bytes;

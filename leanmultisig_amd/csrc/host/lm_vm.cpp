@@ -422,8 +422,8 @@ struct LogCache {
     UVec<uint8_t> defined;
 };
 LogCache& log_cache() {
-    static LogCache c;
-    return c;
+    static LogCache* c = new LogCache();  // never destroyed (its buffers may be pinned by lm_node.cpp: nothing to unpin at exit)
+    return *c;
 }
 }  // namespace
 }  // namespace lmh

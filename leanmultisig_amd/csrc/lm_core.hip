@@ -379,23 +379,36 @@ struct StackJob {
     const u32* src;
     u64 begin, end;  // destination range in uint4 units
 };
+// Each workgroup copies CONTIGUOUS chunks of the destination (grid-stride over chunks of STACK_CHUNK vectors): a lane finds
+// its job by binary search once per chunk and walks forward from there — the jobs are sorted and thousands of vectors long, so
+// the walk almost never moves (a search per vector was ~8 dependent loads in front of every 16-byte copy).
+static constexpr u64 STACK_CHUNK = 256 * 8;
 __global__ __launch_bounds__(256) void k_stack_columns(uint4* __restrict__ dst, u64 n_vec, const StackJob* __restrict__ jobs,
                                                        u32 n_jobs) {
-    for (u64 e = (u64)blockIdx.x * 256 + threadIdx.x; e < n_vec; e += (u64)gridDim.x * 256) {
-        uint4 v = make_uint4(0, 0, 0, 0);
+    const u64 n_chunks = (n_vec + STACK_CHUNK - 1) / STACK_CHUNK;
+    for (u64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const u64 first = c * STACK_CHUNK + threadIdx.x;
+        u32 lo = 0;
         if (n_jobs) {
-            u32 lo = 0, hi = n_jobs - 1;  // last job with begin <= e
+            u32 hi = n_jobs - 1;  // last job with begin <= first
             while (lo < hi) {
                 const u32 mid = (lo + hi + 1) >> 1;
-                if (jobs[mid].begin <= e)
+                if (jobs[mid].begin <= first)
                     lo = mid;
                 else
                     hi = mid - 1;
             }
-            const StackJob j = jobs[lo];
-            if (j.begin <= e && e < j.end) v = reinterpret_cast<const uint4*>(j.src)[e - j.begin];
         }
-        dst[e] = v;
+        StackJob j = n_jobs ? jobs[lo] : StackJob{nullptr, 0, 0};
+#pragma unroll
+        for (int u = 0; u < (int)(STACK_CHUNK / 256); u++) {
+            const u64 e = first + (u64)u * 256;
+            if (e >= n_vec) break;
+            while (lo + 1 < n_jobs && jobs[lo + 1].begin <= e) j = jobs[++lo];
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n_jobs && j.begin <= e && e < j.end) v = reinterpret_cast<const uint4*>(j.src)[e - j.begin];
+            dst[e] = v;
+        }
     }
 }
 
@@ -731,7 +744,7 @@ int lm_stack_columns(lm_ctx* ctx, uint32_t* d_dst, uint64_t total_words, uint32_
         if ((rc = lm_stage_upload(ctx, s, jobs.data(), jobs.size() * sizeof(StackJob)))) return rc;
     }
     const u64 n_vec = total_words / 4;
-    const u32 blocks = (u32)std::min<u64>((n_vec + 255) / 256, 16384);
+    const u32 blocks = (u32)std::min<u64>((n_vec + STACK_CHUNK - 1) / STACK_CHUNK, 16384);
     LM_LAUNCH(ctx, k_stack_columns, dim3(blocks), dim3(256), 0, reinterpret_cast<uint4*>(d_dst), n_vec, (const StackJob*)s,
               (u32)jobs.size());
     LM_HIP(hipGetLastError());

@@ -90,3 +90,19 @@ def test_gkr_abandoned_layer_dismisses_the_resident_tail(ctx, orc, log_n, rounds
     q, pt, cl = pr.prove_gkr_quotient(ctx.to_device(nums2), ctx.ef_to_device_soa(dens2), 13)
     assert np.array_equal(q, rq) and np.array_equal(pt, rpt) and np.array_equal(cl, rcl)
     assert np.array_equal(pr.proof(), ref_proof)
+
+
+def test_gkr_launch_per_round_pair_schedule_matches_oracle():
+    """LM_GKR_NO_TAIL=1 — one k_gkr_step launch per round pair down to the last entries, which is also what a layer falls back to
+    when too many resident tails are alive in the process — must give the same transcripts (the switch is read once per process,
+    so the parity tests above are re-run in a child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_GKR_NO_TAIL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gkr_gpu.py", "-k",
+                        "test_gkr_matches_oracle or test_gkr_active_prefix_matches_oracle"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "16 passed" in r.stdout, r.stdout[-500:]

@@ -29,15 +29,24 @@ def weight(name):
 
 f = glob.glob(f"{base}/pmc_valu/**/*_counter_collection.csv", recursive=True)[0]
 agg = {}
+LARGE_NS = 100_000  # "large launches": the throughput-bound part of a family, without its latency-bound tail of tiny launches
+large = {}
 for r in csv.DictReader(open(f)):
     if r["Counter_Name"] != "SQ_INSTS_VALU":
         continue
     a = agg.setdefault(family(r["Kernel_Name"]), [0, 0.0, 0, 0.0])
     w = weight(r["Kernel_Name"])
+    ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     a[0] += 1
     a[1] += float(r["Counter_Value"])
-    a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    a[2] += ns
     a[3] += float(r["Counter_Value"]) * (w if w else 1.0)
+    if ns >= LARGE_NS:
+        b = large.setdefault(family(r["Kernel_Name"]), [0, 0.0, 0, 0.0])
+        b[0] += 1
+        b[1] += float(r["Counter_Value"])
+        b[2] += ns
+        b[3] += float(r["Counter_Value"]) * (w if w else 1.0)
 out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline --inflight 1",
        "note": "SQ_INSTS_VALU counts wave-level instructions; x64 lanes; peak = 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s; "
@@ -55,6 +64,12 @@ for k, (n, v, ns, vw) in sorted(agg.items(), key=lambda kv: -kv[1][3]):
                            "alu_roofline_ms": round(alu_ms, 4), "alu_roofline_issue_weighted_ms": round(w_ms, 4),
                            "kernel_ms_under_pmc": round(ms, 4), "alu_frac": round(alu_ms / ms, 3) if ms else None,
                            "alu_frac_issue_weighted": round(w_ms / ms, 3) if ms else None}
+out["large_launches"] = {"definition": "launches of >= 100 us under the counter pass", "per_proof": {}}
+for k, (n, v, ns, vw) in sorted(large.items(), key=lambda kv: -kv[1][2]):
+    ms = ns * 1e-6 / n_steps
+    out["large_launches"]["per_proof"][k] = {"launches": n / n_steps, "kernel_ms_under_pmc": round(ms, 4),
+                                             "alu_frac": round(v * 64 / PEAK * 1e3 / n_steps / ms, 3),
+                                             "alu_frac_issue_weighted": round(vw * 64 / PEAK * 1e3 / n_steps / ms, 3)}
 out["total_alu_roofline_ms_per_proof"] = round(tot_alu, 3)
 out["total_alu_roofline_issue_weighted_ms_per_proof"] = round(tot_w, 3)
 out["total_kernel_ms_per_proof_under_pmc"] = round(tot_ms, 3)
@@ -64,3 +79,6 @@ print(json.dumps({k: out[k] for k in ("total_alu_roofline_ms_per_proof", "total_
 for k, v in list(out["per_proof"].items())[:16]:
     print(f"{k:26s} alu {v['alu_roofline_ms']:7.3f} ms  weighted {v['alu_roofline_issue_weighted_ms']:7.3f} ms  kernel {v['kernel_ms_under_pmc']:7.3f} ms  "
           f"frac {v['alu_frac']}  weighted {v['alu_frac_issue_weighted']}")
+print("launches of >= 100 us only:")
+for k, v in out["large_launches"]["per_proof"].items():
+    print(f"  {k:26s} {v['launches']:5.1f} launches  kernel {v['kernel_ms_under_pmc']:7.3f} ms  frac {v['alu_frac']}  weighted {v['alu_frac_issue_weighted']}")

@@ -549,11 +549,26 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cpus():
+    """CPUs this process may use: hardware threads, capped by the cgroup quota (the GPU boxes run under cpu.max = 16 CPUs)"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, whole_node=False):
     """C provers (own lm_ctx each) prove `steps` leaves each, concurrently; returns the aggregate rate.  whole_node: every step is
     lmh_prove_execution_vm (VM run + trace + proof): the leaves' VM runs share the host thread pool, their proofs the GPU."""
     import threading
     import torch
+    # VM threads per leaf when several leaves run their VMs side by side (each on its own leased pool): half of the CPUs this
+    # process may use, split between the leaves that are in their VM phase at a time (measured: 8 of a 16-CPU quota)
+    vm_threads = int(os.environ.get("LM_BENCH_VM_THREADS", "0")) or max(2, effective_cpus() // 2)
     if whole_node:
         ws = [w0] * C
     elif "vm" in w0:  # the same leaf on every context: own VM run and device trace each
@@ -586,7 +601,7 @@ def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, wh
                     from leanmultisig_amd import vm
                     pr = lm.Prover(ctxs[c])
                     v = w0["vm"]
-                    vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], w0["lm_builder"])
+                    vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], w0["lm_builder"], n_threads=vm_threads)
                     pr.proof_pruned()
                 else:
                     run_step(ctxs[c], lm, ws[c]).proof_pruned()
@@ -604,8 +619,12 @@ def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, wh
     dt = time.perf_counter() - t0
     if errors:
         raise errors[0]
-    return {"proofs_in_flight": C, "value": sigs * C * steps / dt, "unit": "xmss_sigs/s", "ms_per_proof": 1e3 * dt / (C * steps),
-            "proofs": C * steps}
+    out = {"proofs_in_flight": C, "value": sigs * C * steps / dt, "unit": "xmss_sigs/s", "ms_per_proof": 1e3 * dt / (C * steps),
+           "proofs": C * steps}
+    if whole_node:
+        out["vm_threads_per_leaf"] = vm_threads
+        out["cpus_available"] = effective_cpus()
+    return out
 
 
 if __name__ == "__main__":

@@ -41,16 +41,32 @@ namespace lmh {
 // ---------------------------------------------------------------------------------------------------------------------
 class Pool {
    public:
-    static Pool& get() {
-        static Pool p;
-        return p;
+    Pool() {}
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_.store(true, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
     }
+    // the segment logs of this pool's worker threads (registered by the worker on its first segment) and the deferred-write list
+    // of the batch in progress: a pool serves ONE run at a time (PoolSet), so they belong to that run's batch
+    std::vector<void*> worker_logs;  // ThreadLog* (defined with the batch code below)
+    std::mutex logs_mu;
+    void* deferred = nullptr;  // UVec<std::pair<u64, u32>>*, owned (created on first use by handle_parallel_batch)
     // Inside a session a worker that has finished a job keeps polling for the next one for ~100 us before it goes back to sleep on
     // the condition variable: a VM run issues its parallel_for's in bursts (resize -> segments -> merge, resolve -> mask) a few
     // microseconds apart, and waking 127 sleeping threads costs ~0.7 ms each time on the 2 x 64-core host.  The poll is BOUNDED:
     // the GPU box runs under a CPU quota (cgroup cpu.max = 16 CPUs per 100 ms), and 127 threads spinning through the sequential
     // parts of a run exhausted it — the whole process, prover thread included, was throttled for 20-60 ms every few proofs.
-    static constexpr u32 SPIN_LIMIT = 4000;  // x pause (~25 ns)
+    static u32 spin_limit() {  // x pause (~25 ns); LM_VM_SPIN overrides (A/B measurements)
+        static const u32 v = [] {
+            const char* e = getenv("LM_VM_SPIN");
+            return e ? (u32)strtoul(e, nullptr, 10) : 4000u;
+        }();
+        return v;
+    }
     void begin_session(u32 n_threads) {
         std::lock_guard<std::mutex> user(user_mu_);
         ensure(resolve(n_threads) - 1);
@@ -83,6 +99,10 @@ class Pool {
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         job_ = nullptr;
     }
+    static Pool*& tl_worker_pool() {  // the pool a worker thread belongs to (nullptr on caller threads)
+        static thread_local Pool* p = nullptr;
+        return p;
+    }
     static u32 default_threads() {
         u32 hw = std::thread::hardware_concurrency();
         if (hw == 0) hw = 1;
@@ -90,15 +110,6 @@ class Pool {
     }
 
    private:
-    Pool() {}
-    ~Pool() {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_.store(true, std::memory_order_release);
-        }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
     static void cpu_relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -125,6 +136,7 @@ class Pool {
         }
     }
     void loop(u32 id) {
+        tl_worker_pool() = this;
         u64 seen = 0;
         for (;;) {
             u64 g;
@@ -133,7 +145,7 @@ class Pool {
                 g = gen_.load(std::memory_order_acquire);
                 if (g != seen) break;
                 if (stop_.load(std::memory_order_acquire)) return;
-                if (spin_.load(std::memory_order_acquire) && spins < SPIN_LIMIT) {  // bounded: see begin_session
+                if (spin_.load(std::memory_order_acquire) && spins < spin_limit()) {  // bounded: see begin_session
                     spins++;
                     cpu_relax();
                     continue;
@@ -160,15 +172,74 @@ class Pool {
     u64 total_ = 0;
 };
 
-void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) { Pool::get().parallel_for(n, n_threads, f); }
-struct PoolSession {  // LM_VM_NO_SPIN=1: the workers sleep between the jobs of a run (for A/B measurements)
-    bool on;
-    explicit PoolSession(u32 n_threads) : on(getenv("LM_VM_NO_SPIN") == nullptr) {
-        if (on) Pool::get().begin_session(n_threads);
+// Pools are leased to ONE run at a time: several provers of a process (leaves in flight) run their VMs side by side, each on its
+// own pool — with a single shared pool their parallel batches took turns, and ten leaves waited for each other's segments.
+// A caller that asks for n threads gets a pool with n - 1 workers (grown on demand); pools are kept for the life of the process.
+class PoolSet {
+   public:
+    static PoolSet& get() {
+        static PoolSet* s = new PoolSet();  // never destroyed (worker threads live as long as the process)
+        return *s;
+    }
+    Pool* acquire() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            for (size_t i = 0; i < pools_.size(); i++)
+                if (!busy_[i]) {
+                    busy_[i] = true;
+                    return pools_[i];
+                }
+            if (pools_.size() < MAX_POOLS) {
+                pools_.push_back(new Pool());
+                busy_.push_back(true);
+                return pools_.back();
+            }
+            cv_.wait(lk);
+        }
+    }
+    void release(Pool* p) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < pools_.size(); i++)
+                if (pools_[i] == p) busy_[i] = false;
+        }
+        cv_.notify_one();
+    }
+
+   private:
+    static constexpr size_t MAX_POOLS = 64;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Pool*> pools_;
+    std::vector<bool> busy_;
+};
+Pool*& tl_run_pool() {  // the pool leased by the run in progress on this (caller) thread
+    static thread_local Pool* p = nullptr;
+    return p;
+}
+void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) {
+    if (Pool* p = tl_run_pool()) {
+        p->parallel_for(n, n_threads, f);
+        return;
+    }
+    Pool* p = PoolSet::get().acquire();  // outside a run (lmh_poseidon16_compress_many): a lease for this one job
+    p->parallel_for(n, n_threads, f);
+    PoolSet::get().release(p);
+}
+struct PoolSession {  // a run's lease of a pool; LM_VM_NO_SPIN=1: its workers sleep between the jobs (for A/B measurements)
+    bool spin;
+    Pool* pool;
+    explicit PoolSession(u32 n_threads) : spin(getenv("LM_VM_NO_SPIN") == nullptr), pool(PoolSet::get().acquire()) {
+        tl_run_pool() = pool;
+        if (spin) pool->begin_session(n_threads);
     }
     ~PoolSession() {
-        if (on) Pool::get().end_session();
+        if (spin) pool->end_session();
+        tl_run_pool() = nullptr;
+        PoolSet::get().release(pool);
     }
+    PoolSession(const PoolSession&) = delete;
+    PoolSession& operator=(const PoolSession&) = delete;
 };
 
 namespace {
@@ -987,37 +1058,41 @@ struct ThreadLog {
     Trace tr;
     UVec<std::pair<u64, u32>> deferred;
 };
-std::mutex g_logs_mu;
-std::vector<ThreadLog*> g_logs;
 ThreadLog& thread_log() {
     static thread_local ThreadLog* mine = nullptr;
     if (!mine) {
         mine = new ThreadLog();  // lives as long as the process (pool threads do)
-        std::lock_guard<std::mutex> lk(g_logs_mu);
-        g_logs.push_back(mine);
+        if (Pool* p = Pool::tl_worker_pool()) {
+            std::lock_guard<std::mutex> lk(p->logs_mu);
+            p->worker_logs.push_back(mine);
+        }
     }
     return *mine;
 }
-void thread_logs_reset() {  // (called by the batch that holds g_batch_mu: no other batch is running)
-    std::lock_guard<std::mutex> lk(g_logs_mu);
-    for (ThreadLog* l : g_logs) {
-        l->tr.pcs.n = l->tr.fps.n = l->tr.pos.n = l->tr.ext.n = l->tr.pending.n = l->deferred.n = 0;
-        l->tr.n_add = l->tr.n_mul = l->tr.n_deref = l->tr.n_jump = 0;
-    }
+void reset_log(ThreadLog* l) {
+    l->tr.pcs.n = l->tr.fps.n = l->tr.pos.n = l->tr.ext.n = l->tr.pending.n = l->deferred.n = 0;
+    l->tr.n_add = l->tr.n_mul = l->tr.n_deref = l->tr.n_jump = 0;
 }
-UVec<std::pair<u64, u32>>& batch_deferred() {
-    static UVec<std::pair<u64, u32>> v;
-    return v;
+// start of a batch: the logs of the run's pool and of the calling thread are empty (the pool is leased to this run alone)
+void thread_logs_reset(Pool* p) {
+    reset_log(&thread_log());
+    std::lock_guard<std::mutex> lk(p->logs_mu);
+    for (void* l : p->worker_logs) reset_log(static_cast<ThreadLog*>(l));
+}
+UVec<std::pair<u64, u32>>& batch_deferred(Pool* p) {
+    if (!p->deferred) p->deferred = new UVec<std::pair<u64, u32>>();
+    return *static_cast<UVec<std::pair<u64, u32>>*>(p->deferred);
 }
 
-// handle_parallel_batch (runner.rs:361-482)
-// The per-thread logs and the deferred-write list are process-wide (they belong to the pool's threads): ONE batch owns them from
-// its reset to its splice.  Concurrent runs (several provers in one process) take turns here — a batch occupies the whole pool
-// anyway — and overlap everywhere else.
-std::mutex g_batch_mu;
+// The per-thread logs and the deferred-write list belong to the run's pool (leased to this run alone, PoolSet): concurrent runs
+// of several provers in one process do not share them.
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
                            u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
-    std::lock_guard<std::mutex> batch_owner(g_batch_mu);
+    Pool* const pool = tl_run_pool();
+    if (!pool) {
+        err.raise("handle_parallel_batch outside a run");
+        return false;
+    }
     MainMem mm{memory};
     const double tp0 = vm_now_ms();
     auto get = [&](u64 at) -> u32 {
@@ -1093,7 +1168,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
         Err err;
     };
     const double tb0 = vm_now_ms();
-    thread_logs_reset();
+    thread_logs_reset(pool);
     std::vector<Seg> segs(n_par);
     u32* base = memory.data();
     vm_parallel_for(n_par, n_threads, [&](u64 i) {
@@ -1135,7 +1210,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     }
     trace.pcs.extend(n_cyc - trace.pcs.size()), trace.fps.extend(n_cyc - trace.fps.size()), trace.pos.extend(n_pos - trace.pos.size());
     trace.ext.extend(n_ext - trace.ext.size()), trace.pending.extend(n_pend - trace.pending.size());
-    UVec<std::pair<u64, u32>>& all_def = batch_deferred();
+    UVec<std::pair<u64, u32>>& all_def = batch_deferred(pool);
     all_def.n = 0;
     all_def.extend(n_def);
     vm_parallel_for(n_par, n_threads, [&](u64 i) {

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <time.h>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
 #include "poseidon16_quad.h"
@@ -287,7 +288,17 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
     hipStream_t stream = aux < 0 ? ctx->stream : ctx->aux_stream[aux];
     // several publishers may be in flight on the stream (their sequence numbers increase): "at least seq" is the condition
     auto reached = [&] { return (int32_t)(*flag - seq) >= 0; };
+    // LM_WAIT_NAP=<spins>: after that many polls the thread sleeps ~20 us between polls (several provers in one process under a
+    // CPU quota: ten spinning prover threads are ten CPUs that the VM runs of the other leaves do not get)
+    static const u64 nap_after = [] {
+        const char* e = getenv("LM_WAIT_NAP");
+        return e ? (u64)strtoull(e, nullptr, 10) : 0ull;
+    }();
     for (u64 spins = 0; !reached(); spins++) {
+        if (nap_after && spins >= nap_after) {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
         if (spins > (1ull << 22)) {  // something is wrong or the kernel is long: fall back to the runtime
             LM_HIP(hipStreamSynchronize(stream));
             if (!reached()) {

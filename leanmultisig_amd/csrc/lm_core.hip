@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include <time.h>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
@@ -288,16 +289,29 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
     hipStream_t stream = aux < 0 ? ctx->stream : ctx->aux_stream[aux];
     // several publishers may be in flight on the stream (their sequence numbers increase): "at least seq" is the condition
     auto reached = [&] { return (int32_t)(*flag - seq) >= 0; };
-    // LM_WAIT_NAP=<spins>: after that many polls the thread sleeps ~20 us between polls (several provers in one process under a
-    // CPU quota: ten spinning prover threads are ten CPUs that the VM runs of the other leaves do not get)
+    // Several provers in one process (leaves in flight): every prover thread spinning here is a CPU that the VM runs of the other
+    // leaves do not get (the GPU boxes run under a quota of 16 CPUs).  When at least LM_WAIT_NAP_WAITERS threads (default 4) are
+    // waiting at once, a wait that has already polled LM_WAIT_NAP times (default 3000, ~30 us) sleeps ~20 us between polls.  A
+    // lone prover never sleeps: its latency is the metric.  LM_WAIT_NAP=0 switches the naps off.
     static const u64 nap_after = [] {
         const char* e = getenv("LM_WAIT_NAP");
-        return e ? (u64)strtoull(e, nullptr, 10) : 0ull;
+        return e ? (u64)strtoull(e, nullptr, 10) : 3000ull;
     }();
+    static const int nap_waiters = [] {
+        const char* e = getenv("LM_WAIT_NAP_WAITERS");
+        return e ? atoi(e) : 4;
+    }();
+    static std::atomic<int> waiters{0};
+    struct WaitScope {
+        std::atomic<int>& w;
+        explicit WaitScope(std::atomic<int>& x) : w(x) { w.fetch_add(1, std::memory_order_relaxed); }
+        ~WaitScope() { w.fetch_sub(1, std::memory_order_relaxed); }
+    } scope(waiters);
     for (u64 spins = 0; !reached(); spins++) {
-        if (nap_after && spins >= nap_after) {
+        if (nap_after && spins >= nap_after && waiters.load(std::memory_order_relaxed) >= nap_waiters) {
             struct timespec ts = {0, 20000};
             nanosleep(&ts, nullptr);
+            spins += 2000;  // (a nap is worth ~2000 polls of wall clock: the give-up point below stays where it was)
         }
         if (spins > (1ull << 22)) {  // something is wrong or the kernel is long: fall back to the runtime
             LM_HIP(hipStreamSynchronize(stream));

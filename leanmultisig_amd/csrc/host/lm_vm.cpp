@@ -99,6 +99,8 @@ class Pool {
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         job_ = nullptr;
     }
+    size_t n_workers() const { return workers_.size(); }  // (read by PoolSet while the pool is free: nobody is growing it)
+    static u32 workers_for(u32 n_threads) { return resolve(n_threads) - 1; }
     static Pool*& tl_worker_pool() {  // the pool a worker thread belongs to (nullptr on caller threads)
         static thread_local Pool* p = nullptr;
         return p;
@@ -181,18 +183,28 @@ class PoolSet {
         static PoolSet* s = new PoolSet();  // never destroyed (worker threads live as long as the process)
         return *s;
     }
-    Pool* acquire() {
+    // `workers`: what the run will use.  Best fit: the free pool with the fewest workers that has enough of them (every job wakes
+    // all sleeping workers of its pool, so a run on 8 threads should not sit on the 127-worker pool of an earlier run); else a new
+    // pool; else (MAX_POOLS reached) the largest free one, grown on demand; else wait.
+    Pool* acquire(u32 workers) {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            for (size_t i = 0; i < pools_.size(); i++)
-                if (!busy_[i]) {
-                    busy_[i] = true;
-                    return pools_[i];
-                }
-            if (pools_.size() < MAX_POOLS) {
+            int best = -1, largest = -1;
+            for (size_t i = 0; i < pools_.size(); i++) {
+                if (busy_[i]) continue;
+                const size_t n = pools_[i]->n_workers();
+                if (n >= workers && (best < 0 || n < pools_[best]->n_workers())) best = (int)i;
+                if (largest < 0 || n > pools_[largest]->n_workers()) largest = (int)i;
+            }
+            if (best < 0 && pools_.size() < MAX_POOLS) {
                 pools_.push_back(new Pool());
                 busy_.push_back(true);
                 return pools_.back();
+            }
+            if (best < 0) best = largest;
+            if (best >= 0) {
+                busy_[best] = true;
+                return pools_[best];
             }
             cv_.wait(lk);
         }
@@ -222,14 +234,14 @@ void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f) {
         p->parallel_for(n, n_threads, f);
         return;
     }
-    Pool* p = PoolSet::get().acquire();  // outside a run (lmh_poseidon16_compress_many): a lease for this one job
+    Pool* p = PoolSet::get().acquire(Pool::workers_for(n_threads));  // outside a run (lmh_poseidon16_compress_many): a lease for this one job
     p->parallel_for(n, n_threads, f);
     PoolSet::get().release(p);
 }
 struct PoolSession {  // a run's lease of a pool; LM_VM_NO_SPIN=1: its workers sleep between the jobs (for A/B measurements)
     bool spin;
     Pool* pool;
-    explicit PoolSession(u32 n_threads) : spin(getenv("LM_VM_NO_SPIN") == nullptr), pool(PoolSet::get().acquire()) {
+    explicit PoolSession(u32 n_threads) : spin(getenv("LM_VM_NO_SPIN") == nullptr), pool(PoolSet::get().acquire(Pool::workers_for(n_threads))) {
         tl_run_pool() = pool;
         if (spin) pool->begin_session(n_threads);
     }

@@ -60,3 +60,38 @@ def test_runner_error_surfaces(ctx, program):
     pr = lm.Prover(ctx)
     with pytest.raises(lm.LmError, match="MemoryAlreadySet"):
         vm.prove_execution_vm(ctx, pr, program, bad, w, lm.WhirBuilder.default(1, security_level=60, pow_bits=6))
+
+
+def test_whole_function_from_several_threads_at_once(ctx, program):
+    """Leaves in flight: four host threads, one context each, prove different leaves with lmh_prove_execution_vm at the same time —
+    every VM run on its own leased pool, uploads from registered runner buffers, the GKR tails resident side by side — and every
+    proof must equal the one the same leaf gives alone."""
+    import threading
+    lm_builder = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    leaves = [xa.build_witness(program, 5 + 4 * t, np.random.default_rng(700 + t))[:2] for t in range(4)]
+    alone = []
+    for pi, w in leaves:
+        pr = lm.Prover(ctx)
+        vm.prove_execution_vm(ctx, pr, program, pi, w, lm_builder, n_threads=4)
+        alone.append(pr.proof().copy())
+    ctxs = [lm.Context(0) for _ in range(4)]
+    bad = []
+
+    def worker(t):
+        try:
+            ctxs[t]._check(ctxs[t].lib.lm_bind_thread(ctxs[t].h))  # the HIP device is per host thread
+            pi, w = leaves[t]
+            for k in range(6):
+                pr = lm.Prover(ctxs[t])
+                vm.prove_execution_vm(ctxs[t], pr, program, pi, w, lm_builder, n_threads=4)
+                if not np.array_equal(pr.proof(), alone[t]):
+                    bad.append((t, k))
+        except Exception as e:  # noqa: BLE001
+            bad.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad

@@ -103,35 +103,69 @@ __device__ __forceinline__ EF block_reduce_ef(EF v, u32* lds /* >= 20 words */) 
 
 // partial[(poly * n_hi + hi)] = eq_hi[hi] * sum_lo v[hi * 2^k_lo + lo] * eq_lo[lo]
 // base values: 5 u64 accumulators with a fold every product (acc < 2^32 p, product < p^2, sum < 2^64).
-__global__ __launch_bounds__(256) void k_mle_partial_base(const u32* __restrict__ evals, u64 stride_words, u32 k_lo,
-                                                          const u32* __restrict__ eq_lo, const u32* __restrict__ eq_hi,
-                                                          u32 n_hi, u32* __restrict__ partial) {
+// A workgroup evaluates MLE_POLYS polynomials on its slice: every eq_lo value it loads (5 words per element, from L2) is used
+// for all of them — with one polynomial per workgroup the kernel moved 5 table words per data word and ran at the L2's pace
+// (2.3 TB/s of HBM-equivalent traffic).
+static constexpr u32 MLE_POLYS_MAX = 4;
+template <u32 MLE_POLYS, class PolyAt>
+__device__ __forceinline__ void mle_partial_base_impl(PolyAt poly_at, u32 n_polys, u32 k_lo, const u32* __restrict__ eq_lo,
+                                                      const u32* __restrict__ eq_hi, u32 n_hi, u32* __restrict__ partial) {
     __shared__ u32 red[32];
-    const u32 hi = blockIdx.x, poly = blockIdx.y;
+    const u32 hi = blockIdx.x, poly0 = blockIdx.y * MLE_POLYS;
     const u32 len_lo = 1u << k_lo;
-    const u32* v = evals + (u64)poly * stride_words + (u64)hi * len_lo;
-    u64 acc[5] = {0, 0, 0, 0, 0};
+    const u32* v[MLE_POLYS];
+#pragma unroll
+    for (u32 q = 0; q < MLE_POLYS; q++) v[q] = poly_at(poly0 + q < n_polys ? poly0 + q : poly0) + (u64)hi * len_lo;
+    u64 acc[MLE_POLYS][5];
+#pragma unroll
+    for (u32 q = 0; q < MLE_POLYS; q++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[q][k] = 0;
     for (u32 i = threadIdx.x; i < len_lo; i += 256) {
-        u32 x = v[i];
+        u32 e[5], x[MLE_POLYS];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            u64 t = acc[k] + (u64)x * eq_lo[(u64)k * len_lo + i];
-            u64 y = t - P_SHL32;
-            acc[k] = t >= P_SHL32 ? y : t;
-        }
+        for (int k = 0; k < 5; k++) e[k] = eq_lo[(u64)k * len_lo + i];
+#pragma unroll
+        for (u32 q = 0; q < MLE_POLYS; q++) x[q] = v[q][i];
+#pragma unroll
+        for (u32 q = 0; q < MLE_POLYS; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const u64 t = acc[q][k] + (u64)x[q] * e[k];
+                const u64 y = t - P_SHL32;
+                acc[q][k] = t >= P_SHL32 ? y : t;
+            }
     }
-    EF s;
-#pragma unroll
-    for (int k = 0; k < 5; k++) s.v[k] = reduce(acc[k]);
-    EF r = block_reduce_ef(s, red);
+    EF e;
     if (threadIdx.x == 0) {
-        EF e;
 #pragma unroll
         for (int k = 0; k < 5; k++) e.v[k] = eq_hi[(u64)k * n_hi + hi];
-        r = ef_mul(r, e);
-#pragma unroll
-        for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
     }
+#pragma unroll
+    for (u32 q = 0; q < MLE_POLYS; q++) {
+        EF s;
+#pragma unroll
+        for (int k = 0; k < 5; k++) s.v[k] = reduce(acc[q][k]);
+        EF r = block_reduce_ef(s, red);
+        if (threadIdx.x == 0 && poly0 + q < n_polys) {
+            r = ef_mul(r, e);
+#pragma unroll
+            for (int k = 0; k < 5; k++) partial[((u64)(poly0 + q) * n_hi + hi) * 5 + k] = r.v[k];
+        }
+    }
+}
+template <u32 MLE_POLYS>
+__global__ __launch_bounds__(256) void k_mle_partial_base(const u32* __restrict__ evals, u64 stride_words, u32 n_polys, u32 k_lo,
+                                                          const u32* __restrict__ eq_lo, const u32* __restrict__ eq_hi,
+                                                          u32 n_hi, u32* __restrict__ partial) {
+    mle_partial_base_impl<MLE_POLYS>([&](u32 p) { return evals + (u64)p * stride_words; }, n_polys, k_lo, eq_lo, eq_hi, n_hi, partial);
+}
+// same with one device pointer per polynomial
+template <u32 MLE_POLYS>
+__global__ __launch_bounds__(256) void k_mle_partial_cols(const u32* const* __restrict__ cols, u32 n_polys, u32 k_lo,
+                                                          const u32* __restrict__ eq_lo, const u32* __restrict__ eq_hi,
+                                                          u32 n_hi, u32* __restrict__ partial) {
+    mle_partial_base_impl<MLE_POLYS>([&](u32 p) { return cols[p]; }, n_polys, k_lo, eq_lo, eq_hi, n_hi, partial);
 }
 // same with one device pointer per polynomial
 __global__ __launch_bounds__(256) void k_mle_partial_cols(const u32* const* __restrict__ cols, u32 k_lo,
@@ -686,12 +720,17 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
     LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
     LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
-    if (!is_ext)
-        LM_LAUNCH(ctx, k_mle_partial_base, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words, k_lo,
-                           d_eq_lo, d_eq_hi, n_hi, d_partial);
-    else
+    if (!is_ext) {
+        if (n_polys >= MLE_POLYS_MAX)
+            LM_LAUNCH(ctx, k_mle_partial_base<MLE_POLYS_MAX>, dim3(n_hi, (n_polys + MLE_POLYS_MAX - 1) / MLE_POLYS_MAX), dim3(256), 0, d_evals,
+                      stride_words, n_polys, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+        else
+            LM_LAUNCH(ctx, k_mle_partial_base<1>, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words, n_polys, k_lo, d_eq_lo, d_eq_hi, n_hi,
+                      d_partial);
+    } else {
         LM_LAUNCH(ctx, k_mle_partial_ext, dim3(n_hi, n_polys), dim3(256), 0, d_evals, stride_words,
                            1ull << n_vars, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+    }
     const bool pinned = (u64)n_polys * 5 <= lm_ctx::RES_WORDS;
     if (pinned) {
         const u32 seq = ++ctx->res_seq;
@@ -732,8 +771,12 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
     LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
     LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
-    LM_LAUNCH(ctx, k_mle_partial_cols, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, k_lo, d_eq_lo, d_eq_hi, n_hi,
-              d_partial);
+    if (n_cols >= MLE_POLYS_MAX)
+        LM_LAUNCH(ctx, k_mle_partial_cols<MLE_POLYS_MAX>, dim3(n_hi, (n_cols + MLE_POLYS_MAX - 1) / MLE_POLYS_MAX), dim3(256), 0,
+                  (const u32* const*)d_ptrs, n_cols, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+    else
+        LM_LAUNCH(ctx, k_mle_partial_cols<1>, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, n_cols, k_lo, d_eq_lo, d_eq_hi, n_hi,
+                  d_partial);
     const u32 seq = ++ctx->res_seq;
     LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());

@@ -91,6 +91,63 @@ __global__ __launch_bounds__(256) void k_gkr_layer_up(const u32* __restrict__ n_
     }
 }
 
+// Two levels per pass: thread i reads the four children of grandparent i (one 16-byte load per plane), stores parents 2i, 2i + 1
+// and the grandparent — the middle level is written but not read back (layer construction traffic 2.0 -> 1.6 GB at 2^25, half
+// the launches).  Same values as two k_gkr_layer_up passes; padding as there: a node whose children are all padding is (0, 1).
+template <bool BASE>
+__global__ __launch_bounds__(256) void k_gkr_layer_up2(const u32* __restrict__ n_in, const u32* __restrict__ d_in, u64 m_out,
+                                                       u32* __restrict__ n_out, u32* __restrict__ d_out, u32* __restrict__ n_out2,
+                                                       u32* __restrict__ d_out2, u64 valid_in, u64 valid_out, u64 valid_out2) {
+    const u64 plane_in = 2 * m_out, m_out2 = m_out / 2;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < valid_out2; i += (u64)gridDim.x * 256) {
+        EF pn[2], pd[2];
+        if (4 * i < valid_in) {  // (valid_in is a multiple of 8: the four children exist together)
+            EF d[4];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(d_in + (u64)k * plane_in + 4 * i);
+                d[0].v[k] = v.x, d[1].v[k] = v.y, d[2].v[k] = v.z, d[3].v[k] = v.w;
+            }
+            if (BASE) {
+                const uint4 v = *reinterpret_cast<const uint4*>(n_in + 4 * i);
+                pn[0] = ef_add(ef_mul_base(d[1], v.x), ef_mul_base(d[0], v.y));
+                pn[1] = ef_add(ef_mul_base(d[3], v.z), ef_mul_base(d[2], v.w));
+            } else {
+                EF n[4];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(n_in + (u64)k * plane_in + 4 * i);
+                    n[0].v[k] = v.x, n[1].v[k] = v.y, n[2].v[k] = v.z, n[3].v[k] = v.w;
+                }
+                pn[0] = ef_add(ef_mul(d[1], n[0]), ef_mul(d[0], n[1]));
+                pn[1] = ef_add(ef_mul(d[3], n[2]), ef_mul(d[2], n[3]));
+            }
+            pd[0] = ef_mul(d[0], d[1]);
+            pd[1] = ef_mul(d[2], d[3]);
+        } else {
+            pn[0] = pn[1] = ef_zero();
+            pd[0] = pd[1] = ef_one();
+        }
+        if (2 * i < valid_out) {  // (valid_out is even: both parents are inside or outside together)
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                *reinterpret_cast<uint2*>(n_out + (u64)k * m_out + 2 * i) = make_uint2(pn[0].v[k], pn[1].v[k]);
+                *reinterpret_cast<uint2*>(d_out + (u64)k * m_out + 2 * i) = make_uint2(pd[0].v[k], pd[1].v[k]);
+            }
+        }
+        EF gn = ef_zero(), gd = ef_one();
+        if (2 * i < valid_out) {
+            gn = ef_add(ef_mul(pd[1], pn[0]), ef_mul(pd[0], pn[1]));
+            gd = ef_mul(pd[0], pd[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            n_out2[(u64)k * m_out2 + i] = gn.v[k];
+            d_out2[(u64)k * m_out2 + i] = gd.v[k];
+        }
+    }
+}
+
 // ---- the layer sumcheck, two rounds per launch -----------------------------------------------------------------------
 // Round t of a layer (sumcheck_utils.rs:65-109, 278-357) sums, over pairs (a, b) = entries (2j, 2j+1) of the four arrays,
 //     w_t(j) * [ c0 = nl_a dr_a + nr_a dl_a + alpha dl_a dr_a ,  c2 = Dnl Ddr + Dnr Ddl + alpha Ddl Ddr ],  D = b - a.
@@ -598,6 +655,10 @@ EF host_ef(const u32* p) {
     memcpy(r.v, p, 20);
     return r;
 }
+bool gkr_two_levels() {  // LM_GKR_ONE_LEVEL=1: one k_gkr_layer_up pass per level (A/B measurements)
+    static const bool on = getenv("LM_GKR_ONE_LEVEL") == nullptr;
+    return on;
+}
 bool gkr_tail_enabled() {
     static const bool on = getenv("LM_GKR_NO_TAIL") == nullptr;
     return on;
@@ -660,27 +721,53 @@ int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_d
     const u32* n_in = d_nums;
     const u32* d_in = d_dens;
     u64 valid_in = g->valid0;
-    for (u32 v = n_vars - 1; v >= 5; v--) {
+    auto alloc_layer = [&](u64 m, u32** nn, u32** dd) {
+        *nn = *dd = nullptr;
+        if (lm_pool_alloc_t(ctx, nn, 5 * m * 4) != hipSuccess || lm_pool_alloc_t(ctx, dd, 5 * m * 4) != hipSuccess) {
+            lm_set_error("lm_gkr_build: device allocation failed");
+            lm_pool_free(ctx, *nn);
+            return false;
+        }
+        g->nums.push_back(*nn);
+        g->dens.push_back(*dd);
+        return true;
+    };
+    for (u32 v = n_vars - 1; v >= 5;) {
         const u64 m = 1ull << v;
         const u64 valid_out = round_up8((valid_in + 1) / 2, m);
-        u32 *nn = nullptr, *dd = nullptr;
-        if (lm_pool_alloc_t(ctx, &nn, 5 * m * 4) != hipSuccess || lm_pool_alloc_t(ctx, &dd, 5 * m * 4) != hipSuccess) {
-            lm_set_error("lm_gkr_build: device allocation failed");
-            lm_pool_free(ctx, nn);
+        u32 *nn, *dd;
+        if (!alloc_layer(m, &nn, &dd)) {
             lm_gkr_free(ctx, g);
             return LM_E_NOMEM;
         }
-        g->nums.push_back(nn);
-        g->dens.push_back(dd);
         g->valid.push_back(valid_out);
+        const bool base = v == n_vars - 1;
+        if (v >= 6 && (valid_in & 7) == 0 && gkr_two_levels()) {  // two levels in one pass (k_gkr_layer_up2)
+            const u64 m2 = m / 2, valid_out2 = round_up8((valid_out + 1) / 2, m2);
+            u32 *nn2, *dd2;
+            if (!alloc_layer(m2, &nn2, &dd2)) {
+                lm_gkr_free(ctx, g);
+                return LM_E_NOMEM;
+            }
+            g->valid.push_back(valid_out2);
+            const u32 blocks = (u32)std::min<u64>((valid_out2 + 255) / 256, 4096);
+            if (base)
+                LM_LAUNCH(ctx, k_gkr_layer_up2<true>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, nn2, dd2, valid_in, valid_out, valid_out2);
+            else
+                LM_LAUNCH(ctx, k_gkr_layer_up2<false>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, nn2, dd2, valid_in, valid_out, valid_out2);
+            n_in = nn2, d_in = dd2, valid_in = valid_out2;
+            v -= 2;
+            continue;
+        }
         const u32 blocks = (u32)std::min<u64>((valid_out + 255) / 256, 4096);
-        if (v == n_vars - 1)
+        if (base)
             LM_LAUNCH(ctx, k_gkr_layer_up<true>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, valid_in, valid_out);
         else
             LM_LAUNCH(ctx, k_gkr_layer_up<false>, dim3(blocks), dim3(256), 0, n_in, d_in, m, nn, dd, valid_in, valid_out);
         n_in = nn;
         d_in = dd;
         valid_in = valid_out;
+        v -= 1;
     }
     // work buffers: the first launch that writes folds the biggest layer (2^(n_vars-1) per array) by two challenges
     g->work_words = std::max<u64>(20ull << (n_vars - 3), 256);

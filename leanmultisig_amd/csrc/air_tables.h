@@ -217,8 +217,17 @@ KB_HD void quintic_mul_air(const T a[5], const T b[5], T out[5]) {
 }
 
 // ---- extension_op ------------------------------------------------------------------------------------------------------
-template <class T>
+// PART < 0: all 34 constraints.  PART 0..3: a subset — the constraint sum is additive, so the small (latency-bound) sumcheck
+// rounds evaluate the four parts in four workgroups side by side (lm_air.hip), each with only the prerequisites it needs:
+//   0: bus, the five boolean checks, the `start` block (alpha^21..25), the seven chaining constraints and the last one  (no product)
+//   1: the `add` and `mul` blocks (alpha^6..15): one quintic product
+//   2: the `poly_eq` block for coefficients 0..2 (alpha^16..18): two dependent quintic products, three of the five outputs
+//   3: the `poly_eq` block for coefficients 3, 4 (alpha^19, 20)
+// The longest part is ~56 extension multiplications deep instead of ~132.
+static constexpr int EXT_PARTS = 4;
+template <class T, int PART = -1>
 KB_HD EF eval_extension_op(const T* flat, const T* shift, const Extra& x) {
+    constexpr bool ALL = PART < 0;
     const T one = a_from_base(kb::ONE, flat[0]);
     const T is_be = flat[0], start = flat[1], len = flat[2], flag_add = flat[3], flag_mul = flat[4], flag_poly_eq = flat[5];
     const T idx_a = flat[6], idx_b = flat[7], idx_r = flat[13];
@@ -232,52 +241,66 @@ KB_HD EF eval_extension_op(const T* flat, const T* shift, const Extra& x) {
         comp_shift[k] = shift[8 + k];
     }
     const T start_shift = shift[1];
-    const T activation_flag = a_mul(start, a_add(a_add(flag_add, flag_mul), flag_poly_eq));
-    const T aux = a_add(a_add(a_add(a_add(a_mulc(is_be, mc(4)), a_mulc(flag_add, mc(8))), a_mulc(flag_mul, mc(16))),
-                              a_mulc(flag_poly_eq, mc(32))),
-                        a_mulc(len, mc(64)));
     Folder<T> f(x);
-    f.assert_zero_ef(bus_column<T>(x, activation_flag, aux, idx_a, idx_b, idx_r));
     const T is_ee = a_sub(one, is_be);
     const T nss = a_sub(one, start_shift);
-    T vaf[5], comp_tail[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        vaf[k] = k == 0 ? va[0] : a_mul(va[k], is_ee);
-        comp_tail[k] = a_mul(comp_shift[k], nss);
+    if constexpr (ALL || PART == 0) {
+        const T activation_flag = a_mul(start, a_add(a_add(flag_add, flag_mul), flag_poly_eq));
+        const T aux = a_add(a_add(a_add(a_add(a_mulc(is_be, mc(4)), a_mulc(flag_add, mc(8))), a_mulc(flag_mul, mc(16))),
+                                  a_mulc(flag_poly_eq, mc(32))),
+                            a_mulc(len, mc(64)));
+        f.k = 0;
+        f.assert_zero_ef(bus_column<T>(x, activation_flag, aux, idx_a, idx_b, idx_r));
+        f.assert_zero(bool_check(is_be));
+        f.assert_zero(bool_check(start));
+        f.assert_zero(bool_check(flag_add));
+        f.assert_zero(bool_check(flag_mul));
+        f.assert_zero(bool_check(flag_poly_eq));
     }
-    f.assert_zero(bool_check(is_be));
-    f.assert_zero(bool_check(start));
-    f.assert_zero(bool_check(flag_add));
-    f.assert_zero(bool_check(flag_mul));
-    f.assert_zero(bool_check(flag_poly_eq));
+    T vaf[5], comp_tail[5], vavb[5];
+    if constexpr (ALL || PART >= 1) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(a_add(vaf[k], vb[k]), comp_tail[k])), flag_add));
-    T vavb[5];
-    quintic_mul_air<T>(vaf, vb, vavb);
-#pragma unroll
-    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(vavb[k], comp_tail[k])), flag_mul));
-    T pev[5], csoo[5], per[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const T base = a_sub(a_sub(a_add(vavb[k], vavb[k]), vaf[k]), vb[k]);
-        pev[k] = k == 0 ? a_add(base, one) : base;
-        csoo[k] = k == 0 ? a_add(comp_tail[0], start_shift) : comp_tail[k];
+        for (int k = 0; k < 5; k++) {
+            vaf[k] = k == 0 ? va[0] : a_mul(va[k], is_ee);
+            comp_tail[k] = a_mul(comp_shift[k], nss);
+        }
+        quintic_mul_air<T>(vaf, vb, vavb);
     }
-    quintic_mul_air<T>(pev, csoo, per);
+    if constexpr (ALL || PART == 1) {
+        f.k = 6;
 #pragma unroll
-    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], per[k]), flag_poly_eq));
+        for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(a_add(vaf[k], vb[k]), comp_tail[k])), flag_add));
 #pragma unroll
-    for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], vres[k]), start));
-    f.assert_zero(a_mul(nss, a_sub(a_sub(len, shift[2]), one)));
-    f.assert_zero(a_mul(nss, a_sub(is_be, shift[0])));
-    f.assert_zero(a_mul(nss, a_sub(flag_add, shift[3])));
-    f.assert_zero(a_mul(nss, a_sub(flag_mul, shift[4])));
-    f.assert_zero(a_mul(nss, a_sub(flag_poly_eq, shift[5])));
-    const T a_inc = a_add(is_be, a_mulc(is_ee, mc(5)));
-    f.assert_zero(a_mul(nss, a_sub(a_sub(shift[6], idx_a), a_inc)));
-    f.assert_zero(a_mul(nss, a_sub(a_sub(shift[7], idx_b), a_from_base(mc(5), one))));
-    f.assert_zero(a_mul(start_shift, a_sub(len, one)));
+        for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], a_add(vavb[k], comp_tail[k])), flag_mul));
+    }
+    if constexpr (ALL || PART == 2 || PART == 3) {
+        T pev[5], csoo[5], per[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const T base = a_sub(a_sub(a_add(vavb[k], vavb[k]), vaf[k]), vb[k]);
+            pev[k] = k == 0 ? a_add(base, one) : base;
+            csoo[k] = k == 0 ? a_add(comp_tail[0], start_shift) : comp_tail[k];
+        }
+        quintic_mul_air<T>(pev, csoo, per);  // (a part uses some of the five outputs: the others are dead code there)
+        constexpr int K0 = PART == 3 ? 3 : 0, K1 = PART == 2 ? 3 : 5;
+        f.k = 16 + K0;
+#pragma unroll
+        for (int k = K0; k < K1; k++) f.assert_zero(a_mul(a_sub(comp[k], per[k]), flag_poly_eq));
+    }
+    if constexpr (ALL || PART == 0) {
+        f.k = 21;
+#pragma unroll
+        for (int k = 0; k < 5; k++) f.assert_zero(a_mul(a_sub(comp[k], vres[k]), start));
+        f.assert_zero(a_mul(nss, a_sub(a_sub(len, shift[2]), one)));
+        f.assert_zero(a_mul(nss, a_sub(is_be, shift[0])));
+        f.assert_zero(a_mul(nss, a_sub(flag_add, shift[3])));
+        f.assert_zero(a_mul(nss, a_sub(flag_mul, shift[4])));
+        f.assert_zero(a_mul(nss, a_sub(flag_poly_eq, shift[5])));
+        const T a_inc = a_add(is_be, a_mulc(is_ee, mc(5)));
+        f.assert_zero(a_mul(nss, a_sub(a_sub(shift[6], idx_a), a_inc)));
+        f.assert_zero(a_mul(nss, a_sub(a_sub(shift[7], idx_b), a_from_base(mc(5), one))));
+        f.assert_zero(a_mul(start_shift, a_sub(len, one)));
+    }
     return f.result();
 }
 

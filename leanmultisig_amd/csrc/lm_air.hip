@@ -198,17 +198,29 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         if (seg == 3) return air::eval_poseidon16_segment<T, 3>(col, x);
         return air::eval_poseidon16_segment<T, 4>(col, x);
     } else {
-        (void)seg;
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
-        T flat[NF], shift[NS];
+        // (one copy of the loads per instantiation of the evaluator: a part of the ExtensionOp constraints leaves the columns it
+        // does not touch unread)
+        auto run = [&](auto PARTC) {
+            T flat[NF], shift[NS];
 #pragma unroll
-        for (int c = 0; c < NF; c++) flat[c] = cols.template at<(TABLE != air::T_EXECUTION)>(c, j, zm);
+            for (int c = 0; c < NF; c++) flat[c] = cols.template at<(TABLE != air::T_EXECUTION)>(c, j, zm);
 #pragma unroll
-        for (int c = 0; c < NS; c++) shift[c] = cols.template at<(TABLE != air::T_EXECUTION)>(NF + c, j, zm);
-        if constexpr (TABLE == air::T_EXECUTION)
-            return air::eval_execution<T>(flat, shift, x);
-        else
-            return air::eval_extension_op<T>(flat, shift, x);
+            for (int c = 0; c < NS; c++) shift[c] = cols.template at<(TABLE != air::T_EXECUTION)>(NF + c, j, zm);
+            if constexpr (TABLE == air::T_EXECUTION)
+                return air::eval_execution<T>(flat, shift, x);
+            else
+                return air::eval_extension_op<T, decltype(PARTC)::value>(flat, shift, x);
+        };
+        if constexpr (TABLE == air::T_EXTENSION_OP && SEG == -2) {  // the part is uniform per workgroup: no divergence
+            if (seg == 0) return run(kb::IntC<0>{});
+            if (seg == 1) return run(kb::IntC<1>{});
+            if (seg == 2) return run(kb::IntC<2>{});
+            return run(kb::IntC<3>{});
+        } else {
+            (void)seg;
+            return run(kb::IntC<-1>{});
+        }
     }
 }
 
@@ -257,6 +269,12 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
             z = y == 0 ? 0 : y + 1;
             slot = y * 4 + (SEG < 2 ? SEG : SEG - 1);
         }
+    } else if constexpr (TABLE == air::T_EXTENSION_OP && SEG == -2) {
+        // small rounds: (point, part of the constraint list) per workgroup, air::eval_extension_op<T, PART>
+        seg = y % air::EXT_PARTS;
+        const u32 zi = y / air::EXT_PARTS;
+        z = zi == 0 ? 0 : zi + 1;
+        slot = y;
     } else {
         seg = 0;
         z = y == 0 ? 0 : y + 1;  // 0, 2, 3, ..., degree
@@ -300,6 +318,187 @@ __global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == si
     }
     if (fin.out) air_finish_inline(partial, blocks_x, fin);
 }
+// ---- lane-cooperative evaluation of the Poseidon table in the small extension-field rounds --------------------------------------
+// In the last rounds a table has a few hundred row pairs at most and k_air_round's one-lane-per-(pair, point, segment) evaluation
+// is a single dependent chain of ~9 k instructions (~25 us however few pairs are left).  Here SIXTEEN lanes evaluate one (pair,
+// point, segment): lane l owns state word l — the S-box layers run in parallel, the circulant MDS is 15 lane rotations inside the
+// 16-lane row (as poseidon16_coop.h does for hashing), the segment's constraints are spread over the lanes as alpha^k * A * B
+// terms with per-lane operands (data selection, no divergent paths), and a row sum collects them.  The chain is 5-9 extension
+// multiplications + 1-2 MDS instead of ~80 + 2.  Exactly the sums of k_air_round (field arithmetic, distributivity):
+//   segments 0 / 1 / 3: sum_l beta[l] * cube(MDS(cube(in + rc))_l + rc') - V        (out_block; lane K < 5 subtracts X^K * V_K)
+//   segment 0 also: alpha^0 * bus + alpha^1..7 * (flag constraints): lanes 1..7 one product each, lanes 8..11 the four products of
+//                   the bus fingerprint, lane 0 finishes the bus value
+//   segment 4: full rounds 6 and 7, then lane i < 8: alpha^(76+3i) gate_i (s_i + in_i - out_i) + alpha^(77+3i) flag_permute (s_i - out_i),
+//              lane 8 + i: alpha^(78+3i) flag_permute (s_{8+i} - out'_i)
+//   segment 2: lane r (and 16 + r for r < 4): alpha^(40+r) * (y_r^3 - partial_rounds[r])
+static constexpr u32 AIR_COOP_PAIRS = 32;   // row pairs per workgroup of 512 threads
+static constexpr u32 AIR_COOP_MAX_PAIRS = AIR_COOP_PAIRS * AIR_INLINE_MAX_BLOCKS;  // (the round finishes inside the kernel)
+
+__device__ __forceinline__ EF coop_row_sum(EF v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 5; k++) v.v[k] = add(v.v[k], (u32)__shfl_xor(v.v[k], off, 16));
+    return v;
+}
+__device__ __forceinline__ EF coop_row_get(const EF& v, u32 src) {
+    EF r;
+#pragma unroll
+    for (int k = 0; k < 5; k++) r.v[k] = (u32)__shfl(v.v[k], src, 16);
+    return r;
+}
+// y_l = sum_t col[t] * s_{(l - t) mod 16}  (the circulant of poseidon16.h: mds_circ16), plane by plane
+__device__ __forceinline__ EF coop_mds(const EF& s, u32 l) {
+    EF y;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        u64 acc = 0;
+        static_for<0, 16>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            constexpr u32 COL[16] = {1, 3, 13, 22, 67, 2, 15, 63, 101, 1, 2, 17, 11, 1, 51, 1};
+            acc += (u64)(u32)__shfl(s.v[k], (l - t) & 15, 16) * opaque_const(COL[t]);
+        });
+        y.v[k] = reduce40(acc);
+    }
+    return y;
+}
+__device__ __forceinline__ EF coop_mul_xk(EF a, u32 kx) {  // a * X^kx, kx < 5 (air::ef_mul_xk with a run-time exponent)
+    for (u32 t = 0; t < kx; t++) {
+        const EF b = a;
+        a.v[0] = b.v[4], a.v[1] = b.v[0], a.v[2] = sub(b.v[1], b.v[4]), a.v[3] = b.v[2], a.v[4] = b.v[3];
+    }
+    return a;
+}
+__device__ __forceinline__ u32 coop_rc(u32 round, u32 l) {
+    const PoseidonConsts& pc = poseidon_consts();
+    return round < 4 ? pc.rc_init[round][l] : pc.rc_term[round - 4][l];
+}
+__device__ __forceinline__ EF coop_select(bool c, const EF& a, const EF& b) {
+    EF r;
+#pragma unroll
+    for (int k = 0; k < 5; k++) r.v[k] = c ? a.v[k] : b.v[k];
+    return r;
+}
+// lane l's share of segment `seg` (uniform per workgroup) of row pair j at the evaluation point: the 16 shares add up to
+// air::eval_poseidon16_segment<EF, seg>
+template <class Cols>
+__device__ __forceinline__ EF coop_segment(const Cols& cols, u64 j, u32 zm, u32 seg, u32 l, const air::Extra& x) {
+    auto col = [&](u32 c) { return cols.template at<false>(c, j, zm); };
+    if (seg == 2) {
+        EF c = ef_zero();
+#pragma unroll
+        for (u32 pass = 0; pass < 2; pass++) {
+            const u32 r = pass * 16 + l;
+            if (r < 20) {  // (lanes 4..15 skip the second pass together: whole groups of 12 lanes)
+                const EF d = ef_sub(air::cube(col(air::POS_VIRT_Y + r)), col(57 + r));
+                c = ef_add(c, ef_mul(x.alpha_powers[40 + r], d));
+            }
+        }
+        return c;
+    }
+    const u32 input_col = seg == 0 ? 9u : seg == 1 ? 25u : seg == 3 ? (u32)air::POS_VIRT_E : 77u;
+    const u32 r0 = seg == 0 ? 0u : seg == 1 ? 2u : seg == 3 ? 4u : 6u;
+    EF s = air::cube(ef_add_base(col(input_col + l), coop_rc(r0, l)));
+    s = coop_mds(s, l);
+    if (seg != 4) {
+        const u32 S = seg == 0 ? 0u : seg == 1 ? 1u : 2u;
+        EF c = ef_mul(x.out_beta[S][l], air::cube(ef_add_base(s, coop_rc(r0 + 1, l))));
+        if (l < 5) c = ef_sub(c, coop_mul_xk(col(air::POS_VIRT_O + 5 * S + l), l));
+        if (seg == 0) {
+            const EF flag_active = col(0), index_b = col(1), index_res = col(2), flag_half = col(3), flag_left = col(4);
+            const EF offset_left = col(5), eff_first = col(6), eff_second = col(7), flag_permute = col(8);
+            const EF one = ef_one();
+            const EF omfl = ef_sub(one, flag_left);
+            const EF index_a = ef_sub(eff_second, ef_mul_base(omfl, to_monty(4)));
+            // precompile data: 1 + 4 half + 8 left + 16 left*offset + 2 permute
+            const EF pdr = ef_add(ef_add(ef_add(ef_add(one, ef_mul_base(flag_half, to_monty(4))), ef_mul_base(flag_left, to_monty(8))),
+                                         ef_mul_base(ef_mul(flag_left, offset_left), to_monty(16))),
+                                  ef_mul_base(flag_permute, to_monty(2)));
+            // one product per lane: A * B
+            EF A = ef_zero(), B = ef_zero();
+            const EF bv = l == 1 ? flag_active : l == 2 ? flag_half : l == 3 ? flag_left : flag_permute;  // bool_check operands
+            if (l >= 1 && l <= 4) A = ef_sub(one, bv), B = bv;
+            if (l == 5) A = flag_permute, B = ef_add(flag_half, flag_left);
+            if (l == 6) A = flag_left, B = ef_sub(offset_left, eff_first);
+            if (l == 7) A = omfl, B = ef_sub(index_a, eff_first);
+            if (l >= 8 && l < 12) {
+                A = x.logup_eq[l - 8];
+                B = l == 8 ? pdr : l == 9 ? index_a : l == 10 ? index_b : index_res;
+            }
+            const EF P = ef_mul(A, B);
+            // the bus value on lane 0: (sum of lanes 8..11 + eq[15]) * beta + flag
+            const EF fp = ef_add(ef_add(coop_row_get(P, 8), coop_row_get(P, 9)), ef_add(coop_row_get(P, 10), coop_row_get(P, 11)));
+            const EF bus = ef_add(ef_mul(ef_add(fp, x.logup_eq[15]), x.bus_beta), flag_active);
+            const EF q = l == 0 ? bus : P;
+            if (l < 8) c = ef_add(c, ef_mul(x.alpha_powers[l], q));
+        }
+        return c;
+    }
+    s = air::cube(ef_add_base(s, coop_rc(7, l)));
+    s = coop_mds(s, l);
+    const EF flag_half = col(3), flag_permute = col(8);
+    const EF not_permute = ef_sub(ef_one(), flag_permute);
+    const EF comp_last4 = ef_sub(not_permute, flag_half);
+    const u32 i = l & 7;
+    const bool lo = l < 8;
+    // every lane: alpha^k * D * G with (lanes 0..7) k = 76 + 3 i, D = s + in_i - out_i, G = the output gate; (lanes 8..15) k = 78 + 3 i,
+    // D = s - out'_i, G = flag_permute.  Lanes 0..7 add alpha^(77 + 3 i) * (s - out_i) * flag_permute.
+    const EF o = col(lo ? 93 + i : 101 + i);
+    const EF d = lo ? ef_sub(ef_add(s, col(9 + i)), o) : ef_sub(s, o);
+    const EF gate = lo ? coop_select(i < 4, not_permute, comp_last4) : flag_permute;
+    EF c = ef_mul(ef_mul(x.alpha_powers[(lo ? 76 : 78) + 3 * i], d), gate);
+    if (lo) c = ef_add(c, ef_mul(ef_mul(x.alpha_powers[77 + 3 * i], ef_sub(s, o)), flag_permute));
+    return c;
+}
+
+// grid = blocks_x * AIR_POS_SLOTS workgroups of 512 threads; group g = threadIdx.x / 16 of tile t evaluates pairs t * 32 + g, ...
+template <class Cols>
+__global__ __launch_bounds__(512) void k_air_round_pos_coop(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+                                                            u32* __restrict__ partial, u32 blocks_x, AirFinish fin) {
+    __shared__ u32 lds[8 * 5];
+    const u32 y = blockIdx.x / blocks_x, tile = blockIdx.x % blocks_x;
+    u32 seg, z;  // slot y -> (segment, point): k_air_round, SEG < 0
+    if (y < 4 * AIR_POS_POINTS) {
+        const u32 s4 = y & 3, zi = y >> 2;
+        seg = s4 < 2 ? s4 : s4 + 1;
+        z = zi == 0 ? 0 : zi + 1;
+    } else {
+        seg = 2;
+        z = y - 4 * AIR_POS_POINTS;
+    }
+    const u32 zm = to_monty(z);
+    const u32 l = threadIdx.x & 15, g = threadIdx.x >> 4;
+    EF acc = ef_zero();
+    for (u64 j = (u64)tile * AIR_COOP_PAIRS + g;; j += (u64)blocks_x * AIR_COOP_PAIRS) {
+        bool is_pad = false;
+        u64 je = j;
+        if (j >= n_pairs) {
+            if (!(fin.pad_on && j == n_pairs)) break;
+            is_pad = true;
+            je = fin.pad_pair;
+        }
+        const EF v = coop_row_sum(coop_segment(cols, je, zm, seg, l, *extra));
+        if (l == 0) acc = ef_add(acc, ef_mul(v, is_pad ? fin.pad_w : eq_split_at(eq, je)));
+        if (is_pad) break;
+    }
+    u32 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = wave_sum_u32(acc.v[k]);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) lds[wave * 5 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        u32 s = 0;
+        for (u32 w = 0; w < 8; w++) s = add(s, lds[w * 5 + threadIdx.x]);
+        lm_store_agent(partial + ((u64)y * blocks_x + tile) * 5 + threadIdx.x, s);
+        lm_wait_stores();
+    }
+    air_finish_inline(partial, blocks_x, fin);
+}
+
 // one block per z: out[zi * 5 + k] = sum over the n = n_seg * blocks_x consecutive partials of point zi
 // out = pinned result buffer; the block that finishes last publishes the sequence number.
 // Block zi sums the n_main consecutive partials of point zi and, for the Poseidon table, adds the degree-3 segment:
@@ -415,6 +614,18 @@ __global__ __launch_bounds__(256) void k_air_virtual_columns(const u32* const* _
     });
 }
 
+// does this round of the Poseidon table (extension-field columns) run on k_air_round_pos_coop?  LM_AIR_NO_COOP=1: never
+static bool air_coop_round(u64 n_pairs, bool padding_pair) {
+    static const bool on = getenv("LM_AIR_NO_COOP") == nullptr;
+    return on && n_pairs + (padding_pair ? 1 : 0) <= AIR_COOP_MAX_PAIRS;
+}
+// does this round of the ExtensionOp table (extension-field columns) split its constraint list over air::EXT_PARTS workgroups per
+// point?  Small rounds only: there the evaluation is one dependent chain per lane and four shorter chains side by side win; in the
+// large rounds the parts would repeat the shared products.  LM_AIR_NO_COOP=1: never
+static bool air_ext_parts_round(u64 n_pairs, bool padding_pair) {
+    static const bool on = getenv("LM_AIR_NO_COOP") == nullptr;
+    return on && n_pairs + (padding_pair ? 1 : 0) <= 256;
+}
 template <int TABLE, class T, class Cols, int SEG>
 static int launch_segment(lm_ctx* ctx, hipStream_t stream, const Cols& c, const dim3& grid, u64 n_pairs, const air::Extra* extra, const EqSplit& eq,
                           u32* partial, const AirFinish& fin) {
@@ -429,6 +640,14 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
         // 165-240).  Extension-field rounds and small rounds: ONE launch with the segment in the workgroup id — the
         // combined extension-field kernel compiles to 148 VGPRs (3 waves per SIMD) where the specialised ones take
         // 256 + AGPRs (1 wave), and small rounds are latency bound anyway (the five chains run side by side).
+        if constexpr (sizeof(T) == sizeof(EF)) {
+            if (air_coop_round(n_pairs, fin.pad_on != 0)) {  // small extension-field round: 16 lanes per (pair, point, segment)
+                LM_LAUNCH_ON(ctx, a->stream, (k_air_round_pos_coop<Cols>), dim3(blocks * AIR_POS_SLOTS), dim3(512), 0, c, n_pairs, extra, eq,
+                             partial, blocks, fin);
+                LM_HIP(hipGetLastError());
+                return LM_OK;
+            }
+        }
         if (sizeof(T) == sizeof(u32) && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
             const dim3 grid(blocks, AIR_POS_POINTS);
             AirFinish none = fin;   // five launches: the partials are summed by k_air_reduce (blocks > AIR_INLINE_MAX_BLOCKS here)
@@ -441,6 +660,11 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
         } else {
             launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial, fin);
         }
+    } else if constexpr (TABLE == air::T_EXTENSION_OP && sizeof(T) == sizeof(EF)) {
+        if (air_ext_parts_round(n_pairs, fin.pad_on != 0))
+            launch_segment<TABLE, T, Cols, -2>(ctx, a->stream, c, dim3(blocks, a->deg * air::EXT_PARTS), n_pairs, extra, eq, partial, fin);
+        else
+            launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial, fin);
     } else {
         launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, a->deg), n_pairs, extra, eq, partial, fin);
     }
@@ -596,6 +820,8 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     // iterations exactly and those are few, add workgroups so that it lands on an idle thread
     if (prefix && n_pairs % ((u64)blocks * 256) == 0 && n_pairs / ((u64)blocks * 256) < 4 && blocks < AIR_MAX_BLOCKS)
         blocks += (blocks & 7) == 0 ? 8 : 1;
+    if (pos && a->cur >= 0 && air_coop_round(n_pairs, prefix))  // tiles of AIR_COOP_PAIRS pairs, the padding pair included
+        blocks = (u32)((n_pairs + (prefix ? 1 : 0) + AIR_COOP_PAIRS - 1) / AIR_COOP_PAIRS);
     u32* s = a->d_partial;
     int rc;
     const EqSplit eq = a->eqt.at(p);
@@ -625,7 +851,8 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     fin.done_counter = a->d_sync;
     fin.seq = seq;
     fin.deg = a->deg;
-    fin.n_main = pos ? 4 * blocks : blocks;
+    const bool ext_parts = a->table == air::T_EXTENSION_OP && a->cur >= 0 && air_ext_parts_round(n_pairs, prefix);
+    fin.n_main = pos ? 4 * blocks : ext_parts ? air::EXT_PARTS * blocks : blocks;
     fin.n_low = pos ? blocks : 0u;
     fin.low_offset = (u64)4 * AIR_POS_POINTS * blocks;
     if (prefix) {

@@ -124,3 +124,19 @@ def test_poseidon_table_large_paths(ctx, orc):
     cols = rand_field(rng, (ob.AIR_N_COLUMNS[2], 1 << lr))
     t = dict(table=2, log_rows=lr, cols=cols, eq_point=rand_field(rng, (lr, 5)), sum=rand_field(rng, 5))
     _run(ctx, orc, [t], alpha, eq16, beta, eta)
+
+
+def test_small_rounds_without_the_cooperative_kernels():
+    """LM_AIR_NO_COOP=1: the small extension-field rounds run on the one-lane-per-evaluation kernel (the path every round took
+    before the 16-lane Poseidon evaluation and the four-part ExtensionOp list) — same round polynomials.  The switch is read once
+    per process, so the parity tests above are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_AIR_NO_COOP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_air_gpu.py", "-k",
+                        "test_single_table_random_columns or test_active_prefix_equals_full_sum or test_three_tables_back_loaded_and_verified"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

@@ -474,6 +474,30 @@ __device__ __forceinline__ void finish40(const Quad2& a, u32* red /* 4 * 40 + 40
         if (threadIdx.x == 0) lm_publish_flag(h_res, seq);
     }
 }
+// Base-field f (the first pass of the opening sumcheck, 1.6 GB): the eight sums as 40 raw 64-bit accumulators — a product of
+// reduced values is < p^2 < 2^62, kb::fold32 brings an accumulator below 2^57 with one multiply-add, after which three more
+// products fit — reduced once at the end.  ~180 VALU instructions per quad instead of ~600: the pass is as much an ALU kernel as
+// a memory kernel (6 instructions per byte with a Montgomery reduction per product).
+struct Quad2Raw {
+    u64 s[8][5];  // order of Quad2: p00, p01, p10, q0, q1, t0, t2, t3
+};
+__device__ __forceinline__ void quad_accumulate_base_raw(const u32 f[4], const EF w[4], Quad2Raw& a) {
+    const u32 d0f = sub(f[2], f[0]), d1f = sub(f[3], f[1]);
+    const EF d0w = ef_sub(w[2], w[0]), d1w = ef_sub(w[3], w[1]);
+    const EF t0w = ef_sub(w[1], w[0]), t3w = ef_sub(w[3], w[2]), t2w = ef_sub(d1w, d0w);
+    const u32 t0f = sub(f[1], f[0]), t3f = sub(f[3], f[2]), t2f = sub(d1f, d0f);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        a.s[0][k] += (u64)w[0].v[k] * f[0];
+        a.s[1][k] += (u64)w[1].v[k] * f[1];
+        a.s[2][k] += (u64)w[2].v[k] * f[2];
+        a.s[3][k] += (u64)d0w.v[k] * d0f;
+        a.s[4][k] += (u64)d1w.v[k] * d1f;
+        a.s[5][k] += (u64)t0w.v[k] * t0f;
+        a.s[6][k] += (u64)t2w.v[k] * t2f;
+        a.s[7][k] += (u64)t3w.v[k] * t3f;
+    }
+}
 // the eight sums on the tables as they are (no fold): lane i < n/4
 template <bool F_BASE>
 __global__ __launch_bounds__(256) void k_prod_round2(const u32* __restrict__ f, const u32* __restrict__ W, u64 quarter,
@@ -483,6 +507,14 @@ __global__ __launch_bounds__(256) void k_prod_round2(const u32* __restrict__ f, 
     const u64 plane = 4 * quarter;
     Quad2 a;
     a.p00 = a.p01 = a.p10 = a.q0 = a.q1 = a.t0 = a.t2 = a.t3 = ef_zero();
+    Quad2Raw raw;
+    if (F_BASE) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) raw.s[q][k] = 0;
+    }
+    u32 room = 4;  // products that still fit the raw accumulators
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < quarter; i += (u64)gridDim.x * 256) {
         EF w[4];
 #pragma unroll
@@ -493,7 +525,15 @@ __global__ __launch_bounds__(256) void k_prod_round2(const u32* __restrict__ f, 
             u32 fb[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) fb[t] = f[i + t * quarter];
-            quad_accumulate_base(fb, w, a);
+            if (room == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) raw.s[q][k] = fold32(raw.s[q][k]);
+                room = 3;
+            }
+            quad_accumulate_base_raw(fb, w, raw);
+            room--;
         } else {
             EF fe[4];
 #pragma unroll
@@ -502,6 +542,13 @@ __global__ __launch_bounds__(256) void k_prod_round2(const u32* __restrict__ f, 
                 for (int k = 0; k < 5; k++) fe[t].v[k] = f[(u64)k * plane + i + t * quarter];
             quad_accumulate(fe, w, a);
         }
+    }
+    if (F_BASE) {
+        EF* e = &a.p00;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) e[q].v[k] = reduce(fold32(raw.s[q][k]));
     }
     finish40(a, red, acc, done_counter, final_out, seq);
 }
@@ -860,7 +907,9 @@ int lm_fold_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t
 int lm_prod_round2(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_t* d_W, uint32_t n_vars, uint32_t out_sums[40]) {
     LM_REQUIRE(ctx && d_f && d_W && out_sums && n_vars >= 2 && n_vars <= 40);
     const u64 quarter = 1ull << (n_vars - 2);
-    const u32 blocks = (u32)std::min<u64>((quarter + 255) / 256, 2048);
+    // 512 workgroups: the kernel is a grid-stride loop that ends in 40 accumulator atomics per workgroup (lm_grid_sum); measured on
+    // the 1.6 GB pass — 256: 0.42 ms, 384: 0.42, 512: 0.40, 768: 0.42, 1024 / 2048 / 4096: 0.44
+    const u32 blocks = (u32)std::min<u64>((quarter + 255) / 256, 512);
     const u32 seq = ++ctx->res_seq;
     LM_PROF_BYTES(ctx, k_prod_round2, (4 * quarter) * (f_is_ext ? 40ull : 24ull));  // every f and W value once
     if (f_is_ext)
@@ -882,7 +931,7 @@ int lm_fold2_round(lm_ctx* ctx, const uint32_t* d_f, int f_is_ext, const uint32_
     LM_REQUIRE(sums < 2 || m >= 4);
     LM_REQUIRE(sums < 1 || m >= 2);
     const u64 lanes = m >= 4 ? m / 4 : 1;
-    const u32 blocks = (u32)std::min<u64>((lanes + 255) / 256, 2048);
+    const u32 blocks = (u32)std::min<u64>((lanes + 255) / 256, 2048);  // (512 .. 4096 workgroups: within 3 % of each other)
     EF a, b;
     memcpy(a.v, r0, 20);
     memcpy(b.v, r1, 20);

@@ -1,7 +1,8 @@
 """Race detector for the latency machinery (fence-free publishes, side streams, staging ring, pooled memory): C provers on one
 GPU prove the SAME leaf over and over from C host threads; proofs are deterministic, so every proof of a prover must equal
 its first one word for word, and EVERY proof is checked by lmh_verify_execution (a reordered publish would corrupt the
-transcript: the proof is rejected).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log]"""
+transcript: the proof is rejected).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log] [whole]
+whole = 1: every proof is the WHOLE function (lmh_prove_execution_vm: VM run on a leased pool, device trace, proof)."""
 import os
 import sys
 import threading
@@ -17,6 +18,7 @@ import leanmultisig_amd as lm  # noqa: E402
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+WHOLE = len(sys.argv) > 4 and sys.argv[4] == "1"
 ctxs = [lm.Context(0) for _ in range(C)]
 ws = [bench.build_vm_workload(ctxs[c], np.random.default_rng(900 + c), max(2, bench.N_SIGS >> SCALE), 1, False, log_bytecode=19 if SCALE == 0 else None)
       for c in range(C)]
@@ -35,7 +37,13 @@ def worker(c):
         ctxs[c]._check(ctxs[c].lib.lm_bind_thread(ctxs[c].h))   # the HIP device is per host thread
         start.wait()
         for i in range(N):
-            pr = bench.run_step(ctxs[c], lm, ws[c])
+            if WHOLE:
+                from leanmultisig_amd import vm
+                v = ws[c]["vm"]
+                pr = lm.Prover(ctxs[c])
+                vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], ws[c]["lm_builder"], n_threads=8)
+            else:
+                pr = bench.run_step(ctxs[c], lm, ws[c])
             p = pr.proof()
             ok, err = lm.verify_execution(ws[c]["w"], pr, ws[c]["lm_builder"])   # every proof goes through lmh_verify_execution
             if not ok:

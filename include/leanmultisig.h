@@ -271,7 +271,13 @@ int lm_logup_build_active(lm_ctx* ctx, const lm_logup_section* sections, uint32_
  *   lm_gkr_layer_begin  start prove_gkr_layer (mod.rs:80-141) for the layer with 2^(K+1) entries: claim point (K x 5), alpha
  *   lm_gkr_round        one sumcheck round, LSB first: out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109);
  *                       prev_r = NULL for the first round, else the previous challenge (fold_and_compute_round)
- *   lm_gkr_layer_end    fold by the last challenge; inner_evals = [n_l, n_r, d_l, d_r] (4 EF) */
+ *   lm_gkr_layer_end    fold by the last challenge; inner_evals = [n_l, n_r, d_l, d_r] (4 EF)
+ * Between lm_gkr_layer_begin and lm_gkr_layer_end (or lm_gkr_free) the context's stream belongs to the layer: once the arrays
+ * are small, a kernel stays RESIDENT on it and receives the challenges of lm_gkr_round through a pinned mailbox instead of
+ * being relaunched, so any other call that launches work on the same context would queue behind it — it
+ * fails after the resident kernel's 3 s timeout and the layer is lost.  Use another lm_ctx for concurrent work (the
+ * reference's prove_gkr_quotient does nothing else between the rounds of a layer either).  lm_gkr_free / a new
+ * lm_gkr_layer_begin dismiss a resident kernel at once.  LM_GKR_NO_TAIL=1 (environment) restores one launch per round pair. */
 typedef struct lm_gkr lm_gkr;
 int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out);
 /* Same with an ACTIVE PREFIX: entries [active_len, 2^n_vars) are the neutral pair (0, 1) and are never read (they need not

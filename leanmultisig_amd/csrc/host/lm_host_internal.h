@@ -9,6 +9,10 @@
 #include "../poseidon16.h"
 
 void lm_set_error(const char* fmt, ...);  // lm_core.hip (thread-local message behind lm_last_error)
+// lm_core.hip: per-context cache of device copies of long-lived host objects, keyed by the object's process-unique id (+ a small
+// tag); the entries are pool allocations of the context (lm_malloc) and die with it
+void* lm_ctx_cache_get(lm_ctx* ctx, unsigned long long key);
+void lm_ctx_cache_put(lm_ctx* ctx, unsigned long long key, void* p);
 
 namespace lmh {
 using kb::EF;

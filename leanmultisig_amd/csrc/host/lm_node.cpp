@@ -184,15 +184,13 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24))) return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
     if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
     mark("alloc + memory upload");
-    // ---- bytecode table: device copy cached in the bytecode object -------------------------------------------------------------
-    u32** slot = vm_bytecode_device_slot(bc, (void*)ctx);
-    if (!*slot) {
-        u32* d;
-        if ((rc = lm_malloc(ctx, 16ull << log_bytecode, &d))) return fail(rc);  // lives as long as the context's pool
-        if ((rc = lm_upload(ctx, d, lmh_bytecode_multilinear(bc), 16ull << log_bytecode))) return fail(rc);
-        *slot = d;
+    // ---- bytecode table: device copy cached in the CONTEXT under the bytecode's unique id --------------------------------------
+    u32* d_bytecode = (u32*)lm_ctx_cache_get(ctx, vm_bytecode_uid(bc) << 4);
+    if (!d_bytecode) {
+        if ((rc = lm_malloc(ctx, 16ull << log_bytecode, &d_bytecode))) return fail(rc);  // lives as long as the context's pool
+        if ((rc = lm_upload(ctx, d_bytecode, lmh_bytecode_multilinear(bc), 16ull << log_bytecode))) return fail(rc);
+        lm_ctx_cache_put(ctx, vm_bytecode_uid(bc) << 4, d_bytecode);
     }
-    u32* const d_bytecode = *slot;
     // ---- tables ----------------------------------------------------------------------------------------------------------------
     for (int tb = 0; tb < 3; tb++) {
         const u32 n_total = kVmTables[tb].n_total, n_com = kVmTables[tb].n_columns;

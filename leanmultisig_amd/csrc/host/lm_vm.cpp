@@ -105,10 +105,42 @@ class Pool {
         static thread_local Pool* p = nullptr;
         return p;
     }
+    // CPUs the cgroup grants this process (cpu.max = "<quota> <period>"), 0 = unlimited / unknown
+    static u32 cgroup_cpus() {
+        static const u32 v = [] {
+            FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+            if (!f) return 0u;
+            char q[32];
+            unsigned long long per = 0;
+            u32 r = 0;
+            if (fscanf(f, "%31s %llu", q, &per) == 2 && strcmp(q, "max") != 0 && per) {
+                const unsigned long long quota = strtoull(q, nullptr, 10);
+                r = (u32)std::max<unsigned long long>(1, quota / per);
+            }
+            fclose(f);
+            return r;
+        }();
+        return v;
+    }
+    // Default width of a run: hardware threads, at most 128 (2 x 64-core EPYC host of the GPU box: 64 threads 2.9 ms, 128 threads
+    // 1.7 ms for the 1549 segments), and at most 4 x the cgroup's CPU quota: a run is a burst of a few milliseconds, which the
+    // quota (CPU time per 100 ms period) tolerates well above its average, but 128 threads every 30 ms on a 16-CPU quota is more
+    // CPU time than the period holds and the whole process is throttled (round 3: VM 4.5 ms alone, 7.4 ms in steady state).
+    // LM_VM_THREADS overrides.
     static u32 default_threads() {
-        u32 hw = std::thread::hardware_concurrency();
-        if (hw == 0) hw = 1;
-        return hw > 128 ? 128 : hw;  // (2 x 64-core EPYC host of the GPU box: 64 threads 2.9 ms, 128 threads 1.7 ms for the 1549 segments)
+        static const u32 v = [] {
+            if (const char* e = getenv("LM_VM_THREADS")) {
+                const u32 x = (u32)strtoul(e, nullptr, 10);
+                if (x) return x;
+            }
+            u32 hw = std::thread::hardware_concurrency();
+            if (hw == 0) hw = 1;
+            if (hw > 128) hw = 128;
+            const u32 q = cgroup_cpus();
+            if (q && 4 * q < hw) hw = 4 * q;
+            return hw;
+        }();
+        return v;
     }
 
    private:
@@ -485,14 +517,16 @@ struct lmh_bytecode {
     mutable std::mutex hash_mu;
     mutable bool hash_done = false;
     mutable u32 hash[8];
-    mutable std::mutex device_mu;
-    mutable std::map<void*, u32*> device;  // context -> device copy of `multilinear` (lm_node.cpp)
+    // process-unique id: the key of this object's device copies in a context's cache (lm_ctx_cache_get: the copies belong to the
+    // context and die with it; an id is never reused, so a context never finds another bytecode's tables under it)
+    const u64 uid = next_uid();
+    static u64 next_uid() {
+        static std::atomic<u64> n{1};
+        return n.fetch_add(1, std::memory_order_relaxed);
+    }
 };
 namespace lmh {
-u32** vm_bytecode_device_slot(const lmh_bytecode* bc, void* ctx) {
-    std::lock_guard<std::mutex> lk(bc->device_mu);
-    return &bc->device[ctx];  // (map nodes are stable)
-}
+u64 vm_bytecode_uid(const lmh_bytecode* bc) { return bc->uid; }
 }  // namespace lmh
 
 // the log buffers of the last released execution: their pages are resident, the next run writes into them without faulting
@@ -830,7 +864,10 @@ struct Machine {
         const u64 size = in.x1, pa = usize(va), pb = usize(vb), pr = usize(vc);
         if (size == 1 && op != OP_POLY_EQ && !solve_unknowns(pa, pb, pr, is_be, op)) return;
         const u64 a_stride = is_be ? 1 : 5;
-        std::vector<EF> elems(size), vbs(size), comp(size);
+        // `size` comes from the bytecode (< 2^25): the operand vectors grow as the operands are read, so a size that runs off the
+        // defined memory fails with UndefinedMemory before anything of its order is allocated
+        std::vector<EF> elems, vbs;
+        elems.reserve(std::min<u64>(size, 1u << 12)), vbs.reserve(std::min<u64>(size, 1u << 12));
         for (u64 i = 0; i < size; i++) {
             EF a, b;
             if (is_be) {
@@ -840,9 +877,10 @@ struct Machine {
             } else if (!need_ef(pa + i * a_stride, a))
                 return;
             if (!need_ef(pb + i * 5, b)) return;
-            elems[i] = compute_elem(a, b, op);
-            vbs[i] = b;
+            elems.push_back(compute_elem(a, b, op));
+            vbs.push_back(b);
         }
+        std::vector<EF> comp(size);
         comp[size - 1] = elems[size - 1];
         for (u64 i = size - 1; i-- > 0;) comp[i] = op == OP_POLY_EQ ? kb::ef_mul(elems[i], comp[i + 1]) : kb::ef_add(elems[i], comp[i + 1]);
         if (!set_ef(pr, comp[0])) return;
@@ -1199,8 +1237,13 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
         m.fp = batch.batch_fp + (i + 1) * stride;
         m.ap = m.fp + batch.frame_size;
         Machine<SegMem>::Batch inner;
-        const int rc = m.run(true, batch.batch_pc, inner);
-        if (rc != 1 && !m.err.set) m.err.raise(rc == 0 ? "Panic: a parallel segment reached the end of the program" : "Panic: nested parallel batch");
+        try {  // (a pool thread has no caller to unwind to: an allocation failure becomes the segment's error)
+            const int rc = m.run(true, batch.batch_pc, inner);
+            if (rc != 1 && !m.err.set) m.err.raise(rc == 0 ? "Panic: a parallel segment reached the end of the program" : "Panic: nested parallel batch");
+        } catch (const std::bad_alloc&) {
+            m.err.set = false;
+            m.err.raise("OutOfMemory (host allocation)");
+        }
         s.err = m.err;
         s.n_cyc = t.pcs.size() - s.o_cyc, s.n_pos = t.pos.size() - s.o_pos, s.n_ext = t.ext.size() - s.o_ext;
         s.n_pend = t.pending.size() - s.o_pend, s.n_def = L.deferred.size() - s.o_def;
@@ -1407,8 +1450,7 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         Witness w{witness->preamble_memory_len, witness->name_entry_begin, witness->entry_offset, witness->data};
         // execute_bytecode_helper (runner.rs:238-343)
         u64 pub = 1;
-        while (pub < n_public_input) pub <<= 1;  // padd_with_zero_to_next_power_of_two
-        if (n_public_input == 0) pub = 0;
+        while (pub < n_public_input) pub <<= 1;  // padd_with_zero_to_next_power_of_two (0usize.next_power_of_two() == 1: one zero word)
         MemBuf& memory = ex->memory;
         memory.len = pub;
         memset(memory.p, 0, 4 * pub);

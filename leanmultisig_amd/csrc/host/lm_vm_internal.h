@@ -8,9 +8,8 @@
 namespace lmh {
 // f(i) for i < n on the persistent host thread pool (the calling thread takes part); n_threads = 0: all hardware threads, <= 128
 void vm_parallel_for(u64 n, u32 n_threads, const std::function<void(u64)>& f);
-// device copy of a bytecode's instructions_multilinear for context `ctx` (cached in the bytecode object, one per context):
-// *slot is nullptr until lm_node.cpp fills it
-u32** vm_bytecode_device_slot(const lmh_bytecode* bc, void* ctx);
+// process-unique id of a bytecode object: the key of its device copies in a context's cache (lm_ctx_cache_get / _put)
+u64 vm_bytecode_uid(const lmh_bytecode* bc);
 // The host buffers of an execution the device uploads from — [0] the memory arena, [1] pcs, [2] fps, [3] Poseidon call records,
 // [4] ExtensionOp rows — with their CAPACITY in bytes (they are recycled from run to run, so a buffer pinned once stays useful).
 struct VmRegion {

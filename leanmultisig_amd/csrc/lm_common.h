@@ -84,6 +84,10 @@ struct lm_ctx {
     std::string prof_select;    // empty = profiling off; "*" = every kernel
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     std::map<std::string, u64> prof_bytes;  // algorithmic bytes of the recorded launches of a kernel (LM_PROF_BYTES at its launch sites)
+    // device copies of long-lived host objects (a bytecode's instruction table, decoded records, hints), keyed by the object's
+    // process-unique id: pool allocations of THIS context, gone with it (lm_ctx_cache_get / _put) — a cache inside the host object
+    // keyed by the context's address would hand a dangling pointer to the next context allocated at the same address
+    std::map<unsigned long long, void*> object_cache;
 };
 
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <time.h>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
@@ -10,6 +11,12 @@
 
 using namespace kb;
 
+// internal (C++ linkage, lm_host_internal.h): per-context cache of device copies of long-lived host objects
+void* lm_ctx_cache_get(lm_ctx* ctx, unsigned long long key) {
+    auto it = ctx->object_cache.find(key);
+    return it == ctx->object_cache.end() ? nullptr : it->second;
+}
+void lm_ctx_cache_put(lm_ctx* ctx, unsigned long long key, void* p) { ctx->object_cache[key] = p; }
 static thread_local char g_err[512] = "";
 void lm_set_error(const char* fmt, ...) {
     va_list ap;
@@ -347,11 +354,40 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
             nanosleep(&ts, nullptr);
             spins += 2000;  // (a nap is worth ~2000 polls of wall clock: the give-up point below stays where it was)
         }
-        if (spins > (1ull << 22)) {  // something is wrong or the kernel is long: fall back to the runtime
-            LM_HIP(hipStreamSynchronize(stream));
-            if (!reached()) {
-                lm_set_error("lm_wait_result: sequence %u never published (flag %u)", seq, *flag);
-                return LM_E_DEVICE;
+        if (spins > (1ull << 22)) {
+            // Something is wrong or the kernel is long.  NOT hipStreamSynchronize: a resident kernel (k_gkr_tail) may own the stream
+            // and be waiting for a mailbox message only this thread can write once it has seen the publication — a blocking sync
+            // would return after the kernel's own timeout, with the flag set by a kernel that is gone.  Ask the runtime whether the
+            // stream still has work and keep polling the flag; give up when the stream is idle without the publication, or after
+            // LM_WAIT_LIMIT_S seconds (default 30) of wall clock.
+            static const double limit_s = [] {
+                const char* e = getenv("LM_WAIT_LIMIT_S");
+                return e ? atof(e) : 30.0;
+            }();
+            const auto t_slow = std::chrono::steady_clock::now();
+            for (u64 polls = 0; !reached(); polls++) {
+                if ((polls & 1023) == 0) {
+                    const hipError_t q = hipStreamQuery(stream);
+                    if (q == hipSuccess) {
+                        if (reached()) break;
+                        lm_set_error("lm_wait_result: sequence %u never published (flag %u, stream idle)", seq, *flag);
+                        return LM_E_DEVICE;
+                    }
+                    if (q != hipErrorNotReady) {
+                        (void)hipGetLastError();
+                        lm_set_error("lm_wait_result: %s while waiting for sequence %u", hipGetErrorString(q), seq);
+                        return LM_E_DEVICE;
+                    }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_slow).count() > limit_s) {
+                        lm_set_error("lm_wait_result: sequence %u not published after %.0f s (flag %u)", seq, limit_s, *flag);
+                        return LM_E_DEVICE;
+                    }
+                    struct timespec ts = {0, 50000};
+                    nanosleep(&ts, nullptr);
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
             }
             break;
         }

@@ -666,10 +666,20 @@ bool gkr_tail_enabled() {
 // Resident workgroups hold their CU slots while they poll, and a tail makes progress only when ALL its workgroups are
 // resident: the tails of every prover of this process together must fit the chip (256 CUs x 2 workgroups of 1024 threads),
 // or tails could wait for each other's slots until their timeouts.  Above the cap a layer falls back to launches.
-static constexpr int GKR_TAIL_MAX_LIVE_WORKGROUPS = 256;
+// The counter is per PROCESS: processes that share one GPU (two ranks on one device in the tests, several provers of a node)
+// must divide the chip between them — LM_GKR_TAIL_MAX_WORKGROUPS sets this process's share (default 256 = the whole chip;
+// a tail that does not get its slots still ends by its own 3 s timeout and the layer is reported as failed, never hung).
+int gkr_tail_max_live() {
+    static const int v = [] {
+        const char* e = getenv("LM_GKR_TAIL_MAX_WORKGROUPS");
+        const int x = e ? atoi(e) : 256;
+        return x < 0 ? 0 : x;
+    }();
+    return v;
+}
 std::atomic<int> g_tail_workgroups{0};
 bool gkr_tail_reserve(u32 W) {
-    if (g_tail_workgroups.fetch_add((int)W, std::memory_order_acq_rel) + (int)W > GKR_TAIL_MAX_LIVE_WORKGROUPS) {
+    if (g_tail_workgroups.fetch_add((int)W, std::memory_order_acq_rel) + (int)W > gkr_tail_max_live()) {
         g_tail_workgroups.fetch_sub((int)W, std::memory_order_acq_rel);
         return false;
     }
@@ -883,6 +893,14 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         }
     } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8 &&
                gkr_tail_reserve((u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
+        // the reservation is given back on every early return below (a leaked one would silently push later layers onto launches)
+        struct TailReservation {
+            int n;
+            bool keep = false;
+            ~TailReservation() {
+                if (!keep) g_tail_workgroups.fetch_sub(n, std::memory_order_acq_rel);
+            }
+        } reservation{(int)std::max<u64>(1, m_out / GKR_TAIL_SLICE)};
         seq = ++ctx->res_seq;
         GkrTailEq eqs;
         {
@@ -921,6 +939,8 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             GKR_TAIL(2, 2, nul, nul, (const u32*)g->work[g->cur]);
         }
 #undef GKR_TAIL
+        LM_HIP(hipGetLastError());
+        reservation.keep = true;  // from here gkr_tail_release / gkr_tail_dismiss give it back
         g->tail_live = true;
         n_threads = m_out;
     } else {

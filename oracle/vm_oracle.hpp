@@ -638,7 +638,7 @@ struct ExecutionResult {
 
 static inline ExecutionResult execute_bytecode(const Bytecode& bc, const uint32_t* public_input, size_t n_public_input, const WitnessHints& w) {
     ExecutionResult r;
-    size_t pub = n_public_input ? 1 : 0;
+    size_t pub = 1;  // padd_with_zero_to_next_power_of_two: 0usize.next_power_of_two() == 1, an empty public input is one zero word
     while (pub < n_public_input) pub <<= 1;
     r.memory.cells.assign(pub, F(0));
     for (size_t i = 0; i < n_public_input; i++) r.memory.cells[i] = public_input[i];

@@ -326,6 +326,17 @@ typedef struct {
 /* n_threads = 0: all hardware threads (capped at 128).  LM_E_INVALID + lm_last_error = the RunnerError and its pc. */
 int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
                          uint32_t n_threads, lmh_execution** out);
+/* The same run with the PARALLEL LOOP BATCHES of the program (Hint::ParallelBatchStart, handle_parallel_batch, runner.rs:369-482) on
+ * the device of `ctx`: the host runs the sequential parts, every independent segment of a batch is interpreted by one wavefront
+ * (csrc/lm_vm_device.hip: frame in LDS, Poseidon16 on 16 lanes, SegmentMemory semantics), the segments' logs and frames stay in
+ * HBM, resolve_deref_hints runs there, and lmh_get_execution_trace on the same context builds the tables from them without an
+ * upload.  A batch the device cannot take (fewer than 32 segments, a frame above 14000 words, more than 16 call-frame arguments)
+ * or in which anything irregular happens (a RunnerError in a segment, conflicting deferred writes) is run by the host pool exactly
+ * as lmh_execute_bytecode does — results and errors are the same on both paths.  The execution must be freed before `ctx` is
+ * destroyed, on the context's thread.  lmh_execution_view downloads the log on its first call. */
+int lmh_execute_bytecode_device(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
+                                const lm_vm_witness* witness, uint32_t n_threads, lmh_execution** out);
+int lmh_execution_on_device(const lmh_execution* e); /* 1: at least one batch ran on the device and the log is resident there */
 void lmh_execution_free(lmh_execution* e);
 void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* out);
 

@@ -150,6 +150,8 @@ _HOST_SIGS = {
     "lmh_bytecode_ending_pc": (C.c_uint32, [vp]),
     "lmh_bytecode_multilinear": (vp, [vp]),
     "lmh_execute_bytecode": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]),
+    "lmh_execute_bytecode_device": (C.c_int, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]),
+    "lmh_execution_on_device": (C.c_int, [vp]),
     "lmh_execution_free": (None, [vp]),
     "lmh_execution_view": (None, [vp, vp]),
     "lmh_get_execution_trace": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]),

@@ -18,6 +18,7 @@
 
 #include "lm_host_internal.h"
 #include "lm_vm_internal.h"
+#include "lm_vm_device.h"
 
 using namespace lmh;
 
@@ -56,8 +57,10 @@ bool pin_enabled() {
     static const bool on = getenv("LM_VM_NO_PIN") == nullptr;
     return on;
 }
+}  // namespace
+namespace lmh {
 // make [base, base + need) registered (need <= capacity); best effort: an upload from an unregistered buffer is still correct
-void ensure_pinned(const VmRegion& reg, size_t need) {
+void vm_ensure_pinned(const VmRegion& reg, size_t need) {
     if (!pin_enabled() || !reg.base || need == 0 || need > reg.bytes) return;
     static std::once_flag hook_once;
     std::call_once(hook_once, [] {
@@ -80,6 +83,9 @@ void ensure_pinned(const VmRegion& reg, size_t need) {
     else
         (void)hipGetLastError();
 }
+}  // namespace lmh
+namespace {
+void ensure_pinned(const VmRegion& reg, size_t need) { vm_ensure_pinned(reg, need); }
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -103,8 +109,19 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     }
     *out = nullptr;
     lm_vm_execution_view v;
-    lmh_execution_view(e, &v);
-    {
+    VmDeviceView dv;
+    const bool resident = vm_execution_device(e, &dv);  // the run's batches executed on the device: log and image are already in HBM
+    if (resident) {
+        if (dv.ctx != ctx) {
+            lm_set_error("lmh_get_execution_trace: the execution is resident on another context");
+            return LM_E_INVALID;
+        }
+        memset(&v, 0, sizeof v);
+        v.n_cycles = dv.n_cycles, v.memory_len = dv.memory_len, v.n_poseidon_calls = dv.n_poseidon_calls, v.n_extension_rows = dv.n_extension_rows;
+        v.public_memory_size = dv.public_memory_size;
+    } else
+        lmh_execution_view(e, &v);
+    if (!resident) {
         VmRegion reg[5];
         vm_execution_regions(e, reg);
         ensure_pinned(reg[0], (size_t)(v.memory_len + 24) * 4);
@@ -181,7 +198,20 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         lm_set_error("lmh_get_execution_trace: no room for the zero vector behind the memory");
         return fail(LM_E_INVALID);
     }
-    if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24))) return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
+    if (resident) {  // None -> 0 on the way into the committed buffer; [0 x 16 | poseidon16(0)] behind it (trace_gen.rs:106-110)
+        static const struct Tail {
+            alignas(64) u32 w[24];
+            Tail() {
+                alignas(64) u32 st[16];
+                memset(st, 0, sizeof st);
+                memset(w, 0, sizeof w);
+                host_compress(st);
+                memcpy(w + 16, st, 32);
+            }
+        } tail;
+        if ((rc = vm_dev_image_export(ctx, d_memory, dv.image, L, nullptr)) || (rc = lm_upload_async(ctx, d_memory + L, tail.w, 24))) return fail(rc);
+    } else if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24)))
+        return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
     if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
     mark("alloc + memory upload");
     // ---- bytecode table: device copy cached in the CONTEXT under the bytecode's unique id --------------------------------------
@@ -201,9 +231,11 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     }
     // execution table (trace_gen.rs:27-100) + its padding row (execution/mod.rs:59-74, the 4 temporary columns included)
     {
-        u32 *d_pcs, *d_fps;
-        if (!dev(v.n_cycles, &d_pcs) || !dev(v.n_cycles, &d_fps)) return fail(rc);
-        if ((rc = lm_upload_async(ctx, d_pcs, v.pcs, v.n_cycles)) || (rc = lm_upload_async(ctx, d_fps, v.fps, v.n_cycles))) return fail(rc);
+        u32 *d_pcs = const_cast<u32*>(dv.pcs), *d_fps = const_cast<u32*>(dv.fps);
+        if (!resident) {
+            if (!dev(v.n_cycles, &d_pcs) || !dev(v.n_cycles, &d_fps)) return fail(rc);
+            if ((rc = lm_upload_async(ctx, d_pcs, v.pcs, v.n_cycles)) || (rc = lm_upload_async(ctx, d_fps, v.fps, v.n_cycles))) return fail(rc);
+        }
         if ((rc = lm_execution_table_trace(ctx, d_pcs, d_fps, v.n_cycles, d_bytecode, 1ull << log_bytecode, d_memory, padded,
                                            t->cols[0].data())))
             return fail(rc);
@@ -217,8 +249,8 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     // Poseidon16 table: call records -> flag / index / input columns, padding rows, then the permutation columns of every row
     {
         const u64 n = v.n_poseidon_calls, rows = 1ull << log_rows[2];
-        u32* d_calls = nullptr;
-        if (n) {
+        u32* d_calls = resident ? const_cast<u32*>(dv.poseidon_calls) : nullptr;
+        if (n && !resident) {
             if (!dev(n * LM_VM_POSEIDON_CALL_WORDS, &d_calls)) return fail(rc);
             if ((rc = lm_upload_async(ctx, d_calls, v.poseidon_calls, n * LM_VM_POSEIDON_CALL_WORDS))) return fail(rc);
         }
@@ -233,8 +265,8 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     // ExtensionOp table
     {
         const u64 n = v.n_extension_rows, rows = 1ull << log_rows[1];
-        u32* d_rows = nullptr;
-        if (n) {
+        u32* d_rows = resident ? const_cast<u32*>(dv.extension_rows) : nullptr;
+        if (n && !resident) {
             if (!dev(n * LM_VM_EXTENSION_ROW_WORDS, &d_rows)) return fail(rc);
             if ((rc = lm_upload_async(ctx, d_rows, v.extension_rows, n * LM_VM_EXTENSION_ROW_WORDS))) return fail(rc);
         }
@@ -281,7 +313,7 @@ int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, c
     }
     const double t0 = now_ms();
     lmh_execution* ex = nullptr;
-    int rc = lmh_execute_bytecode(bc, public_input, n_public_input, witness, n_threads, &ex);
+    int rc = lmh_execute_bytecode_device(ctx, bc, public_input, n_public_input, witness, n_threads, &ex);  // (LM_VM_HOST=1: all on the host pool)
     if (rc) return rc;
     const double t1 = now_ms();
     lmh_vm_trace* tr = nullptr;

@@ -33,6 +33,7 @@
 
 #include "lm_host_internal.h"
 #include "lm_vm_internal.h"
+#include "lm_vm_device.h"
 
 namespace lmh {
 
@@ -309,6 +310,19 @@ constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
 struct MemBuf {
     u32* p = nullptr;
     u64 len = 0;
+    // [dev_lo, dev_hi): cells whose current value lives in the DEVICE image only (the frames of a batch that ran on the device,
+    // lm_vm_device.hip).  The sequential runner checks every access against the window; the first touch brings the cells back
+    // (on_touch) and closes the window.  Empty (0, 0) on the host-only path.
+    u64 dev_lo = 0, dev_hi = 0;
+    std::function<bool()> on_touch;
+    bool touch_failed = false;
+    inline void guard(u64 i) {
+        if (__builtin_expect(i - dev_lo < dev_hi - dev_lo, 0)) touch();
+    }
+    void touch() {
+        if (on_touch && !on_touch()) touch_failed = true;
+        dev_lo = dev_hi = 0;
+    }
     MemBuf() {
         {  // an arena released by an earlier run: its pages are already resident
             std::lock_guard<std::mutex> lk(cache_mu());
@@ -426,8 +440,12 @@ struct Err {
 // ---------------------------------------------------------------------------------------------------------------------
 struct MainMem {  // Memory: grows on write, write-once cells
     MemBuf& m;
-    u32 peek(u64 i) const { return i < m.len ? m.p[i] : UNDEF; }
+    u32 peek(u64 i) const {
+        m.guard(i);
+        return i < m.len ? m.p[i] : UNDEF;
+    }
     bool set(u64 i, u32 v, Err& e) {
+        m.guard(i);
         if (i >= m.len) {
             if (i >= MAX_MEMORY) {
                 e.raise("OutOfMemory");
@@ -477,18 +495,9 @@ struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, 
 // ---------------------------------------------------------------------------------------------------------------------
 // decoded program
 // ---------------------------------------------------------------------------------------------------------------------
-enum : u8 { K_ADD = 0, K_MUL, K_DEREF, K_JUMP, K_POSEIDON, K_EXTOP };
-struct Instr {
-    u8 kind, ma, mb, mc;  // LM_VM_ARG_* of the three operands (nu_a, nu_b, nu_c)
-    u32 a, b, c;          // canonical: offset, or the constant
-    u32 am, bm, cm;       // the constant as a Montgomery word
-    u32 x0, x1;           // poseidon: flags (1 permute, 2 half_output, 4 hardcoded_left), offset; extension op: mode flags, size
-};
-struct HintRec {
-    u32 kind;
-    u32 args[4];
-    u8 mode[4];
-};
+enum : u8 { K_ADD = VM_K_ADD, K_MUL = VM_K_MUL, K_DEREF = VM_K_DEREF, K_JUMP = VM_K_JUMP, K_POSEIDON = VM_K_POSEIDON, K_EXTOP = VM_K_EXTOP };
+typedef VmInstr Instr;      // (lm_vm_device.h: the device interpreter reads the same records)
+typedef VmHintRec HintRec;
 
 struct Trace {  // runner.rs:70-76
     UVec<u32> pcs, fps;
@@ -545,6 +554,11 @@ LogCache& log_cache() {
 }  // namespace
 }  // namespace lmh
 
+namespace lmh {
+struct DevRun;
+void dev_run_free(DevRun* d);
+}  // namespace lmh
+
 struct lmh_execution {
     lmh_execution() {
         LogCache& c = log_cache();
@@ -555,6 +569,7 @@ struct lmh_execution {
         c.full = false;
     }
     ~lmh_execution() {
+        lmh::dev_run_free(dev);
         LogCache& c = log_cache();
         std::lock_guard<std::mutex> lk(c.mu);
         if (c.full) return;
@@ -565,6 +580,8 @@ struct lmh_execution {
     MemBuf memory;                 // UNDEF -> 0 after the run
     UVec<uint8_t> defined;
     u64 public_memory_size = 0, runtime_memory_size = 0;
+    lmh::DevRun* dev = nullptr;    // a run whose parallel batches executed on the device (lmh_execute_bytecode_device): the logs and the
+                                   // memory image are resident in HBM; the host view is materialised on demand (lmh_execution_view)
 };
 
 namespace lmh {
@@ -1016,6 +1033,7 @@ struct Machine {
         u64 batch_pc = 0, batch_fp = 0, frame_size = 0;
         u32 n_args = 0, end_mode = 0, end_value = 0;
         std::vector<u64> hint_indices_at_start;
+        size_t cyc_at_arm = 0, pos_at_arm = 0, ext_at_arm = 0, pend_at_arm = 0;  // log sizes when iteration 0 started (its footprint sizes the device slots)
         bool armed = false;
     };
     int run(bool has_stop, u64 stop_pc, Batch& batch) {
@@ -1040,6 +1058,8 @@ struct Machine {
                         batch.end_mode = hr.mode[1];
                         batch.end_value = hr.args[1];
                         batch.hint_indices_at_start = cur.index;
+                        batch.cyc_at_arm = tr.pcs.size() - 1, batch.pos_at_arm = tr.pos.size() / LM_VM_POSEIDON_CALL_WORDS;
+                        batch.ext_at_arm = tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS, batch.pend_at_arm = tr.pending.size();
                     }
                     continue;
                 }
@@ -1289,6 +1309,393 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     return true;
 }
 
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// parallel batches on the device (lm_vm_device.hip): what the host keeps of a run whose segments were interpreted by wavefronts
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevBatch {
+    VmSegArgs a;  // the device slots and their capacities
+    u64 n_par = 0;
+    u64* d_offsets = nullptr;  // per segment: exclusive prefix sums of (cycles, Poseidon calls, extension rows, pending derefs)
+    u64 tot[4] = {0, 0, 0, 0};
+    size_t host_cyc_at = 0, host_pos_at = 0, host_ext_at = 0, host_pend_at = 0;  // where the batch sits in the host logs (entries)
+    u64 win_lo = 0, win_hi = 0;                                                    // the segment frames: valid in the device image only
+    std::vector<u32*> owned;
+};
+struct DevRun {
+    lm_ctx* ctx = nullptr;
+    const VmInstr* d_code = nullptr;  // cached in the context under the bytecode's id
+    const u32* d_hint_begin = nullptr;
+    const VmHintRec* d_hints = nullptr;
+    u32* d_wit_data = nullptr;  // this run's hint streams
+    u64 *d_wit_off = nullptr, *d_wit_names = nullptr;
+    u32* d_image = nullptr;  // the memory image, VM_UNDEF = None
+    u64 image_cap = 0;
+    std::vector<DevBatch> batches;
+    bool windows_open = false;
+    // after finalisation: the complete log, resident
+    u32 *d_pcs = nullptr, *d_fps = nullptr, *d_pos = nullptr, *d_ext = nullptr;
+    u64 n_cycles = 0, n_pos = 0, n_ext = 0, image_len = 0;
+    u64 n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;  // of the segments
+    bool finalized = false, host_valid = false;
+    std::vector<u32*> owned;
+    std::vector<std::vector<u64>> keep64;  // host staging that asynchronous uploads read: kept until the next synchronisation
+    std::vector<std::vector<u32>> keep32;
+};
+void dev_run_free(DevRun* d) {
+    if (!d) return;
+    for (DevBatch& b : d->batches)
+        for (u32* p : b.owned) lm_free(d->ctx, p);
+    for (u32* p : d->owned) lm_free(d->ctx, p);
+    delete d;
+}
+
+namespace {
+bool vm_device_enabled() {
+    static const bool on = getenv("LM_VM_HOST") == nullptr;  // LM_VM_HOST=1: parallel batches on the host thread pool (A/B measurements)
+    return on;
+}
+template <class T>
+bool dev_alloc(DevRun& D, std::vector<u32*>& owner, u64 n_elems, T** out) {
+    u32* p = nullptr;
+    const u64 words = (n_elems * sizeof(T) + 3) / 4;
+    if (lm_malloc(D.ctx, words ? words : 1, &p) != LM_OK) return false;
+    owner.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return true;
+}
+// device copies of the decoded program: one per (bytecode, context), owned by the context
+bool dev_program(DevRun& D, const lmh_bytecode& bc) {
+    const u64 key = bc.uid << 4;
+    D.d_code = (const VmInstr*)lm_ctx_cache_get(D.ctx, key | 1);
+    D.d_hint_begin = (const u32*)lm_ctx_cache_get(D.ctx, key | 2);
+    D.d_hints = (const VmHintRec*)lm_ctx_cache_get(D.ctx, key | 3);
+    if (D.d_code && D.d_hint_begin && D.d_hints) return true;
+    u32 *c = nullptr, *hb = nullptr, *h = nullptr;
+    const u64 wc = (bc.code.size() * sizeof(VmInstr) + 3) / 4, wh = (bc.hints.size() * sizeof(VmHintRec) + 3) / 4;
+    if (lm_malloc(D.ctx, wc ? wc : 1, &c) || lm_malloc(D.ctx, bc.hint_begin.size(), &hb) || lm_malloc(D.ctx, wh ? wh : 1, &h)) return false;
+    if (vm_dev_upload(D.ctx, c, bc.code.data(), bc.code.size() * sizeof(VmInstr)) || vm_dev_upload(D.ctx, hb, bc.hint_begin.data(), bc.hint_begin.size() * 4) ||
+        vm_dev_upload(D.ctx, h, bc.hints.data(), bc.hints.size() * sizeof(VmHintRec)) || lm_sync(D.ctx))
+        return false;
+    lm_ctx_cache_put(D.ctx, key | 1, c), lm_ctx_cache_put(D.ctx, key | 2, hb), lm_ctx_cache_put(D.ctx, key | 3, h);
+    D.d_code = (const VmInstr*)c, D.d_hint_begin = hb, D.d_hints = (const VmHintRec*)h;
+    return true;
+}
+bool dev_witness(DevRun& D, const lm_vm_witness* w) {
+    if (D.d_wit_names) return true;
+    const u64 n_entries = w->n_names ? w->name_entry_begin[w->n_names] : 0;
+    const u64 n_words = n_entries ? w->entry_offset[n_entries] : 0;
+    if (!dev_alloc(D, D.owned, n_words, &D.d_wit_data) || !dev_alloc(D, D.owned, n_entries + 1, &D.d_wit_off) ||
+        !dev_alloc(D, D.owned, (u64)w->n_names + 1, &D.d_wit_names))
+        return false;
+    static const u64 zero = 0;
+    return vm_dev_upload(D.ctx, D.d_wit_data, w->data, n_words * 4) == LM_OK &&
+           vm_dev_upload(D.ctx, D.d_wit_off, n_entries ? w->entry_offset : &zero, (n_entries + 1) * 8) == LM_OK &&
+           vm_dev_upload(D.ctx, D.d_wit_names, w->n_names ? w->name_entry_begin : &zero, ((u64)w->n_names + 1) * 8) == LM_OK;
+}
+// [lo, hi) of the arena -> the device image, skipping the frames of earlier device batches (current in the image only)
+bool dev_upload_host_owned(DevRun& D, MemBuf& memory, u64 lo, u64 hi) {
+    u64 at = lo;
+    auto up = [&](u64 a, u64 b) { return a >= b || vm_dev_upload(D.ctx, D.d_image + a, memory.p + a, (b - a) * 4) == LM_OK; };
+    if (D.windows_open)
+        for (const DevBatch& b : D.batches) {  // (ascending: memory grows upwards)
+            if (b.win_hi <= at || b.win_lo >= hi) continue;
+            if (!up(at, std::min(b.win_lo, hi))) return false;
+            at = std::max(at, b.win_hi);
+        }
+    return up(at, hi);
+}
+bool dev_image_reserve(DevRun& D, u64 need) {
+    if (need <= D.image_cap) return true;
+    const u64 cap = need + (1u << 16);
+    u32* n = nullptr;
+    if (lm_malloc(D.ctx, cap, &n) != LM_OK) return false;
+    if (D.d_image && lm_copy_d2d(D.ctx, n, D.d_image, D.image_cap) != LM_OK) return false;
+    if (vm_dev_fill(D.ctx, n + D.image_cap, VM_UNDEF, cap - D.image_cap) != LM_OK) return false;
+    if (D.d_image) {
+        for (u32*& p : D.owned)
+            if (p == D.d_image) p = n;
+        lm_free(D.ctx, D.d_image);  // (stream-ordered pool: the copy above is queued before any reuse)
+    } else
+        D.owned.push_back(n);
+    D.d_image = n, D.image_cap = cap;
+    return true;
+}
+// the frames of every device batch back into the arena (a sequential part of the program, or a host batch, reads them)
+bool dev_close_windows(DevRun& D, MemBuf& memory) {
+    if (!D.windows_open) return true;
+    D.windows_open = false;
+    for (const DevBatch& b : D.batches)
+        if (vm_dev_download(D.ctx, memory.p + b.win_lo, D.d_image + b.win_lo, (b.win_hi - b.win_lo) * 4) != LM_OK) return false;
+    return true;
+}
+
+enum { DEV_DONE = 0, DEV_FALLBACK = 1, DEV_ERROR = 2 };
+// handle_parallel_batch with the segments on the device.  DEV_FALLBACK: nothing of the run's state has changed in a way the host
+// batch would notice — the caller runs handle_parallel_batch (which also reports every RunnerError: the device never does).
+int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp, u64& ap,
+                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D) {
+    MainMem mm{memory};
+    Err scratch;
+    const double t0 = vm_now_ms();
+    auto get = [&](u64 at) -> u32 {
+        const u32 v = mm.peek(at);
+        if (v == UNDEF) scratch.raise("undefined");
+        return v;
+    };
+    const u32 sv = get(batch.batch_fp + 2);
+    const u32 ev = batch.end_mode == LM_VM_ARG_CONST ? 0 : get(batch.batch_fp + batch.end_value);
+    if (scratch.set) return DEV_FALLBACK;
+    const u64 start_value = kb::from_monty(sv), end_value = batch.end_mode == LM_VM_ARG_CONST ? batch.end_value : kb::from_monty(ev);
+    if (end_value <= start_value + 1) return DEV_FALLBACK;
+    const u64 n_iters = end_value - start_value, n_par = n_iters - 1, stride = fp - batch.batch_fp;
+    const u32 return_pc = get(fp), saved_fp = get(fp + 1);
+    if (scratch.set || batch.n_args > VM_DEV_MAX_ARGS || batch.n_args == 0 || bc.n_names > VM_DEV_MAX_NAMES || stride == 0 || stride > VM_DEV_MAX_STRIDE ||
+        n_par < 32 || n_par >= (1u << 24) || fp <= batch.batch_fp)
+        return DEV_FALLBACK;
+    u32 args[VM_DEV_MAX_ARGS];
+    for (u32 i = 0; i < batch.n_args; i++) args[i] = get(batch.batch_fp + 2 + i);
+    if (scratch.set) return DEV_FALLBACK;
+    const u64 max_addr = batch.batch_fp + (n_iters + 1) * stride, split_at = batch.batch_fp + stride, frames_end = batch.batch_fp + n_iters * stride;
+    if (max_addr > MAX_MEMORY) return DEV_FALLBACK;
+    std::vector<u64> per_iter(cur.index.size());
+    for (size_t k = 0; k < per_iter.size(); k++) per_iter[k] = cur.index[k] - batch.hint_indices_at_start[k];
+    if (memory.touch_failed) return DEV_ERROR;
+    if (!dev_program(D, bc) || !dev_witness(D, witness)) return DEV_ERROR;
+
+    // ---- host side of the batch: the memory grows to max_addr, the frame the sequential runner continues in gets its call frame.
+    // The frames of the segments are NOT touched here: they exist in the device image only (window) until something reads them.
+    const u64 old_len = memory.len;
+    auto fill_host = [&](u64 a, u64 b) {  // [a, b) <- None, on the pool
+        if (a >= b) return;
+        const u64 chunk = 1u << 15;
+        u32* mp = memory.p;
+        vm_parallel_for((b - a + chunk - 1) / chunk, n_threads, [&](u64 c) {
+            const u64 e = std::min(b, a + (c + 1) * chunk);
+            for (u64 i = a + c * chunk; i < e; i++) mp[i] = UNDEF;
+        });
+    };
+    bool host_grown = false;
+    auto fallback = [&](DevBatch* b) {
+        if (b)
+            for (u32* p : b->owned) lm_free(D.ctx, p);
+        if (host_grown) fill_host(std::max(old_len, split_at), frames_end);  // the host batch expects its frames initialised
+        if (!dev_close_windows(D, memory)) return (int)DEV_ERROR;
+        memory.dev_lo = memory.dev_hi = 0;
+        return (int)DEV_FALLBACK;
+    };
+    fill_host(std::max(old_len, frames_end), max_addr);
+    if (max_addr > memory.len) memory.len = max_addr;
+    host_grown = true;
+    {  // write_call_frame for the last iteration (the loop comes back to the sequential runner in it)
+        Err e;
+        const u64 f = frames_end;
+        const u64 iter_val = end_value;
+        bool ok = mm.set(f, return_pc, e) && mm.set(f + 1, saved_fp, e) && mm.set(f + 2, kb::to_monty((u32)(iter_val % kb::P)), e);
+        for (u32 j = 1; j < batch.n_args && ok; j++) ok = mm.set(f + 2 + j, args[j], e);
+        if (!ok) return fallback(nullptr);
+    }
+    // ---- device image: what the host holds, minus the not yet existing frames
+    {
+        VmRegion reg[5];
+        reg[0] = {(void*)memory.p, (size_t)MAX_MEMORY * 4};
+        vm_ensure_pinned(reg[0], (size_t)(memory.len + 24) * 4);
+    }
+    if (!dev_image_reserve(D, memory.len)) return DEV_ERROR;
+    if (!dev_upload_host_owned(D, memory, 0, std::max(split_at, std::min(old_len, frames_end))) || !dev_upload_host_owned(D, memory, frames_end, memory.len))
+        return DEV_ERROR;
+    // ---- slots sized from what iteration 0 logged on the host
+    DevBatch B;
+    B.n_par = n_par;
+    B.host_cyc_at = trace.pcs.size(), B.host_pos_at = trace.pos.size() / LM_VM_POSEIDON_CALL_WORDS;
+    B.host_ext_at = trace.ext.size() / LM_VM_EXTENSION_ROW_WORDS, B.host_pend_at = trace.pending.size();
+    B.win_lo = split_at, B.win_hi = frames_end;
+    VmSegArgs& a = B.a;
+    memset(&a, 0, sizeof a);
+    a.cap_cyc = (u32)std::min<u64>(2 * (B.host_cyc_at - batch.cyc_at_arm) + 64, 1u << 22);
+    a.cap_pos = (u32)std::min<u64>(2 * (B.host_pos_at - batch.pos_at_arm) + 16, 1u << 20);
+    a.cap_ext = (u32)std::min<u64>(2 * (B.host_ext_at - batch.ext_at_arm) + 16, 1u << 20);
+    a.cap_pend = (u32)std::min<u64>(2 * (B.host_pend_at - batch.pend_at_arm) + 16, 1u << 20);
+    a.cap_def = 64 + 2 * batch.n_args;
+    const u32 dirty_cap = (u32)(4 * n_par + 64);
+    u32* d_summary = nullptr;
+    u64 *d_cur = nullptr, *d_per = nullptr;
+    if (!dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.pcs) || !dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.fps) ||
+        !dev_alloc(D, B.owned, n_par * a.cap_pos * LM_VM_POSEIDON_CALL_WORDS, &a.pos) ||
+        !dev_alloc(D, B.owned, n_par * a.cap_ext * LM_VM_EXTENSION_ROW_WORDS, &a.ext) || !dev_alloc(D, B.owned, n_par * a.cap_pend * 2, &a.pend) ||
+        !dev_alloc(D, B.owned, n_par * a.cap_def * 2, &a.def) || !dev_alloc(D, B.owned, n_par * VM_SEG_WORDS, &a.counts) ||
+        !dev_alloc(D, B.owned, n_par * 4, &B.d_offsets) || !dev_alloc(D, B.owned, (u64)VM_SUMMARY_WORDS + 2 * dirty_cap, &d_summary) ||
+        !dev_alloc(D, B.owned, cur.index.size() + 1, &d_cur) || !dev_alloc(D, B.owned, cur.index.size() + 1, &d_per)) {
+        for (u32* p : B.owned) lm_free(D.ctx, p);
+        return DEV_ERROR;
+    }
+    D.keep64.push_back(cur.index), D.keep64.push_back(per_iter);
+    const std::vector<u64>&k_cur = D.keep64[D.keep64.size() - 2], &k_per = D.keep64.back();
+    a.code = D.d_code, a.hint_begin = D.d_hint_begin, a.hints = D.d_hints;
+    a.n_instructions = (u32)bc.n_instructions, a.ending_pc = bc.ending_pc;
+    a.wit_data = D.d_wit_data, a.wit_entry_offset = D.d_wit_off, a.wit_name_begin = D.d_wit_names, a.cur_index = d_cur, a.per_iter = d_per;
+    a.n_names = bc.n_names;
+    a.image = D.d_image, a.init_len = old_len, a.split_at = split_at, a.stride = stride, a.batch_fp = batch.batch_fp, a.frame_size = batch.frame_size;
+    a.batch_pc = (u32)batch.batch_pc, a.return_pc_m = return_pc, a.saved_fp_m = saved_fp, a.start_value = start_value, a.n_args = batch.n_args;
+    memcpy(a.args_m, args, sizeof(u32) * batch.n_args);
+    a.coop_tab = vm_dev_coop_table(D.ctx);
+    {
+        const kb::FrobeniusTable& ft = kb::frobenius_table();
+        for (int i = 0; i < 5; i++) a.frob[i] = ft.img[i];
+    }
+    std::vector<u32> summary((size_t)VM_SUMMARY_WORDS + 2 * dirty_cap);
+    const double t1 = vm_now_ms();
+    if (vm_dev_upload(D.ctx, d_cur, k_cur.data(), k_cur.size() * 8) || vm_dev_upload(D.ctx, d_per, k_per.data(), k_per.size() * 8) ||
+        lm_memset_zero(D.ctx, d_summary, VM_SUMMARY_WORDS) || vm_dev_segments(D.ctx, a, n_par) ||
+        vm_dev_apply_deferred(D.ctx, a, n_par, D.image_cap, split_at, frames_end, B.d_offsets, d_summary, dirty_cap) ||
+        vm_dev_download(D.ctx, summary.data(), d_summary, summary.size() * 4)) {
+        for (u32* p : B.owned) lm_free(D.ctx, p);
+        return DEV_ERROR;
+    }
+    D.keep64.clear();  // (the stream is idle: nothing reads the staging any more)
+    const double t2 = vm_now_ms();
+    if (summary[0] || summary[2] || summary[3] || summary[1] > dirty_cap) {
+        if (vm_times())
+            fprintf(stderr, "[vm] device batch of %llu segments handed back to the host: %u conflicting deferred writes, %u beyond the image, first failed segment %u "
+                            "(code %u, pc %u, aux %u), %u dirty cells\n", (unsigned long long)n_par, summary[0], summary[2], summary[3], summary[4], summary[5],
+                    summary[6], summary[1]);
+        return fallback(&B);
+    }
+    // ---- success: mirror the cells outside the frames that deferred writes defined, then commit
+    for (u32 k = 0; k < summary[1]; k++) {
+        Err e;
+        if (!mm.set(summary[VM_SUMMARY_WORDS + 2 * k], summary[VM_SUMMARY_WORDS + 2 * k + 1], e)) return fallback(&B);  // (cannot happen: the device image agreed)
+    }
+    const u64* tot = reinterpret_cast<const u64*>(summary.data() + 8);
+    for (int k = 0; k < 4; k++) B.tot[k] = tot[k];
+    D.n_add += tot[4], D.n_mul += tot[5], D.n_deref += tot[6], D.n_jump += tot[7];
+    D.batches.push_back(B);
+    D.windows_open = true;
+    memory.dev_lo = D.batches.front().win_lo, memory.dev_hi = frames_end;  // hull of every open window
+    for (size_t k = 0; k < cur.index.size(); k++) cur.index[k] += n_par * per_iter[k];
+    pc = batch.batch_pc;
+    fp = batch.batch_fp + n_iters * stride;
+    ap = fp + batch.frame_size;
+    if (vm_times())
+        fprintf(stderr, "[vm] device batch of %llu segments: host preparation + uploads %.2f ms, segments + deferred writes + summary %.2f ms, commit %.2f ms "
+                        "(%llu cycles, %llu Poseidon calls, %u dirty cells)\n", (unsigned long long)n_par, t1 - t0, t2 - t1, vm_now_ms() - t2,
+                (unsigned long long)tot[0], (unsigned long long)tot[1], summary[1]);
+    return DEV_DONE;
+}
+
+// End of a run with device batches: the complete log and the memory image are assembled in HBM — host parts uploaded around the
+// spliced segment logs —, then resolve_deref_hints runs there.  false + anomaly: the caller repeats the run on the host.
+bool device_finalize(lmh_execution* ex, DevRun& D, bool& anomaly) {
+    anomaly = false;
+    Trace& tr = ex->tr;
+    MemBuf& memory = ex->memory;
+    const u64 L = memory.len;
+    if (memory.touch_failed) return false;
+    if (!dev_image_reserve(D, L)) return false;
+    {
+        VmRegion reg{(void*)memory.p, (size_t)MAX_MEMORY * 4};
+        vm_ensure_pinned(reg, (size_t)(L + 24) * 4);
+    }
+    if (!dev_upload_host_owned(D, memory, 0, L)) return false;
+    u64 n_cyc = tr.pcs.size(), n_pos = tr.pos.size() / LM_VM_POSEIDON_CALL_WORDS, n_ext = tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS, n_pend = tr.pending.size();
+    for (const DevBatch& b : D.batches) n_cyc += b.tot[0], n_pos += b.tot[1], n_ext += b.tot[2], n_pend += b.tot[3];
+    u32* d_pend = nullptr;
+    uint8_t* d_status = nullptr;
+    u32* d_info = nullptr;
+    std::vector<u32*> tmp;
+    auto drop_tmp = [&] {
+        for (u32* p : tmp) lm_free(D.ctx, p);
+    };
+    if (!dev_alloc(D, D.owned, n_cyc, &D.d_pcs) || !dev_alloc(D, D.owned, n_cyc, &D.d_fps) || !dev_alloc(D, D.owned, n_pos * LM_VM_POSEIDON_CALL_WORDS, &D.d_pos) ||
+        !dev_alloc(D, D.owned, n_ext * LM_VM_EXTENSION_ROW_WORDS, &D.d_ext) || !dev_alloc(D, tmp, n_pend * 2, &d_pend) || !dev_alloc(D, tmp, n_pend, &d_status) ||
+        !dev_alloc(D, tmp, (u64)VM_RESOLVE_INFO_WORDS, &d_info)) {
+        drop_tmp();
+        return false;
+    }
+    // the host's pending list as (target, src) words
+    D.keep32.emplace_back(tr.pending.size() * 2);
+    std::vector<u32>& hp = D.keep32.back();
+    for (size_t i = 0; i < tr.pending.size(); i++) hp[2 * i] = (u32)tr.pending[i].first, hp[2 * i + 1] = (u32)tr.pending[i].second;
+    {
+        VmRegion r1{(void*)tr.pcs.data(), tr.pcs.cap * 4}, r2{(void*)tr.fps.data(), tr.fps.cap * 4}, r3{(void*)tr.pos.data(), tr.pos.cap * 4},
+            r4{(void*)tr.ext.data(), tr.ext.cap * 4};
+        vm_ensure_pinned(r1, tr.pcs.size() * 4), vm_ensure_pinned(r2, tr.fps.size() * 4), vm_ensure_pinned(r3, tr.pos.size() * 4), vm_ensure_pinned(r4, tr.ext.size() * 4);
+    }
+    bool ok = true;
+    u64 h_cyc = 0, h_pos = 0, h_ext = 0, h_pend = 0;  // host entries consumed so far
+    u64 o_cyc = 0, o_pos = 0, o_ext = 0, o_pend = 0;  // positions in the final arrays
+    auto host_part = [&](u64 cyc_to, u64 pos_to, u64 ext_to, u64 pend_to) {
+        ok = ok && vm_dev_upload(D.ctx, D.d_pcs + o_cyc, tr.pcs.data() + h_cyc, (cyc_to - h_cyc) * 4) == LM_OK &&
+             vm_dev_upload(D.ctx, D.d_fps + o_cyc, tr.fps.data() + h_cyc, (cyc_to - h_cyc) * 4) == LM_OK &&
+             vm_dev_upload(D.ctx, D.d_pos + o_pos * LM_VM_POSEIDON_CALL_WORDS, tr.pos.data() + h_pos * LM_VM_POSEIDON_CALL_WORDS,
+                           (pos_to - h_pos) * LM_VM_POSEIDON_CALL_WORDS * 4) == LM_OK &&
+             vm_dev_upload(D.ctx, D.d_ext + o_ext * LM_VM_EXTENSION_ROW_WORDS, tr.ext.data() + h_ext * LM_VM_EXTENSION_ROW_WORDS,
+                           (ext_to - h_ext) * LM_VM_EXTENSION_ROW_WORDS * 4) == LM_OK &&
+             vm_dev_upload(D.ctx, d_pend + o_pend * 2, hp.data() + h_pend * 2, (pend_to - h_pend) * 8) == LM_OK;
+        o_cyc += cyc_to - h_cyc, o_pos += pos_to - h_pos, o_ext += ext_to - h_ext, o_pend += pend_to - h_pend;
+        h_cyc = cyc_to, h_pos = pos_to, h_ext = ext_to, h_pend = pend_to;
+    };
+    for (const DevBatch& b : D.batches) {
+        host_part(b.host_cyc_at, b.host_pos_at, b.host_ext_at, b.host_pend_at);
+        const u64 base[4] = {o_cyc, o_pos, o_ext, o_pend};
+        ok = ok && vm_dev_splice(D.ctx, b.a, b.n_par, b.d_offsets, base, D.d_pcs, D.d_fps, D.d_pos, D.d_ext, d_pend) == LM_OK;
+        o_cyc += b.tot[0], o_pos += b.tot[1], o_ext += b.tot[2], o_pend += b.tot[3];
+    }
+    host_part(tr.pcs.size(), tr.pos.size() / LM_VM_POSEIDON_CALL_WORDS, tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS, tr.pending.size());
+    // resolve_deref_hints on the assembled image
+    ok = ok && lm_memset_zero(D.ctx, (u32*)d_status, (n_pend + 3) / 4 ? (n_pend + 3) / 4 : 1) == LM_OK && lm_memset_zero(D.ctx, d_info, VM_RESOLVE_INFO_WORDS) == LM_OK;
+    u32 info[VM_RESOLVE_INFO_WORDS] = {0};
+    for (u32 first = 0; ok && n_pend;) {
+        const u32 rounds = 3;
+        if (first + rounds >= VM_RESOLVE_INFO_WORDS - 1) {  // a dependency chain deeper than the counters: the host's sequential loop takes it
+            anomaly = true;
+            break;
+        }
+        ok = vm_dev_resolve(D.ctx, D.d_image, L, d_pend, n_pend, d_status, d_info, first, rounds) == LM_OK &&
+             vm_dev_download(D.ctx, info, d_info, sizeof info) == LM_OK;
+        if (!ok) break;
+        if (info[0]) anomaly = true;
+        if (anomaly || info[1 + first + rounds - 1] == 0) break;
+        first += rounds;
+    }
+    if (ok && !n_pend) ok = lm_sync(D.ctx) == LM_OK;
+    D.keep32.clear();
+    drop_tmp();
+    for (DevBatch& b : D.batches) {
+        for (u32* p : b.owned) lm_free(D.ctx, p);
+        b.owned.clear();
+    }
+    if (!ok || anomaly) return false;
+    D.n_cycles = n_cyc, D.n_pos = n_pos, D.n_ext = n_ext, D.image_len = L;
+    D.finalized = true;
+    return true;
+}
+
+// the host view of a device run (lmh_execution_view): one download of the image and of the logs
+bool device_materialize(lmh_execution* ex) {
+    DevRun& D = *ex->dev;
+    if (D.host_valid) return true;
+    Trace& tr = ex->tr;
+    const u64 L = D.image_len;
+    tr.pcs.n = tr.fps.n = tr.pos.n = tr.ext.n = 0;
+    tr.pcs.extend(D.n_cycles), tr.fps.extend(D.n_cycles), tr.pos.extend(D.n_pos * LM_VM_POSEIDON_CALL_WORDS), tr.ext.extend(D.n_ext * LM_VM_EXTENSION_ROW_WORDS);
+    if (vm_dev_download(D.ctx, ex->memory.p, D.d_image, L * 4) || vm_dev_download(D.ctx, tr.pcs.data(), D.d_pcs, D.n_cycles * 4) ||
+        vm_dev_download(D.ctx, tr.fps.data(), D.d_fps, D.n_cycles * 4) ||
+        (D.n_pos && vm_dev_download(D.ctx, tr.pos.data(), D.d_pos, D.n_pos * LM_VM_POSEIDON_CALL_WORDS * 4)) ||
+        (D.n_ext && vm_dev_download(D.ctx, tr.ext.data(), D.d_ext, D.n_ext * LM_VM_EXTENSION_ROW_WORDS * 4)))
+        return false;
+    ex->defined.n = 0;
+    ex->defined.extend(L);
+    for (u64 i = 0; i < L; i++) {
+        const bool d = ex->memory.p[i] != UNDEF;
+        ex->defined[i] = d;
+        if (!d) ex->memory.p[i] = 0;
+    }
+    D.host_valid = true;
+    return true;
+}
+
 bool decode_instruction(const u32* row, Instr& in, std::string& why) {
     u32 c[12];
     for (int k = 0; k < 12; k++) c[k] = kb::from_monty(row[k]);
@@ -1363,6 +1770,14 @@ void vm_execution_regions(const lmh_execution* e, VmRegion out[5]) {
     out[4] = {(void*)e->tr.ext.data(), e->tr.ext.cap * sizeof(u32)};
 }
 void vm_set_release_hook(void (*hook)(void*)) { g_release_hook.store(hook, std::memory_order_release); }
+bool vm_execution_device(const lmh_execution* e, VmDeviceView* out) {
+    if (!e->dev || !e->dev->finalized) return false;
+    const DevRun& D = *e->dev;
+    out->ctx = D.ctx, out->image = D.d_image, out->memory_len = D.image_len, out->pcs = D.d_pcs, out->fps = D.d_fps, out->n_cycles = D.n_cycles;
+    out->poseidon_calls = D.d_pos, out->n_poseidon_calls = D.n_pos, out->extension_rows = D.d_ext, out->n_extension_rows = D.n_ext;
+    out->public_memory_size = e->public_memory_size;
+    return true;
+}
 }  // namespace lmh
 
 extern "C" {
@@ -1435,8 +1850,9 @@ void lmh_bytecode_hash(const lmh_bytecode* bc, uint32_t out[8]) {
     memcpy(out, bc->hash, 32);
 }
 
-int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
-                         uint32_t n_threads, lmh_execution** out) {
+// ctx != nullptr: parallel batches run on that context's device (lm_vm_device.hip) when they qualify, else on the host pool
+static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
+                        uint32_t n_threads, lmh_execution** out) {
     if (!bc || !out || (n_public_input && !public_input) || !witness || witness->n_names != bc->n_names ||
         (bc->n_names && (!witness->name_entry_begin || !witness->entry_offset))) {
         lm_set_error("lmh_execute_bytecode: bad arguments (the witness must carry one hint stream per name of the bytecode)");
@@ -1465,18 +1881,42 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         m.fp = fp, m.ap = initial_ap, m.pc = 0;
         const double t_start = vm_now_ms();
         double t_batches = 0;
+        DevRun* D = nullptr;
+        if (ctx && vm_device_enabled()) {
+            D = new DevRun();
+            D->ctx = ctx;
+            ex->dev = D;
+            memory.on_touch = [D, &memory] { return dev_close_windows(*D, memory); };
+            if (!dev_witness(*D, witness)) {  // the hint streams travel while the sequential head of the program runs
+                delete ex;
+                return LM_E_DEVICE;
+            }
+        }
+        bool device_failed = false;
         for (;;) {
             Machine<MainMem>::Batch batch;
             const int rc = m.run(false, 0, batch);
             if (rc == 0) break;
             if (rc < 0) break;
             const double tb = vm_now_ms();
-            const bool ok = handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
+            int how = DEV_FALLBACK;
+            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D);
+            if (how == DEV_ERROR) {
+                device_failed = true;
+                break;
+            }
+            const bool ok = how == DEV_DONE || handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
             t_batches += vm_now_ms() - tb;
             if (!ok) break;
         }
+        if (memory.touch_failed) device_failed = true;
+        if (device_failed) {
+            delete ex;
+            return LM_E_DEVICE;  // (lm_last_error holds the device call that failed)
+        }
         const double t_loop = vm_now_ms();
-        if (!m.err.set) resolve_deref_hints(mm, ex->tr.pending, n_threads, m.err);
+        const bool on_device = D && !D->batches.empty();
+        if (!m.err.set && !on_device) resolve_deref_hints(mm, ex->tr.pending, n_threads, m.err);
         const double t_resolve = vm_now_ms();
         if (!m.err.set)
             for (u32 k = 0; k < bc->n_names; k++)
@@ -1494,6 +1934,27 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
         ex->tr.fps.push_back((u32)m.fp);
         ex->public_memory_size = pub;
         ex->runtime_memory_size = m.ap - initial_ap;
+        if (on_device) {
+            // the log and the image are assembled in HBM and resolve_deref_hints runs there; anything the device cannot decide (a
+            // conflict, an undefined source: a RunnerError or a panic of the reference) repeats the run on the host, which reports it
+            bool anomaly = false;
+            const bool ok = device_finalize(ex, *D, anomaly);
+            if (vm_times())
+                fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, device assembly + resolve_deref_hints %.2f ms%s\n", t_loop - t_start - t_batches,
+                        t_batches, vm_now_ms() - t_resolve, anomaly ? " (anomaly: the run is repeated on the host)" : "");
+            if (!ok) {
+                delete ex;
+                if (!anomaly) return LM_E_DEVICE;
+                return execute_impl(nullptr, bc, public_input, n_public_input, witness, n_threads, out);
+            }
+            *out = ex;
+            return LM_OK;
+        }
+        if (D) {  // no batch ran on the device: a plain host run
+            ex->dev = nullptr;
+            dev_run_free(D);
+            memory.on_touch = nullptr;
+        }
         const u64 n = memory.size();
         ex->defined.extend(n);
         uint8_t* def = ex->defined.data();
@@ -1527,9 +1988,34 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
     *out = ex;
     return LM_OK;
 }
+int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
+                         uint32_t n_threads, lmh_execution** out) {
+    return execute_impl(nullptr, bc, public_input, n_public_input, witness, n_threads, out);
+}
+int lmh_execute_bytecode_device(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
+                                uint32_t n_threads, lmh_execution** out) {
+    if (!ctx) {
+        lm_set_error("lmh_execute_bytecode_device: no context");
+        return LM_E_INVALID;
+    }
+    return execute_impl(ctx, bc, public_input, n_public_input, witness, n_threads, out);
+}
+int lmh_execution_on_device(const lmh_execution* e) { return e && e->dev && e->dev->finalized; }
 void lmh_execution_free(lmh_execution* e) { delete e; }
 void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* v) {
     memset(v, 0, sizeof *v);
+    if (e->dev && e->dev->finalized) {  // the log lives in HBM: the host view is one download, made on the first request
+        lmh_execution* me = const_cast<lmh_execution*>(e);
+        if (!device_materialize(me)) return;  // (v stays empty: n_cycles = 0)
+        const u64 n = me->memory.size();
+        if (n + 24 <= MAX_MEMORY) {
+            alignas(64) u32 st[16];
+            memset(st, 0, sizeof st);
+            memset(me->memory.p + n, 0, 16 * 4);
+            host_compress(st);
+            memcpy(me->memory.p + n + 16, st, 32);
+        }
+    }
     v->n_cycles = e->tr.pcs.size();
     v->pcs = e->tr.pcs.data();
     v->fps = e->tr.fps.data();
@@ -1543,6 +2029,7 @@ void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* v) {
     v->n_extension_rows = e->tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS;
     v->extension_rows = e->tr.ext.data();
     v->n_add = e->tr.n_add, v->n_mul = e->tr.n_mul, v->n_deref = e->tr.n_deref, v->n_jump = e->tr.n_jump;
+    if (e->dev && e->dev->finalized) v->n_add += e->dev->n_add, v->n_mul += e->dev->n_mul, v->n_deref += e->dev->n_deref, v->n_jump += e->dev->n_jump;
 }
 
 void lmh_poseidon16_compress_many(uint32_t* states, uint64_t n, uint32_t n_threads) {

@@ -17,6 +17,24 @@ struct VmRegion {
     size_t bytes;
 };
 void vm_execution_regions(const lmh_execution* e, VmRegion out[5]);
+// make [base, base + need) registered with the HIP runtime (need <= capacity; best effort — lm_node.cpp): uploads from a
+// registered buffer are plain DMA
+void vm_ensure_pinned(const VmRegion& reg, size_t need);
+// a run whose parallel batches executed on the device (lmh_execute_bytecode_device): the complete log and the memory image
+// (VM_UNDEF = None, lm_vm_device.h) are resident on `ctx`
+struct VmDeviceView {
+    lm_ctx* ctx;
+    const u32* image;
+    u64 memory_len;
+    const u32 *pcs, *fps;
+    u64 n_cycles;
+    const u32* poseidon_calls;
+    u64 n_poseidon_calls;
+    const u32* extension_rows;
+    u64 n_extension_rows;
+    u64 public_memory_size;
+};
+bool vm_execution_device(const lmh_execution* e, VmDeviceView* out);
 // called with a buffer's base address right before the runner frees or moves it (lm_node.cpp unpins it there)
 void vm_set_release_hook(void (*hook)(void* base));
 }  // namespace lmh

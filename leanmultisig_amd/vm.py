@@ -379,10 +379,16 @@ def _view(ptr, n, dtype=np.uint32):
 class Execution:
     """lmh_execution: the ExecutionResult of one run (copied out on demand)."""
 
-    def __init__(self, lib, handle):
+    def __init__(self, lib, handle, lazy=False):
         self.lib, self.h = lib, handle
+        self.on_device = bool(lib.lmh_execution_on_device(handle))  # the batches ran on the device: the log is resident in HBM
+        self.view = None
+        if not lazy:
+            self.load()
+
+    def load(self):
         v = VmExecutionView()
-        lib.lmh_execution_view(handle, C.byref(v))
+        self.lib.lmh_execution_view(self.h, C.byref(v))
         self.view = v
         self.n_cycles, self.memory_len = int(v.n_cycles), int(v.memory_len)
         self.public_memory_size, self.runtime_memory_size = int(v.public_memory_size), int(v.runtime_memory_size)
@@ -419,15 +425,19 @@ class Execution:
             pass
 
 
-def execute(bytecode, public_input, witness, n_threads=0):
-    """execute_bytecode (runner.rs:57-68): raises LmError with the RunnerError on failure"""
+def execute(bytecode, public_input, witness, n_threads=0, ctx=None, lazy=False):
+    """execute_bytecode (runner.rs:57-68): raises LmError with the RunnerError on failure.  ctx: the parallel loop batches run on that
+    context's device (lmh_execute_bytecode_device); lazy: do not download the log (Execution.load() does it)."""
     lib = capi.load()
     pi = np.ascontiguousarray(public_input, dtype=np.uint32)
     out = C.c_void_p()
-    rc = lib.lmh_execute_bytecode(bytecode.handle(), pi.ctypes.data, pi.size, C.byref(witness.c), n_threads, C.byref(out))
+    if ctx is None:
+        rc = lib.lmh_execute_bytecode(bytecode.handle(), pi.ctypes.data, pi.size, C.byref(witness.c), n_threads, C.byref(out))
+    else:
+        rc = lib.lmh_execute_bytecode_device(ctx.h, bytecode.handle(), pi.ctypes.data, pi.size, C.byref(witness.c), n_threads, C.byref(out))
     if rc != 0:
         raise LmError(lib.lm_last_error().decode())
-    return Execution(lib, out.value)
+    return Execution(lib, out.value, lazy=lazy)
 
 
 def poseidon16_compress_many(states, n_threads=0):

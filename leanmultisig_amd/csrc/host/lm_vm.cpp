@@ -1533,7 +1533,9 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     D.keep64.push_back(cur.index), D.keep64.push_back(per_iter);
     const std::vector<u64>&k_cur = D.keep64[D.keep64.size() - 2], &k_per = D.keep64.back();
     a.code = D.d_code, a.hint_begin = D.d_hint_begin, a.hints = D.d_hints;
-    a.n_instructions = (u32)bc.n_instructions, a.ending_pc = bc.ending_pc;
+    a.n_instructions = (u32)bc.n_instructions, a.ending_pc = bc.ending_pc, a.n_hints = (u32)bc.hints.size();
+    a.prefix_cache = (u32)std::min<u64>(split_at, VM_DEV_PREFIX_CACHE);
+    if (const char* e = getenv("LM_VM_DBG")) a.dbg = (u32)strtoul(e, nullptr, 10);
     a.wit_data = D.d_wit_data, a.wit_entry_offset = D.d_wit_off, a.wit_name_begin = D.d_wit_names, a.cur_index = d_cur, a.per_iter = d_per;
     a.n_names = bc.n_names;
     a.image = D.d_image, a.init_len = old_len, a.split_at = split_at, a.stride = stride, a.batch_fp = batch.batch_fp, a.frame_size = batch.frame_size;

@@ -44,6 +44,7 @@ enum {
 static constexpr u32 VM_UNDEF = 0xFFFFFFFFu;  // "None" (values are < p < 2^31)
 static constexpr u32 VM_DEV_MAX_ARGS = 16;    // call-frame arguments of a batch
 static constexpr u32 VM_DEV_MAX_NAMES = 64;   // named hint streams
+static constexpr u32 VM_DEV_PREFIX_CACHE = 2048;  // words of the lowest addresses every workgroup keeps in LDS
 static constexpr u32 VM_DEV_MAX_STRIDE = 14000;  // frame words kept in LDS (56 KB of the CU's 160 KB: two segments per CU stay resident)
 
 struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
@@ -51,7 +52,7 @@ struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
     const VmInstr* code;
     const u32* hint_begin;
     const VmHintRec* hints;
-    u32 n_instructions, ending_pc;
+    u32 n_instructions, ending_pc, n_hints;
     // hint streams (ExecutionWitness): entries of name k are [name_begin[k], name_begin[k + 1]); words of entry e are data[offset[e] .. offset[e + 1])
     const u32* wit_data;
     const u64* wit_entry_offset;
@@ -64,6 +65,8 @@ struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
     u32* image;
     u64 init_len, split_at, stride, batch_fp, frame_size;
     u32 batch_pc;
+    u32 prefix_cache;  // image[0 .. prefix_cache) is also kept in LDS (<= split_at, <= VM_DEV_PREFIX_CACHE)
+    u32 dbg;           // LM_VM_DBG (timing experiments only: results are wrong): 1 skip the permutation, 2 skip the call records, 4 skip the pc / fp log
     // call frames (write_call_frame, runner.rs:353-367)
     u32 return_pc_m, saved_fp_m;  // Montgomery words
     u64 start_value;

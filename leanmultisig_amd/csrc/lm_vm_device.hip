@@ -30,6 +30,12 @@ constexpr u32 UNDEF = VM_UNDEF;
 constexpr u32 R2 = 0x17f7efe4u;  // 2^64 mod p: mul(x, R2) = x * 2^32 mod p
 static_assert((u32)(((u64)ONE * ONE) % P) == R2, "R2 = (2^32 mod p)^2 mod p");
 
+constexpr u32 VM_WIN = 48;   // instruction window (records)
+constexpr u32 VM_HWIN = 32;  // hint window (records)
+__host__ __device__ constexpr u32 vm_wave_lds_words(u32 stride_pad) {  // frame | cursors | instruction window | hint range | hint window
+    return stride_pad + 2 * VM_DEV_MAX_NAMES + VM_WIN * 9 + (VM_WIN + 2) + VM_HWIN * 6;
+}
+
 __device__ __forceinline__ u32 to_monty_d(u32 x) { return mul(x % P, R2); }
 __device__ __forceinline__ u32 rfl(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ u64 rfl64(u64 x) { return ((u64)rfl((u32)(x >> 32)) << 32) | rfl((u32)x); }
@@ -40,15 +46,42 @@ __device__ __forceinline__ u32 lanes_below(u64 mask) {  // set bits of `mask` be
 struct Machine {
     const VmSegArgs& A;
     const u32* coop_tab;  // LDS copy of the 16-lane Poseidon table (poseidon16_coop.h): loaded into registers per call, not held across the loop
-    u32* frame;    // LDS: the segment's frame, A.stride words
+    const u32* pcache;    // LDS copy of image[0 .. k_prefix_cache): the lowest addresses (constants, tables) are what every segment reads
+    u32* frame;    // LDS: the segment's frame, k_stride words
     u64* cursors;  // LDS: named hint cursors
-    u64 seg_start;
+    // instruction window (LDS): records [win_base, win_base + VM_WIN) and their hint ranges, refilled with one coalesced load when
+    // the pc leaves it — a leanVM program runs ~8 instructions between jumps, a global load per instruction would cost ~1 us each
+    u32* wcode;    // VM_WIN x 9 words
+    u32* whb;      // VM_WIN + 1 words: hint_begin[win_base ..]
+    u32* whint;    // VM_HWIN x 6 words: hints [hwin_base, hwin_base + VM_HWIN)
+    u32 win_base = 0xFFFFFFFFu, win_n = 0, hwin_base = 0xFFFFFFFFu, hwin_n = 0;
+    // Addresses are 32-bit here: every address the interpreter forms is the sum of two values below 2^31 (an fp or a pointer read from
+    // memory — field elements — plus an operand offset / a small index); hint operands are checked on entry (run_hint).
+    u32 seg_start;
     u32 lane;
     u32 pc;
-    u64 fp, ap;
+    u32 fp;
+    u64 ap;
     u32 n_cyc = 0, n_pos = 0, n_ext = 0, n_pend = 0, n_def = 0, n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
     u32 err = 0, err_aux = 0;
     u32 *pcs, *fps, *pos, *ext, *pend, *def;  // this segment's slots
+    // hot kernel arguments as plain members behind an opaque copy (hot_args): left in the kernarg segment the compiler re-loads them
+    // with scalar loads at every use under register pressure (373 s_load in the first version, a wait on each)
+    u32 k_split_at, k_stride;
+    u32 k_prefix_cache, k_cap_cyc, k_cap_pos, k_cap_ext, k_cap_pend, k_cap_def, k_batch_pc, k_ending_pc, k_n_instructions, k_n_hints, k_dbg;
+    u32* k_image;
+    const VmInstr* k_code;
+    const u32* k_hint_begin;
+    const VmHintRec* k_hints;
+    __device__ __forceinline__ void hot_args() {
+        k_split_at = (u32)A.split_at, k_stride = (u32)A.stride, k_prefix_cache = A.prefix_cache, k_cap_cyc = A.cap_cyc, k_cap_pos = A.cap_pos, k_cap_ext = A.cap_ext;
+        k_cap_pend = A.cap_pend, k_cap_def = A.cap_def, k_batch_pc = A.batch_pc, k_ending_pc = A.ending_pc, k_n_instructions = A.n_instructions;
+        k_n_hints = A.n_hints, k_dbg = A.dbg, k_image = A.image, k_code = A.code, k_hint_begin = A.hint_begin, k_hints = A.hints;
+        asm volatile("" : "+s"(k_split_at), "+s"(k_stride), "+s"(k_prefix_cache), "+s"(k_cap_cyc), "+s"(k_cap_pos), "+s"(k_cap_ext), "+s"(k_cap_pend),
+                     "+s"(k_cap_def));
+        asm volatile("" : "+s"(k_batch_pc), "+s"(k_ending_pc), "+s"(k_n_instructions), "+s"(k_n_hints), "+s"(k_dbg), "+s"(k_image), "+s"(k_code),
+                     "+s"(k_hint_begin), "+s"(k_hints));
+    }
 
     __device__ __forceinline__ Machine(const VmSegArgs& a) : A(a) {}
 
@@ -56,33 +89,34 @@ struct Machine {
         if (!err) err = code, err_aux = (u32)aux;
     }
     // ---- SegmentMemory (memory.rs:118-189) ------------------------------------------------------------------------------------------
-    __device__ __forceinline__ u32 peek(u64 a) const {  // any lane, any address
-        if (a < A.split_at) return A.image[a];
-        const u64 o = a - seg_start;
-        if (a >= seg_start && o < A.stride) return frame[o];
+    __device__ __forceinline__ u32 peek(u32 a) const {  // any lane, any address
+        if (a < k_prefix_cache) return pcache[a];
+        if (a < k_split_at) return k_image[a];
+        const u32 o = a - seg_start;  // (wraps to a huge value below the frame)
+        if (o < k_stride) return frame[o];
         return UNDEF;
     }
-    __device__ __forceinline__ u32 peek_u(u64 a) const { return rfl(peek(a)); }  // wave-uniform address
+    __device__ __forceinline__ u32 peek_u(u32 a) const { return rfl(peek(a)); }  // wave-uniform address
     // deferred write list: the lanes of `active` append (addr, value) in lane order
-    __device__ __forceinline__ void defer_lanes(bool active, u64 a, u32 v) {
+    __device__ __forceinline__ void defer_lanes(bool active, u32 a, u32 v) {
         const u64 m = __ballot(active);
         if (!m) return;
         const u32 cnt = (u32)__popcll(m);
-        if (n_def + cnt > A.cap_def) {
+        if (n_def + cnt > k_cap_def) {
             fail(VM_E_LOG_CAPACITY, 5);
             return;
         }
         if (active) {
             const u32 at = n_def + lanes_below(m);
-            def[2 * at] = (u32)a;
+            def[2 * at] = a;
             def[2 * at + 1] = v;
         }
         n_def += cnt;
     }
     // per-lane write (distinct addresses per lane): own frame = write-once cell, everything else is deferred
-    __device__ __forceinline__ void set_lanes(bool active, u64 a, u32 v) {
-        const u64 o = a - seg_start;
-        const bool mine = a >= seg_start && o < A.stride;
+    __device__ __forceinline__ void set_lanes(bool active, u32 a, u32 v) {
+        const u32 o = a - seg_start;
+        const bool mine = o < k_stride;
         bool clash = false;
         if (active && mine) {
             const u32 c = frame[o];
@@ -95,15 +129,26 @@ struct Machine {
             fail(VM_E_MEMORY_ALREADY_SET, a);
             return;
         }
-        if (__ballot(active && a > 0xFFFFFFFFull)) {  // (a 32-bit hint operand on top of fp: the host runner reports OutOfMemory)
-            fail(VM_E_UNSUPPORTED, 1);
-            return;
-        }
         defer_lanes(active && !mine, a, v);
     }
-    __device__ __forceinline__ void set_u(u64 a, u32 v) { set_lanes(lane == 0, a, v); }  // wave-uniform write
+    // wave-uniform write: every lane holds the same (a, v) — no ballots, every lane stores the same word
+    __device__ __forceinline__ void set_u(u32 a, u32 v) {
+        const u32 o = a - seg_start;
+        if (o < k_stride) {
+            const u32 c = rfl(frame[o]);
+            if (c == UNDEF)
+                frame[o] = v;
+            else if (c != v)
+                fail(VM_E_MEMORY_ALREADY_SET, a);
+        } else if (n_def >= k_cap_def)
+            fail(VM_E_LOG_CAPACITY, 5);
+        else {
+            if (lane == 0) def[2 * n_def] = a, def[2 * n_def + 1] = v;
+            n_def++;
+        }
+    }
 
-    __device__ __forceinline__ u32 need_mem(u64 a) {
+    __device__ __forceinline__ u32 need_mem(u32 a) {
         const u32 v = peek_u(a);
         if (v == UNDEF) fail(VM_E_UNDEFINED_MEMORY, a);
         return v;
@@ -112,23 +157,27 @@ struct Machine {
     __device__ __forceinline__ u32 read(u32 mode, u32 canon, u32 monty) const {
         if (mode == LM_VM_ARG_CONST) return monty;
         if (mode == LM_VM_ARG_MEM) return peek_u(fp + canon);
-        return to_monty_d((u32)((fp + canon) % P));
+        return to_monty_d(fp + canon);
     }
     __device__ __forceinline__ u32 need(u32 mode, u32 canon, u32 monty) {
         const u32 v = read(mode, canon, monty);
         if (v == UNDEF) fail(VM_E_UNDEFINED_MEMORY, fp + canon);
         return v;
     }
-    static __device__ __forceinline__ u64 usize(u32 monty) { return from_monty(monty); }
+    static __device__ __forceinline__ u32 usize(u32 monty) { return from_monty(monty); }
 
     // ---- hints (isa/hint.rs:270-386, CustomHint::execute :137-203) ----------------------------------------------------------------------
     __device__ __forceinline__ u32 hint_arg(const VmHintRec& h, int k) {
         const u32 mode = h.mode[k];
         if (mode == LM_VM_ARG_CONST) return to_monty_d(h.args[k]);
         if (mode == LM_VM_ARG_MEM) return need_mem(fp + h.args[k]);
-        return to_monty_d((u32)((fp + h.args[k]) % P));
+        return to_monty_d(fp + h.args[k]);
     }
     __device__ __forceinline__ void run_hint(const VmHintRec& h) {
+        if ((h.args[0] | h.args[1] | h.args[2] | h.args[3]) >> 30) {  // (32-bit address arithmetic: such an operand goes to the host runner)
+            fail(VM_E_UNSUPPORTED, 2);
+            return;
+        }
         switch (h.kind) {
             case LM_VM_HINT_REQUEST_MEMORY: {
                 const u32 size = hint_arg(h, 1);
@@ -144,7 +193,7 @@ struct Machine {
                 break;
             }
             case LM_VM_HINT_DEREF: {
-                if (n_pend >= A.cap_pend) {
+                if (n_pend >= k_cap_pend) {
                     fail(VM_E_LOG_CAPACITY, 4);
                     return;
                 }
@@ -240,9 +289,13 @@ struct Machine {
                     dest = usize(p);
                 }
                 const u64 k0 = rfl64(A.wit_entry_offset[e]), k1 = rfl64(A.wit_entry_offset[e + 1]);
+                if ((k1 - k0) >> 30) {
+                    fail(VM_E_UNSUPPORTED, 3);
+                    return;
+                }
                 for (u64 k = k0; k < k1 && !err; k += 64) {
                     const bool on = k + lane < k1;
-                    set_lanes(on, dest + (k - k0) + lane, on ? A.wit_data[k + lane] : 0u);
+                    set_lanes(on, (u32)(dest + (k - k0)) + lane, on ? A.wit_data[k + lane] : 0u);
                 }
                 break;
             }
@@ -272,30 +325,44 @@ struct Machine {
     // ---- Poseidon16Precompile::execute (poseidon_16/mod.rs:209-289) ------------------------------------------------------------------------
     __device__ __forceinline__ void poseidon(const VmInstr& in, u32 va, u32 vb, u32 vc) {
         const bool permute = in.x0 & 1, half = in.x0 & 2, hard = in.x0 & 4;
-        const u64 arg_a = usize(va), arg_b = usize(vb), res = usize(vc);
-        const u64 left_first = hard ? in.x1 : arg_a;
-        const u64 left_second = hard ? arg_a : arg_a + 4;
-        if (n_pos >= A.cap_pos) {
+        const u32 arg_a = usize(va), arg_b = usize(vb), res = usize(vc);
+        const u32 left_first = hard ? in.x1 : arg_a;
+        const u32 left_second = hard ? arg_a : arg_a + 4;
+        if (n_pos >= k_cap_pos) {
             fail(VM_E_LOG_CAPACITY, 2);
             return;
         }
         const u32 l = lane & 15;  // the four 16-lane rows of the wave compute the same permutation
-        const u64 src = l < 4 ? left_first + l : (l < 8 ? left_second + (l - 4) : arg_b + (l - 8));
+        const u32 src = l < 4 ? left_first + l : (l < 8 ? left_second + (l - 4) : arg_b + (l - 8));
         const u32 s = peek(src);
         if (__ballot(s == UNDEF)) {
             fail(VM_E_UNDEFINED_MEMORY, src);
             return;
         }
         CoopRegs R;
-        coop_load(R, coop_tab);
-        const u32 o = permute ? coop_permute(s, R) : coop_compress(s, R);
+        {   // the LDS copy is TRANSPOSED (word i of lane l at 16 + i * 16 + l): the 16 lanes of a row read 16 consecutive banks; in the
+            // global layout (l * 128 + i) they would all hit one bank, a 16-way conflict on each of the 119 loads
+            const u32 l = lane & 15;
+            u32* dst = reinterpret_cast<u32*>(&R.t);
+#pragma unroll
+            for (u32 i = 0; i < COOP_TAB_STRIDE - 9; i++) dst[i] = coop_tab[16 + i * 16 + l];
+#pragma unroll
+            for (int k = 0; k < 16; k++) R.mds[k] = coop_tab[k];  // uniform
+        }
+        {   // all 135 table words in registers BEFORE the dependent chain starts: left to the scheduler the loads sink next to their
+            // uses and every multiply of the permutation waits for its own LDS round trip (14 us per call instead of 3)
+            u32* rw = reinterpret_cast<u32*>(&R);
+#pragma unroll
+            for (u32 i = 0; i < sizeof(CoopRegs) / 4; i++) asm volatile("" : "+v"(rw[i]));
+        }
+        const u32 o = (k_dbg & 1) ? s : (permute ? coop_permute(s, R) : coop_compress(s, R));
         const u32 n_out = permute ? 16u : (half ? 4u : 8u);
         set_lanes(lane < n_out, res + lane, o);
         if (err) return;
-        if (lane == 0) {
+        if (lane == 0 && !(k_dbg & 2)) {
             u32* rec = pos + (u64)n_pos * LM_VM_POSEIDON_CALL_WORDS;
-            rec[0] = (u32)arg_a, rec[1] = (u32)arg_b, rec[2] = (u32)res, rec[3] = half ? 1u : 0u, rec[4] = hard ? 1u : 0u, rec[5] = hard ? in.x1 : 0u;
-            rec[6] = (u32)left_first, rec[7] = (u32)left_second, rec[8] = permute ? 1u : 0u;
+            rec[0] = arg_a, rec[1] = arg_b, rec[2] = res, rec[3] = half ? 1u : 0u, rec[4] = hard ? 1u : 0u, rec[5] = hard ? in.x1 : 0u;
+            rec[6] = left_first, rec[7] = left_second, rec[8] = permute ? 1u : 0u;
         }
         n_pos++;
     }
@@ -412,7 +479,7 @@ struct Machine {
         const bool is_be = in.x0 & 4;
         const u64 size = in.x1, pa = usize(va), pb = usize(vb), pr = usize(vc);
         if (size == 1 && op != OP_POLY_EQ && !solve_unknowns(pa, pb, pr, is_be, op)) return;
-        if ((u64)n_ext + size > A.cap_ext) {
+        if ((u64)n_ext + size > k_cap_ext) {
             fail(VM_E_LOG_CAPACITY, 3);
             return;
         }
@@ -451,25 +518,30 @@ struct Machine {
             case VM_K_ADD:
             case VM_K_MUL: {  // nu_a (arg_a) op nu_c (arg_c) = nu_b (res)
                 const bool mu = in.kind == VM_K_MUL;
-                const u32 r = read(in.mb, in.b, in.bm);
+                // the three operand reads are independent and free of side effects: issued together (one LDS round trip, not three)
+                const u32 r = read(in.mb, in.b, in.bm), a = read(in.ma, in.a, in.am), c = read(in.mc, in.c, in.cm);
                 if (r == UNDEF) {
-                    const u32 a = need(in.ma, in.a, in.am);
-                    if (err) return;
-                    const u32 c = need(in.mc, in.c, in.cm);
-                    if (err) return;
+                    if (a == UNDEF) {
+                        fail(VM_E_UNDEFINED_MEMORY, fp + in.a);
+                        return;
+                    }
+                    if (c == UNDEF) {
+                        fail(VM_E_UNDEFINED_MEMORY, fp + in.c);
+                        return;
+                    }
                     set_u(fp + in.b, mu ? mul(a, c) : add(a, c));
                 } else {
-                    const u32 a = read(in.ma, in.a, in.am);
                     if (a == UNDEF) {  // a = res inv_op c
-                        const u32 c = need(in.mc, in.c, in.cm);
-                        if (err) return;
+                        if (c == UNDEF) {
+                            fail(VM_E_UNDEFINED_MEMORY, fp + in.c);
+                            return;
+                        }
                         if (mu && c == 0) {
                             fail(VM_E_DIV_BY_ZERO, 0);
                             return;
                         }
                         set_u(fp + in.a, mu ? mul(r, inv(c)) : sub(r, c));
                     } else {
-                        const u32 c = read(in.mc, in.c, in.cm);
                         if (c == UNDEF) {
                             if (in.mc != LM_VM_ARG_MEM) {
                                 fail(VM_E_NOT_A_POINTER, 0);
@@ -539,12 +611,11 @@ struct Machine {
                 break;
             }
             default: {
-                const u32 a = need(in.ma, in.a, in.am);
-                if (err) return;
-                const u32 b = need(in.mb, in.b, in.bm);
-                if (err) return;
-                const u32 c = need(in.mc, in.c, in.cm);
-                if (err) return;
+                const u32 a = read(in.ma, in.a, in.am), b = read(in.mb, in.b, in.bm), c = read(in.mc, in.c, in.cm);
+                if (a == UNDEF || b == UNDEF || c == UNDEF) {
+                    fail(VM_E_UNDEFINED_MEMORY, fp + (a == UNDEF ? in.a : (b == UNDEF ? in.b : in.c)));
+                    return;
+                }
                 if (in.kind == VM_K_POSEIDON)
                     poseidon(in, a, b, c);
                 else
@@ -559,31 +630,45 @@ struct Machine {
     // run_loop (runner.rs:121-204) from batch_pc until the loop comes back to it
     __device__ __forceinline__ void run() {
         for (;;) {
-            if (pc == A.ending_pc) {
+            if (pc == k_ending_pc) {
                 fail(VM_E_REACHED_END, 0);
                 return;
             }
-            if (pc >= A.n_instructions) {
+            if (pc >= k_n_instructions) {
                 fail(VM_E_PC_OUT_OF_BOUNDS, 0);
                 return;
             }
-            if (n_cyc >= A.cap_cyc) {
+            if (n_cyc >= k_cap_cyc) {
                 fail(VM_E_LOG_CAPACITY, 1);
                 return;
             }
-            if (lane == 0) pcs[n_cyc] = pc, fps[n_cyc] = (u32)fp;
+            if (lane == 0 && !(k_dbg & 4)) pcs[n_cyc] = pc, fps[n_cyc] = (u32)fp;
             n_cyc++;
-            const u32 h0 = rfl(A.hint_begin[pc]), h1 = rfl(A.hint_begin[pc + 1]);
+            if (pc - win_base >= win_n) {  // refill the instruction window at pc
+                win_base = pc;
+                win_n = min((u32)VM_WIN, k_n_instructions - pc);
+                const u32* src = reinterpret_cast<const u32*>(k_code + pc);
+                for (u32 k = lane; k < win_n * 9; k += 64) wcode[k] = src[k];
+                for (u32 k = lane; k <= win_n; k += 64) whb[k] = k_hint_begin[pc + k];
+            }
+            const u32 wi = pc - win_base;
+            const u32 h0 = rfl(whb[wi]), h1 = rfl(whb[wi + 1]);
             for (u32 h = h0; h < h1; h++) {
+                if (h - hwin_base >= hwin_n) {  // refill the hint window at h
+                    hwin_base = h;
+                    hwin_n = min((u32)VM_HWIN, k_n_hints - h);
+                    const u32* src = reinterpret_cast<const u32*>(k_hints + h);
+                    for (u32 k = lane; k < hwin_n * 6; k += 64) whint[k] = src[k];
+                }
                 VmHintRec hr;
                 {
-                    const u32* src = reinterpret_cast<const u32*>(A.hints + h);
+                    const u32* src = whint + (h - hwin_base) * 6;
                     u32* dst = reinterpret_cast<u32*>(&hr);
 #pragma unroll
                     for (int k = 0; k < 6; k++) dst[k] = rfl(src[k]);
                 }
                 if (hr.kind == LM_VM_HINT_PARALLEL_BATCH_START) {
-                    if (pc != A.batch_pc) {  // an inner batch: left to the host runner
+                    if (pc != k_batch_pc) {  // an inner batch: left to the host runner
                         fail(VM_E_NESTED_BATCH, 0);
                         return;
                     }
@@ -594,7 +679,7 @@ struct Machine {
             }
             VmInstr in;
             {
-                const u32* src = reinterpret_cast<const u32*>(A.code + pc);
+                const u32* src = wcode + wi * 9;
                 u32* dst = reinterpret_cast<u32*>(&in);
 #pragma unroll
                 for (int k = 0; k < 9; k++) dst[k] = rfl(src[k]);
@@ -602,35 +687,48 @@ struct Machine {
             step(in);
             if (err) return;
             pc = rfl(pc);
-            fp = rfl64(fp);
-            if (pc == A.batch_pc) return;  // StopReason::LoopBack
+            fp = rfl(fp);
+            if (pc == k_batch_pc) return;  // StopReason::LoopBack
         }
     }
 };
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vm_segments(const VmSegArgs A) {
+// blockDim.x / 64 segments per workgroup: the waves are independent after the common set-up (table, prefix cache), each on its own
+// LDS slice; LDS layout in words: [coop table | prefix cache | per wave: frame, cursors, instruction window, hint window]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vm_segments(const VmSegArgs A, u32 n_par) {
     extern __shared__ u32 lds[];
-    const u32 seg = blockIdx.x, lane = threadIdx.x;
-    const u64 stride_pad = (A.stride + 1) & ~1ull;
-    Machine m(A);
-    m.frame = lds;
-    m.cursors = reinterpret_cast<u64*>(lds + stride_pad);
-    {
-        u32* tab = lds + stride_pad + 2 * VM_DEV_MAX_NAMES;
-        for (u32 k = lane; k < COOP_TAB_WORDS; k += 64) tab[k] = A.coop_tab[k];
-        m.coop_tab = tab;
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 seg = blockIdx.x * (blockDim.x >> 6) + wave;
+    const u32 stride_pad = (u32)((A.stride + 1) & ~1ull);
+    const u32 pc_pad = (A.prefix_cache + 1) & ~1u;
+    u32* tab = lds;
+    u32* pcache = lds + COOP_TAB_WORDS;
+    for (u32 k = threadIdx.x; k < COOP_TAB_WORDS; k += blockDim.x) {  // transposed lane tables behind the 16 uniform words (Machine::poseidon)
+        const u32 l = (k - 16) / COOP_TAB_STRIDE, i = (k - 16) % COOP_TAB_STRIDE;
+        tab[k < 16 ? k : 16 + i * 16 + l] = A.coop_tab[k];
     }
-    m.seg_start = A.split_at + (u64)seg * A.stride;
+    for (u32 k = threadIdx.x; k < A.prefix_cache; k += blockDim.x) pcache[k] = A.image[k];
+    __syncthreads();
+    if (seg >= n_par) return;
+    u32* mine = lds + COOP_TAB_WORDS + pc_pad + wave * vm_wave_lds_words(stride_pad);
+    Machine m(A);
+    m.hot_args();
+    m.coop_tab = tab, m.pcache = pcache;
+    m.frame = mine;
+    m.cursors = reinterpret_cast<u64*>(mine + stride_pad);
+    m.wcode = mine + stride_pad + 2 * VM_DEV_MAX_NAMES;
+    m.whb = m.wcode + VM_WIN * 9;
+    m.whint = m.whb + VM_WIN + 2;
+    m.seg_start = (u32)(A.split_at + (u64)seg * A.stride);
     m.lane = lane;
-    for (u64 k = lane; k < A.stride; k += 64) {
-        const u64 a = m.seg_start + k;
+    for (u32 k = lane; k < A.stride; k += 64) {
+        const u32 a = m.seg_start + k;
         m.frame[k] = a < A.init_len ? A.image[a] : UNDEF;
     }
     for (u32 k = lane; k < A.n_names; k += 64) m.cursors[k] = A.cur_index[k] + (u64)seg * A.per_iter[k];
     m.pcs = A.pcs + (u64)seg * A.cap_cyc, m.fps = A.fps + (u64)seg * A.cap_cyc;
     m.pos = A.pos + (u64)seg * A.cap_pos * LM_VM_POSEIDON_CALL_WORDS, m.ext = A.ext + (u64)seg * A.cap_ext * LM_VM_EXTENSION_ROW_WORDS;
     m.pend = A.pend + (u64)seg * A.cap_pend * 2, m.def = A.def + (u64)seg * A.cap_def * 2;
-    __syncthreads();
     // write_call_frame (runner.rs:353-367) for iteration seg + 1: its frame starts at the segment's own slice
     m.pc = A.batch_pc;
     m.fp = m.seg_start;
@@ -640,8 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!m.err) m.set_u(m.fp + 2, to_monty_d((u32)((A.start_value + seg + 1) % P)));
     for (u32 j = 1; j < A.n_args && !m.err; j++) m.set_u(m.fp + 2 + j, A.args_m[j]);
     if (!m.err) m.run();
-    __syncthreads();
-    for (u64 k = lane; k < A.stride; k += 64) A.image[m.seg_start + k] = m.frame[k];
+    for (u32 k = lane; k < A.stride; k += 64) A.image[m.seg_start + k] = m.frame[k];
     if (lane == 0) {
         u32* c = A.counts + (u64)seg * VM_SEG_WORDS;
         c[VM_SEG_CYC] = m.n_cyc, c[VM_SEG_POS] = m.n_pos, c[VM_SEG_EXT] = m.n_ext, c[VM_SEG_PEND] = m.n_pend, c[VM_SEG_DEF] = m.n_def;
@@ -797,9 +894,17 @@ __global__ __launch_bounds__(256) void k_vm_image_export(u32* __restrict__ dst, 
 namespace lmh {
 int vm_dev_segments(lm_ctx* ctx, const VmSegArgs& a, u64 n_par) {
     LM_REQUIRE(ctx && n_par > 0 && n_par < (1ull << 31) && a.stride > 0 && a.stride <= VM_DEV_MAX_STRIDE && a.n_names <= VM_DEV_MAX_NAMES &&
-               a.n_args <= VM_DEV_MAX_ARGS);
-    const size_t lds_bytes = (size_t)((a.stride + 1) & ~1ull) * 4 + (size_t)VM_DEV_MAX_NAMES * 8 + (size_t)COOP_TAB_WORDS * 4;
-    LM_LAUNCH(ctx, k_vm_segments, dim3((unsigned)n_par), dim3(64), lds_bytes, a);
+               a.n_args <= VM_DEV_MAX_ARGS && a.prefix_cache <= VM_DEV_PREFIX_CACHE && a.prefix_cache <= a.split_at);
+    // segments per workgroup: as many (<= 4) as keep two workgroups on a CU (160 KB of LDS, 8 waves at 2 per SIMD)
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_vm_segments, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    const u32 stride_pad = (u32)((a.stride + 1) & ~1ull);
+    const size_t shared_words = (size_t)COOP_TAB_WORDS + ((a.prefix_cache + 1) & ~1u);
+    u32 spw = 4;
+    while (spw > 1 && (shared_words + (size_t)spw * vm_wave_lds_words(stride_pad)) * 4 > (attr_ok ? 80u : 64u) * 1024) spw >>= 1;
+    const size_t lds_bytes = (shared_words + (size_t)spw * vm_wave_lds_words(stride_pad)) * 4;
+    LM_REQUIRE(lds_bytes <= (attr_ok ? 160u : 64u) * 1024);
+    (void)hipGetLastError();
+    LM_LAUNCH(ctx, k_vm_segments, dim3((unsigned)((n_par + spw - 1) / spw)), dim3(64 * spw), lds_bytes, a, (u32)n_par);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py — XMSS signatures aggregated per second, 1550 signatures, WHIR rate 1/2 (BASELINE configs[1]).
+"""bench.py — XMSS signatures aggregated per second, whole node, 1550 signatures, WHIR rate 1/2 (BASELINE configs[1]).
 
 Default workload: the hand-assembled XMSS aggregation program (leanmultisig_amd/programs/xmss_aggregate.py: the reference's
-zkDSL program at the ISA level, looped, 2^19-row bytecode table) on 1550 REAL signatures.  The execution trace is produced by the
-library itself — lmh_execute_bytecode (the leanVM runner on the host thread pool) + lmh_get_execution_trace (every table column
-on the device) — and two things are timed:
-  value             one `lmh_prove_execution` per step: the reference's prove_execution from the execution trace (resident in
-                    HBM) to the proof — stack + WHIR commit (LDE 2^20 x 128, Merkle), logup fill + GKR over 2^25 pairs + column
-                    evaluations, batched AIR sumcheck (3 tables), 252-claim WHIR open with 124-bit parameters;
-  whole_node.value  one `lmh_prove_execution_vm` per step: what the reference's metric times (aggregate_type_1 ->
+zkDSL program at the ISA level, looped, 2^19-row bytecode table) on 1550 REAL signatures.
+  value             one `lmh_prove_execution_vm` per step = what the reference's metric times (aggregate_type_1 ->
                     prove_execution(bytecode, public_input, witness): VM run + trace generation + proof,
-                    rec_aggregation/src/benchmark.rs:397-431), from hints in host memory to the proof.
+                    rec_aggregation/src/benchmark.rs:397-431), from hints in host memory to the pruned proof: the leanVM runner
+                    (sequential parts on the host, the 1549 per-signature segments of the parallel batch one wavefront each on the
+                    device), every table column built on the device from the resident log, stack + WHIR commit (LDE 2^20 x 128,
+                    Merkle), logup fill + GKR over 2^25 pairs + column evaluations, batched AIR sumcheck (3 tables), 252-claim WHIR
+                    open with 124-bit parameters.  The same definition at every N (one leaf per rank);
+  hot_path.value    one `lmh_prove_execution` per step: from an execution trace resident in HBM to the proof (rounds 1-3's headline).
 Not built: the zkDSL compiler (config["missing"]).
 
 Multi-GPU (north_star / SURVEY.md §8(e)): independent 1550-signature leaves, one per GPU, no data-path collective; the
@@ -61,7 +61,7 @@ def build_vm_workload(ctx, rng, n_sigs, log_inv_rate, capacity, log_bytecode=19)
     bc = xa.build_program(log_bytecode)
     signer = xa.Xmss(compress=lambda x: ctx.poseidon16(x, compress=True))  # key generation / signing hashes on the device (untimed)
     pi, wit, info = xa.build_witness(bc, n_sigs, rng, xmss=signer)
-    ex = vm.execute(bc, pi, wit)
+    ex = vm.execute(bc, pi, wit, ctx=ctx)
     dt = vm.DeviceTrace(ctx, bc, ex, pi, log_inv_rate)
     tr = dt.view
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
@@ -118,29 +118,6 @@ def oracle_witness(orc, ob, w):
     return ob.VmRun(orc, v["bc"], v["pi"], v["wit"]).trace(w["log_inv_rate"])
 
 
-def time_whole_node(ctx, lm, w, steps, warmup, n_threads=0):
-    """lmh_prove_execution_vm: hints in host memory -> VM run -> trace on the device -> proof; ms per phase (mean over steps)"""
-    from leanmultisig_amd import vm
-    v = w["vm"]
-    acc = np.zeros(3)
-    t_tot = 0.0
-    # the runner bursts onto up to 128 host threads under the box's CPU quota (cgroup cpu.max: 16 CPUs per 100 ms): start from a
-    # fresh quota period, not from whatever the timed region before this leg left of the current one
-    time.sleep(0.25)
-    for i in range(warmup + steps):
-        pr = lm.Prover(ctx)
-        t0 = time.perf_counter()
-        times = vm.prove_execution_vm(ctx, pr, v["bc"], v["pi"], v["wit"], w["lm_builder"], n_threads=n_threads)
-        dt = time.perf_counter() - t0
-        if os.environ.get("LM_BENCH_DEBUG"):
-            import ctypes
-            print(f"# whole node step {i}: {1e3 * dt:.2f} ms = " + " + ".join(f"{x:.2f}" for x in times) + f" (cpu {ctypes.CDLL(None).sched_getcpu()})", file=sys.stderr)
-        if i >= warmup:
-            acc += np.asarray(times)
-            t_tot += dt
-    return t_tot / steps, acc / steps, pr
-
-
 def pin_witness(w):
     """--host-resident: pinned host copies of every committed column / memory image, re-uploaded at the start of each step
     (what a node pays when the trace builder leaves the witness in host memory): (device ptr, pinned tensor) pairs."""
@@ -159,10 +136,21 @@ def pin_witness(w):
     return pairs
 
 
-def run_step(ctx, lm, w):
+def run_step(ctx, lm, w, whole_node=None, phases=None):
+    """One step.  whole_node (default: whenever the workload carries its program): lmh_prove_execution_vm — VM run, trace, proof;
+    else lmh_prove_execution from the trace resident in HBM.  phases: list that receives [vm_ms, trace_ms, prove_ms]."""
+    if whole_node is None:
+        whole_node = "vm" in w
+    pr = lm.Prover(ctx)
+    if whole_node:
+        from leanmultisig_amd import vm
+        v = w["vm"]
+        t = vm.prove_execution_vm(ctx, pr, v["bc"], v["pi"], v["wit"], w["lm_builder"], n_threads=w.get("vm_threads", 0))
+        if phases is not None:
+            phases.append(t)
+        return pr
     for dptr, t in w.get("pinned", ()):  # PCIe-inclusive mode: host -> HBM copies are part of the step
         ctx._check(ctx.lib.lm_upload_async(ctx.h, dptr, t.data_ptr(), t.numel()))
-    pr = lm.Prover(ctx)
     pr.prove_execution(w["tr"], w["cfg"])
     return pr
 
@@ -350,32 +338,44 @@ def main():
         assert not vm_path, "--host-resident applies to the synthetic witnesses; the default workload reports whole_node (hints -> proof)"
         w["pinned"] = pin_witness(w)
 
-    # ---- the timed region: K steps, one step = ONE proof of one 1550-signature leaf on this rank's GPU, which is what the
-    # reference's metric times (n_xmss / mean elapsed of one aggregate_type_1, rec_aggregation/src/benchmark.rs:397-431).
+    # ---- the timed region: K steps, one step = ONE leaf of 1550 signatures on this rank's GPU from hints to proof, which is what
+    # the reference's metric times (n_xmss / mean elapsed of one aggregate_type_1, rec_aggregation/src/benchmark.rs:397-431).
     # N ranks prove N independent leaves (weak scaling) and exchange roots + pruned proofs after every step.
     dominant = "k_air_round"
     hbm_kernels = ("k_fold2_round", "k_prod_round2")  # the HBM-bound passes of the WHIR opening sumcheck: live GB/s line
+    if vm_path:
+        # sequential parts of the VM + the host pool of a batch the device hands back: this rank's share of the CPUs the cgroup grants
+        w["vm_threads"] = max(2, min(128, 4 * effective_cpus()) // world)
     for _ in range(args.warmup):
         pr = run_step(ctx, lm, w)
         exchange_step(step_root(pr), pr.proof_pruned(), device)
     ctx.sync()
     ctx.profile_select(",".join((dominant,) + hbm_kernels))
+    ctx.wait_log(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     gathered = None
+    phases, stage_acc, step_s = [], {}, []
     for _ in range(args.steps):
-        pr = run_step(ctx, lm, w)
+        ts = time.perf_counter()
+        pr = run_step(ctx, lm, w, phases=phases)
         gathered = exchange_step(step_root(pr), pr.proof_pruned(), device)
+        step_s.append(time.perf_counter() - ts)
+        for k, v in pr.stage_times().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
         if os.environ.get("LM_BENCH_DEBUG"):
             import ctypes
-            print(f"# hot path step on cpu {ctypes.CDLL(None).sched_getcpu()}", file=sys.stderr)
+            print(f"# step {1e3 * step_s[-1]:.2f} ms" + (" = " + " + ".join(f"{x:.2f}" for x in phases[-1]) if phases else "") +
+                  f" on cpu {ctypes.CDLL(None).sched_getcpu()}", file=sys.stderr)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    waits = ctx.wait_log_read()
+    ctx.wait_log(False)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -437,8 +437,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)",
             "data": "synthetic",
             "config": {
-                "workload": f"xmss --n-signatures {sigs} --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): ONE prove_execution "
-                            "per step, from the execution trace to the pruned proof, "
+                "workload": f"xmss --n-signatures {sigs} --log-inv-rate {args.log_inv_rate} (BASELINE configs[{args.log_inv_rate}]): ONE "
+                            + ("prove_execution(bytecode, public_input, witness) per step — leanVM run (parallel batch on the device), trace build, proof — "
+                               if vm_path else "prove_execution per step, from the execution trace to the pruned proof, ")
                             + (f"on the trace of the XMSS aggregation program (leanmultisig_amd/programs/xmss_aggregate.py, looped, hand-assembled) "
                                f"verifying {sigs} REAL signatures, executed by lmh_execute_bytecode: {ww['counts']['cycles']} cycles "
                                f"({ww['counts']['add']} ADD, {ww['counts']['mul']} MUL, {ww['counts']['deref']} DEREF, {ww['counts']['jump']} JUMP), "
@@ -448,17 +449,18 @@ def main():
                               f"bytecode 2^{ww['log_bytecode']}, stacked 2^{w['n_vars']}, 124-bit WHIR"
                             + (" (CapacityBound: prox-gaps-conjecture)" if capacity else "")
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
-                "value_definition": "signatures of one leaf x ranks / latency of one proof (the reference's n_xmss / mean elapsed of "
-                                    "one aggregate_type_1); `inflight` below is the throughput with several independent leaves "
-                                    "queued on the same GPU",
-                "stages": ["fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
+                "value_definition": "WHOLE NODE: signatures of one leaf x ranks / latency of one step from hints in host memory to the pruned "
+                                    "proof (the reference's n_xmss / mean elapsed of one aggregate_type_1); `hot_path` = the same without the VM "
+                                    "run and the trace build; `inflight` = the throughput with several independent leaves queued on the same GPU",
+                "stages": ["leanvm_run(host head + device batch)", "trace_build(device)", "fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
                            "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)", "merkle_path_pruning",
                            "exchange(roots+pruned proofs)"],
                 "missing": ["the zkDSL compiler (crates/lean_compiler): the aggregation program is assembled by hand at the ISA level, raw "
                             "signatures only (no recursion branch: that code is the in-VM WHIR verifier)"],
                 "per_gpu_signatures": sigs,
                 "witness": "re-uploaded from pinned host memory every step (PCIe inclusive)" if args.host_resident
-                           else "resident in HBM before the timed region",
+                           else ("hints in host memory at the start of every step (the VM log is produced on the device)" if vm_path
+                                 else "resident in HBM before the timed region"),
                 "whir_config": "lmh_whir_config_new (the library's own WhirConfig::new)",
                 "source_sha": sha,
             },
@@ -490,17 +492,44 @@ def main():
                         "the library at the launch sites (lm_profile_read_bytes)"})(
                 sum(v[0] for v in hbm_live.values()), sum(v[1] for v in hbm_live.values()), sum(v[2] for v in hbm_live.values())),
         }
-        if vm_path and world == 1 and not args.no_whole_node:
-            # ---- the reference's metric proper: prove_execution(bytecode, public_input, witness) = VM run + trace + proof per step
-            hw_threads = min(128, hw)
-            t_step, phases, pr_node = time_whole_node(ctx, lm, w, max(5, args.steps), 4)
-            out["whole_node"] = {"value": sigs / t_step, "unit": "xmss_sigs/s", "ms_per_step": 1e3 * t_step,
-                                 "witness_ms": float(phases[0] + phases[1]), "vm_run_ms": float(phases[0]), "trace_ms": float(phases[1]),
-                                 "prove_ms": float(phases[2]), "host_threads": hw_threads,
-                                 "definition": "lmh_prove_execution_vm per step: hints in host memory -> leanVM runner (host thread pool) -> "
-                                               "upload of the VM log + every table column built on the device -> proof; what "
-                                               "rec_aggregation/src/benchmark.rs:397-431 times around aggregate_type_1",
-                                 "proof_equals_hot_path_proof": bool(np.array_equal(pr_node.proof(), pr.proof()))}
+        # ---- the reference's own time breakdown (tracing spans) and its NodeStats fields (benchmark.rs:50-66)
+        st = np.asarray(step_s)
+        out["node_stats"] = {"time_secs": float(st.mean()), "time_ci_secs": float(1.96 * st.std(ddof=1) / np.sqrt(st.size)) if st.size > 1 else 0.0,
+                             "samples": int(st.size), "time_min_secs": float(st.min()), "time_max_secs": float(st.max()), "n_xmss": sigs}
+        if "counts" in ww:
+            out["node_stats"].update(cycles=ww["counts"]["cycles"], memory=1 << ww["log_memory"], poseidons=ww["counts"]["poseidon"],
+                                     dots=ww["counts"]["extension_op"])
+        stages = {k: v / args.steps for k, v in stage_acc.items()}
+        if phases:
+            ph = np.asarray(phases).mean(axis=0)
+            stages = {"Witness generation: Executing bytecode": float(ph[0]), "Witness generation: Building execution trace": float(ph[1]), **stages}
+            out["witness_ms"], out["prove_ms"] = float(ph[0] + ph[1]), float(ph[2])
+        out["stages_ms"] = stages
+        if waits.size:
+            out["exchanges"] = {"per_step": waits.size / args.steps, "p50_us": float(np.percentile(waits, 50)), "p99_us": float(np.percentile(waits, 99)),
+                                "mean_us": float(waits.mean()), "waiting_ms_per_step": float(waits.sum()) / 1e3 / args.steps,
+                                "under_20us": float((waits < 20).sum()) / args.steps,
+                                "definition": "host <-> device exchanges of the prover thread (one Fiat-Shamir step each: a launched kernel or a "
+                                              "message to a resident one): how long lm_wait_result waited for the published result"}
+        if vm_path and not args.no_whole_node:
+            # ---- rounds 1-3's headline, kept for comparison: one lmh_prove_execution per step from the trace resident in HBM
+            ctx.sync()
+            k = max(5, args.steps)
+            for _ in range(2):
+                run_step(ctx, lm, w, whole_node=False)
+            th = time.perf_counter()
+            for _ in range(k):
+                pr_hot = run_step(ctx, lm, w, whole_node=False)
+                pr_hot.proof_pruned()
+            ctx.sync()
+            th = (time.perf_counter() - th) / k
+            out["hot_path"] = {"value": sigs / th, "unit": "xmss_sigs/s", "ms_per_step": 1e3 * th,
+                               "definition": "lmh_prove_execution per step: the reference's prove_execution from the execution trace (resident "
+                                             "in HBM) to the pruned proof, without the VM run and the trace build (this rank, no exchange)",
+                               "proof_equals_whole_node_proof": bool(np.array_equal(pr_hot.proof(), pr.proof()))}
+            out["whole_node"] = {"value": value, "unit": "xmss_sigs/s", "ms_per_step": ms_per_step, "witness_ms": out.get("witness_ms"),
+                                 "vm_run_ms": float(ph[0]), "trace_ms": float(ph[1]), "prove_ms": float(ph[2]), "host_threads": w["vm_threads"],
+                                 "cpus_available": effective_cpus(), "definition": "= value (kept under its round-3 name)"}
         if args.shape == "recursion":  # side measurement: not the BASELINE metric
             lr = w["w"]["log_rows"]
             out["metric"], out["unit"], out["value"] = "recursion_shaped_proofs_per_sec", "proofs/s", world / (dt / args.steps)
@@ -534,9 +563,12 @@ def main():
         C = args.inflight if args.inflight > 0 else max(1, min(10, hw // 2))
         if world == 1 and C > 1:
             ctxs = [ctx] + [lm.Context(local_rank) for _ in range(C - 1)]
-            out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs)
-            if vm_path and "whole_node" in out:
-                out["whole_node"]["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs, whole_node=True)
+            if vm_path:  # whole node in flight (the headline's definition), then the hot path alone
+                out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs, whole_node=True)
+                if "hot_path" in out:
+                    out["hot_path"]["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs)
+            else:
+                out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs)
         if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(orc, ob, ctx, args.witness)
         print(json.dumps(out), flush=True)
@@ -585,12 +617,9 @@ def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, wh
     else:
         ws = [w0] + [build_workload(ctxs[c], orc, ob, np.random.default_rng(2000 + c), args.scale_log, args.log_inv_rate, args.shape,
                                     args.soundness == "capacity", args.witness) for c in range(1, C)]
+    ws = [dict(x, vm_threads=vm_threads) for x in ws]
     for c in range(C):
-        if whole_node:
-            from leanmultisig_amd import vm
-            vm.prove_execution_vm(ctxs[c], lm.Prover(ctxs[c]), w0["vm"]["bc"], w0["vm"]["pi"], w0["vm"]["wit"], w0["lm_builder"])
-        else:
-            run_step(ctxs[c], lm, ws[c])
+        run_step(ctxs[c], lm, ws[c], whole_node=whole_node)
         ctxs[c].sync()
     errors = []
     start = threading.Barrier(C + 1)
@@ -600,14 +629,7 @@ def measure_inflight(lm, orc, ob, local_rank, ctxs, w0, C, steps, args, sigs, wh
             torch.cuda.set_device(local_rank)  # the HIP device is per host thread
             start.wait()
             for _ in range(steps):
-                if whole_node:
-                    from leanmultisig_amd import vm
-                    pr = lm.Prover(ctxs[c])
-                    v = w0["vm"]
-                    vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], w0["lm_builder"], n_threads=vm_threads)
-                    pr.proof_pruned()
-                else:
-                    run_step(ctxs[c], lm, ws[c]).proof_pruned()
+                run_step(ctxs[c], lm, ws[c], whole_node=whole_node).proof_pruned()
             ctxs[c].sync()
         except Exception as e:  # noqa: BLE001 — reported after the join
             errors.append(e)

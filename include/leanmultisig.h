@@ -62,6 +62,11 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
 uint64_t lm_profile_read_bytes(lm_ctx* ctx, const char* kernel_name);
 /* names of the kernels with recorded launches, '\n'-separated; returns the buffer size needed (buf may be NULL) */
 uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap);
+/* Host <-> device exchanges: with the log on, every wait of the prover thread for a published result (one Fiat-Shamir step: a
+ * launched kernel or a message to a resident one) records its duration in microseconds.  lm_wait_log clears the log;
+ * lm_wait_log_read copies up to `cap` entries and returns how many there are. */
+int lm_wait_log(lm_ctx* ctx, int on);
+uint64_t lm_wait_log_read(lm_ctx* ctx, float* out_us, uint64_t cap);
 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr);

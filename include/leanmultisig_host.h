@@ -199,6 +199,17 @@ typedef struct {
     uint32_t* d_stacked;
 } lm_execution_trace;
 uint32_t lmh_stacked_n_vars(const lm_execution_trace* trace); /* compute_stacked_n_vars, stacked_pcs.rs:183-196 */
+/* Wall clock of the last lmh_prove_execution on this prover, per stage, in ms — the reference's tracing spans around the same code
+ * (`--tracing`, crates/utils/src/logs.rs): no synchronisation is added, a boundary is where the host holds the stage's result. */
+#define LMH_STAGE_COMMIT 0        /* stack_polynomials_and_commit (stacked_pcs.rs:98): access counts, "FFT", "build merkle tree", "ood evaluation" */
+#define LMH_STAGE_LOGUP_FILL 1    /* prove_generic_logup (logup.rs:26), numerators / denominators */
+#define LMH_STAGE_GKR 2           /* prove_gkr_quotient (quotient_gkr/mod.rs:31) */
+#define LMH_STAGE_COLUMN_EVALS 3  /* the column evaluations at the GKR point (logup.rs:224-308) */
+#define LMH_STAGE_AIR 4           /* "batched AIR sumcheck" (prove_execution.rs:209) */
+#define LMH_STAGE_WHIR_PROVE 5    /* statement assembly + "WHIR prove" (open.rs:36) */
+#define LMH_N_STAGES 8
+int lmh_prover_stage_times(const lmh_prover* p, double out_ms[LMH_N_STAGES]);
+
 /* returns LM_E_INVALID with lm_last_error "logup sum != 0" when the witness is inconsistent (prove_generic_logup asserts) */
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* trace, const lm_whir_config* cfg);
 

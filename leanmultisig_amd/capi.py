@@ -29,6 +29,8 @@ _SIGS = {
     "lm_ctx_stream": (vp, [vp]),
     "lm_profile_select": (C.c_int, [vp, C.c_char_p]),
     "lm_profile_names": (C.c_uint64, [vp, vp, C.c_uint64]),
+    "lm_wait_log": (C.c_int, [vp, C.c_int]),
+    "lm_wait_log_read": (C.c_uint64, [vp, vp, C.c_uint64]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
     "lm_profile_read_bytes": (C.c_uint64, [vp, C.c_char_p]),
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
@@ -141,6 +143,7 @@ _HOST_SIGS = {
     "lmh_prove_batched_air_sumcheck": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "lmh_stacked_n_vars": (C.c_uint32, [vp]),
     "lmh_prove_execution": (C.c_int, [vp, vp, vp, vp]),
+    "lmh_prover_stage_times": (C.c_int, [vp, vp]),
     "lmh_whir_prove": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
     # leanVM (leanmultisig_amd/vm.py)
     "lmh_bytecode_new": (vp, [vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint64, C.c_uint32]),
@@ -515,6 +518,18 @@ class Context:
         self._check(self.lib.lm_profile_read(self.h, kernel_name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def wait_log(self, on=True):
+        """start (and clear) / stop the log of host <-> device exchanges (lm_wait_log)"""
+        self._check(self.lib.lm_wait_log(self.h, 1 if on else 0))
+
+    def wait_log_read(self):
+        """-> float32 array: microseconds the prover thread waited in each exchange since wait_log()"""
+        n = int(self.lib.lm_wait_log_read(self.h, None, 0))
+        out = np.zeros(n, dtype=np.float32)
+        if n:
+            self.lib.lm_wait_log_read(self.h, out.ctypes.data, n)
+        return out
+
     # ---- memory -------------------------------------------------------------------------------------
     def alloc(self, n_words):
         return DeviceBuffer(self, n_words)
@@ -735,6 +750,15 @@ class Prover:
     def add_base_scalars(self, s):
         s = _u32(s).reshape(-1)
         self.lib.lmh_add_base_scalars(self.h, _ptr(s), s.size)
+
+    STAGES = ("commit: stack + access counts + FFT + build merkle tree + ood evaluation", "logup fill", "prove GKR quotient", "column evaluations",
+              "batched AIR sumcheck", "WHIR prove")
+
+    def stage_times(self):
+        """{stage: ms} of the last prove_execution on this prover (lmh_prover_stage_times; the reference's tracing spans)"""
+        t = (C.c_double * 8)()
+        self.ctx._check(self.lib.lmh_prover_stage_times(self.h, t))
+        return {name: float(t[i]) for i, name in enumerate(self.STAGES)}
 
     def proof(self):
         n = self.lib.lmh_proof_words(self.h)

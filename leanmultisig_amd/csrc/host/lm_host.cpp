@@ -25,23 +25,28 @@ using lmh::log2_ceil_u64;
 
 namespace {
 
-// LM_STAGE_TIMES=1: wall clock per stage on stderr (each mark synchronises the stream, so the total is slightly pessimistic)
+// Wall clock per stage of prove_execution.  Always recorded into the prover object (lmh_prover_stage_times: no synchronisation, the
+// boundaries are where the host holds the stage's result); LM_STAGE_TIMES=1 additionally synchronises the stream at every mark and
+// prints the stage on stderr (the total is then slightly pessimistic).
 struct StageClock {
     const char* prefix = "";
     lm_ctx* ctx;
     bool on;
+    double* sink = nullptr;  // LMH_N_STAGES slots of the prover (top-level clock only)
     std::chrono::steady_clock::time_point t0;
-    explicit StageClock(lm_ctx* c) : ctx(c), on(getenv("LM_STAGE_TIMES") != nullptr) {
-        if (on) {
-            lm_sync(ctx);
-            t0 = std::chrono::steady_clock::now();
-        }
+    explicit StageClock(lm_ctx* c, double* stage_ms = nullptr) : ctx(c), on(getenv("LM_STAGE_TIMES") != nullptr), sink(stage_ms) {
+        if (sink)
+            for (int i = 0; i < LMH_N_STAGES; i++) sink[i] = 0;
+        if (on) lm_sync(ctx);
+        t0 = std::chrono::steady_clock::now();
     }
-    void mark(const char* name) {
-        if (!on) return;
-        lm_sync(ctx);
+    void mark(const char* name, int slot = -1) {
+        if (!on && !sink) return;
+        if (on) lm_sync(ctx);
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "# stage %s%-28s %8.3f ms\n", prefix, name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (sink && slot >= 0 && slot < LMH_N_STAGES) sink[slot] += ms;
+        if (on) fprintf(stderr, "# stage %s%-28s %8.3f ms\n", prefix, name, ms);
         t0 = t1;
     }
 };
@@ -1112,11 +1117,17 @@ uint32_t lmh_stacked_n_vars(const lm_execution_trace* t) {
     return log2_ceil_u64(total);
 }
 
+int lmh_prover_stage_times(const lmh_prover* p, double out_ms[LMH_N_STAGES]) {
+    if (!p || !out_ms) return LM_E_INVALID;
+    memcpy(out_ms, p->stage_ms, sizeof p->stage_ms);
+    return LM_OK;
+}
+
 int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr, const lm_whir_config* cfg) {
     if (!ctx || !p || !tr || !cfg) return LM_E_INVALID;
     int rc;
     if ((rc = lm_bind_thread(ctx))) return rc;
-    StageClock clk(ctx);
+    StageClock clk(ctx, p->stage_ms);
     int order[3];
     const u32 log_rows[3] = {tr->tables[0].log_rows, tr->tables[1].log_rows, tr->tables[2].log_rows};
     lmh::sorted_tables(log_rows, order);
@@ -1224,9 +1235,9 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     }
     if (!in_place && (rc = lm_stack_columns(ctx, poly.p, 1ull << stacked_n_vars, (u32)srcs.size(), srcs.data(), offs.data(), lens.data()))) return rc;
     lmh_witness* wit = nullptr;
-    clk.mark("stack");
+    clk.mark("stack", LMH_STAGE_COMMIT);
     if ((rc = lmh_whir_commit(ctx, p, cfg, d_poly, off, &wit))) return rc;
-    clk.mark("whir_commit");
+    clk.mark("whir_commit", LMH_STAGE_COMMIT);
     // (the root has been published behind the counting kernels on the same stream: the stream is idle, the count final)
     if (const u32 n_bad = lm_access_errors(ctx, 0)) {
         lm_set_error("%u lookup rows address words outside the memory / bytecode image (the reference panics on these)", n_bad);
@@ -1309,11 +1320,11 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     if ((rc = lm_malloc(ctx, 5ull << gkr_n_vars, &dens.p))) return fail(rc);
     u64 gkr_active = 0;  // = loff: the tail up to 2^gkr_n_vars is neutral padding, never materialised
     if ((rc = lm_logup_build_active(ctx, secs.data(), (u32)secs.size(), logup_c.v, aeq[0].v, gkr_n_vars, nums.p, dens.p, &gkr_active))) return fail(rc);
-    clk.mark("logup_fill");
+    clk.mark("logup_fill", LMH_STAGE_LOGUP_FILL);
     u32 quotient[5], claims[10];
     std::vector<u32> gkr_pt((size_t)gkr_n_vars * 5);
     if ((rc = lmh_prove_gkr_quotient_active(ctx, p, nums.p, dens.p, gkr_n_vars, gkr_active, quotient, gkr_pt.data(), claims))) return fail(rc);
-    clk.mark("logup_gkr");
+    clk.mark("logup_gkr", LMH_STAGE_GKR);
     if (quotient[0] | quotient[1] | quotient[2] | quotient[3] | quotient[4]) {  // assert_eq!(sum, ZERO)
         lm_set_error("logup sum != 0: the witness is inconsistent (a lookup reads a value the memory / bytecode does not hold, or the access counters are wrong)");
         return fail(LM_E_INVALID);
@@ -1372,7 +1383,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
             columns_values[t].push_back({want[i], E(i)});
         }
     }
-    clk.mark("column_evaluations");
+    clk.mark("column_evaluations", LMH_STAGE_COLUMN_EVALS);
     // ---- AIR (prove_execution.rs:152-223) ----
     std::vector<EF> tmp;
     if (!sample_vec(p, 1, tmp)) return fail(LM_E_INVALID);
@@ -1401,7 +1412,7 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     std::vector<u32> air_point((size_t)n_max * 5), col_evals((size_t)n_evals_total * 5);
     if ((rc = lmh_prove_batched_air_sumcheck(ctx, p, at, 3, air_alpha.v, aeq[0].v, bus_beta.v, air_eta.v, air_point.data(), col_evals.data())))
         return fail(rc);
-    clk.mark("batched_air_sumcheck");
+    clk.mark("batched_air_sumcheck", LMH_STAGE_AIR);
     // ---- public memory, statements (:225-260; stacked_pcs.rs:40-97) ----
     const u32 lpm = log2_ceil_u64(tr->public_memory_size);
     std::vector<EF> pm_pt;
@@ -1411,13 +1422,13 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     lmh::Statements S;
     lmh::assemble_statements(S, log_rows, log_mem, log_bc, tr->ending_pc, gkr_pt.data(), gkr_n_vars, value_memory, value_memory_acc,
                              value_bytecode_acc, lpm ? pm_pt[0].v : nullptr, lpm, pm_eval, columns_values, air_point.data(), col_evals.data());
-    clk.mark("statement_assembly");
+    clk.mark("statement_assembly", LMH_STAGE_WHIR_PROVE);
     std::vector<u32> out_point((size_t)stacked_n_vars * 5);
     lmh_witness* w = wit;
     wit = nullptr;  // consumed by lmh_whir_prove
     rc = lmh_whir_prove(ctx, p, cfg, S.sts.data(), (u32)S.sts.size(), S.pts.data(), S.pts.size() / 5, S.sels.data(), S.vals.data(),
                         S.sels.size(), w, d_poly, out_point.data());
-    clk.mark("whir_open");
+    clk.mark("whir_open", LMH_STAGE_WHIR_PROVE);
     return rc;
 }
 

@@ -92,6 +92,7 @@ struct lmh_prover {
     std::vector<lmh::Opening> openings;
     std::vector<lmh::u32> batch_sizes;  // openings per hint_merkle_paths call (one query set of one commitment), in order
     // the pruned blob of the current state (size query + copy are two calls): valid while the three sizes are unchanged
+    double stage_ms[LMH_N_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};  // wall clock of the last lmh_prove_execution per stage (lmh_prover_stage_times)
     mutable std::vector<lmh::u32> pruned_cache;
     mutable size_t pruned_key[3] = {~(size_t)0, 0, 0};
 };

@@ -88,6 +88,9 @@ struct lm_ctx {
     // process-unique id: pool allocations of THIS context, gone with it (lm_ctx_cache_get / _put) — a cache inside the host object
     // keyed by the context's address would hand a dangling pointer to the next context allocated at the same address
     std::map<unsigned long long, void*> object_cache;
+    // host <-> device exchanges (lm_wait_log): how long each lm_wait_result of the prover thread waited, in microseconds
+    bool wait_log_on = false;
+    std::vector<float> wait_us;
 };
 
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)

@@ -324,6 +324,19 @@ int lm_aux_stream(lm_ctx* ctx, int aux, hipStream_t* out) {
     *out = ctx->aux_stream[aux];
     return LM_OK;
 }
+extern "C" int lm_wait_log(lm_ctx* ctx, int on) {
+    LM_REQUIRE(ctx);
+    ctx->wait_log_on = on != 0;
+    ctx->wait_us.clear();
+    return LM_OK;
+}
+extern "C" uint64_t lm_wait_log_read(lm_ctx* ctx, float* out_us, uint64_t cap) {
+    if (!ctx) return 0;
+    const uint64_t n = ctx->wait_us.size();
+    if (out_us)
+        for (uint64_t i = 0; i < n && i < cap; i++) out_us[i] = ctx->wait_us[i];
+    return n;
+}
 int lm_wait_result(lm_ctx* ctx, u32 seq) { return lm_wait_result_aux(ctx, -1, seq); }
 int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
     volatile u32* flag = ctx->h_res + lm_ctx::RES_FLAG + (aux + 1);
@@ -348,6 +361,16 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
         explicit WaitScope(std::atomic<int>& x) : w(x) { w.fetch_add(1, std::memory_order_relaxed); }
         ~WaitScope() { w.fetch_sub(1, std::memory_order_relaxed); }
     } scope(waiters);
+    struct WaitLog {  // lm_wait_log: the duration of this exchange as the prover thread saw it
+        lm_ctx* c;
+        std::chrono::steady_clock::time_point t0;
+        explicit WaitLog(lm_ctx* x) : c(x) {
+            if (c->wait_log_on) t0 = std::chrono::steady_clock::now();
+        }
+        ~WaitLog() {
+            if (c->wait_log_on) c->wait_us.push_back(std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } wait_log(ctx);
     for (u64 spins = 0; !reached(); spins++) {
         if (nap_after && spins >= nap_after && waiters.load(std::memory_order_relaxed) >= nap_waiters) {
             struct timespec ts = {0, 20000};

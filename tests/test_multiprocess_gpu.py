@@ -16,7 +16,8 @@ def test_bench_two_ranks_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, LM_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    # two processes share the chip: each gets half of the resident GKR tail workgroups (csrc/lm_gkr.hip: the cap is per process)
+    env = dict(os.environ, LM_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", LM_GKR_TAIL_MAX_WORKGROUPS="128")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--scale-log", "5", "--dist-backend", "gloo", "--no-cpu-baseline", "--verify"]
@@ -27,3 +28,8 @@ def test_bench_two_ranks_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["proof_verified_by_oracle"] is True and "inflight" not in j  # the in-flight side measurement is N = 1 only
+    # the headline is the whole node at every N: VM run (parallel batch on the device) + trace + proof per step and rank
+    assert j["whole_node"]["value"] == j["value"] and j["whole_node"]["vm_run_ms"] > 0 and j["hot_path"]["ms_per_step"] < j["ms_per_step"]
+    assert j["hot_path"]["proof_equals_whole_node_proof"] is True
+    assert "Witness generation: Executing bytecode" in j["stages_ms"] and "batched AIR sumcheck" in j["stages_ms"]
+    assert j["exchanges"]["per_step"] > 10 and j["node_stats"]["n_xmss"] == j["config"]["per_gpu_signatures"]

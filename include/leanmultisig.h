@@ -76,6 +76,9 @@ int lm_upload(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_word
 int lm_upload_async(lm_ctx* ctx, uint32_t* d_dst, const uint32_t* src, uint64_t n_words);
 int lm_download(lm_ctx* ctx, uint32_t* dst, const uint32_t* d_src, uint64_t n_words);
 int lm_memset_zero(lm_ctx* ctx, uint32_t* d_dst, uint64_t n_words);
+/* d_cols[c][offset .. offset + count) = values[c] for c < n_cols in one launch (d_cols, values: HOST arrays; the padding rows of a
+ * table's columns, lmh_pad_table). */
+int lm_fill_columns(lm_ctx* ctx, uint32_t* const* d_cols, const uint32_t* values, uint32_t n_cols, uint64_t offset, uint64_t count);
 int lm_ef_aos_to_soa(lm_ctx* ctx, const uint32_t* d_aos, uint32_t* d_soa, uint64_t n);
 int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64_t n);
 

@@ -39,6 +39,7 @@ _SIGS = {
     "lm_upload_async": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_download": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_memset_zero": (C.c_int, [vp, vp, C.c_uint64]),
+    "lm_fill_columns": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint64]),
     "lm_ef_aos_to_soa": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_ef_soa_to_aos": (C.c_int, [vp, vp, vp, C.c_uint64]),
     "lm_poseidon16_permute": (C.c_int, [vp, vp, C.c_uint64]),

@@ -1439,8 +1439,9 @@ uint32_t lmh_table_log_rows(uint64_t n_rows) {  // log2_ceil(h + 1).max(MIN_LOG_
     while ((1ull << l) < n_rows + 1) l++;
     return std::max<u32>(l, lmh::MIN_LOG_N_ROWS_PER_TABLE);
 }
-int lmh_pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr,
-                  uint32_t null_hash_ptr, uint32_t ending_pc) {
+}  // extern "C"
+int lmh::pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr,
+                   uint32_t null_hash_ptr, uint32_t ending_pc, bool with_virtual) {
     if (!ctx || !d_cols || table > 2 || log_rows > 30 || n_rows >= (1ull << log_rows)) {
         lm_set_error("lmh_pad_table: bad arguments (a table needs at least one padding row: n_rows < 2^log_rows)");
         return LM_E_INVALID;
@@ -1465,23 +1466,35 @@ int lmh_pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t
         row[6] = zero_vec_ptr;                                // effective_index_left_first
         row[7] = zero_vec_ptr + 4;                            // effective_index_left_second (+ HALF_DIGEST_LEN)
     }
-    hipStream_t stream = (hipStream_t)lm_ctx_stream(ctx);
-    const u64 count = (1ull << log_rows) - n_rows;
+    // the virtual columns behind the committed ones (bus data of the padding rows): execution nu_a / nu_b / ... (execution/mod.rs:59-74),
+    // ExtensionOp and Poseidon16 precompile-data columns — filled when the caller's pointer array carries them (n_total entries)
+    const u32 n_total = lmh::kVmTables[table].n_total;
+    std::vector<u32> vals(n_total, 0);
     for (u32 c = 0; c < n_cols; c++) {
-        if (!d_cols[c]) {
-            lm_set_error("lmh_pad_table: column %u is null", c);
-            return LM_E_INVALID;
-        }
         if (row[c] >= kb::P) {
             lm_set_error("lmh_pad_table: value out of the field");
             return LM_E_INVALID;
         }
-        if (hipMemsetD32Async((hipDeviceptr_t)(d_cols[c] + n_rows), (int)kb::to_monty(row[c]), count, stream) != hipSuccess) {
-            lm_set_error("lmh_pad_table: fill failed");
-            return LM_E_DEVICE;
-        }
+        vals[c] = kb::to_monty(row[c]);
     }
-    return LM_OK;
+    u32 n_fill = n_cols;
+    if (with_virtual) {
+        if (table == 0) vals[21] = kb::to_monty(1), vals[22] = kb::to_monty(ending_pc);
+        if (table == 1) vals[30] = kb::to_monty(64);
+        if (table == 2) vals[109] = kb::to_monty(zero_vec_ptr), vals[110] = kb::to_monty(1);
+        n_fill = n_total;
+    }
+    for (u32 c = 0; c < n_fill; c++)
+        if (!d_cols[c]) {
+            lm_set_error("lmh_pad_table: column %u is null", c);
+            return LM_E_INVALID;
+        }
+    return lm_fill_columns(ctx, d_cols, vals.data(), n_fill, n_rows, (1ull << log_rows) - n_rows);
+}
+extern "C" {
+int lmh_pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr,
+                  uint32_t null_hash_ptr, uint32_t ending_pc) {
+    return lmh::pad_table(ctx, table, d_cols, n_rows, log_rows, zero_vec_ptr, null_hash_ptr, ending_pc, false);
 }
 
 }  // extern "C"

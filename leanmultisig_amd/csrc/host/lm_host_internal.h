@@ -99,6 +99,9 @@ struct lmh_prover {
 
 namespace lmh {
 std::vector<PrunedBatch> prune(const lmh_prover* p);  // MerklePaths::prune per batch (lm_host.cpp)
+// lmh_pad_table; with_virtual: d_cols has n_total entries and the virtual bus columns of the padding rows are filled as well
+int pad_table(lm_ctx* ctx, uint32_t table, uint32_t* const* d_cols, uint64_t n_rows, uint32_t log_rows, uint32_t zero_vec_ptr, uint32_t null_hash_ptr,
+              uint32_t ending_pc, bool with_virtual);
 
 // ---- leanVM table metadata the prover needs (bus and memory lookups) ------------------------------------------------
 // lean_vm/src/tables/execution/mod.rs:29-60, extension_op/mod.rs:90-123, poseidon_16/mod.rs:126-174

@@ -89,14 +89,6 @@ void ensure_pinned(const VmRegion& reg, size_t need) { vm_ensure_pinned(reg, nee
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int fill_words(lm_ctx* ctx, u32* d, u32 canonical, u64 count) {
-    if (count == 0) return LM_OK;
-    if (hipMemsetD32Async((hipDeviceptr_t)d, (int)kb::to_monty(canonical), count, (hipStream_t)lm_ctx_stream(ctx)) != hipSuccess) {
-        lm_set_error("lmh_get_execution_trace: fill failed");
-        return LM_E_DEVICE;
-    }
-    return LM_OK;
-}
 }  // namespace
 
 extern "C" {
@@ -239,11 +231,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         if ((rc = lm_execution_table_trace(ctx, d_pcs, d_fps, v.n_cycles, d_bytecode, 1ull << log_bytecode, d_memory, padded,
                                            t->cols[0].data())))
             return fail(rc);
-        if ((rc = lmh_pad_table(ctx, 0, t->cols[0].data(), v.n_cycles, log_rows[0], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
-        const u64 pad = (1ull << log_rows[0]) - v.n_cycles;
-        if ((rc = fill_words(ctx, t->cols[0][20] + v.n_cycles, 0, pad)) || (rc = fill_words(ctx, t->cols[0][21] + v.n_cycles, 1, pad)) ||
-            (rc = fill_words(ctx, t->cols[0][22] + v.n_cycles, ending_pc, pad)) || (rc = fill_words(ctx, t->cols[0][23] + v.n_cycles, 0, pad)))
-            return fail(rc);
+        if ((rc = pad_table(ctx, 0, t->cols[0].data(), v.n_cycles, log_rows[0], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc, true))) return fail(rc);
     }
     mark("execution table");
     // Poseidon16 table: call records -> flag / index / input columns, padding rows, then the permutation columns of every row
@@ -255,9 +243,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
             if ((rc = lm_upload_async(ctx, d_calls, v.poseidon_calls, n * LM_VM_POSEIDON_CALL_WORDS))) return fail(rc);
         }
         if ((rc = lm_poseidon_table_from_calls(ctx, d_calls, n, d_memory, padded, t->cols[2].data()))) return fail(rc);
-        if ((rc = lmh_pad_table(ctx, 2, t->cols[2].data(), n, log_rows[2], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
-        if ((rc = fill_words(ctx, t->cols[2][109] + n, (u32)zero_vec_ptr, rows - n)) || (rc = fill_words(ctx, t->cols[2][110] + n, 1, rows - n)))
-            return fail(rc);
+        if ((rc = pad_table(ctx, 2, t->cols[2].data(), n, log_rows[2], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc, true))) return fail(rc);
         if ((rc = lm_poseidon_trace(ctx, t->cols[2].data(), rows))) return fail(rc);
         if ((rc = lm_poseidon_trace_outputs_from_memory(ctx, t->cols[2].data(), n, d_memory, padded))) return fail(rc);
     }
@@ -272,8 +258,7 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
         }
         if ((rc = lm_extension_table_from_rows(ctx, d_rows, n, t->cols[1].data()))) return fail(rc);
         if ((rc = lm_extension_op_trace(ctx, d_memory, padded, t->cols[1][6], t->cols[1].data() + 14, n))) return fail(rc);
-        if ((rc = lmh_pad_table(ctx, 1, t->cols[1].data(), n, log_rows[1], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc))) return fail(rc);
-        if ((rc = fill_words(ctx, t->cols[1][29] + n, 0, rows - n)) || (rc = fill_words(ctx, t->cols[1][30] + n, 64, rows - n))) return fail(rc);
+        if ((rc = pad_table(ctx, 1, t->cols[1].data(), n, log_rows[1], (u32)zero_vec_ptr, (u32)null_hash_ptr, ending_pc, true))) return fail(rc);
     }
     mark("extension table");
     // the uploads above read the runner's host buffers asynchronously: they are consumed before this returns

@@ -153,6 +153,144 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const u32* __restrict__ in, u3
     }
 }
 
+// ---- register-resident radix-16 passes (round 4) ---------------------------------------------------------------------------------
+// k_ntt_pass does three layers per LDS round trip with one index computation per 12 butterflies and, when S > 0, two Montgomery
+// products per butterfly (46 lane-operations per butterfly measured).  The two kernels below are the same layers for the shapes the
+// big matrices take (the first 12 layers of a column; layers S+1 .. S+8 behind them): a thread keeps SIXTEEN values in registers for
+// four layers (32 butterflies), the values cross lanes through LDS once between such phases and enter / leave through registers:
+//   k_ntt_first12   global -> registers (16 consecutive outputs of the replicated input: the first log_rate layers see equal pairs and
+//                   are skipped, twiddles of index 0 are 1: 15 of the 32 butterflies of the first phase need no product) -> LDS ->
+//                   registers (stride 16) -> LDS -> registers (stride 256) -> global (coalesced): 2 LDS writes + 2 reads per value
+//                   instead of 5 + 5; twiddles straight from the layered table (L1 / scalar cache), no per-workgroup staging;
+//   k_ntt_second8   tile = 256 block indices (hi) x 32 consecutive positions (lo): global -> registers (hi = 16 G + k) -> LDS ->
+//                   registers (hi = t + 16 k) -> global.  The twiddle of layer S + q + 1 is w_{2^(q+1)}^(hi mod 2^q) * w_{2^(S+q+1)}^lo:
+//                   the second factor depends on (q, lo) — one LDS word per lane and layer —, the first on the thread's 15 pair
+//                   classes per phase: 15 products per 32 butterflies (11 in the first phase, where hi mod 2^q = 0 gives 1)
+//                   instead of 32.
+template <int S0>
+__device__ __forceinline__ void ntt_phase16(u32 (&v)[16], const u32 (&w)[15], u32 skip_layers) {
+    // four layers on 16 values: layer s pairs (i, i + 2^s), twiddle class i mod 2^s -> w[(1 << s) - 1 + class]
+    static_for<0, 4>([&](auto SS) {
+        constexpr int s = decltype(SS)::value;
+        if ((u32)s < skip_layers) return;  // replicated input: both values of a pair are equal, the layer is the identity
+        static_for<0, 16>([&](auto II) {
+            constexpr int i = decltype(II)::value;
+            if constexpr ((i >> s & 1) == 0) {
+                constexpr int cls = i & ((1 << s) - 1);
+                u32 d = sub(v[i + (1 << s)], v[i]);
+                if constexpr (!(S0 == 0 && cls == 0)) d = mul(d, w[(1 << s) - 1 + cls]);  // (S0 == 0: class 0 is w^0 = 1)
+                const u32 t = v[i];
+                v[i] = add(t, d);
+                v[i + (1 << s)] = sub(t, d);
+            }
+        });
+    });
+}
+__device__ __forceinline__ u32 ntt_pad(u32 x) { return x + ((x >> 8) << 4); }  // 16 words of padding per 256: stride-256 columns spread over the banks
+
+__global__ __launch_bounds__(256) void k_ntt_first12(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ tw_small, NttArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 data[4096 + 256];
+    const u32 g = threadIdx.x;
+    const u64 col = blockIdx.y, h = 1ull << a.log_h;
+    const u64 base = (u64)blockIdx.x << 12;
+    const u32* src = in + (col / a.cols_per_plane) * a.in_plane_stride + (col % a.cols_per_plane) * a.in_col_len;
+    u32 v[16], w[15];
+    // phase 1: layers 1..4 on 16 consecutive outputs
+    if (a.log_rate == 1) {
+        const uint4* p = reinterpret_cast<const uint4*>(src + ((base + 16 * g) >> 1));
+        const uint4 p0 = p[0], p1 = p[1];
+        v[0] = v[1] = p0.x, v[2] = v[3] = p0.y, v[4] = v[5] = p0.z, v[6] = v[7] = p0.w;
+        v[8] = v[9] = p1.x, v[10] = v[11] = p1.y, v[12] = v[13] = p1.z, v[14] = v[15] = p1.w;
+    } else {
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) v[k] = src[(base + 16 * g + k) >> a.log_rate];
+    }
+#pragma unroll
+    for (u32 k = 0; k < 15; k++) w[k] = tw_small[k + 1];  // entry (1 << s) + j = w_{2^(s+1)}^j (uniform: scalar loads)
+    ntt_phase16<0>(v, w, a.log_rate < 4 ? a.log_rate : 4);
+    {
+        uint4* d4 = reinterpret_cast<uint4*>(data + ntt_pad(16 * g));
+        d4[0] = make_uint4(v[0], v[1], v[2], v[3]), d4[1] = make_uint4(v[4], v[5], v[6], v[7]);
+        d4[2] = make_uint4(v[8], v[9], v[10], v[11]), d4[3] = make_uint4(v[12], v[13], v[14], v[15]);
+    }
+    // phase 2: layers 5..8, values x0 + 16 k, twiddle class of the thread tq = g & 15
+    {
+        const u32 tq = g & 15;
+#pragma unroll
+        for (u32 s = 0; s < 4; s++)
+#pragma unroll
+            for (u32 j = 0; j < (1u << s); j++) w[(1u << s) - 1 + j] = tw_small[(16u << s) + tq + 16 * j];
+    }
+    __syncthreads();
+    {
+        const u32 x0 = ((g >> 4) << 8) | (g & 15);
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) v[k] = data[ntt_pad(x0 + 16 * k)];
+        ntt_phase16<4>(v, w, 0);
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) data[ntt_pad(x0 + 16 * k)] = v[k];
+    }
+    // phase 3: layers 9..12, values g + 256 k, twiddle class g
+#pragma unroll
+    for (u32 s = 0; s < 4; s++)
+#pragma unroll
+        for (u32 j = 0; j < (1u << s); j++) w[(1u << s) - 1 + j] = tw_small[(256u << s) + g + 256 * j];
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) v[k] = data[g + 272 * k];  // ntt_pad(g + 256 k)
+    ntt_phase16<8>(v, w, 0);
+    u32* dst = out + col * h + base + g;
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) dst[256 * k] = v[k];
+}
+
+// layers S + 1 .. S + 8 in place (S >= 5): workgroup = 512 threads, tile = 256 hi x 32 lo
+__global__ __launch_bounds__(512) void k_ntt_second8(u32* __restrict__ out, const u32* __restrict__ tw_big, const u32* __restrict__ tw_small, NttArgs a) {
+    __shared__ u32 data[8192];
+    __shared__ u32 twlo[8 * 32];
+    const u32 tid = threadIdx.x, lo_l = tid & 31, G = tid >> 5;
+    const u32 S = a.S;
+    const u64 h = 1ull << a.log_h;
+    const u32 lo_tiles_log = S - 5;
+    const u64 blk = blockIdx.x >> lo_tiles_log;
+    const u32 lo_tile = blockIdx.x & ((1u << lo_tiles_log) - 1);
+    const u64 base = (blk << (S + 8)) + ((u64)lo_tile << 5);
+    u32* col = out + (u64)blockIdx.y * h + base + lo_l;
+    u32 v[16], w[15];
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) v[k] = col[(u64)(16 * G + k) << S];
+    if (tid < 256) {  // w_{2^(S+q+1)}^lo for the 8 layers x 32 positions of the tile
+        const u32 q = tid >> 5;
+        const u64 lo = ((u64)lo_tile << 5) + lo_l;
+        twlo[tid] = tw_big[lo << (LM_TW_LOG - (S + q + 1))];
+    }
+    __syncthreads();
+    // phase A: layers q = 0..3 over k (hi = 16 G + k: hi mod 2^q = k mod 2^q, the same classes in every thread)
+#pragma unroll
+    for (u32 s = 0; s < 4; s++) {
+        const u32 u = twlo[32 * s + lo_l];
+        w[(1u << s) - 1] = u;  // class 0: w^0 = 1
+#pragma unroll
+        for (u32 j = 1; j < (1u << s); j++) w[(1u << s) - 1 + j] = mul(u, tw_small[(1u << s) + j]);
+    }
+    ntt_phase16<1>(v, w, 0);
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) data[(16 * G + k) * 32 + lo_l] = v[k];
+    // phase B: layers q = 4..7 over hi = G + 16 k: class of pair (q, j) = G + 16 j
+#pragma unroll
+    for (u32 s = 0; s < 4; s++) {
+        const u32 u = twlo[32 * (4 + s) + lo_l];
+#pragma unroll
+        for (u32 j = 0; j < (1u << s); j++) w[(1u << s) - 1 + j] = mul(u, tw_small[(16u << s) + G + 16 * j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) v[k] = data[(G + 16 * k) * 32 + lo_l];
+    ntt_phase16<5>(v, w, 0);
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) col[(u64)(G + 16 * k) << S] = v[k];
+}
+
 // columns: n_planes x cols_per_plane inputs of in_col_len = h >> log_rate words (planes in_plane_stride apart) at d_in;
 // output column-major (n_planes * cols_per_plane) x h.  All planes go through the same launches.
 static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 cols_per_plane, u32 n_planes, u64 in_plane_stride, u32 log_h,
@@ -165,13 +303,21 @@ static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 cols_per_pl
                                   hipMemcpyDeviceToDevice, ctx->stream));
         return LM_OK;
     }
+    static const bool radix16 = getenv("LM_NTT_RADIX8") == nullptr;  // LM_NTT_RADIX8=1: the LDS radix-8 passes only (A/B measurements)
     const u32 K1 = log_h < 12 ? log_h : 12;
+    const u64 in_col_len = (1ull << log_h) >> log_rate;
     u32 done = 0;
     {
-        NttArgs a{log_h, 0, K1, 0, 1, log_rate, (1ull << log_h) >> log_rate, cols_per_plane, in_plane_stride};
+        NttArgs a{log_h, 0, K1, 0, 1, log_rate, in_col_len, cols_per_plane, in_plane_stride};
         dim3 grid(1u << (log_h - K1), n_cols);
-        size_t sh = ((1u << K1) * 2) * 4;
-        LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        // (the uint4 loads of the rate-1/2 path need 16-byte aligned columns)
+        const bool aligned = log_rate != 1 || (((uintptr_t)d_in | (in_col_len * 4) | (in_plane_stride * 4)) & 15) == 0;
+        if (radix16 && K1 == 12 && aligned) {
+            LM_LAUNCH(ctx, k_ntt_first12, grid, dim3(256), 0, d_in, d_out, (const u32*)ctx->d_tw_small, a);
+        } else {
+            size_t sh = ((1u << K1) * 2) * 4;
+            LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        }
         done = K1;
     }
     u32 rem = log_h - done;
@@ -181,9 +327,14 @@ static int lde_columns(lm_ctx* ctx, const u32* d_in, u32* d_out, u32 cols_per_pl
         u32 m = 13 - K;
         if (m > done) m = done;
         NttArgs a{log_h, done, K, m, 0, 0, 0, cols_per_plane, in_plane_stride};
-        dim3 grid(1u << (log_h - K - m), n_cols);
-        size_t sh = ((1u << (K + m)) + (1u << K) + (K << m)) * 4;
-        LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        if (radix16 && K == 8 && m == 5) {
+            dim3 grid(1u << (log_h - 13), n_cols);
+            LM_LAUNCH(ctx, k_ntt_second8, grid, dim3(512), 0, d_out, (const u32*)ctx->d_tw, (const u32*)ctx->d_tw_small, a);
+        } else {
+            dim3 grid(1u << (log_h - K - m), n_cols);
+            size_t sh = ((1u << (K + m)) + (1u << K) + (K << m)) * 4;
+            LM_LAUNCH(ctx, k_ntt_pass, grid, dim3(256), sh, d_in, d_out, ctx->d_tw, ctx->d_tw_small, a);
+        }
         done += K;
         rem -= K;
     }

@@ -48,6 +48,9 @@ def test_poseidon_quad_matches_oracle(ctx, orc, n):
     (16, 7, 1, 0.40),
     (18, 4, 3, 1.0),     # h = 2^17 rows: 12 + 5 layer passes
     (19, 5, 0, 1.0),     # rate 1, h = 2^14
+    (23, 4, 1, 1.0),     # h = 2^20 rows: the register-resident radix-16 passes (12 layers + 8 layers), rate 1/2 (uint4 loads, layer 1 skipped)
+    (22, 4, 2, 1.0),     # the same at rate 1/4 (layers 1-2 skipped)
+    (21, 4, 3, 0.9),     # rate 1/8, a zero tail
 ])
 def test_commit_base_matches_oracle(ctx, orc, n_vars, fold, rate, frac):
     rng = np.random.default_rng(n_vars * 100 + fold)

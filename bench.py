@@ -46,11 +46,13 @@ def signer_ranges(n_total, world):
     return out
 
 
-# BASELINE configs[3] stand-in (SURVEY.md §8(d) "Config 4"): a recursion node's trace is dominated by the in-VM verifier —
-# long dot products / eq polynomials on the ExtensionOp table, Merkle paths on the Poseidon table, a 2x longer execution
-# table.  Real shapes are unknown without the reference VM; these are the survey's synthetic ones.
-RECURSION_EXT_CALLS = [("mul", False, 64, 3000), ("mul", True, 128, 800), ("poly_eq", False, 20, 4000), ("poly_eq", True, 9, 2000),
-                       ("add", False, 1, 20000), ("mul", False, 1, 20000), ("add", True, 2, 3000)]
+# BASELINE configs[3] stand-in (`recursion --n 4 --log-inv-rate 2`): the root's program is the in-VM verifier of four child proofs,
+# which cannot be compiled here (no zkDSL compiler); its table shapes and its mix of ExtensionOp calls are DERIVED by counting
+# (tools/recursion_shape.py: Merkle openings, leaf folds, eq factors, sumcheck / GKR / AIR verification per child from the library's own
+# WhirConfig::new and the loop structure of the zkDSL sources): execution 2^19, ExtensionOp 2^18, Poseidon16 2^16, memory 2^22.
+def recursion_shape():
+    from tools import recursion_shape as rs
+    return rs.derive()
 
 
 def build_vm_workload(ctx, rng, n_sigs, log_inv_rate, capacity, log_bytecode=19):
@@ -90,10 +92,13 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss",
             rows[:, c] = cols[c].download()
 
     if shape == "recursion":
-        ext = [(op, be, size, max(1, cnt >> sh)) for op, be, size, cnt in RECURSION_EXT_CALLS]
-        w = synth_witness.build(orc, rng, n_calls=100000 >> sh, n_blocks=4096 >> min(sh, 6), log_exec=21 - sh, log_pos=17 - sh,
-                                log_ext=19 - sh, log_memory=max(23 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows,
-                                n_arith=300000 >> sh, ext_calls=ext)
+        d = recursion_shape()
+        sp, root = d["shape"], d["root"]
+        ext = [(op, be, size, max(1, cnt >> sh)) for op, be, size, cnt in d["ext_calls"]]
+        n_pos_calls, n_ext_calls = root["poseidon_calls"] >> sh, sum(c for _, _, _, c in ext)
+        w = synth_witness.build(orc, rng, n_calls=n_pos_calls, n_blocks=4096 >> min(sh, 6), log_exec=sp["log_exec"] - sh, log_pos=sp["log_pos"] - sh,
+                                log_ext=sp["log_ext"] - sh, log_memory=max(sp["log_memory"] - sh, 16), log_bytecode=sp["log_bytecode"] - sh,
+                                fill_rows=fill_rows, n_arith=max(0, (root["cycles"] >> sh) - n_pos_calls - n_ext_calls), ext_calls=ext)
     else:
         w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,
                                 log_ext=8, log_memory=max(20 - sh, 16), log_bytecode=19 - sh, fill_rows=fill_rows)
@@ -295,7 +300,7 @@ def main():
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
     ap.add_argument("--shape", choices=["xmss", "recursion"], default="xmss",
                     help="xmss = BASELINE configs[1]/[2] (the metric); recursion = configs[3] stand-in: ExtensionOp table 2^19, "
-                         "Poseidon 2^17, execution 2^21 (side measurement, reported as proofs/s)")
+                         "Poseidon 2^16, execution 2^19 — derived by tools/recursion_shape.py (side measurement, reported as proofs/s)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
     ap.add_argument("--profile-all", action="store_true", help="print the per-kernel HIP-event table of one extra step")
     args = ap.parse_args()
@@ -533,7 +538,8 @@ def main():
         if args.shape == "recursion":  # side measurement: not the BASELINE metric
             lr = w["w"]["log_rows"]
             out["metric"], out["unit"], out["value"] = "recursion_shaped_proofs_per_sec", "proofs/s", world / (dt / args.steps)
-            out["config"]["workload"] = (f"BASELINE configs[3] stand-in (SURVEY.md §8(d)): tables 2^{lr[0]}x20 / 2^{lr[1]}x29 / 2^{lr[2]}x109, "
+            out["config"]["workload"] = (f"BASELINE configs[3] stand-in, shapes DERIVED by counting the in-VM verifier's work for 4 children of 775 signatures "
+                                         f"(tools/recursion_shape.py): tables 2^{lr[0]}x20 / 2^{lr[1]}x29 / 2^{lr[2]}x109, "
                                          f"memory 2^{w['w']['log_memory']}, stacked 2^{w['n_vars']}, rate 1/{1 << args.log_inv_rate}; ADD/MUL/DEREF "
                                          "instructions, all six ExtensionOp modes, Poseidon calls")
             out["config"].pop("per_gpu_signatures")

@@ -211,7 +211,7 @@ def test_mixed_program_matches_oracle(ctx, orc):
 
 
 def test_recursion_shaped_tables_verify(ctx, orc):
-    """BASELINE configs[3] stand-in: the ExtensionOp table is as tall as the execution table (the reference requires execution >= every table, stacked_pcs.rs:111; ~2^15 active rows of long
+    """BASELINE configs[3] stand-in, reduced (the full derived size: test_recursion_derived_shape_equals_oracle_prover): the ExtensionOp table is as tall as the execution table (the reference requires execution >= every table, stacked_pcs.rs:111; ~2^15 active rows of long
     dot products / poly_eq chains), the Poseidon table 32x shorter — the batched AIR sumcheck starts on the execution and
     ExtensionOp AIRs and the Poseidon AIR joins late.  Production parameters; checked by the oracle verifier."""
     rng = np.random.default_rng(6)
@@ -223,6 +223,22 @@ def test_recursion_shaped_tables_verify(ctx, orc):
     proof = _device_proof(ctx, orc, w, ob.whir_builder(log_inv_rate=2))
     ok, err = ob.verify_execution(orc, w, proof, None)
     assert ok, err
+
+
+def test_recursion_derived_shape_equals_oracle_prover(ctx, orc):
+    """BASELINE configs[3] (`recursion --n 4 --log-inv-rate 2`) stand-in at the FULL size tools/recursion_shape.py derives by counting
+    the in-VM verifier's work for four children of 775 signatures (execution 2^19, ExtensionOp 2^18 with the derived mix of leaf folds /
+    eq chains / single products, Poseidon16 2^16, memory 2^22; rate 1/4, production parameters): the device proof equals the oracle
+    PROVER's proof word for word (a few minutes of oracle time on 16 threads)."""
+    import bench
+    d = bench.recursion_shape()
+    assert d["shape"] == dict(log_exec=19, log_pos=16, log_ext=18, log_memory=22, log_bytecode=19) and d["child"]["stacked_n_vars"] == 25
+    w = bench.build_workload(ctx, orc, ob, np.random.default_rng(11), 0, 2, "recursion", False, "synthetic")
+    assert w["w"]["log_rows"] == {0: 19, 1: 18, 2: 16}
+    proof = bench.run_step(ctx, lm, w).proof()
+    ob.set_threads(orc, 16)
+    ref = ob.prove_execution(orc, w["w"], synth_witness.header(w["w"]), bench.oracle_builder(ob, w))
+    assert proof.size == ref.size and np.array_equal(proof, ref)
 
 
 def test_extension_op_trace_gather(ctx, orc):

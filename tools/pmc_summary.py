@@ -35,10 +35,10 @@ fetch, write = collect("pmc_fetch", "FETCH_SIZE"), collect("pmc_write", "WRITE_S
 out = {
     "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline --inflight 1 (two separate passes)",
-    "unit_note": "counters are KiB. On gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streams "
-                 "(MI355X_MICROARCH.md §HBM): calibrated on k_leaf_sponge (4 B/lane column reads: 2 x raw matches the byte count "
-                 "to 0.2 %); the same x2 is applied to the other kernels and is an upper bound where requests are 64 B. "
-                 "WRITE_SIZE matches byte counts exactly.",
+    "unit_note": "counters are KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes read, for EVERY access width this library "
+                 "uses: calibrated with tools/ubench/fetch_calib.hip on 1 GiB streams (profiles/r04_fetch_calibration.txt: 4, 8 and 16 bytes "
+                 "per lane 0.500, the 5-plane uint2 pattern of k_air_round / k_gkr_step 0.526 = 0.500 + the over-fetch of its plane tails) — "
+                 "so x2 is applied to all kernels.  WRITE_SIZE matches byte counts exactly (1.000 for 4 and 16 bytes per lane).",
     "source_sha": bench.source_sha(),
     "steps_in_trace": n_steps,
     "per_step": {},

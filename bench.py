@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 N_SIGS = 1550
 P = 0x7F000001
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6300.0  # ... of which a wide streaming copy reaches ~6.3 TB/s
 
 
 def signer_ranges(n_total, world):
@@ -231,8 +232,11 @@ def load_profile(name, sha):
 
 
 VALU_PEAK_T = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMD-32 units x lanes per cycle x clock = 78.6 T lane-ops/s (MI355X_MICROARCH.md)
+SPONGE_PERM_CEILING_G = VALU_PEAK_T * 1e3 / (6196 * 1.70)  # issue-bound ceiling of the one-lane permutation: 7.5 G/s
+KB_MUL_T, MAD_T = 5.65, 34.3  # measured: one Montgomery product, v_mad_u64_u32 (tools/ubench/int_rates.hip, profiles/r03_int_rates.txt)
 
 
+PROFILE_TAG = "r04"  # profiles/<tag>_{pmc,valu}_bench.json: the counter summaries of the current kernel sources (sha-guarded)
 _XBUF = {}
 
 
@@ -347,7 +351,9 @@ def main():
     # the reference's metric times (n_xmss / mean elapsed of one aggregate_type_1, rec_aggregation/src/benchmark.rs:397-431).
     # N ranks prove N independent leaves (weak scaling) and exchange roots + pruned proofs after every step.
     dominant = "k_air_round"
-    hbm_kernels = ("k_fold2_round", "k_prod_round2")  # the HBM-bound passes of the WHIR opening sumcheck: live GB/s line
+    # the HBM-bound launches: the two-rounds-per-pass product sumcheck of the WHIR opening, the GKR steps on >= 2^20 outputs
+    # (recorded as k_gkr_step_big) and the single pass that writes the weight polynomial: live GB/s lines
+    hbm_kernels = ("k_fold2_round", "k_prod_round2", "k_gkr_step_big", "k_weights_init")
     if vm_path:
         # sequential parts of the VM + the host pool of a batch the device hands back: this rank's share of the CPUs the cgroup grants
         w["vm_threads"] = max(2, min(128, 4 * effective_cpus()) // world)
@@ -355,7 +361,7 @@ def main():
         pr = run_step(ctx, lm, w)
         exchange_step(step_root(pr), pr.proof_pruned(), device)
     ctx.sync()
-    ctx.profile_select(",".join((dominant,) + hbm_kernels))
+    ctx.profile_select(",".join((dominant, "k_leaf_sponge") + hbm_kernels))
     ctx.wait_log(True)
     torch.cuda.synchronize()
     if world > 1:
@@ -386,6 +392,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     n_launch, k_ms = ctx.profile_read(dominant)
+    sponge_n, sponge_ms = ctx.profile_read("k_leaf_sponge")
+    sponge_perms = int(ctx.lib.lm_profile_read_bytes(ctx.h, b"k_leaf_sponge"))  # (this kernel's "bytes" are permutations, lm_commit.hip)
     hbm_live = {k: ctx.profile_read(k) + (int(ctx.lib.lm_profile_read_bytes(ctx.h, k.encode())),) for k in hbm_kernels}
     ctx.profile_select(None)
     assert gathered.shape[0] == world
@@ -417,12 +425,12 @@ def main():
         # with the sha of the kernel sources they were taken from)
         traffic, alu, notes = None, None, []
         full = args.scale_log == 0 and args.shape == "xmss" and args.log_inv_rate == 1 and not capacity
-        pmc, why = load_profile("r03_pmc_bench.json", sha) if full else (None, "counter profiles are of the default workload")
+        pmc, why = load_profile(PROFILE_TAG + "_pmc_bench.json", sha) if full else (None, "counter profiles are of the default workload")
         if pmc and dominant in pmc["per_step"] and n_launch:
             traffic = pmc["per_step"][dominant]["hbm_bytes"] / pmc["per_step"][dominant]["launches"]
         elif why:
             notes.append(why)
-        valu, why = load_profile("r03_valu_bench.json", sha) if full else (None, None)
+        valu, why = load_profile(PROFILE_TAG + "_valu_bench.json", sha) if full else (None, None)
         if valu and dominant in valu["per_proof"] and k_ms > 0:
             jv = valu["per_proof"][dominant]
             lane_ops = jv["valu_wave_insts"] * 64
@@ -430,7 +438,7 @@ def main():
             wf = jv.get("issue_cycle_weight")  # issue cycles per instruction / 2, from the kernel's ISA mix (tools/isa_mix.py)
             alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": VALU_PEAK_T, "frac": ach / VALU_PEAK_T,
                    "issue_cycle_weight": wf, "frac_issue_weighted": ach * wf / VALU_PEAK_T if wf else None,
-                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r03_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
+                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r04_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
                              "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
                              "v_mul_lo/hi_u32, v_mad_u64_u32 at 4 cycles per wave64, v_lshl_add_u64 at its measured 7.4, the rest 2 "
                              "(profiles/r03_int_rates.txt)"}
@@ -480,23 +488,47 @@ def main():
                 "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None},
-                "traffic_source": "profiles/r03_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                "traffic_source": "profiles/r04_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                   "FETCH x2 per MI355X_MICROARCH.md); refused when recorded for other kernel sources",
                 "note": "live: HIP events on the prover's streams around every k_air_round launch of the timed region (one proof "
-                        "alone on the chip); instruction counts from profiles/r03_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
+                        "alone on the chip); instruction counts from profiles/r04_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
                         "The constraint evaluation is integer-ALU bound — see DESIGN.md §3",
                 "alu": alu,
+                # ~20 G modular multiplications per proof for the Poseidon16 AIR sumcheck at 2^18 rows (+ ~1 G for the two
+                # small tables), scaled to the active rows of this workload: the family's algorithmic rate
+                "algorithmic": (lambda mm: {"modmuls_per_step": mm, "achieved_T_modmul_per_s": mm * args.steps / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None,
+                                            "montgomery_product_T_per_s": KB_MUL_T, "multiply_add_T_per_s": MAD_T,
+                                            "frac_of_multiply_add_rate": mm * args.steps / (k_ms * 1e-3) / 1e12 / MAD_T if k_ms > 0 else None})(
+                    21e9 * (int(w["tr"].tables[2].non_padded_n_rows) or (1 << ww["log_rows"][2])) / float(1 << 18)),
                 "profile_notes": notes,
             },
             "roofline_hbm": (lambda n, ms, by: {
                 "kernel": "+".join(hbm_kernels), "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9 if ms > 0 else None, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "launches": n, "avg_launch_ms": ms / n if n else None,
-                "algorithmic_bytes_per_step": by / args.steps,
-                "note": "live: HIP events around every launch of the two-rounds-per-pass product sumcheck kernels (WHIR opening) in the "
-                        "timed region; algorithmic bytes = every f and W value read once + the folded tables written once, accumulated by "
-                        "the library at the launch sites (lm_profile_read_bytes)"})(
+                "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                "frac_of_copy_rate": by / (ms * 1e-3) / 1e9 / HBM_COPY_GBS if ms > 0 else None, "copy_rate": HBM_COPY_GBS,
+                "launches": n, "avg_launch_ms": ms / n if n else None, "algorithmic_bytes_per_step": by / args.steps,
+                "per_kernel": {k: {"launches": v[0] / args.steps, "ms_per_step": v[1] / args.steps, "algorithmic_GB_per_step": v[2] / args.steps / 1e9,
+                                   "GB_per_s": v[2] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else None} for k, v in hbm_live.items()},
+                "note": "live: HIP events around every launch of the HBM-bound kernels in the timed region; algorithmic bytes = every input "
+                        "value read once + every output written once, accumulated by the library at the launch sites (lm_profile_read_bytes); "
+                        "peak = 8 TB/s spec, copy_rate = the 6.3 TB/s a float4 copy reaches (MI355X_MICROARCH.md)"})(
                 sum(v[0] for v in hbm_live.values()), sum(v[1] for v in hbm_live.values()), sum(v[2] for v in hbm_live.values())),
         }
+        # ---- the largest single kernel: the leaf sponge of the Merkle commitments (integer ALU): live permutations / s against the issue
+        # ceiling of its own instruction stream, and algorithmic modular multiplications / s (~1.6 k per permutation in
+        # the reference's sparse form) against the measured rate of one Montgomery product and of the 32 x 32 -> 64 multiply-add
+        if sponge_ms > 0:
+            perm_s = sponge_perms / (sponge_ms * 1e-3)
+            out["roofline_sponge"] = {
+                "kernel": "k_leaf_sponge", "bound": "int-alu", "launches": sponge_n / args.steps, "ms_per_step": sponge_ms / args.steps,
+                "permutations_per_step": sponge_perms / args.steps, "achieved": perm_s / 1e9, "unit": "G Poseidon1-16 permutations/s",
+                "peak": SPONGE_PERM_CEILING_G, "frac": perm_s / 1e9 / SPONGE_PERM_CEILING_G,
+                "algorithmic": {"modmuls_per_permutation": 1600, "achieved_T_modmul_per_s": perm_s * 1600 / 1e12, "montgomery_product_T_per_s": KB_MUL_T,
+                                "multiply_add_T_per_s": MAD_T, "frac_of_multiply_add_rate": perm_s * 1600 / 1e12 / MAD_T},
+                "note": "live HIP events; peak = 78.6 T VALU lane-ops/s / (6196 instructions per permutation x issue weight 1.70, "
+                        "profiles/r03_isa_mix.json) = 7.5 G permutations/s; a modular multiplication inside a delayed-reduction dot product costs "
+                        "one multiply-add, so the algorithmic rate is priced against the multiply-add issue rate (34.3 T/s measured, "
+                        "profiles/r03_int_rates.txt), the Montgomery-product rate (5.65 T/s) is shown for scale"}
         # ---- the reference's own time breakdown (tracing spans) and its NodeStats fields (benchmark.rs:50-66)
         st = np.asarray(step_s)
         out["node_stats"] = {"time_secs": float(st.mean()), "time_ci_secs": float(1.96 * st.std(ddof=1) / np.sqrt(st.size)) if st.size > 1 else 0.0,

@@ -18,6 +18,10 @@ SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("LM_PUBLISH_FENCES"):  # conservative hand-over with release fences (csrc/lm_common.h)
     FLAGS.append("-DLM_PUBLISH_FENCES=1")
+# The conservative variant (release fences before every flag / ticket instead of the fence-free hand-over of lm_common.h) is built
+# next to the product library so that the parity tests can run on it (tests/test_fences_gpu.py: LM_LIB selects the library).
+FENCES_OBJ = os.path.join(HERE, "_obj_fences")
+FENCES_LIB = os.path.join(HERE, "libleanmultisig_hip_fences.so")
 
 
 def _sources():
@@ -51,9 +55,9 @@ def _includes(src, headers_by_name, seen):
                 _includes(h, headers_by_name, seen)
 
 
-def _stamp(src, headers_by_name):
+def _stamp(src, headers_by_name, flags=None):
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags or FLAGS).encode())
     seen = set()
     _includes(src, headers_by_name, seen)
     for f in [src] + sorted(seen):
@@ -62,42 +66,50 @@ def _stamp(src, headers_by_name):
     return h.hexdigest()
 
 
-def _obj_path(src):
+def _obj_path(src, obj_dir=None):
     rel = os.path.relpath(src, CSRC).replace(os.sep, "_")
-    return os.path.join(OBJ, rel + ".o")
+    return os.path.join(obj_dir or OBJ, rel + ".o")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(flags=None, obj_dir=None, lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
     headers_by_name = {os.path.basename(h): h for h in _headers()}
     for s in _sources():
-        o = _obj_path(s)
-        if not os.path.exists(o) or not os.path.exists(o + ".sha") or open(o + ".sha").read() != _stamp(s, headers_by_name):
+        o = _obj_path(s, obj_dir)
+        if not os.path.exists(o) or not os.path.exists(o + ".sha") or open(o + ".sha").read() != _stamp(s, headers_by_name, flags):
             return True
-    return os.path.getmtime(LIB) < max(os.path.getmtime(_obj_path(s)) for s in _sources())
+    return os.path.getmtime(lib) < max(os.path.getmtime(_obj_path(s, obj_dir)) for s in _sources())
 
 
-def build(force=False, verbose=True):
-    """hipcc --offload-arch=gfx950 -> leanmultisig_amd/libleanmultisig_hip.so"""
+def build(force=False, verbose=True, variants=True):
+    """hipcc --offload-arch=gfx950 -> leanmultisig_amd/libleanmultisig_hip.so (+ the release-fence variant libleanmultisig_hip_fences.so)"""
     consts = os.path.join(CSRC, "poseidon16_consts.inc")
     gen = os.path.join(CSRC, "gen_poseidon_consts.py")
     if not os.path.exists(consts) or os.path.getmtime(gen) > os.path.getmtime(consts):
         subprocess.check_call([sys.executable, gen])
-    if not force and not needs_build():
-        return LIB
-    os.makedirs(OBJ, exist_ok=True)
+    _build_one(FLAGS, OBJ, LIB, force, verbose)
+    if variants and "-DLM_PUBLISH_FENCES=1" not in FLAGS:
+        _build_one(FLAGS + ["-DLM_PUBLISH_FENCES=1"], FENCES_OBJ, FENCES_LIB, force, verbose)
+    return LIB
+
+
+def _build_one(flags, obj_dir, lib, force, verbose):
+    if not force and not needs_build(flags, obj_dir, lib):
+        return lib
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers_by_name = {os.path.basename(h): h for h in _headers()}
     todo = []
     for s in _sources():
-        o, st = _obj_path(s), _stamp(s, headers_by_name)
+        o, st = _obj_path(s, obj_dir), _stamp(s, headers_by_name, flags)
         if force or not os.path.exists(o) or not os.path.exists(o + ".sha") or open(o + ".sha").read() != st:
             todo.append((s, o, st))
 
     def compile_one(job):
         s, o, st = job
-        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        cmd = [hipcc, *flags, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -106,11 +118,11 @@ def build(force=False, verbose=True):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj_path(s) for s in _sources()], "-o", LIB, "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj_path(s, obj_dir) for s in _sources()], "-o", lib, "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libleanmultisig_hip.so")
+# LM_LIB selects another build of the same sources (the release-fence variant libleanmultisig_hip_fences.so, tests/test_fences_gpu.py)
+LIB_PATH = os.environ.get("LM_LIB") or os.path.join(HERE, "libleanmultisig_hip.so")
 
 P = 0x7F000001
 u32p = C.POINTER(C.c_uint32)

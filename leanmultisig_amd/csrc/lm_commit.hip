@@ -729,8 +729,11 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
     if (h <= COOP_MAX_PERMS)
         LM_LAUNCH(ctx, k_leaf_sponge_coop, dim3((unsigned)((h * 16 + 255) / 256)), dim3(256), 0, (const u32*)t->d_matrix,
                   t->d_digests, la, coop);
-    else
+    else {
         LM_LAUNCH(ctx, k_leaf_sponge, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, t->d_matrix, t->d_digests, la);
+        // (profile leg of bench.py: the "bytes" of this kernel are its PERMUTATIONS — the first two chunks of a row share one)
+        LM_PROF_BYTES(ctx, k_leaf_sponge, (u64)h * (la.has_init ? la.data_chunks : la.total_chunks - 1));
+    }
     // levels: one permutation per lane while the level fills the chip, 16 lanes per node below that, and the last levels
     // (<= 64 nodes) in a single workgroup
     u64 off = 0;

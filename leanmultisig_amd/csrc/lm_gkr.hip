@@ -947,8 +947,21 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32 blocks = (u32)std::min<u64>((n_threads + 255) / 256, 1024);
     seq = ++ctx->res_seq;
     u32* counter = ctx->d_sync + 1;
-#define GKR_STEP(MODE, FF, LL, NI, DI, AI) \
-    LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq)
+    // HBM-bound launches (>= 2^20 outputs) are recorded under their own profile name (bench.py's live HBM line): algorithmic bytes =
+    // the valid inputs read once (input layer: 4 + 20 bytes per entry, owned layer: 20 + 20, work arrays: 4 x 20 per array entry) + the
+    // four folded arrays written once
+    const bool big = n_threads >= (1ull << 20);
+    const u64 alg_bytes = (g->cur < 0 ? (input_layer ? 24ull : 40ull) * valid_in : 80ull * std::min<u64>(arr_in_valid, m_out << F)) + (F ? 80ull * n_threads : 0);
+#define k_gkr_step_big k_gkr_step
+#define GKR_STEP(MODE, FF, LL, NI, DI, AI)                                                                                                                     \
+    do {                                                                                                                                                      \
+        if (big) {                                                                                                                                            \
+            /* (LM_LAUNCH_ON directly: one more macro level would expand the alias before it is stringified) */                                            \
+            LM_LAUNCH_ON(ctx, (ctx)->stream, (k_gkr_step_big<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq); \
+            LM_PROF_BYTES(ctx, k_gkr_step_big, alg_bytes);                                                                                                    \
+        } else                                                                                                                                                \
+            LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq); \
+    } while (0)
     if (g->cur < 0) {
         LM_REQUIRE(la);  // K >= 5: the launches that read layer storage always cover two rounds
         if (F == 0) {
@@ -970,6 +983,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             GKR_STEP(2, 2, false, nul, nul, (const u32*)g->work[g->cur]);
     }
 #undef GKR_STEP
+#undef k_gkr_step_big
     }
     LM_HIP(hipGetLastError());
     if ((rc = lm_wait_result(ctx, seq))) {

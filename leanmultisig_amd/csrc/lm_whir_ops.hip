@@ -820,6 +820,7 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
                          merged[0].item_end - merged[0].item_begin, merged.size() - 1);
         LM_LAUNCH(ctx, k_weights_init, dim3((unsigned)((plane + W_CHUNK - 1) / W_CHUNK)), dim3(256), 0, d_W, plane,
                   (const WGroup*)(s + o_merged), (u32)merged.size(), (const WItem*)(s + o_items), s + o_arena);
+        LM_PROF_BYTES(ctx, k_weights_init, 20ull * plane);  // W written exactly once (5 planes)
     }
     for (size_t g0 = 0; g0 < rest.size();) {
         size_t g1 = g0;

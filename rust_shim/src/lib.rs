@@ -268,4 +268,34 @@ mod tests {
         };
         lean_prover::verify_execution::verify_execution(&bytecode, &public_input, proof).expect("reference verifier");
     }
+
+    /// Second pin (round 4): the REAL-signature path.  `tests/golden/external_pin_xmss/{proof.bin, instance.lz4}` come from
+    /// `python tools/write_proof.py tests/golden/external_pin_xmss --xmss`: the hand-assembled aggregation program verifying 40 XMSS
+    /// signatures, run by the library's own leanVM (parallel batch on the device), proven at default_whir_config.  instance.lz4 is
+    /// instance.bin's word layout, lz4 size-prepended.  `make pin REFERENCE=<checkout>` runs both tests.
+    #[test]
+    fn reference_verifier_accepts_the_hip_proof_of_real_signatures() {
+        let dir = std::env::var("LM_PROOF_DIR_XMSS").unwrap_or_else(|_| "../tests/golden/external_pin_xmss".into());
+        let proof = proof_from_bytes(&std::fs::read(format!("{dir}/proof.bin")).expect("proof.bin")).expect("postcard decode of Proof<F>");
+        let inst = lz4_flex::decompress_size_prepended(&std::fs::read(format!("{dir}/instance.lz4")).expect("instance.lz4")).expect("lz4");
+        let w: Vec<u32> = inst.chunks_exact(4).map(|c| u32::from_le_bytes(c.try_into().unwrap())).collect();
+        let (log_bytecode, ending_pc, n_pub) = (w[0] as usize, w[1] as usize, w[2] as usize);
+        let f = |x: u32| backend::F::new_monty(x);
+        let hash: [backend::F; 8] = std::array::from_fn(|i| f(w[3 + i]));
+        let public_input: Vec<backend::F> = w[11..11 + n_pub].iter().map(|&x| f(x)).collect();
+        let rows: Vec<backend::F> = w[11 + n_pub..].iter().map(|&x| f(x)).collect();
+        assert_eq!(rows.len(), 16 << log_bytecode);
+        let bytecode = lean_vm::Bytecode {
+            code: vec![Default::default(); 1 << log_bytecode],
+            instructions_multilinear: rows,
+            starting_frame_memory: 0,
+            ending_pc,
+            hash,
+            function_locations: Default::default(),
+            filepaths: Default::default(),
+            source_code: Default::default(),
+            pc_to_location: Vec::new(),
+        };
+        lean_prover::verify_execution::verify_execution(&bytecode, &public_input, proof).expect("reference verifier");
+    }
 }

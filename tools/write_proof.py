@@ -21,6 +21,35 @@ from tests import oracle_binding as ob  # noqa: E402
 from tests import synth_witness  # noqa: E402
 
 out_dir = next((a for a in sys.argv[1:] if not a.startswith("--")), ROOT)
+if "--xmss" in sys.argv:
+    # Second fixture (round 4): the REAL-signature path.  The hand-assembled aggregation program (smallest power-of-two bytecode)
+    # verifies 40 XMSS signatures; lmh_prove_execution_vm — leanVM run with the parallel batch on the device, trace build, proof at the
+    # reference's default_whir_config — produces the proof.  instance.lz4 = the same words as instance.bin, lz4 size-prepended (the
+    # bytecode table is 2^17 x 16 words, mostly padding).  rust_shim: reference_verifier_accepts_the_hip_proof_of_real_signatures.
+    from leanmultisig_amd import vm
+    from leanmultisig_amd.programs import xmss_aggregate as xa
+    ctx = lm.Context(0)
+    bc = xa.build_program()
+    pi, wit, _ = xa.build_witness(bc, 40, np.random.default_rng(2026), xmss=xa.Xmss(compress=lambda x: ctx.poseidon16(x, compress=True)))
+    lb = lm.WhirBuilder.default(1)
+    pr = lm.Prover(ctx)
+    vm.prove_execution_vm(ctx, pr, bc, pi, wit, lb)
+    data = pr.proof_bytes()
+    ex = vm.execute(bc, pi, wit, ctx=ctx)
+    assert ex.on_device
+    w = dict(log_bytecode=bc.log_size, ending_pc=bc.ending_pc, public_input=np.asarray(pi, dtype=np.uint32), bytecode_hash=bc.hash(), bytecode=bc.multilinear)
+    inst = np.concatenate([np.array([w["log_bytecode"], w["ending_pc"], w["public_input"].size], dtype=np.uint32), w["bytecode_hash"],
+                           w["public_input"], w["bytecode"].reshape(-1)]).astype("<u4")
+    os.makedirs(out_dir, exist_ok=True)
+    open(os.path.join(out_dir, "proof.bin"), "wb").write(data)
+    z = lm.lz4_compress(inst.tobytes())
+    assert lm.lz4_decompress(z) == inst.tobytes()
+    open(os.path.join(out_dir, "instance.lz4"), "wb").write(z)
+    ok, err = lm.verify_execution(w, data, None)  # the library's verifier, default_whir_config read off the proof as the reference does
+    assert ok, err
+    print(f"wrote {out_dir}/proof.bin ({len(data)} bytes, sha256 {hashlib.sha256(data).hexdigest()[:16]}..) and instance.lz4 ({len(z)} bytes for {inst.size} words): "
+          f"{ex.n_cycles} cycles, {ex.n_poseidon_calls} Poseidon calls, bytecode 2^{bc.log_size}")
+    sys.exit(0)
 v = json.load(open(os.path.join(ROOT, "tests", "golden", "vectors_r01.json")))["prove_execution"]
 orc = ob.load()
 w = synth_witness.build(orc, np.random.default_rng(v["seed"]), n_calls=v["n_calls"])

@@ -343,8 +343,9 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
  * HBM, resolve_deref_hints runs there, and lmh_get_execution_trace on the same context builds the tables from them without an
  * upload.  A batch the device cannot take (fewer than 32 segments, a frame above 14000 words, more than 16 call-frame arguments)
  * or in which anything irregular happens (a RunnerError in a segment, conflicting deferred writes) is run by the host pool exactly
- * as lmh_execute_bytecode does — results and errors are the same on both paths.  The execution must be freed before `ctx` is
- * destroyed, on the context's thread.  lmh_execution_view downloads the log on its first call. */
+ * as lmh_execute_bytecode does — results and errors are the same on both paths.  lmh_execution_view downloads the log on its
+ * first call (on the context's thread); an execution released after its context was destroyed only drops its host side (the device
+ * buffers went with the context's pool). */
 int lmh_execute_bytecode_device(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
                                 const lm_vm_witness* witness, uint32_t n_threads, lmh_execution** out);
 int lmh_execution_on_device(const lmh_execution* e); /* 1: at least one batch ran on the device and the log is resident there */

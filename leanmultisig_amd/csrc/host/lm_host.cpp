@@ -1003,13 +1003,17 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     auto since = [](std::chrono::steady_clock::time_point a) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
+    std::vector<bool> launched(n_tables, false);
+    std::vector<u32> launch_order(n_tables);
+    for (u32 i = 0; i < n_tables; i++) launch_order[i] = i;
+    std::stable_sort(launch_order.begin(), launch_order.end(), [&](u32 a, u32 b) { return tables[a].table > tables[b].table; });
     for (u32 round = 0; round < n_rounds; round++) {
         std::vector<EF> combined(max_full_degree + 1, kb::ef_zero());
         std::vector<std::vector<EF>> bare(n_tables);
         // the sessions are independent until the challenge: enqueue every active table's round, then collect
         const auto tl0 = std::chrono::steady_clock::now();
         for (u32 i = 0; i < n_tables; i++)
-            if (round >= n_rounds - ss[i].n_vars) {
+            if (round >= n_rounds - ss[i].n_vars && !launched[i]) {  // (first round of a session: later ones were launched behind their fold)
                 int rc = lm_air_round_launch(ctx, ss[i].h);
                 if (rc) return cleanup(rc);
             }
@@ -1058,9 +1062,15 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
         if (!sample_vec(p, 1, cv)) return cleanup(LM_E_INVALID);
         const EF ch = cv[0];
         challenges.push_back(ch);
-        for (u32 i = 0; i < n_tables; i++) {
+        // The sessions' chains (fold -> next round kernel) run on their own streams, but their launch calls are issued by this one
+        // thread, ~4-5 us each: a session's next round is enqueued right behind its fold, the session with the longest small-round
+        // kernel first (Poseidon16, ExtensionOp, execution) — with all folds first and all rounds after, the last round kernel started
+        // six launch calls after the challenge was known.
+        for (u32 oi = 0; oi < n_tables; oi++) {
+            const u32 i = launch_order[oi];
             Session& s = ss[i];
             const u32 join = n_rounds - s.n_vars;
+            launched[i] = false;
             if (round < join) {
                 k[i] = kb::ef_mul(k[i], ch);
                 continue;
@@ -1075,6 +1085,10 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             int rc = lm_air_bind(ctx, s.h, ch.v);
             if (rc) return cleanup(rc);
             s.eq_factor.pop_back();
+            if (round + 1 < n_rounds) {
+                if ((rc = lm_air_round_launch(ctx, s.h))) return cleanup(rc);
+                launched[i] = true;
+            }
         }
     }
     if (clk_on) {

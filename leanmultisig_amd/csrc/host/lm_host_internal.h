@@ -11,6 +11,8 @@
 void lm_set_error(const char* fmt, ...);  // lm_core.hip (thread-local message behind lm_last_error)
 // lm_core.hip: per-context cache of device copies of long-lived host objects, keyed by the object's process-unique id (+ a small
 // tag); the entries are pool allocations of the context (lm_malloc) and die with it
+unsigned long long lm_ctx_uid(lm_ctx* ctx);         // process-unique id of a live context
+lm_ctx* lm_ctx_by_uid(unsigned long long uid);      // nullptr once that context has been destroyed
 void* lm_ctx_cache_get(lm_ctx* ctx, unsigned long long key);
 void lm_ctx_cache_put(lm_ctx* ctx, unsigned long long key, void* p);
 

@@ -1325,6 +1325,7 @@ struct DevBatch {
 };
 struct DevRun {
     lm_ctx* ctx = nullptr;
+    u64 ctx_uid = 0;  // the context may be destroyed before the execution is released (a garbage collector): its pool went with it
     const VmInstr* d_code = nullptr;  // cached in the context under the bytecode's id
     const u32* d_hint_begin = nullptr;
     const VmHintRec* d_hints = nullptr;
@@ -1345,9 +1346,11 @@ struct DevRun {
 };
 void dev_run_free(DevRun* d) {
     if (!d) return;
-    for (DevBatch& b : d->batches)
-        for (u32* p : b.owned) lm_free(d->ctx, p);
-    for (u32* p : d->owned) lm_free(d->ctx, p);
+    if (lm_ctx_by_uid(d->ctx_uid) == d->ctx) {  // (else: the context is gone, and its device pool with it)
+        for (DevBatch& b : d->batches)
+            for (u32* p : b.owned) lm_free(d->ctx, p);
+        for (u32* p : d->owned) lm_free(d->ctx, p);
+    }
     delete d;
 }
 
@@ -1520,23 +1523,20 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     a.cap_def = 64 + 2 * batch.n_args;
     const u32 dirty_cap = (u32)(4 * n_par + 64);
     u32* d_summary = nullptr;
-    u64 *d_cur = nullptr, *d_per = nullptr;
     if (!dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.pcs) || !dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.fps) ||
         !dev_alloc(D, B.owned, n_par * a.cap_pos * LM_VM_POSEIDON_CALL_WORDS, &a.pos) ||
         !dev_alloc(D, B.owned, n_par * a.cap_ext * LM_VM_EXTENSION_ROW_WORDS, &a.ext) || !dev_alloc(D, B.owned, n_par * a.cap_pend * 2, &a.pend) ||
         !dev_alloc(D, B.owned, n_par * a.cap_def * 2, &a.def) || !dev_alloc(D, B.owned, n_par * VM_SEG_WORDS, &a.counts) ||
-        !dev_alloc(D, B.owned, n_par * 4, &B.d_offsets) || !dev_alloc(D, B.owned, (u64)VM_SUMMARY_WORDS + 2 * dirty_cap, &d_summary) ||
-        !dev_alloc(D, B.owned, cur.index.size() + 1, &d_cur) || !dev_alloc(D, B.owned, cur.index.size() + 1, &d_per)) {
+        !dev_alloc(D, B.owned, n_par * 4, &B.d_offsets) || !dev_alloc(D, B.owned, (u64)VM_SUMMARY_WORDS + 2 * dirty_cap, &d_summary)) {
         for (u32* p : B.owned) lm_free(D.ctx, p);
         return DEV_ERROR;
     }
-    D.keep64.push_back(cur.index), D.keep64.push_back(per_iter);
-    const std::vector<u64>&k_cur = D.keep64[D.keep64.size() - 2], &k_per = D.keep64.back();
     a.code = D.d_code, a.hint_begin = D.d_hint_begin, a.hints = D.d_hints;
+    for (size_t k = 0; k < cur.index.size(); k++) a.cur_index[k] = cur.index[k], a.per_iter[k] = per_iter[k];  // (kernel arguments: <= 64 names)
     a.n_instructions = (u32)bc.n_instructions, a.ending_pc = bc.ending_pc, a.n_hints = (u32)bc.hints.size();
     a.prefix_cache = (u32)std::min<u64>(split_at, VM_DEV_PREFIX_CACHE);
     if (const char* e = getenv("LM_VM_DBG")) a.dbg = (u32)strtoul(e, nullptr, 10);
-    a.wit_data = D.d_wit_data, a.wit_entry_offset = D.d_wit_off, a.wit_name_begin = D.d_wit_names, a.cur_index = d_cur, a.per_iter = d_per;
+    a.wit_data = D.d_wit_data, a.wit_entry_offset = D.d_wit_off, a.wit_name_begin = D.d_wit_names;
     a.n_names = bc.n_names;
     a.image = D.d_image, a.init_len = old_len, a.split_at = split_at, a.stride = stride, a.batch_fp = batch.batch_fp, a.frame_size = batch.frame_size;
     a.batch_pc = (u32)batch.batch_pc, a.return_pc_m = return_pc, a.saved_fp_m = saved_fp, a.start_value = start_value, a.n_args = batch.n_args;
@@ -1548,14 +1548,13 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     }
     std::vector<u32> summary((size_t)VM_SUMMARY_WORDS + 2 * dirty_cap);
     const double t1 = vm_now_ms();
-    if (vm_dev_upload(D.ctx, d_cur, k_cur.data(), k_cur.size() * 8) || vm_dev_upload(D.ctx, d_per, k_per.data(), k_per.size() * 8) ||
-        lm_memset_zero(D.ctx, d_summary, VM_SUMMARY_WORDS) || vm_dev_segments(D.ctx, a, n_par) ||
+    a.summary = d_summary;  // (zeroed by the segment kernel's first workgroup: no fill command in front of it)
+    if (vm_dev_segments(D.ctx, a, n_par) ||
         vm_dev_apply_deferred(D.ctx, a, n_par, D.image_cap, split_at, frames_end, B.d_offsets, d_summary, dirty_cap) ||
         vm_dev_download(D.ctx, summary.data(), d_summary, summary.size() * 4)) {
         for (u32* p : B.owned) lm_free(D.ctx, p);
         return DEV_ERROR;
     }
-    D.keep64.clear();  // (the stream is idle: nothing reads the staging any more)
     const double t2 = vm_now_ms();
     if (summary[0] || summary[2] || summary[3] || summary[1] > dirty_cap) {
         if (vm_times())
@@ -1678,6 +1677,10 @@ bool device_finalize(lmh_execution* ex, DevRun& D, bool& anomaly) {
 bool device_materialize(lmh_execution* ex) {
     DevRun& D = *ex->dev;
     if (D.host_valid) return true;
+    if (lm_ctx_by_uid(D.ctx_uid) != D.ctx) {
+        lm_set_error("lmh_execution_view: the context this execution is resident on has been destroyed");
+        return false;
+    }
     Trace& tr = ex->tr;
     const u64 L = D.image_len;
     tr.pcs.n = tr.fps.n = tr.pos.n = tr.ext.n = 0;
@@ -1773,7 +1776,7 @@ void vm_execution_regions(const lmh_execution* e, VmRegion out[5]) {
 }
 void vm_set_release_hook(void (*hook)(void*)) { g_release_hook.store(hook, std::memory_order_release); }
 bool vm_execution_device(const lmh_execution* e, VmDeviceView* out) {
-    if (!e->dev || !e->dev->finalized) return false;
+    if (!e->dev || !e->dev->finalized || lm_ctx_by_uid(e->dev->ctx_uid) != e->dev->ctx) return false;
     const DevRun& D = *e->dev;
     out->ctx = D.ctx, out->image = D.d_image, out->memory_len = D.image_len, out->pcs = D.d_pcs, out->fps = D.d_fps, out->n_cycles = D.n_cycles;
     out->poseidon_calls = D.d_pos, out->n_poseidon_calls = D.n_pos, out->extension_rows = D.d_ext, out->n_extension_rows = D.n_ext;
@@ -1887,6 +1890,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
         if (ctx && vm_device_enabled()) {
             D = new DevRun();
             D->ctx = ctx;
+            D->ctx_uid = lm_ctx_uid(ctx);
             ex->dev = D;
             memory.on_touch = [D, &memory] { return dev_close_windows(*D, memory); };
             if (!dev_witness(*D, witness)) {  // the hint streams travel while the sequential head of the program runs

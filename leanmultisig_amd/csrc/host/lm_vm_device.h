@@ -57,8 +57,8 @@ struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
     const u32* wit_data;
     const u64* wit_entry_offset;
     const u64* wit_name_begin;
-    const u64* cur_index;  // cursor of every name when segment 0 starts
-    const u64* per_iter;   // entries an iteration consumes per name
+    u64 cur_index[VM_DEV_MAX_NAMES];  // cursor of every name when segment 0 starts
+    u64 per_iter[VM_DEV_MAX_NAMES];   // entries an iteration consumes per name
     u32 n_names;
     // memory: image[0 .. init_len) is what the host had when the batch started (VM_UNDEF = None); the segment frames are written
     // back to image[split_at + i * stride ..)
@@ -75,6 +75,7 @@ struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
     // per-segment log slots
     u32 cap_cyc, cap_pos, cap_ext, cap_pend, cap_def;
     u32 *pcs, *fps, *pos, *ext, *pend, *def, *counts;
+    u32* summary;  // VM_SUMMARY_WORDS header words of the batch's summary block, zeroed by the segment kernel
     const u32* coop_tab;
     kb::EF frob[5];  // images of the basis under Frobenius (extension-field inverse)
 };

@@ -42,6 +42,7 @@ void lm_set_error(const char* fmt, ...);
     } while (0)
 
 struct lm_ctx {
+    unsigned long long uid = 0;  // process-unique: objects that outlive a context (a device-resident lmh_execution) find out through lm_ctx_by_uid
     int device = 0;
     hipStream_t stream = nullptr;
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <time.h>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
@@ -11,6 +12,27 @@
 
 using namespace kb;
 
+// internal (C++ linkage, lm_host_internal.h): live contexts by unique id.  An object that holds device memory of a context and may be
+// freed after it (a device-resident lmh_execution released by a garbage collector) asks lm_ctx_by_uid first: a destroyed context took
+// its pool — and the object's buffers — with it.
+static std::mutex g_ctx_mu;
+static std::map<unsigned long long, lm_ctx*> g_ctx_live;
+static unsigned long long g_ctx_next_uid = 1;
+unsigned long long lm_ctx_uid(lm_ctx* ctx) { return ctx->uid; }
+lm_ctx* lm_ctx_by_uid(unsigned long long uid) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx_live.find(uid);
+    return it == g_ctx_live.end() ? nullptr : it->second;
+}
+static void ctx_register(lm_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    c->uid = g_ctx_next_uid++;
+    g_ctx_live[c->uid] = c;
+}
+static void ctx_unregister(lm_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctx_live.erase(c->uid);
+}
 // internal (C++ linkage, lm_host_internal.h): per-context cache of device copies of long-lived host objects
 void* lm_ctx_cache_get(lm_ctx* ctx, unsigned long long key) {
     auto it = ctx->object_cache.find(key);
@@ -560,6 +582,7 @@ int lm_ctx_create(int device, lm_ctx** out) {
     LM_REQUIRE(out);
     LM_HIP(hipSetDevice(device));
     lm_ctx* c = new lm_ctx();
+    ctx_register(c);
     const int rc = ctx_create_impl(device, c);
     if (rc) {
         lm_ctx_destroy(c);  // releases whatever was allocated before the failure
@@ -616,6 +639,7 @@ static int ctx_create_impl(int device, lm_ctx* c) {
 }
 void lm_ctx_destroy(lm_ctx* c) {
     if (!c) return;
+    ctx_unregister(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < lm_ctx::N_AUX; i++)
         if (c->aux_stream[i]) {

@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         tab[k < 16 ? k : 16 + i * 16 + l] = A.coop_tab[k];
     }
     for (u32 k = threadIdx.x; k < A.prefix_cache; k += blockDim.x) pcache[k] = A.image[k];
+    if (blockIdx.x == 0 && threadIdx.x < VM_SUMMARY_WORDS) A.summary[threadIdx.x] = 0;  // (k_vm_apply_deferred follows on the stream)
     __syncthreads();
     if (seg >= n_par) return;
     u32* mine = lds + COOP_TAB_WORDS + pc_pad + wave * vm_wave_lds_words(stride_pad);

@@ -269,22 +269,31 @@ mod tests {
         lean_prover::verify_execution::verify_execution(&bytecode, &public_input, proof).expect("reference verifier");
     }
 
-    /// Second pin (round 4): the REAL-signature path.  `tests/golden/external_pin_xmss/{proof.bin, instance.lz4}` come from
+    /// Second pin (round 4): the REAL-signature path.  `tests/golden/external_pin_xmss/{proof.bin, instance.zlib}` come from
     /// `python tools/write_proof.py tests/golden/external_pin_xmss --xmss`: the hand-assembled aggregation program verifying 40 XMSS
-    /// signatures, run by the library's own leanVM (parallel batch on the device), proven at default_whir_config.  instance.lz4 is
-    /// instance.bin's word layout, lz4 size-prepended.  `make pin REFERENCE=<checkout>` runs both tests.
+    /// signatures, run by the library's own leanVM (parallel batch on the device), proven at default_whir_config.  instance.zlib holds
+    /// CANONICAL words, zlib-compressed: [log_bytecode, ending_pc, n_public_input, bytecode_hash x 8, public_input.., rows x 12 columns..].
+    /// `make pin REFERENCE=<checkout>` runs both tests.
     #[test]
     fn reference_verifier_accepts_the_hip_proof_of_real_signatures() {
+        use std::io::Read;
         let dir = std::env::var("LM_PROOF_DIR_XMSS").unwrap_or_else(|_| "../tests/golden/external_pin_xmss".into());
         let proof = proof_from_bytes(&std::fs::read(format!("{dir}/proof.bin")).expect("proof.bin")).expect("postcard decode of Proof<F>");
-        let inst = lz4_flex::decompress_size_prepended(&std::fs::read(format!("{dir}/instance.lz4")).expect("instance.lz4")).expect("lz4");
+        let mut inst = Vec::new();
+        flate2::read::ZlibDecoder::new(std::fs::File::open(format!("{dir}/instance.zlib")).expect("instance.zlib")).read_to_end(&mut inst).expect("zlib");
         let w: Vec<u32> = inst.chunks_exact(4).map(|c| u32::from_le_bytes(c.try_into().unwrap())).collect();
         let (log_bytecode, ending_pc, n_pub) = (w[0] as usize, w[1] as usize, w[2] as usize);
-        let f = |x: u32| backend::F::new_monty(x);
+        let f = |x: u32| backend::F::new(x);  // canonical values
         let hash: [backend::F; 8] = std::array::from_fn(|i| f(w[3 + i]));
         let public_input: Vec<backend::F> = w[11..11 + n_pub].iter().map(|&x| f(x)).collect();
-        let rows: Vec<backend::F> = w[11 + n_pub..].iter().map(|&x| f(x)).collect();
-        assert_eq!(rows.len(), 16 << log_bytecode);
+        assert_eq!(w.len() - 11 - n_pub, 12 << log_bytecode);
+        // instructions_multilinear: 16 words per row, the 12 instruction columns followed by 4 zeros (lean_vm/src/isa/bytecode.rs)
+        let mut rows = vec![backend::F::ZERO; 16 << log_bytecode];
+        for (r, chunk) in w[11 + n_pub..].chunks_exact(12).enumerate() {
+            for (c, &x) in chunk.iter().enumerate() {
+                rows[16 * r + c] = f(x);
+            }
+        }
         let bytecode = lean_vm::Bytecode {
             code: vec![Default::default(); 1 << log_bytecode],
             instructions_multilinear: rows,

@@ -93,3 +93,24 @@ def test_tampering_matches_the_oracle_verifier(orc, small):
         assert ok_lm == ok_orc, pos
         rejected += not ok_lm
     assert rejected >= 30  # (redundant siblings are pruned away before the proof travels: corrupting one changes nothing)
+
+
+def test_external_pin_fixture_of_real_signatures_is_accepted_by_the_library_verifier():
+    """tests/golden/external_pin_xmss (tools/write_proof.py --xmss: a device proof of the aggregation program on 40 real XMSS signatures,
+    VM run with the parallel batch on the device, default_whir_config) — what `make pin` feeds to the REFERENCE's verify_execution —
+    is accepted by lmh_verify_execution, and a flipped public-input word is rejected.  Host code only."""
+    import os
+    import zlib
+    from leanmultisig_amd.vm import to_monty
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "external_pin_xmss")
+    c = np.frombuffer(zlib.decompress(open(os.path.join(d, "instance.zlib"), "rb").read()), dtype="<u4")
+    lb, ep, n_pub = int(c[0]), int(c[1]), int(c[2])
+    rows = np.zeros((1 << lb, 16), dtype=np.uint32)
+    rows[:, :12] = to_monty(c[11 + n_pub:].reshape(-1, 12)).astype(np.uint32)
+    w = dict(log_bytecode=lb, ending_pc=ep, public_input=to_monty(c[11:11 + n_pub]).astype(np.uint32), bytecode_hash=to_monty(c[3:11]).astype(np.uint32),
+             bytecode=rows)
+    proof = open(os.path.join(d, "proof.bin"), "rb").read()
+    ok, err = lm.verify_execution(w, proof, None)
+    assert ok, err
+    bad = dict(w, public_input=np.roll(w["public_input"], 1))
+    assert not lm.verify_execution(bad, proof, None)[0]

@@ -2,11 +2,12 @@
 # Round profile set (run on the GPU box through gpurun).  Outputs under gpurun_out/$1/; the summaries the judge reads are
 # then copied to profiles/ (tools/collect_profiles.sh only produces them).  All counter passes run ONE prover alone
 # (bench.py --inflight 1) with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   stats_inflight1/   rocprofv3 --kernel-trace --stats of the default timed region (one proof per step)
+#   stats_inflight1/   rocprofv3 --kernel-trace --stats of the default timed region (one WHOLE-NODE step per proof: VM batch on the
+#                      device, trace build, proof)
 #   pmc_fetch/, pmc_write/, pmc_valu/   FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate)
 #   *.json             plain bench lines for the BASELINE configs and side measurements
 set -u
-TAG=${1:-r03_final}
+TAG=${1:-r04_final}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -20,7 +21,7 @@ cd $ROOT
 python tools/pmc_summary.py $OUT 4 $OUT/pmc_bench.json > $OUT/pmc_bench.txt
 python tools/valu_summary.py $OUT 4 $OUT/valu_bench.json profiles/${TAG%%_*}_isa_mix.json > $OUT/valu_bench.txt
 python tools/timeline.py $OUT/stats_inflight1 > $OUT/timeline.txt
-for k in k_gkr_step k_air_round k_fold_round; do python tools/launch_hist.py $OUT/stats_inflight1 $k 4; done > $OUT/launch_hist.txt
+for k in k_gkr_step k_air_round k_fold_round k_ntt k_vm_ ""; do python tools/launch_hist.py $OUT/stats_inflight1 "$k" 4; done > $OUT/launch_hist.txt
 (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 int_rates.hip -o int_rates 2>/dev/null && ./int_rates) > $OUT/int_rates.txt 2>&1
 # the plain bench lines come AFTER the summaries above have been published (tools/publish_profiles.sh), so that bench.py finds
 # counter files for the current sources: tools/bench_lines.sh

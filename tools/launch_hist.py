@@ -9,7 +9,7 @@ f = glob.glob(f"{base}/**/*_kernel_trace.csv", recursive=True)[0]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
 per = len(d) // n
 last = sorted(d[-per:], reverse=True)
-print(f"{pat}: {per} launches per proof, {sum(last) * 1e-3:.3f} ms")
+print(f"{pat or 'ALL KERNELS'}: {per} launches per proof, {sum(last) * 1e-3:.3f} ms")
 print("longest (us):", " ".join(f"{x:.0f}" for x in last[:40]))
 for lim in (5, 10, 20, 50):
     sel = [x for x in last if x < lim]

@@ -24,8 +24,7 @@ out_dir = next((a for a in sys.argv[1:] if not a.startswith("--")), ROOT)
 if "--xmss" in sys.argv:
     # Second fixture (round 4): the REAL-signature path.  The hand-assembled aggregation program (smallest power-of-two bytecode)
     # verifies 40 XMSS signatures; lmh_prove_execution_vm — leanVM run with the parallel batch on the device, trace build, proof at the
-    # reference's default_whir_config — produces the proof.  instance.lz4 = the same words as instance.bin, lz4 size-prepended (the
-    # bytecode table is 2^17 x 16 words, mostly padding).  rust_shim: reference_verifier_accepts_the_hip_proof_of_real_signatures.
+    # reference's default_whir_config — produces the proof.  rust_shim: reference_verifier_accepts_the_hip_proof_of_real_signatures.
     from leanmultisig_amd import vm
     from leanmultisig_amd.programs import xmss_aggregate as xa
     ctx = lm.Context(0)
@@ -42,12 +41,17 @@ if "--xmss" in sys.argv:
                            w["public_input"], w["bytecode"].reshape(-1)]).astype("<u4")
     os.makedirs(out_dir, exist_ok=True)
     open(os.path.join(out_dir, "proof.bin"), "wb").write(data)
-    z = lm.lz4_compress(inst.tobytes())
-    assert lm.lz4_decompress(z) == inst.tobytes()
-    open(os.path.join(out_dir, "instance.lz4"), "wb").write(z)
+    # instance.zlib: CANONICAL words (small integers compress; the bytecode table is 2^17 rows, of which ~98 k are the unrolled blocks of
+    # the public-key hash): [log_bytecode, ending_pc, n_public_input, bytecode_hash x 8, public_input.., instruction rows x 12 columns..]
+    import zlib
+    from leanmultisig_amd.vm import from_monty
+    canon = np.concatenate([inst[:3], from_monty(inst[3:11 + w["public_input"].size]).astype(np.uint32),
+                            from_monty(w["bytecode"][:, :12]).astype(np.uint32).reshape(-1)]).astype("<u4")
+    z = zlib.compress(canon.tobytes(), 9)
+    open(os.path.join(out_dir, "instance.zlib"), "wb").write(z)
     ok, err = lm.verify_execution(w, data, None)  # the library's verifier, default_whir_config read off the proof as the reference does
     assert ok, err
-    print(f"wrote {out_dir}/proof.bin ({len(data)} bytes, sha256 {hashlib.sha256(data).hexdigest()[:16]}..) and instance.lz4 ({len(z)} bytes for {inst.size} words): "
+    print(f"wrote {out_dir}/proof.bin ({len(data)} bytes, sha256 {hashlib.sha256(data).hexdigest()[:16]}..) and instance.zlib ({len(z)} bytes for {inst.size} words): "
           f"{ex.n_cycles} cycles, {ex.n_poseidon_calls} Poseidon calls, bytecode 2^{bc.log_size}")
     sys.exit(0)
 v = json.load(open(os.path.join(ROOT, "tests", "golden", "vectors_r01.json")))["prove_execution"]

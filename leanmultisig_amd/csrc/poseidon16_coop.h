@@ -51,13 +51,20 @@ __device__ __forceinline__ void coop_load(CoopRegs& R, const u32* __restrict__ t
     for (int k = 0; k < 16; k++) R.mds[k] = tab[k];  // uniform
 }
 
+// lane K of every 16-lane row to the whole row: one DPP move (row_newbcast, gfx90a+) instead of a trip through the LDS crossbar
+// (ds_bpermute, ~60 cycles of latency on each of the 20 strictly sequential partial rounds)
+template <int K>
+__device__ __forceinline__ u32 coop_bcast(u32 x) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 | K, 0xf, 0xf, false);  // row_newbcast:K
+}
 __device__ __forceinline__ u32 coop_mds(u32 s, const CoopRegs& R) {
-    u64 acc = (u64)s * R.mds[0];
+    // four partial sums: the 16 multiply-adds are 4 deep instead of a chain of 16 (the permutation is one dependent chain per row)
+    u64 acc[4] = {(u64)s * R.mds[0], 0, 0, 0};
     static_for<1, 16>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        acc += (u64)coop_rot<k>(s) * R.mds[k];
+        acc[k & 3] += (u64)coop_rot<k>(s) * R.mds[k];
     });
-    return reduce40(acc);
+    return reduce40((acc[0] + acc[1]) + (acc[2] + acc[3]));
 }
 
 // s: this lane's state word; returns the permuted word.  All 16 lanes of the row must be active.
@@ -88,7 +95,7 @@ __device__ __forceinline__ u32 coop_permute(u32 s, const CoopRegs& R) {
     static_for<0, 20>([&](auto RR) {
         constexpr int r = decltype(RR)::value;
         const u32 y = add(reduce(fold32(r < 16 ? A : B)), r < 16 ? T.ca : T.cb);  // meaningful in the owner lane only
-        const u32 q = (u32)__shfl((int)cube(y), r & 15, 16);
+        const u32 q = coop_bcast<(r & 15)>(cube(y));
         if (r % 3 == 0) {  // room: one product per round since the last fold
             A = fold32(A);
             B = fold32(B);

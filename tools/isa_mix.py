@@ -57,7 +57,7 @@ def all_kernels(out_path):
         for n, d in zip(names, dem):
             v = mx[n]
             v.pop("top")
-            res[d.replace("void ", "").split("(")[0]] = v
+            res[d.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]] = v
     json.dump({"source_sha": bench.source_sha(), "cycles_per_wave64": {**CYCLES, "other": 2}, "kernels": res}, open(out_path, "w"), indent=1)
     print("wrote", out_path, len(res), "kernels")
 

@@ -13,7 +13,7 @@ base, n_steps, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
 
 def family(name):
-    n = name.replace("void ", "").split("(")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     return n.split("<")[0]
 
 

@@ -19,11 +19,11 @@ PEAK = 256 * 4 * 32 * 2.4e9  # lane-instructions / s
 
 
 def family(name):
-    return name.replace("void ", "").split("(")[0].split("<")[0]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
 
 
 def weight(name):
-    k = name.replace("void ", "").split("(")[0]
+    k = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     return mix[k]["issue_cycle_weight"] if k in mix else None
 
 

@@ -10,16 +10,15 @@ f = glob.glob(f"{sys.argv[1]}/**/*_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n_steps = max(1, sum(1 for r in rows if "k_logup_fill" in r["Kernel_Name"]))
+# one WHOLE-NODE step: from the step's VM batch (the last k_vm_segments launch of the trace) to the end of the trace; traces without
+# the device VM: from the last stacking copy / commit on
+vm = [i for i, r in enumerate(rows) if "k_vm_segments" in r["Kernel_Name"]]
 first = [i for i, r in enumerate(rows) if "k_stack_columns" in r["Kernel_Name"]]
-step = rows[first[-1]:] if first else rows[-(len(rows) // n_steps):]
-# the access-counter kernels run before the stacking copy of the same step
-while first and first[-1] > 0 and "k_access" in rows[first[-1] - 1]["Kernel_Name"] or (first and "k_counts" in rows[first[-1] - 1]["Kernel_Name"]):
-    first[-1] -= 1
-    step = rows[first[-1]:]
+step = rows[vm[-1]:] if vm else (rows[first[-1]:] if first else rows[-(len(rows) // n_steps):])
 
 
 def fam(name):
-    n = name.replace("void ", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n)
     return re.sub(r"<.*", "", n)
 

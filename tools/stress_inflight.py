@@ -2,7 +2,7 @@
 GPU prove the SAME leaf over and over from C host threads; proofs are deterministic, so every proof of a prover must equal
 its first one word for word, and EVERY proof is checked by lmh_verify_execution (a reordered publish would corrupt the
 transcript: the proof is rejected).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log] [whole]
-whole = 1: every proof is the WHOLE function (lmh_prove_execution_vm: VM run on a leased pool, device trace, proof)."""
+whole = 1: every proof is the WHOLE function (lmh_prove_execution_vm: VM run with the parallel batch on the device, trace, proof)."""
 import os
 import sys
 import threading
@@ -24,7 +24,7 @@ ws = [bench.build_vm_workload(ctxs[c], np.random.default_rng(900 + c), max(2, be
       for c in range(C)]
 first = []
 for c in range(C):
-    pr = bench.run_step(ctxs[c], lm, ws[c])
+    pr = bench.run_step(ctxs[c], lm, ws[c], whole_node=False)
     ok, err = lm.verify_execution(ws[c]["w"], pr.proof_bytes(compressed=True), ws[c]["lm_builder"], compressed=True)
     assert ok, err
     first.append(pr.proof().copy())
@@ -37,13 +37,7 @@ def worker(c):
         ctxs[c]._check(ctxs[c].lib.lm_bind_thread(ctxs[c].h))   # the HIP device is per host thread
         start.wait()
         for i in range(N):
-            if WHOLE:
-                from leanmultisig_amd import vm
-                v = ws[c]["vm"]
-                pr = lm.Prover(ctxs[c])
-                vm.prove_execution_vm(ctxs[c], pr, v["bc"], v["pi"], v["wit"], ws[c]["lm_builder"], n_threads=8)
-            else:
-                pr = bench.run_step(ctxs[c], lm, ws[c])
+            pr = bench.run_step(ctxs[c], lm, ws[c], whole_node=WHOLE)
             p = pr.proof()
             ok, err = lm.verify_execution(ws[c]["w"], pr, ws[c]["lm_builder"])   # every proof goes through lmh_verify_execution
             if not ok:

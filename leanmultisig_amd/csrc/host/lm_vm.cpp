@@ -29,6 +29,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "lm_host_internal.h"
@@ -307,6 +308,17 @@ constexpr u64 MAX_MEMORY = 1ull << MAX_LOG_MEMORY_SIZE;
 
 // The VM memory: 2^26 words of address space reserved up front (untouched pages cost nothing), so that growing never moves
 // the image and the segments of a parallel batch can fill and first-touch their own frames concurrently.
+template <class T>
+struct UVec;
+// extension_op/exec.rs: one element of an ExtensionOp (mode flags of the instruction: 8 add, 16 mul, 32 poly_eq)
+enum { VM_OP_ADD = 8, VM_OP_MUL = 16, VM_OP_POLY_EQ = 32 };
+inline EF vm_compute_elem(const EF& a, const EF& b, u32 op) {
+    if (op == VM_OP_ADD) return kb::ef_add(a, b);
+    const EF ab = kb::ef_mul(a, b);
+    if (op == VM_OP_MUL) return ab;
+    return kb::ef_add_base(kb::ef_sub(kb::ef_sub(kb::ef_dbl(ab), a), b), kb::ONE);  // 2ab - a - b + 1
+}
+
 struct MemBuf {
     u32* p = nullptr;
     u64 len = 0;
@@ -323,12 +335,112 @@ struct MemBuf {
         if (on_touch && !on_touch()) touch_failed = true;
         dev_lo = dev_hi = 0;
     }
+    // ---- deferred Poseidon16 calls of the sequential runner -------------------------------------------------------------------------
+    // A program's sequential parts hold long hash chains (the aggregation program hashes the 1550 public keys before its parallel
+    // loop: 1750 dependent permutations, 0.7 ms of one host core) whose results nothing reads until much later.  With `lazy_on` the
+    // sequential runner records such a call instead of executing it: the output cells stay None in the arena, `owner` (a shadow of
+    // the arena) names the call that will define them, and the first access to one of them (peek / set of MainMem) executes the call
+    // and whatever pending calls its inputs hang on.  What is still pending when a batch goes to the device is executed while the
+    // segment kernel runs (device_batch) — the segments see None in those cells, and one that reads them fails and sends the batch to
+    // the host, as any other irregularity does.  Deferring changes no result and no error: a call is deferred only when all its inputs
+    // are defined or pending and all its output cells are fresh (anything else takes the eager path, which raises what the reference
+    // raises, at the same cycle), so executing it later cannot fail, and every later write to a pending cell executes the call first.
+    // The same holds for an ExtensionOp whose operands and result are ALL defined or pending: it writes nothing, it is a check
+    // (copy_8(computed_hash, expected_hash) behind a hash chain is the case that matters: executed at once it would pull the whole
+    // chain in front of the parallel loop) plus the values of its table rows.  Rows are reserved in the log when the instruction is
+    // met and filled when the check is executed.  A deferred check CAN fail, and an error met while checks are pending may not be the
+    // first one of the program: in both cases the run is repeated with everything executed at once (execute_impl), which reports
+    // what the reference reports.
+    struct LazyCall {
+        u64 left_first, left_second, arg_b, res;  // ExtensionOp: left_first = a, arg_b = b, res = result pointer
+        u64 size, row_at;                         // ExtensionOp: elements, first word of its rows in the log
+        u32 op;
+        u8 kind, permute, n_out, done, is_be;     // kind 0 Poseidon16, 1 ExtensionOp check
+    };
+    UVec<u32>* lazy_rows = nullptr;  // the run's ExtensionOp log
+    bool lazy_failed = false;        // a deferred check did not hold
+    u64 lazy_checks = 0;             // checks ever deferred in this run
+    bool lazy_on = false;
+    u64 lazy_open = 0;              // calls recorded and not yet executed
+    u64 lazy_total = 0;             // calls ever deferred in this run (statistics)
+    std::vector<LazyCall> lazy;     // in program order
+    size_t lazy_drained = 0;        // every call before this index is done
+    u32* owner = nullptr;           // owner[i] = 1 + index of the pending call that defines cell i, 0 otherwise (allocated on first use)
+    bool lazy_alloc() {
+        if (owner) return true;
+        void* q = mmap(nullptr, (1ull << MAX_LOG_MEMORY_SIZE) * 4, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (q == MAP_FAILED) return false;
+        owner = (u32*)q;
+        return true;
+    }
+    void lazy_execute_check(LazyCall& c);
+    void lazy_execute(LazyCall& c) {  // all inputs are defined by now
+        if (c.kind == 1) {
+            lazy_execute_check(c);
+            c.done = 1;
+            lazy_open--;
+            return;
+        }
+        alignas(64) u32 st[16];
+        memcpy(st, p + c.left_first, 16), memcpy(st + 4, p + c.left_second, 16), memcpy(st + 8, p + c.arg_b, 32);
+        if (c.permute)
+            host_permute(st);
+        else
+            host_compress(st);
+        memcpy(p + c.res, st, 4u * c.n_out);
+        memset(owner + c.res, 0, 4u * c.n_out);
+        c.done = 1;
+        lazy_open--;
+    }
+    void lazy_force(u32 k) {  // call k and, first, the pending calls its inputs hang on (an explicit stack: a chain can be long)
+        if (lazy[k].done) return;
+        std::vector<u32> stack(1, k);
+        while (!stack.empty()) {
+            LazyCall& c = lazy[stack.back()];
+            if (c.done) {
+                stack.pop_back();
+                continue;
+            }
+            u32 dep = 0;
+            auto scan = [&](u64 at, u64 n) {
+                for (u64 j = 0; j < n && !dep; j++) dep = owner[at + j];
+            };
+            if (c.kind == 0)
+                scan(c.left_first, 4), scan(c.left_second, 4), scan(c.arg_b, 8);
+            else
+                scan(c.left_first, c.is_be ? c.size : 5 * c.size), scan(c.arg_b, 5 * c.size), scan(c.res, 5);
+            if (dep)
+                stack.push_back(dep - 1);
+            else {
+                lazy_execute(c);
+                stack.pop_back();
+            }
+        }
+    }
+    u32 lazy_cell(u64 i) {  // value of cell i after executing the call that defines it (UNDEF: no call does)
+        const u32 o = owner[i];
+        if (!o) return 0xFFFFFFFFu;
+        lazy_force(o - 1);
+        return p[i];
+    }
+    void lazy_drain() {  // everything pending, in program order (dependencies point backwards)
+        for (; lazy_drained < lazy.size(); lazy_drained++)
+            if (!lazy[lazy_drained].done) lazy_force((u32)lazy_drained);
+        lazy.clear();
+        lazy_drained = 0;
+    }
+    void lazy_reset() {  // an aborted run: forget the pending calls
+        for (LazyCall& c : lazy)
+            if (!c.done && c.kind == 0) memset(owner + c.res, 0, 4u * c.n_out);
+        lazy.clear();
+        lazy_drained = 0, lazy_open = 0;
+    }
     MemBuf() {
         {  // an arena released by an earlier run: its pages are already resident
             std::lock_guard<std::mutex> lk(cache_mu());
             auto& c = cache();
             if (!c.empty()) {
-                p = c.back();
+                p = c.back().first, owner = c.back().second;
                 c.pop_back();
                 return;
             }
@@ -339,15 +451,17 @@ struct MemBuf {
     }
     ~MemBuf() {
         if (!p) return;
+        if (owner) lazy_reset();
         {
             std::lock_guard<std::mutex> lk(cache_mu());
             if (cache().size() < 4) {
-                cache().push_back(p);
+                cache().push_back(std::make_pair(p, owner));
                 return;
             }
         }
         notify_release(p);
         munmap(p, MAX_MEMORY * 4);
+        if (owner) munmap(owner, MAX_MEMORY * 4);
     }
     MemBuf(const MemBuf&) = delete;
     MemBuf& operator=(const MemBuf&) = delete;
@@ -362,8 +476,8 @@ struct MemBuf {
         static std::mutex m;
         return m;
     }
-    static std::vector<u32*>& cache() {
-        static std::vector<u32*> c;
+    static std::vector<std::pair<u32*, u32*>>& cache() {
+        static std::vector<std::pair<u32*, u32*>> c;
         return c;
     }
 };
@@ -417,6 +531,32 @@ struct UVec {
     }
 };
 
+// a deferred ExtensionOp check (exec_multi_row, exec.rs:106-190, with every operand defined): the values of its rows, result == c
+inline void MemBuf::lazy_execute_check(LazyCall& c) {
+    const u64 size = c.size, a_stride = c.is_be ? 1 : 5;
+    std::vector<EF> elems(size), vbs(size), comp(size);
+    for (u64 i = 0; i < size; i++) {
+        EF a, b;
+        if (c.is_be)
+            a = kb::ef_from_base(p[c.left_first + i]);
+        else
+            memcpy(a.v, p + c.left_first + i * a_stride, 20);
+        memcpy(b.v, p + c.arg_b + i * 5, 20);
+        elems[i] = vm_compute_elem(a, b, c.op);
+        vbs[i] = b;
+    }
+    comp[size - 1] = elems[size - 1];
+    for (u64 i = size - 1; i-- > 0;) comp[i] = c.op == VM_OP_POLY_EQ ? kb::ef_mul(elems[i], comp[i + 1]) : kb::ef_add(elems[i], comp[i + 1]);
+    if (memcmp(comp[0].v, p + c.res, 20) != 0) lazy_failed = true;
+    u32* rows = lazy_rows->data() + c.row_at;
+    for (u64 i = 0; i < size; i++) {
+        u32* r = rows + i * LM_VM_EXTENSION_ROW_WORDS;
+        memcpy(r + 9, vbs[i].v, 20);
+        memcpy(r + 14, comp[0].v, 20);
+        memcpy(r + 19, comp[i].v, 20);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // errors (lean_vm/src/diagnostics/error.rs)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -442,7 +582,10 @@ struct MainMem {  // Memory: grows on write, write-once cells
     MemBuf& m;
     u32 peek(u64 i) const {
         m.guard(i);
-        return i < m.len ? m.p[i] : UNDEF;
+        if (i >= m.len) return UNDEF;
+        const u32 v = m.p[i];
+        if (__builtin_expect(v == UNDEF && m.lazy_open, 0)) return m.lazy_cell(i);  // (a deferred Poseidon call defines it: MemBuf)
+        return v;
     }
     bool set(u64 i, u32 v, Err& e) {
         m.guard(i);
@@ -454,6 +597,7 @@ struct MainMem {  // Memory: grows on write, write-once cells
             m.grow(i + 1);
         }
         u32& c = m.p[i];
+        if (__builtin_expect(c == UNDEF && m.lazy_open, 0)) (void)m.lazy_cell(i);  // the deferred call wrote first
         if (c == UNDEF)
             c = v;
         else if (c != v) {
@@ -774,19 +918,52 @@ struct Machine {
             if (!mem.set(at + i, v[i], err)) return false;
         return true;
     }
+    // The call is recorded instead of executed (MemBuf: deferred Poseidon16 calls) when that cannot change anything: every input cell
+    // is defined or the output of a pending call, every output cell is fresh.  false: the caller executes it now.
+    bool lazy_poseidon(u64 left_first, u64 left_second, u64 arg_b, u64 res, bool permute, u32 n_out) {
+        if constexpr (std::is_same<Mem, MainMem>::value) {
+            MemBuf& m = mem.m;
+            if (!m.lazy_on || res + n_out > MAX_MEMORY || m.lazy.size() >= 0x7FFFFFF0u) return false;
+            auto known = [&](u64 at, u32 n) {
+                for (u32 j = 0; j < n; j++) {
+                    m.guard(at + j);
+                    if (at + j >= m.len || (m.p[at + j] == UNDEF && !m.owner[at + j])) return false;
+                }
+                return true;
+            };
+            if (!known(left_first, 4) || !known(left_second, 4) || !known(arg_b, 8)) return false;
+            for (u32 j = 0; j < n_out; j++) {
+                m.guard(res + j);
+                if (res + j < m.len && (m.p[res + j] != UNDEF || m.owner[res + j])) return false;
+            }
+            if (res + n_out > m.len) m.grow(res + n_out);
+            if (!m.lazy_open && !m.lazy.empty()) m.lazy.clear(), m.lazy_drained = 0;  // (everything recorded so far has been executed)
+            MemBuf::LazyCall c;
+            memset(&c, 0, sizeof c);
+            c.left_first = left_first, c.left_second = left_second, c.arg_b = arg_b, c.res = res, c.permute = permute, c.n_out = (u8)n_out;
+            m.lazy.push_back(c);
+            const u32 tag = (u32)m.lazy.size();
+            for (u32 j = 0; j < n_out; j++) m.owner[res + j] = tag;
+            m.lazy_open++, m.lazy_total++;
+            return true;
+        } else
+            return false;
+    }
     void poseidon(const Instr& in, u32 va, u32 vb, u32 vc) {  // Poseidon16Precompile::execute (poseidon_16/mod.rs:209-289)
         const bool permute = in.x0 & 1, half = in.x0 & 2, hard = in.x0 & 4;
         const u64 arg_a = usize(va), arg_b = usize(vb), res = usize(vc);
         const u64 left_first = hard ? in.x1 : arg_a;
         const u64 left_second = hard ? arg_a : arg_a + 4;
-        alignas(64) u32 st[16];
-        if (!get_slice(left_first, 4, st) || !get_slice(left_second, 4, st + 4) || !get_slice(arg_b, 8, st + 8)) return;
-        if (permute) {
-            host_permute(st);
-            if (!set_slice(res, 16, st)) return;
-        } else {
-            host_compress(st);
-            if (!set_slice(res, half ? 4 : 8, st)) return;
+        if (!lazy_poseidon(left_first, left_second, arg_b, res, permute, permute ? 16u : (half ? 4u : 8u))) {
+            alignas(64) u32 st[16];
+            if (!get_slice(left_first, 4, st) || !get_slice(left_second, 4, st + 4) || !get_slice(arg_b, 8, st + 8)) return;
+            if (permute) {
+                host_permute(st);
+                if (!set_slice(res, 16, st)) return;
+            } else {
+                host_compress(st);
+                if (!set_slice(res, half ? 4 : 8, st)) return;
+            }
         }
         const u32 rec[LM_VM_POSEIDON_CALL_WORDS] = {(u32)arg_a, (u32)arg_b, (u32)res, half ? 1u : 0u, hard ? 1u : 0u, hard ? in.x1 : 0u,
                                                     (u32)left_first, (u32)left_second, permute ? 1u : 0u};
@@ -794,12 +971,44 @@ struct Machine {
     }
 
     // extension_op/exec.rs
-    enum { OP_ADD = 8, OP_MUL = 16, OP_POLY_EQ = 32 };
-    static EF compute_elem(const EF& a, const EF& b, u32 op) {
-        if (op == OP_ADD) return kb::ef_add(a, b);
-        const EF ab = kb::ef_mul(a, b);
-        if (op == OP_MUL) return ab;
-        return kb::ef_add_base(kb::ef_sub(kb::ef_sub(kb::ef_dbl(ab), a), b), kb::ONE);  // 2ab - a - b + 1
+    enum { OP_ADD = VM_OP_ADD, OP_MUL = VM_OP_MUL, OP_POLY_EQ = VM_OP_POLY_EQ };
+    static EF compute_elem(const EF& a, const EF& b, u32 op) { return vm_compute_elem(a, b, op); }
+    // An ExtensionOp over operands and a result that are all defined or pending, at least one of them pending, is recorded instead of
+    // executed (MemBuf: it is a check).  false: the caller executes it now.
+    bool lazy_extension_check(u64 pa, u64 pb, u64 pr, bool is_be, u32 op, u64 size) {
+        if constexpr (std::is_same<Mem, MainMem>::value) {
+            MemBuf& m = mem.m;
+            if (!m.lazy_on || !m.lazy_open || !m.lazy_rows || size == 0 || size > 256 || m.lazy.size() >= 0x7FFFFFF0u) return false;
+            bool pending = false;
+            auto known = [&](u64 at, u64 n) {
+                for (u64 j = 0; j < n; j++) {
+                    m.guard(at + j);
+                    if (at + j >= m.len) return false;
+                    if (m.p[at + j] == UNDEF) {
+                        if (!m.owner[at + j]) return false;
+                        pending = true;
+                    }
+                }
+                return true;
+            };
+            if (!known(pa, is_be ? size : 5 * size) || !known(pb, 5 * size) || !known(pr, 5) || !pending) return false;
+            MemBuf::LazyCall c;
+            memset(&c, 0, sizeof c);
+            c.left_first = pa, c.arg_b = pb, c.res = pr, c.size = size, c.op = op, c.kind = 1, c.is_be = is_be;
+            c.row_at = tr.ext.size();
+            const u64 a_stride = is_be ? 1 : 5;
+            u32* rows = tr.ext.extend(size * LM_VM_EXTENSION_ROW_WORDS);
+            for (u64 i = 0; i < size; i++) {
+                u32* r = rows + i * LM_VM_EXTENSION_ROW_WORDS;
+                memset(r, 0, 4 * LM_VM_EXTENSION_ROW_WORDS);
+                r[0] = is_be, r[1] = i == 0, r[2] = op == OP_ADD, r[3] = op == OP_MUL, r[4] = op == OP_POLY_EQ, r[5] = (u32)(size - i);
+                r[6] = (u32)(pa + i * a_stride), r[7] = (u32)(pb + i * 5), r[8] = (u32)pr;
+            }
+            m.lazy.push_back(c);
+            m.lazy_open++, m.lazy_checks++;
+            return true;
+        } else
+            return false;
     }
     bool peek_ef(u64 at, EF& out) const {
         for (int k = 0; k < 5; k++) {
@@ -879,6 +1088,7 @@ struct Machine {
         const u32 op = in.x0 & (OP_ADD | OP_MUL | OP_POLY_EQ);
         const bool is_be = in.x0 & 4;
         const u64 size = in.x1, pa = usize(va), pb = usize(vb), pr = usize(vc);
+        if (lazy_extension_check(pa, pb, pr, is_be, op, size)) return;
         if (size == 1 && op != OP_POLY_EQ && !solve_unknowns(pa, pb, pr, is_be, op)) return;
         const u64 a_stride = is_be ? 1 : 5;
         // `size` comes from the bytecode (< 2^25): the operand vectors grow as the operands are read, so a size that runs off the
@@ -1158,6 +1368,11 @@ UVec<std::pair<u64, u32>>& batch_deferred(Pool* p) {
 // of several provers in one process do not share them.
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
                            u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
+    memory.lazy_drain();  // the segments read the arena directly
+    if (memory.lazy_failed) {
+        err.raise("a deferred check failed");  // (execute_impl repeats the run)
+        return false;
+    }
     Pool* const pool = tl_run_pool();
     if (!pool) {
         err.raise("handle_parallel_batch outside a run");
@@ -1549,9 +1764,16 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     std::vector<u32> summary((size_t)VM_SUMMARY_WORDS + 2 * dirty_cap);
     const double t1 = vm_now_ms();
     a.summary = d_summary;  // (zeroed by the segment kernel's first workgroup: no fill command in front of it)
-    if (vm_dev_segments(D.ctx, a, n_par) ||
-        vm_dev_apply_deferred(D.ctx, a, n_par, D.image_cap, split_at, frames_end, B.d_offsets, d_summary, dirty_cap) ||
-        vm_dev_download(D.ctx, summary.data(), d_summary, summary.size() * 4)) {
+    bool launched = (!memory.lazy_open || vm_dev_mark(D.ctx) == LM_OK) && vm_dev_segments(D.ctx, a, n_par) == LM_OK &&
+                    vm_dev_apply_deferred(D.ctx, a, n_par, D.image_cap, split_at, frames_end, B.d_offsets, d_summary, dirty_cap) == LM_OK;
+    // the deferred Poseidon calls and checks of the sequential part (MemBuf) are executed while the segments run: their results reach the
+    // image with the host-owned cells at the end of the run (device_finalize), the segments saw None there
+    const double t_lazy0 = vm_now_ms();
+    const u64 n_lazy = memory.lazy_open;
+    if (launched && n_lazy) launched = vm_dev_wait_mark(D.ctx) == LM_OK;  // (the image upload has read the arena: the segments see None, not a race)
+    memory.lazy_drain();
+    const double t_lazy1 = vm_now_ms();
+    if (!launched || vm_dev_download(D.ctx, summary.data(), d_summary, summary.size() * 4)) {
         for (u32* p : B.owned) lm_free(D.ctx, p);
         return DEV_ERROR;
     }
@@ -1580,8 +1802,9 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     ap = fp + batch.frame_size;
     if (vm_times())
         fprintf(stderr, "[vm] device batch of %llu segments: host preparation + uploads %.2f ms, segments + deferred writes + summary %.2f ms, commit %.2f ms "
-                        "(%llu cycles, %llu Poseidon calls, %u dirty cells)\n", (unsigned long long)n_par, t1 - t0, t2 - t1, vm_now_ms() - t2,
-                (unsigned long long)tot[0], (unsigned long long)tot[1], summary[1]);
+                        "(%llu cycles, %llu Poseidon calls, %u dirty cells; %llu deferred host Poseidon calls executed meanwhile in %.2f ms)\n",
+                (unsigned long long)n_par, t1 - t0, t2 - t1, vm_now_ms() - t2, (unsigned long long)tot[0], (unsigned long long)tot[1], summary[1],
+                (unsigned long long)n_lazy, t_lazy1 - t_lazy0);
     return DEV_DONE;
 }
 
@@ -1857,7 +2080,7 @@ void lmh_bytecode_hash(const lmh_bytecode* bc, uint32_t out[8]) {
 
 // ctx != nullptr: parallel batches run on that context's device (lm_vm_device.hip) when they qualify, else on the host pool
 static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input, const lm_vm_witness* witness,
-                        uint32_t n_threads, lmh_execution** out) {
+                        uint32_t n_threads, lmh_execution** out, bool allow_deferred = true) {
     if (!bc || !out || (n_public_input && !public_input) || !witness || witness->n_names != bc->n_names ||
         (bc->n_names && (!witness->name_entry_begin || !witness->entry_offset))) {
         lm_set_error("lmh_execute_bytecode: bad arguments (the witness must carry one hint stream per name of the bytecode)");
@@ -1898,6 +2121,13 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
                 return LM_E_DEVICE;
             }
         }
+        // deferred Poseidon calls (MemBuf) pay off when a batch runs on the device; LM_VM_LAZY=1 / 0 forces them on (host runs too) / off
+        if (const char* e = getenv("LM_VM_LAZY"))
+            memory.lazy_on = e[0] == '1';
+        else
+            memory.lazy_on = D != nullptr;
+        if (!allow_deferred || (memory.lazy_on && !memory.lazy_alloc())) memory.lazy_on = false;
+        memory.lazy_rows = &ex->tr.ext;
         bool device_failed = false;
         for (;;) {
             Machine<MainMem>::Batch batch;
@@ -1913,7 +2143,15 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             }
             const bool ok = how == DEV_DONE || handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
             t_batches += vm_now_ms() - tb;
-            if (!ok) break;
+            if (!ok || memory.lazy_failed) break;
+        }
+        if (!m.err.set && !device_failed) memory.lazy_drain();
+        if (!device_failed && (memory.lazy_failed || (m.err.set && memory.lazy_checks))) {
+            // a deferred check failed, or an error was met with checks deferred: the first error of the program is what a run
+            // without deferred work reports
+            if (vm_times()) fprintf(stderr, "[vm] deferred checks: the run is repeated with every instruction executed at once\n");
+            delete ex;
+            return execute_impl(ctx, bc, public_input, n_public_input, witness, n_threads, out, false);
         }
         if (memory.touch_failed) device_failed = true;
         if (device_failed) {

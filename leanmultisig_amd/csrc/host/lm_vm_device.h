@@ -98,6 +98,9 @@ int vm_dev_resolve(lm_ctx* ctx, u32* image, u64 image_len, const u32* pend, u64 
 int vm_dev_fill(lm_ctx* ctx, u32* d, u32 word, u64 n);
 int vm_dev_download(lm_ctx* ctx, void* dst, const void* d_src, size_t bytes);  // synchronises the stream
 int vm_dev_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);    // asynchronous: src must stay valid until the next synchronisation
+// an event behind what has been enqueued so far / wait for it (the host may then overwrite the sources of the uploads in front of it)
+int vm_dev_mark(lm_ctx* ctx);
+int vm_dev_wait_mark(lm_ctx* ctx);
 const u32* vm_dev_coop_table(lm_ctx* ctx);
 // dst[i] = src[i] == VM_UNDEF ? 0 : src[i]; optional defined mask
 int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined);

@@ -949,6 +949,14 @@ int vm_dev_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     LM_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return LM_OK;
 }
+int vm_dev_mark(lm_ctx* ctx) {
+    LM_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+    return LM_OK;
+}
+int vm_dev_wait_mark(lm_ctx* ctx) {
+    LM_HIP(hipEventSynchronize(ctx->fork_event));
+    return LM_OK;
+}
 const u32* vm_dev_coop_table(lm_ctx* ctx) { return ctx->d_coop; }
 int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined) {
     if (n == 0) return LM_OK;

@@ -45,6 +45,14 @@ def fails(orc, p, match, hints=None, pi=PI):
 FP0 = 10  # next_multiple_of(8 + 0, 5)
 
 
+@pytest.fixture(autouse=True, params=["eager", "deferred"])
+def poseidon_mode(request, monkeypatch):
+    """every test of this module runs twice: with the sequential runner's Poseidon calls executed at once, and recorded and executed
+    on first use (csrc/host/lm_vm.cpp: MemBuf — the mode of a run with a device context; LM_VM_LAZY forces it on the host)"""
+    monkeypatch.setenv("LM_VM_LAZY", "1" if request.param == "deferred" else "0")
+    return request.param
+
+
 def test_computation_all_unknown_cases(orc):
     p = Program()
     p.starting_frame_memory = 32
@@ -142,6 +150,94 @@ def test_poseidon_variants(orc):
     calls = ex.poseidon_calls()
     assert calls.shape == (5, 9)
     assert list(calls[2]) == [FP0, 0, FP0 + 56, 0, 1, 4, 4, FP0, 0] and list(calls[4][3:]) == [0, 0, 0, FP0, FP0 + 4, 1]
+
+
+def test_poseidon_chain_cells_written_and_read_around_the_calls(orc):
+    """a hash chain nobody reads for a while (deferred mode: pending calls), then every way of meeting a pending cell: a read that has
+    to execute the chain, writes of the right and of a wrong value to an output cell — before and after the call —, a call whose output
+    lands on a defined cell, a call on an undefined input, an extension operation over pending cells"""
+    rng = np.random.default_rng(7)
+    blob = ob.rand_field(rng, 16)
+
+    def chain(p, n=6):
+        p.hint_witness("blob", 0)
+        p.poseidon16(FP(0), FP(8), FP(40))
+        for k in range(1, n):
+            p.poseidon16(FP(40 + 8 * (k - 1)), FP(8), FP(40 + 8 * k), half=(k == n - 1))
+        p.poseidon16(FP(40), FP(48), FP(100), permute=True)
+
+    def expected():
+        h = [orc.poseidon16_compress(np.concatenate([blob[:8], blob[8:]]))[0][:8]]
+        for k in range(1, 6):
+            h.append(orc.poseidon16_compress(np.concatenate([h[-1], blob[8:]]))[0][:8])
+        return h, orc.poseidon16_permute(np.concatenate([h[0], h[1]]))[0]
+
+    h, perm = expected()
+    hc, permc = [from_monty(x) for x in h], from_monty(perm)
+
+    def prog(build, before=None):
+        p = Program()
+        p.starting_frame_memory = 160
+        if before:
+            before(p)
+        chain(p)
+        build(p)
+        p.return_from_main(150)
+        return p
+
+    # nothing reads the chain: it is executed when the run ends
+    ex, mem, defd, _, _ = both(orc, prog(lambda p: None), {"blob": [blob]})
+    assert np.array_equal(mem[FP0 + 40:FP0 + 48], hc[0]) and np.array_equal(mem[FP0 + 80:FP0 + 84], hc[5][:4]) and not defd[FP0 + 84]
+    assert np.array_equal(mem[FP0 + 100:FP0 + 116], permc)
+    # a read in the middle of the chain, an unknown operand solved from a pending cell, the right value written onto pending cells
+    def reads(p):
+        p.add(M(64), K(1), M(120))                       # h[3][0] + 1
+        p.add(M(121), M(82), K(5))                       # a unknown: 5 - h[5][2]
+        p.add(K(0), K(int(hc[2][3])), M(59))             # the value the pending call will write
+        p.add(K(0), K(int(permc[15])), M(115))
+        p.extension_op("add", FP(72), FP(100), FP(130))  # h[4][0..5] + perm[0..5]
+    ex, mem, _, _, _ = both(orc, prog(reads), {"blob": [blob]})
+    assert mem[FP0 + 120] == (int(hc[3][0]) + 1) % P and mem[FP0 + 121] == (5 - int(hc[5][2])) % P
+    assert list(mem[FP0 + 130:FP0 + 135]) == [(int(a) + int(b)) % P for a, b in zip(hc[4][:5], permc[:5])]
+    # an output cell defined BEFORE the call: the right value passes, a wrong one is the call's MemoryAlreadySet
+    both(orc, prog(lambda p: None, before=lambda p: p.add(K(0), K(int(hc[1][7])), M(55))), {"blob": [blob]})
+    fails(orc, prog(lambda p: None, before=lambda p: p.add(K(0), K((int(hc[1][7]) + 1) % P), M(55))), "MemoryAlreadySet", {"blob": [blob]})
+    # a wrong value written AFTER the call
+    fails(orc, prog(lambda p: p.add(K(0), K((int(hc[4][0]) + 1) % P), M(72))), "NotEqual", {"blob": [blob]})
+    fails(orc, prog(lambda p: (p.add(K(0), FP(0), M(122)), p.deref(122, 109, K((int(permc[9]) + 1) % P)))), "MemoryAlreadySet", {"blob": [blob]})
+    both(orc, prog(lambda p: (p.add(K(0), FP(0), M(122)), p.deref(122, 109, K(int(permc[9]))))), {"blob": [blob]})
+    # checks over pending cells (deferred mode: recorded, executed with the chain): copy_5 onto the right / a wrong expected value, a dot
+    # product against a defined result; a failing check followed by another error reports the check (the first error of the program),
+    # a passing one followed by an error reports that error
+    def expect(p, value5, at=140):
+        for k in range(5):
+            p.add(K(0), K(int(value5[k]) % P), M(at + k))
+    one = lambda p: (p.add(K(0), K(1), M(135)), [p.add(K(0), K(0), M(136 + k)) for k in range(4)])  # noqa: E731
+    def copy_check(delta, then=None):
+        def build(p):
+            one(p)
+            expect(p, [int(hc[4][0]) + delta] + list(hc[4][1:5]))
+            p.extension_op("mul", FP(72), FP(135), FP(140))
+            if then:
+                then(p)
+        return build
+    ex, _, _, _, _ = both(orc, prog(copy_check(0)), {"blob": [blob]})
+    assert ex.n_extension_rows == 1
+    fails(orc, prog(copy_check(1)), "NotEqual", {"blob": [blob]})
+    fails(orc, prog(copy_check(1, then=lambda p: p.add(M(0), K(1), M(0)))), "NotEqual", {"blob": [blob]})
+    fails(orc, prog(copy_check(0, then=lambda p: p.jump(K(1), K(100000), FP(0)))), "PCOutOfBounds", {"blob": [blob]})
+    dot = sum(int(a) * int(b) for a, b in zip(hc[2][:3], hc[3][:3])) % P  # base-by-extension dot product of size 1: h[2][0] * (h[3][0..5])
+    def dot_check(delta):
+        def build(p):
+            prod = [(int(hc[2][0]) * int(x)) % P for x in hc[3][:5]]
+            expect(p, [prod[0] + delta] + prod[1:])
+            p.extension_op("mul", FP(56), FP(64), FP(140), is_be=True)
+        return build
+    both(orc, prog(dot_check(0)), {"blob": [blob]})
+    fails(orc, prog(dot_check(1)), "InvalidExtensionOp|NotEqual|MemoryAlreadySet", {"blob": [blob]})
+    # a call over an undefined input behind pending ones; a call whose output runs into a pending cell of another call
+    fails(orc, prog(lambda p: p.poseidon16(FP(80), FP(8), FP(140))), "UndefinedMemory", {"blob": [blob]})   # h[5] is a half output
+    fails(orc, prog(lambda p: p.poseidon16(FP(40), FP(8), FP(36))), "MemoryAlreadySet", {"blob": [blob]})  # 36..44 overlaps h[0]
 
 
 @pytest.mark.parametrize("op,is_be,size", [("add", False, 1), ("mul", False, 1), ("mul", False, 4), ("mul", True, 3), ("poly_eq", False, 3),

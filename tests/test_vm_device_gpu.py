@@ -42,10 +42,11 @@ def same_as_oracle(ctx, orc, bc, pi, w, expect_device=True, n_threads=2):
     return ex, run
 
 
-def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=False):
+def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=False, head=None):
     """main calls a PARALLEL loop over i in [0, n): frame = [ret, fp, i, end, out, perm, (extra args) | d, inv, nz, omnz, locals...];
     body(p, L) emits the iteration (L = first free frame offset); after(p) emits code behind the loop in main; second_loop: main then
-    calls a second, sequential copy of the loop (one run_loop arms one batch, runner.rs:150-163: a later ParallelBatchStart is ignored)."""
+    calls a second, sequential copy of the loop (one run_loop arms one batch, runner.rs:150-163: a later ParallelBatchStart is ignored);
+    head(p) emits code in main in front of the loop (main's frame grows to 200 cells, 64.. are free)."""
     p = Program()
     N, OUT, PERM, LF, LF2 = 0, 1, 2, 3, 4
     n_args = 4 + n_extra_args
@@ -54,6 +55,8 @@ def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=Fa
     p.hint_request_memory(OUT, M(N))
     p.hint_request_memory(PERM, M(N))
     p.hint_witness("perm", PERM, indirect=True)
+    if head:
+        head(p)
 
     def call(lf, label, ret):
         p.hint_request_memory(lf, K(Label("@frame")))
@@ -74,7 +77,7 @@ def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=Fa
     if after:
         after(p)
     p.return_from_main(21)
-    p.starting_frame_memory = 64
+    p.starting_frame_memory = 200 if head else 64
     I, END = 2, 3
     d, inv, nz, omnz = 2 + n_args, 3 + n_args, 4 + n_args, 5 + n_args
     L = 6 + n_args
@@ -262,6 +265,80 @@ def test_sequential_loop_behind_the_device_batch(ctx, orc):
     w = Witness(bc, 0, h)
     ex, run = same_as_oracle(ctx, orc, bc, PI, w)
     assert ex.n_poseidon_calls == 4 * n
+
+
+def chain_head(n_links, expected, read_in_body=False):
+    """main hashes a chain of n_links compressions over a hinted block in front of the loop and checks the last digest against five
+    expected words (copy_5): with a device context the runner records these calls and the check (csrc/host/lm_vm.cpp: MemBuf) and
+    executes them while the segments run"""
+    def head(p):
+        p.hint_witness("head_block", 64)                       # 16 words at 64..80
+        p.poseidon16(FP(64), FP(72), FP(80))
+        for k in range(1, n_links):
+            p.poseidon16(FP(80 + 8 * (k - 1)), FP(72), FP(80 + 8 * k))
+        last = 80 + 8 * (n_links - 1)
+        p.add(K(0), K(1), M(190))
+        for k in range(4):
+            p.add(K(0), K(0), M(191 + k))
+        for k in range(5):
+            p.add(K(0), K(int(expected[k])), M(195 + k))
+        p.extension_op("mul", FP(last), FP(190), FP(195))
+    return head
+
+
+def chain_digest(orc, block, n_links):
+    h = orc.poseidon16_compress(np.concatenate([block[:8], block[8:]]))[0][:8]
+    for _ in range(1, n_links):
+        h = orc.poseidon16_compress(np.concatenate([h, block[8:]]))[0][:8]
+    return from_monty(h)
+
+
+def test_hash_chain_and_its_check_in_front_of_the_device_batch(ctx, orc):
+    n, links = 100, 12
+    rng = np.random.default_rng(17)
+    block = ob.rand_field(rng, 16)
+    d = chain_digest(orc, block, links)
+    hints = hints_for(n, rng)
+    hints["head_block"] = [block]
+    bc = loop_program(hash_and_store_body, head=chain_head(links, d)).finalize()
+    ex, run = same_as_oracle(ctx, orc, bc, PI, Witness(bc, 0, hints))
+    assert ex.n_poseidon_calls == 2 * n + links and ex.n_extension_rows == 1
+    # the expected digest is wrong: the check fails while the segments run, and the error is the host runner's
+    bad = d.copy()
+    bad[2] = (bad[2] + 1) % P
+    bc = loop_program(hash_and_store_body, head=chain_head(links, bad)).finalize()
+    w = Witness(bc, 0, hints)
+    with pytest.raises(lm.LmError, match="NotEqual") as dev:
+        execute(bc, PI, w, n_threads=2, ctx=ctx)
+    with pytest.raises(lm.LmError) as host:
+        execute(bc, PI, w, n_threads=2)
+    assert str(dev.value) == str(host.value)
+
+
+def test_segments_reading_a_pending_digest_send_the_batch_to_the_host(ctx, orc):
+    """iteration i reads a word of the chain's digest number which[i] through main's frame pointer (saved in its call frame).  Iteration
+    0 — run by the host, which executes what it needs of the chain — reads link 0; the later links are still None in the image the
+    segments get: they fail there, and the batch runs on the host pool — same log as the oracle's"""
+    n, links = 64, 5
+    rng = np.random.default_rng(18)
+    block = ob.rand_field(rng, 16)
+    d = chain_digest(orc, block, links)
+
+    def body(p, L):
+        used = hash_and_store_body(p, L)
+        w, w8, ptr, v = L + used, L + used + 1, L + used + 2, L + used + 3
+        p.hint_witness("which", w)
+        p.mul(M(w), K(8), M(w8))
+        p.add(M(1), M(w8), M(ptr))                            # main's fp + 8 * which
+        p.deref(ptr, 80 + 3, M(v))                            # word 3 of that link's digest
+        p.add(M(v), K(1), M(v + 1))
+        return used + 5
+
+    hints = hints_for(n, rng)
+    hints["head_block"] = [block]
+    hints["which"] = [mont([0])] + [mont([int(x)]) for x in rng.integers(1, links, n - 1)]
+    bc = loop_program(body, head=chain_head(links, d)).finalize()
+    same_as_oracle(ctx, orc, bc, PI, Witness(bc, 0, hints), expect_device=False)
 
 
 def test_conflicting_deferred_writes_give_the_host_runners_error(ctx, orc):

@@ -284,14 +284,20 @@ __device__ __forceinline__ void gkr_entry(const u32* __restrict__ n_in, const u3
 
 // sums of one entry: its own bracket e and the quad's difference forms of its lane class (see above); w = eq weight of the quad
 // (LA) or of the pair (!LA).  All four lanes of a quad call this together (idle lanes with x = 0).
-template <bool LA>
+// BASE0: x[0] (the left numerators) is a base-field value in every lane of the quad — the caller's input layer before any fold —, so
+// its three products are base-by-extension (5 multiplications instead of 25) and only its plane 0 travels through the quad.
+template <bool LA, bool BASE0 = false>
 __device__ __forceinline__ void gkr_quad_sums(const EF (&x)[4], const EF& w, u32 cls, EF& acc_e, EF& acc_x, EF& acc_y) {
-    const EF e = ef_add(ef_mul(x[0], x[3]), ef_mul(x[1], x[2]));
+    const EF e = ef_add(BASE0 ? ef_mul_base(x[3], x[0].v[0]) : ef_mul(x[0], x[3]), ef_mul(x[1], x[2]));
     EF A[4], H[4];
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int k = 0; k < 5; k++) {
+            if (BASE0 && q == 0 && k > 0) {
+                A[q].v[k] = 0, H[q].v[k] = 0;
+                continue;
+            }
             const u32 v = x[q].v[k];
             const u32 v0 = quad_bcast<0>(v), v1 = quad_bcast<1>(v), v2 = quad_bcast<2>(v), v3 = quad_bcast<3>(v);
             const u32 d1 = sub(v1, v0), d3 = sub(v3, v2);
@@ -303,11 +309,11 @@ __device__ __forceinline__ void gkr_quad_sums(const EF (&x)[4], const EF& w, u32
                 A[q].v[k] = cls == 1 ? d1 : d3;
             }
         }
-    const EF X = ef_add(ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
+    const EF X = ef_add(BASE0 ? ef_mul_base(A[3], A[0].v[0]) : ef_mul(A[0], A[3]), ef_mul(A[1], A[2]));
     acc_e = ef_add(acc_e, ef_mul(e, w));
     acc_x = ef_add(acc_x, ef_mul(X, w));
     if (LA) {
-        const EF Y = ef_add(ef_mul(H[0], H[3]), ef_mul(H[1], H[2]));
+        const EF Y = ef_add(BASE0 ? ef_mul_base(H[3], H[0].v[0]) : ef_mul(H[0], H[3]), ef_mul(H[1], H[2]));
         acc_y = ef_add(acc_y, ef_mul(Y, w));
     }
 }
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
         }
         // ---- sums: own entry, then the quad's differences ----
         const EF w = eq_split_at(eq, active ? (LA ? i >> 2 : i >> 1) : 0);  // (n_threads is a multiple of 4: a quad is all-active or all-idle)
-        gkr_quad_sums<LA>(x, w, cls, acc_e, acc_x, acc_y);
+        gkr_quad_sums<LA, MODE == 0 && F == 0>(x, w, cls, acc_e, acc_x, acc_y);  // (padding and idle lanes: x[0] = 0, a base value too)
     }
     gkr_block_sums(acc_e, acc_x, acc_y, lds, tot);
     if (gridDim.x > 1 && !lm_grid_sum<GKR_SUM_WORDS>(tot, acc, done_counter, tot)) return;

@@ -23,7 +23,9 @@ struct lm_air {
     u32* d_virt = nullptr;              // their base-field values, n_virt x 2^log_rows
     const u32** d_base_cols = nullptr;  // device array of n_cols + n_virt device pointers (caller's base columns, then virtual)
     u32* ef[2] = {nullptr, nullptr};    // ping-pong: (n_cols + n_virt + n_shift) columns x 5 planes
-    int cur = -1;
+    int cur = -1;                       // -1: base columns; -2: base columns seen through the first challenge (FoldCols); 0 / 1: ef[cur]
+    bool lazy_ok = false;               // the first fold may stay unmaterialised (lm_air_new)
+    EF r1;                              // cur == -2: the first challenge
     air::Extra* d_extra = nullptr;
     air::Extra h_extra;                  // host copies outlive the asynchronous uploads (no synchronisation in lm_air_new)
     std::vector<const u32*> h_cols;
@@ -90,6 +92,49 @@ struct ExtCols {
         }
         return lerp(lo, hi, zm);
     }
+};
+
+// The table after its FIRST fold, not materialised: row i of the folded table is a_{2i} + r (a_{2i+1} - a_{2i}) with base-field a's, so
+// a column's value at the evaluation point z of the folded pair (2j, 2j+1) is  [a0 + z (a2 - a0)] + r [(a1 - a0) + z ((a3 - a2) - (a1 -
+// a0))]  from the FOUR base words 4j .. 4j+3: two base products by z and one base-by-extension product.  Round 1 reads 16 bytes per
+// column and pair instead of 40 from a folded copy, and the copy — the largest one of the session, 5 x the committed columns — is never
+// written: the second challenge folds the base columns twice in one pass (k_air_fold2_base).  Same field values as ExtCols over the
+// output of k_air_fold_base.
+template <bool SHIFT>  // SHIFT = false: the table has no shift columns (the Poseidon table): no second path behind every access
+struct FoldCols {
+    const u32* const* cols;
+    u64 n_rows;  // of the BASE table
+    u32 n_flat;
+    EF r;
+    template <bool RELOAD>
+    __device__ __forceinline__ EF at(u32 c, u64 j, u32 zm) const {
+        // (the pointer table is re-read next to every use, whatever RELOAD says: hoisted out of the row loop, the 160 column pointers of
+        // the Poseidon table are 320 SGPRs, spilled to VGPR lanes — BaseCols::at, ExtCols::at)
+        const u32* const* cp = cols;
+        asm volatile("" : "+s"(cp));
+        u32 a0, a1, a2, a3;
+        if (!SHIFT || c < n_flat) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cp[c] + 4 * j);
+            a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+        } else {  // shift view: row i of the view is row min(i + 1, n_rows - 1) of the column
+            const u32* p = cp[c - n_flat];
+            const u64 i = 4 * j;
+            a0 = p[i + 1], a1 = p[i + 2], a2 = p[i + 3], a3 = p[(i + 4 < n_rows) ? i + 4 : n_rows - 1];
+        }
+        const u32 d0 = sub(a1, a0), d1 = sub(a3, a2);
+        EF o = ef_mul_base(r, lerp(d0, d1, zm));
+        o.v[0] = add(o.v[0], lerp(a0, a2, zm));
+        return o;
+    }
+};
+
+template <class C>
+struct cols_lazy_fold {
+    static constexpr bool value = false;
+};
+template <bool S>
+struct cols_lazy_fold<FoldCols<S>> {
+    static constexpr bool value = true;
 };
 
 #ifndef AIR_EXT_WAVES
@@ -233,7 +278,7 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
 // SEG >= 0: one launch per segment (large rounds: each segment gets its own register budget).
 // (the combined extension-field Poseidon kernel fits 3 waves per SIMD; asking for it keeps the allocator from drifting to 2)
 template <int TABLE, class T, class Cols, int SEG>
-__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? 3 : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : (TABLE == air::T_EXECUTION ? 2 : (sizeof(T) == sizeof(u32) ? AIR_EXT_WAVES : 1)))) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
+__global__ __launch_bounds__(256, (TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(EF) && SEG < 0) ? (cols_lazy_fold<Cols>::value ? 2 : 3) : ((TABLE == air::T_POSEIDON16 && sizeof(T) == sizeof(u32) && SEG >= 0) ? AIR_BASE_SEG_WAVES : (TABLE == air::T_EXECUTION ? 2 : (sizeof(T) == sizeof(u32) ? AIR_EXT_WAVES : 1)))) void k_air_round(Cols cols, u64 n_pairs, const air::Extra* __restrict__ extra, EqSplit eq,
                                                    u32* __restrict__ partial, u32 blocks_x, u32 ny, AirFinish fin) {
     __shared__ u32 lds[20];
     u32 tile, y;
@@ -581,6 +626,27 @@ __global__ __launch_bounds__(256) void k_air_fold_ext(ExtCols cols, u64 n_out, E
     }
 }
 
+// the first TWO folds of the base columns in one pass (see FoldCols): out[c][k][j] from the base rows 4j .. 4j+3
+__global__ __launch_bounds__(256) void k_air_fold2_base(BaseCols cols, u64 n_out, EF r1, EF r2, u32* __restrict__ out) {
+    const u32 c = blockIdx.y;
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < n_out; j += (u64)gridDim.x * 256) {
+        u32 a0, a1, a2, a3;
+        if (c < cols.n_flat) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cols.cols[c] + 4 * j);
+            a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+        } else {
+            const u32* p = cols.cols[c - cols.n_flat];
+            const u64 i = 4 * j;
+            a0 = p[i + 1], a1 = p[i + 2], a2 = p[i + 3], a3 = p[(i + 4 < cols.n_rows) ? i + 4 : cols.n_rows - 1];
+        }
+        EF y0 = ef_mul_base(r1, sub(a1, a0)), y1 = ef_mul_base(r1, sub(a3, a2));
+        y0.v[0] = add(y0.v[0], a0), y1.v[0] = add(y1.v[0], a2);
+        const EF o = ef_add(y0, ef_mul(r2, ef_sub(y1, y0)));
+#pragma unroll
+        for (int k = 0; k < 5; k++) out[((u64)c * 5 + k) * n_out + j] = o.v[k];
+    }
+}
+
 // Virtual columns of the Poseidon table (air_tables.h: POS_VIRT_Y / POS_VIRT_E / POS_VIRT_O): per row the 20 + 16 affine
 // forms of the partial block over u = (beginning_full_rounds[1] (16), partial_rounds (20)), and the 3 x 5 coefficient planes
 // of the challenge-weighted output blocks V_s = sum_i alpha^(k_s + i) * out_s[i].  Base-field in, base-field out.
@@ -648,7 +714,11 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
                 return LM_OK;
             }
         }
-        if (sizeof(T) == sizeof(u32) && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS) {
+        bool split = false;
+        if constexpr (sizeof(T) == sizeof(u32)) split = n_pairs >= AIR_SPLIT_LAUNCH_PAIRS;
+        if constexpr (sizeof(T) != sizeof(u32)) {
+            launch_segment<TABLE, T, Cols, -1>(ctx, a->stream, c, dim3(blocks, AIR_POS_SLOTS), n_pairs, extra, eq, partial, fin);
+        } else if (split) {
             const dim3 grid(blocks, AIR_POS_POINTS);
             AirFinish none = fin;   // five launches: the partials are summed by k_air_reduce (blocks > AIR_INLINE_MAX_BLOCKS here)
             none.out = nullptr;
@@ -673,9 +743,14 @@ static int launch_cols(lm_ctx* ctx, lm_air* a, const Cols& c, u64 n_pairs, u32 b
 }
 template <int TABLE>
 static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const EqSplit& eq, u32* partial, const AirFinish& fin) {
-    if (a->cur < 0) {
+    if (a->cur == -1) {
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
+    }
+    if (a->cur == -2) {
+        using FC = FoldCols<TABLE != air::T_POSEIDON16>;
+        FC c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt, a->r1};
+        return launch_cols<TABLE, EF, FC>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
     }
     ExtCols c{a->ef[a->cur], 1ull << (a->log_rows - a->round)};  // (rows of the folded table: n_pairs may be the active prefix only)
     return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
@@ -748,6 +823,10 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     a->eqt.buf_words = PrefixEqTables::words_needed(log_rows);
     a->h_cols.assign(d_cols, d_cols + a->n_cols);
     for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
+    // FoldCols reads four consecutive rows of a column with one 16-byte load (LM_AIR_NO_LAZY_FOLD=1: every fold is materialised)
+    static const bool lazy = getenv("LM_AIR_NO_LAZY_FOLD") == nullptr;
+    a->lazy_ok = lazy && log_rows >= 2;
+    for (const u32* cp : a->h_cols) a->lazy_ok = a->lazy_ok && (reinterpret_cast<uintptr_t>(cp) & 15) == 0;
     int rc;
     if ((rc = lm_stage_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||
         (rc = lm_stage_upload(ctx, a->d_extra, &a->h_extra, sizeof(air::Extra)))) {
@@ -820,7 +899,7 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     // iterations exactly and those are few, add workgroups so that it lands on an idle thread
     if (prefix && n_pairs % ((u64)blocks * 256) == 0 && n_pairs / ((u64)blocks * 256) < 4 && blocks < AIR_MAX_BLOCKS)
         blocks += (blocks & 7) == 0 ? 8 : 1;
-    if (pos && a->cur >= 0 && air_coop_round(n_pairs, prefix))  // tiles of AIR_COOP_PAIRS pairs, the padding pair included
+    if (pos && a->cur != -1 && air_coop_round(n_pairs, prefix))  // tiles of AIR_COOP_PAIRS pairs, the padding pair included
         blocks = (u32)((n_pairs + (prefix ? 1 : 0) + AIR_COOP_PAIRS - 1) / AIR_COOP_PAIRS);
     u32* s = a->d_partial;
     int rc;
@@ -845,13 +924,13 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a) {
     AirFinish fin;
     memset(&fin, 0, sizeof fin);
     if (pos) fin.lag = pos_lag;
-    const bool inline_finish = blocks <= AIR_INLINE_MAX_BLOCKS && !(pos && a->cur < 0 && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS);
+    const bool inline_finish = blocks <= AIR_INLINE_MAX_BLOCKS && !(pos && a->cur == -1 && n_pairs >= AIR_SPLIT_LAUNCH_PAIRS);
     fin.out = inline_finish ? ctx->h_res + a->res_off : nullptr;
     fin.flag_word = ctx->h_res + lm_ctx::RES_FLAG + 1 + a->aux;
     fin.done_counter = a->d_sync;
     fin.seq = seq;
     fin.deg = a->deg;
-    const bool ext_parts = a->table == air::T_EXTENSION_OP && a->cur >= 0 && air_ext_parts_round(n_pairs, prefix);
+    const bool ext_parts = a->table == air::T_EXTENSION_OP && a->cur != -1 && air_ext_parts_round(n_pairs, prefix);
     fin.n_main = pos ? 4 * blocks : ext_parts ? air::EXT_PARTS * blocks : blocks;
     fin.n_low = pos ? blocks : 0u;
     fin.low_offset = (u64)4 * AIR_POS_POINTS * blocks;
@@ -907,7 +986,14 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
     const u64 n_out = 1ull << (a->log_rows - a->round - 1);
     const u32 blocks = (u32)std::min<u64>((n_out + 255) / 256, 1024);
     const dim3 grid(blocks, a->n_cols + a->n_virt + a->n_shift);
-    if (a->cur < 0) {
+    if (a->cur == -1 && a->lazy_ok) {  // the first fold stays unmaterialised: round 1 reads the base columns through FoldCols
+        a->r1 = r;
+        a->cur = -2;
+    } else if (a->cur == -2) {
+        BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
+        LM_LAUNCH_ON(ctx, a->stream, k_air_fold2_base, grid, dim3(256), 0, c, n_out, a->r1, r, a->ef[0]);
+        a->cur = 0;
+    } else if (a->cur < 0) {
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         LM_LAUNCH_ON(ctx, a->stream, k_air_fold_base, grid, dim3(256), 0, c, n_out, r, a->ef[0]);
         a->cur = 0;

@@ -33,7 +33,7 @@ def _run(ctx, orc, tables, alpha, eq16, beta, eta):
     return proof
 
 
-@pytest.mark.parametrize("table,log_rows", [(0, 1), (0, 5), (1, 4), (2, 3), (2, 6)])
+@pytest.mark.parametrize("table,log_rows", [(0, 1), (0, 2), (1, 2), (2, 2), (0, 5), (1, 4), (2, 3), (2, 6)])
 def test_single_table_random_columns(ctx, orc, table, log_rows):
     """Random (unsatisfied) columns: checks the constraint POLYNOMIALS, every alpha power and the fold schedule."""
     rng = np.random.default_rng(table * 10 + log_rows)
@@ -135,6 +135,22 @@ def test_small_rounds_without_the_cooperative_kernels():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LM_AIR_NO_COOP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_air_gpu.py", "-k",
+                        "test_single_table_random_columns or test_active_prefix_equals_full_sum or test_three_tables_back_loaded_and_verified"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+def test_rounds_with_every_fold_materialised():
+    """LM_AIR_NO_LAZY_FOLD=1: the first fold of a session writes the folded extension-field columns (k_air_fold_base) and round 1
+    reads them, as every round did before round 1 read the base columns through the first challenge (FoldCols, k_air_fold2_base) —
+    same round polynomials.  The switch is read once per process: the parity tests above are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_AIR_NO_LAZY_FOLD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_air_gpu.py", "-k",
                         "test_single_table_random_columns or test_active_prefix_equals_full_sum or test_three_tables_back_loaded_and_verified"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=1200)

@@ -382,8 +382,9 @@ KB_HD void full_round(T s[16]) {
     mds16(s);
 }
 
-// A segment of the Poseidon AIR (see above) in two halves, so that the first S-box layer — which has degree 3 in the row
-// variable — can be evaluated at 4 points only and extrapolated (lm_air.hip: k_air_round_pos_ef2):
+// A segment of the Poseidon AIR (see above) in two halves.  (The state behind the first half has degree 3 in the row variable, so it
+// could be evaluated at 4 points and extrapolated to the round's 10 — not built: the 16 x 4 extension values to extrapolate from do
+// not fit a lane's registers next to the evaluation, and through LDS or across lanes the saving is ~20 % of the large rounds)
 //   seg_first  : the 16 input columns of the segment through full round R0 (S-box + MDS)
 //   seg_finish : [segment 0: bus + flag constraints] full round R0 + 1, then the segment's constraints
 template <int SEG>

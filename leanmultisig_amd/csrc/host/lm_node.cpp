@@ -61,7 +61,9 @@ bool pin_enabled() {
 namespace lmh {
 // make [base, base + need) registered (need <= capacity); best effort: an upload from an unregistered buffer is still correct
 void vm_ensure_pinned(const VmRegion& reg, size_t need) {
-    if (!pin_enabled() || !reg.base || need == 0 || need > reg.bytes) return;
+    // only whole pages that belong to the buffer alone (the VM's arena is a mapping of its own, its logs are page-aligned allocations
+    // of whole pages: lm_vm.cpp, UVec): never a chunk of the malloc heap that shares a page with something else
+    if (!pin_enabled() || !reg.base || need == 0 || need > reg.bytes || (reinterpret_cast<uintptr_t>(reg.base) & 4095) || (reg.bytes & 4095)) return;
     static std::once_flag hook_once;
     std::call_once(hook_once, [] {
         vm_set_release_hook(unpin_hook);

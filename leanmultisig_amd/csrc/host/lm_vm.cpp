@@ -501,14 +501,22 @@ struct UVec {
     const T& operator[](size_t i) const { return p[i]; }
     const T* begin() const { return p; }
     const T* end() const { return p + n; }
+    // Whole pages of its own: the buffers that hold a run's log are registered with the HIP runtime for the uploads (vm_ensure_pinned),
+    // and a registered range must not share a page with other allocations — the runtime pins pageable copy targets on the fly, page
+    // by page, and releases them again (a registered chunk of the malloc heap next to such a target lost its device mapping now and
+    // then: "Memory access fault by GPU" on a heap address, once in a few runs of the test suite).
+    static constexpr size_t PAGE = 4096;
     void reserve(size_t c) {
         if (c <= cap) return;
         size_t nc = cap ? cap : 256;
         while (nc < c) nc *= 2;
+        const size_t bytes = (nc * sizeof(T) + PAGE - 1) / PAGE * PAGE;
+        void* q = nullptr;
+        if (posix_memalign(&q, PAGE, bytes) != 0 || !q) throw std::bad_alloc();
+        if (n) memcpy(q, p, n * sizeof(T));
         notify_release(p);
-        T* q = (T*)realloc(p, nc * sizeof(T));
-        if (!q) throw std::bad_alloc();
-        p = q, cap = nc;
+        free(p);
+        p = (T*)q, cap = bytes / sizeof(T);
     }
     void push_back(const T& v) {
         if (n == cap) reserve(n + 1);

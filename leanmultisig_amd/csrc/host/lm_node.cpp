@@ -118,11 +118,14 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
     if (!resident) {
         VmRegion reg[5];
         vm_execution_regions(e, reg);
+        // the arena always (a private mapping); a log only when it is a mapping of its own too (allocations of >= 32 MB never come
+        // from the malloc heap: M_MMAP_THRESHOLD's upper bound) — registered chunks of the heap are not safe, see vm_ensure_pinned
+        const size_t own_mapping = 32u << 20;
         ensure_pinned(reg[0], (size_t)(v.memory_len + 24) * 4);
-        ensure_pinned(reg[1], (size_t)v.n_cycles * 4);
-        ensure_pinned(reg[2], (size_t)v.n_cycles * 4);
-        ensure_pinned(reg[3], (size_t)v.n_poseidon_calls * LM_VM_POSEIDON_CALL_WORDS * 4);
-        ensure_pinned(reg[4], (size_t)v.n_extension_rows * LM_VM_EXTENSION_ROW_WORDS * 4);
+        for (int k = 1; k < 5; k++)
+            if (reg[k].bytes >= own_mapping)
+                ensure_pinned(reg[k], k < 3 ? (size_t)v.n_cycles * 4
+                                            : (k == 3 ? (size_t)v.n_poseidon_calls * LM_VM_POSEIDON_CALL_WORDS * 4 : (size_t)v.n_extension_rows * LM_VM_EXTENSION_ROW_WORDS * 4));
     }
     lmh_vm_trace* t = new lmh_vm_trace();
     memset(&t->view, 0, sizeof t->view);

@@ -392,6 +392,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     n_launch, k_ms = ctx.profile_read(dominant)
+    k_busy_ms = ctx.profile_busy_ms()  # the family's launches overlap (three AIR sessions on three streams): time with >= 1 of them running
     sponge_n, sponge_ms = ctx.profile_read("k_leaf_sponge")
     sponge_perms = int(ctx.lib.lm_profile_read_bytes(ctx.h, b"k_leaf_sponge"))  # (this kernel's "bytes" are permutations, lm_commit.hip)
     hbm_live = {k: ctx.profile_read(k) + (int(ctx.lib.lm_profile_read_bytes(ctx.h, k.encode())),) for k in hbm_kernels}
@@ -438,6 +439,10 @@ def main():
             wf = jv.get("issue_cycle_weight")  # issue cycles per instruction / 2, from the kernel's ISA mix (tools/isa_mix.py)
             alu = {"unit": "T VALU lane-instructions/s", "achieved": ach, "peak": VALU_PEAK_T, "frac": ach / VALU_PEAK_T,
                    "issue_cycle_weight": wf, "frac_issue_weighted": ach * wf / VALU_PEAK_T if wf else None,
+                   # the same instructions over the time during which at least one launch of the family was running: the sessions' launches
+                   # overlap on the chip, so the summed launch durations count shared time once per launch
+                   "busy_ms_per_step": k_busy_ms / args.steps, "summed_ms_per_step": k_ms / args.steps,
+                   "frac_issue_weighted_over_busy_time": (lane_ops * args.steps / (k_busy_ms * 1e-3) / 1e12 * wf / VALU_PEAK_T) if wf and k_busy_ms > 0 else None,
                    "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r04_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
                              "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
                              "v_mul_lo/hi_u32, v_mad_u64_u32 at 4 cycles per wave64, v_lshl_add_u64 at its measured 7.4, the rest 2 "

@@ -56,6 +56,9 @@ void* lm_ctx_stream(lm_ctx* ctx);
  * lm_profile_read synchronises, returns launch count and summed duration for one kernel and clears its records. */
 int lm_profile_select(lm_ctx* ctx, const char* kernel_name);
 int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, double* total_ms);
+/* of the launches the last lm_profile_read consumed: the time during which at least one of them was running (launches of one
+ * kernel family on several streams overlap — the AIR sessions —, so this is less than their summed duration) */
+double lm_profile_busy_ms(lm_ctx* ctx);
 /* the ALGORITHMIC HBM bytes of the recorded launches of an HBM-bound kernel (k_prod_round2 / k_fold2_round: every f and W value
  * read once, the folded tables written once), for GB/s = bytes / HIP-event time; clears the counter.  lm_profile_select accepts
  * a comma-separated list of kernel names. */

@@ -33,6 +33,7 @@ _SIGS = {
     "lm_wait_log": (C.c_int, [vp, C.c_int]),
     "lm_wait_log_read": (C.c_uint64, [vp, vp, C.c_uint64]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
+    "lm_profile_busy_ms": (C.c_double, [vp]),
     "lm_profile_read_bytes": (C.c_uint64, [vp, C.c_char_p]),
     "lm_malloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "lm_free": (C.c_int, [vp, vp]),
@@ -519,6 +520,10 @@ class Context:
         n, ms = C.c_uint64(0), C.c_double(0.0)
         self._check(self.lib.lm_profile_read(self.h, kernel_name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_busy_ms(self):
+        """of the launches the last profile_read consumed: the time during which at least one of them ran (streams overlap)"""
+        return float(self.lib.lm_profile_busy_ms(self.h))
 
     def wait_log(self, on=True):
         """start (and clear) / stop the log of host <-> device exchanges (lm_wait_log)"""

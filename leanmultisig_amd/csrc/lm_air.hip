@@ -747,10 +747,11 @@ static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const E
         BaseCols c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt};
         return launch_cols<TABLE, u32, BaseCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
     }
-    if (a->cur == -2) {
-        using FC = FoldCols<TABLE != air::T_POSEIDON16>;
-        FC c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt, a->r1};
-        return launch_cols<TABLE, EF, FC>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
+    if constexpr (TABLE == air::T_POSEIDON16) {  // (lm_air_new: only that table's first fold stays unmaterialised)
+        if (a->cur == -2) {
+            FoldCols<false> c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt, a->r1};
+            return launch_cols<TABLE, EF, FoldCols<false>>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
+        }
     }
     ExtCols c{a->ef[a->cur], 1ull << (a->log_rows - a->round)};  // (rows of the folded table: n_pairs may be the active prefix only)
     return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
@@ -825,7 +826,9 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     for (u32 v = 0; v < a->n_virt; v++) a->h_cols.push_back(a->d_virt + ((u64)v << log_rows));
     // FoldCols reads four consecutive rows of a column with one 16-byte load (LM_AIR_NO_LAZY_FOLD=1: every fold is materialised)
     static const bool lazy = getenv("LM_AIR_NO_LAZY_FOLD") == nullptr;
-    a->lazy_ok = lazy && log_rows >= 2;
+    // The Poseidon table only: the ExtensionOp evaluation with its shift views compiles to 445 VGPRs over FoldCols (one wave per SIMD:
+    // a 2^18-row table took 7 ms longer), and the execution table's first fold is small.
+    a->lazy_ok = lazy && log_rows >= 2 && table == air::T_POSEIDON16;
     for (const u32* cp : a->h_cols) a->lazy_ok = a->lazy_ok && (reinterpret_cast<uintptr_t>(cp) & 15) == 0;
     int rc;
     if ((rc = lm_stage_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||

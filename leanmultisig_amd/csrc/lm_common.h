@@ -84,6 +84,8 @@ struct lm_ctx {
     // optional per-kernel HIP-event timing (bench.py roofline leg): only launches whose kernel name is selected
     std::string prof_select;    // empty = profiling off; "*" = every kernel
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    hipEvent_t prof_origin = nullptr;  // recorded by lm_profile_select: the time origin of lm_profile_busy_ms
+    double prof_last_busy_ms = 0.0;
     std::map<std::string, u64> prof_bytes;  // algorithmic bytes of the recorded launches of a kernel (LM_PROF_BYTES at its launch sites)
     // device copies of long-lived host objects (a bytecode's instruction table, decoded records, hints), keyed by the object's
     // process-unique id: pool allocations of THIS context, gone with it (lm_ctx_cache_get / _put) — a cache inside the host object

@@ -647,6 +647,7 @@ void lm_ctx_destroy(lm_ctx* c) {
             (void)hipStreamDestroy(c->aux_stream[i]);
         }
     if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+    if (c->prof_origin) (void)hipEventDestroy(c->prof_origin);
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_tw_small) (void)hipFree(c->d_tw_small);
     if (c->d_coop) (void)hipFree(c->d_coop);
@@ -686,8 +687,13 @@ void* lm_ctx_stream(lm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int lm_profile_select(lm_ctx* ctx, const char* kernel_name) {
     LM_REQUIRE(ctx);
     ctx->prof_select = kernel_name ? kernel_name : "";
+    if (!ctx->prof_select.empty()) {  // time origin for lm_profile_busy_ms: in front of every launch that will be recorded
+        if (!ctx->prof_origin) LM_HIP(hipEventCreate(&ctx->prof_origin));
+        LM_HIP(hipEventRecord(ctx->prof_origin, ctx->stream));
+    }
     return LM_OK;
 }
+double lm_profile_busy_ms(lm_ctx* ctx) { return ctx ? ctx->prof_last_busy_ms : 0.0; }
 // names of the kernels that have recorded launches, '\n'-separated (template arguments stripped); returns the length needed
 uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap) {
     if (!ctx) return 0;
@@ -727,6 +733,7 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
     *total_ms = 0.0;
     // template instantiations are recorded as "name<args>": a bare name matches all of them
     const std::string want = kernel_name;
+    std::vector<std::pair<double, double>> spans;  // (start, end) of every launch, ms after lm_profile_select
     for (auto it = ctx->prof_events.begin(); it != ctx->prof_events.end();) {
         std::string key = it->first;
         if (!key.empty() && key[0] == '(') key = key.substr(1);
@@ -736,15 +743,29 @@ int lm_profile_read(lm_ctx* ctx, const char* kernel_name, uint64_t* n_launches, 
             continue;
         }
         for (auto& pr : it->second) {
-            float ms = 0.f;
+            float ms = 0.f, t0 = 0.f;
             LM_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
             *total_ms += ms;
             *n_launches += 1;
+            if (ctx->prof_origin && hipEventElapsedTime(&t0, ctx->prof_origin, pr.first) == hipSuccess) spans.emplace_back((double)t0, (double)t0 + ms);
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
         it = ctx->prof_events.erase(it);
     }
+    (void)hipGetLastError();
+    // launches of one family on several streams overlap (the AIR sessions): the time during which at least one of them ran
+    std::sort(spans.begin(), spans.end());
+    double busy = 0.0, lo = 0.0, hi = -1.0;
+    for (auto& sp : spans) {
+        if (hi < lo || sp.first > hi) {
+            if (hi >= lo) busy += hi - lo;
+            lo = sp.first, hi = sp.second;
+        } else if (sp.second > hi)
+            hi = sp.second;
+    }
+    if (hi >= lo) busy += hi - lo;
+    ctx->prof_last_busy_ms = busy;
     return LM_OK;
 }
 

@@ -442,6 +442,8 @@ def main():
                    # the same instructions over the time during which at least one launch of the family was running: the sessions' launches
                    # overlap on the chip, so the summed launch durations count shared time once per launch
                    "busy_ms_per_step": k_busy_ms / args.steps, "summed_ms_per_step": k_ms / args.steps,
+                   # and with the family's launches serialised (the counter pass of the same sources: one kernel at a time)
+                   "frac_issue_weighted_serialised": jv.get("alu_frac_issue_weighted"), "serialised_ms_per_step": jv.get("kernel_ms_under_pmc"),
                    "frac_issue_weighted_over_busy_time": (lane_ops * args.steps / (k_busy_ms * 1e-3) / 1e12 * wf / VALU_PEAK_T) if wf and k_busy_ms > 0 else None,
                    "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r04_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
                              "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
@@ -497,7 +499,10 @@ def main():
                                   "FETCH x2 per MI355X_MICROARCH.md); refused when recorded for other kernel sources",
                 "note": "live: HIP events on the prover's streams around every k_air_round launch of the timed region (one proof "
                         "alone on the chip); instruction counts from profiles/r04_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
-                        "The constraint evaluation is integer-ALU bound — see DESIGN.md §3",
+                        "The constraint evaluation is integer-ALU bound — see DESIGN.md §3.  `frac` divides by the SUM of the launch "
+                        "durations; the three AIR sessions run on three streams and their large launches overlap, so shared time is "
+                        "counted once per launch: alu.frac_issue_weighted_over_busy_time uses the time with at least one launch running, "
+                        "alu.frac_issue_weighted_serialised the counter pass (one kernel at a time)",
                 "alu": alu,
                 # ~20 G modular multiplications per proof for the Poseidon16 AIR sumcheck at 2^18 rows (+ ~1 G for the two
                 # small tables), scaled to the active rows of this workload: the family's algorithmic rate

@@ -1728,6 +1728,14 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
         reg[0] = {(void*)memory.p, (size_t)MAX_MEMORY * 4};
         vm_ensure_pinned(reg[0], (size_t)(memory.len + 24) * 4);
     }
+    // a pending call whose output cells lie at or above split_at (iteration 0 hashed into the next frame) would define them in the arena
+    // behind the window, where the end-of-run upload does not look: such calls are executed before the image goes up
+    for (const MemBuf::LazyCall& c : memory.lazy)
+        if (!c.done && c.kind == 0 && c.res + c.n_out > split_at) {
+            memory.lazy_drain();
+            break;
+        }
+    if (memory.lazy_failed) return fallback(nullptr);
     if (!dev_image_reserve(D, memory.len)) return DEV_ERROR;
     if (!dev_upload_host_owned(D, memory, 0, std::max(split_at, std::min(old_len, frames_end))) || !dev_upload_host_owned(D, memory, frames_end, memory.len))
         return DEV_ERROR;

@@ -11,6 +11,7 @@ TAG=${1:-r04_final}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
+rm -rf $OUT/stats_inflight1  # (an older trace in the same directory would be picked up by the summaries)
 cd /tmp && export TMPDIR=/tmp
 B1="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 --no-whole-node"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inflight1 -- $B1 > $OUT/bench_under_rocprof.json 2> $OUT/stats1.err

@@ -13,6 +13,8 @@ void lm_set_error(const char* fmt, ...);  // lm_core.hip (thread-local message b
 // tag); the entries are pool allocations of the context (lm_malloc) and die with it
 unsigned long long lm_ctx_uid(lm_ctx* ctx);         // process-unique id of a live context
 lm_ctx* lm_ctx_by_uid(unsigned long long uid);      // nullptr once that context has been destroyed
+// fn(ctx, arg) under the registry lock iff context `uid` is alive and is `expect` (the context cannot be destroyed meanwhile)
+bool lm_ctx_with_live(unsigned long long uid, lm_ctx* expect, void (*fn)(lm_ctx*, void*), void* arg);
 void* lm_ctx_cache_get(lm_ctx* ctx, unsigned long long key);
 void lm_ctx_cache_put(lm_ctx* ctx, unsigned long long key, void* p);
 

@@ -1569,11 +1569,14 @@ struct DevRun {
 };
 void dev_run_free(DevRun* d) {
     if (!d) return;
-    if (lm_ctx_by_uid(d->ctx_uid) == d->ctx) {  // (else: the context is gone, and its device pool with it)
-        for (DevBatch& b : d->batches)
-            for (u32* p : b.owned) lm_free(d->ctx, p);
-        for (u32* p : d->owned) lm_free(d->ctx, p);
-    }
+    // (context gone: its device pool went with it.)  May run on any thread (a garbage collector): the registry lock is held across the
+    // frees, so the context cannot be destroyed under them, and the pool has its own lock (round-4 advisor finding)
+    lm_ctx_with_live(d->ctx_uid, d->ctx, [](lm_ctx* ctx, void* arg) {
+        DevRun* r = (DevRun*)arg;
+        for (DevBatch& b : r->batches)
+            for (u32* p : b.owned) lm_free(ctx, p);
+        for (u32* p : r->owned) lm_free(ctx, p);
+    }, d);
     delete d;
 }
 
@@ -1600,10 +1603,12 @@ bool dev_program(DevRun& D, const lmh_bytecode& bc) {
     if (D.d_code && D.d_hint_begin && D.d_hints) return true;
     u32 *c = nullptr, *hb = nullptr, *h = nullptr;
     const u64 wc = (bc.code.size() * sizeof(VmInstr) + 3) / 4, wh = (bc.hints.size() * sizeof(VmHintRec) + 3) / 4;
-    if (lm_malloc(D.ctx, wc ? wc : 1, &c) || lm_malloc(D.ctx, bc.hint_begin.size(), &hb) || lm_malloc(D.ctx, wh ? wh : 1, &h)) return false;
-    if (vm_dev_upload(D.ctx, c, bc.code.data(), bc.code.size() * sizeof(VmInstr)) || vm_dev_upload(D.ctx, hb, bc.hint_begin.data(), bc.hint_begin.size() * 4) ||
-        vm_dev_upload(D.ctx, h, bc.hints.data(), bc.hints.size() * sizeof(VmHintRec)) || lm_sync(D.ctx))
+    if (lm_malloc(D.ctx, wc ? wc : 1, &c) || lm_malloc(D.ctx, bc.hint_begin.size(), &hb) || lm_malloc(D.ctx, wh ? wh : 1, &h) ||
+        vm_dev_upload(D.ctx, c, bc.code.data(), bc.code.size() * sizeof(VmInstr)) || vm_dev_upload(D.ctx, hb, bc.hint_begin.data(), bc.hint_begin.size() * 4) ||
+        vm_dev_upload(D.ctx, h, bc.hints.data(), bc.hints.size() * sizeof(VmHintRec)) || lm_sync(D.ctx)) {
+        lm_free(D.ctx, c), lm_free(D.ctx, hb), lm_free(D.ctx, h);  // (lm_free(nullptr) is a no-op)
         return false;
+    }
     lm_ctx_cache_put(D.ctx, key | 1, c), lm_ctx_cache_put(D.ctx, key | 2, hb), lm_ctx_cache_put(D.ctx, key | 3, h);
     D.d_code = (const VmInstr*)c, D.d_hint_begin = hb, D.d_hints = (const VmHintRec*)h;
     return true;
@@ -1637,8 +1642,10 @@ bool dev_image_reserve(DevRun& D, u64 need) {
     const u64 cap = need + (1u << 16);
     u32* n = nullptr;
     if (lm_malloc(D.ctx, cap, &n) != LM_OK) return false;
-    if (D.d_image && lm_copy_d2d(D.ctx, n, D.d_image, D.image_cap) != LM_OK) return false;
-    if (vm_dev_fill(D.ctx, n + D.image_cap, VM_UNDEF, cap - D.image_cap) != LM_OK) return false;
+    if ((D.d_image && lm_copy_d2d(D.ctx, n, D.d_image, D.image_cap) != LM_OK) || vm_dev_fill(D.ctx, n + D.image_cap, VM_UNDEF, cap - D.image_cap) != LM_OK) {
+        lm_free(D.ctx, n);
+        return false;
+    }
     if (D.d_image) {
         for (u32*& p : D.owned)
             if (p == D.d_image) p = n;
@@ -1704,8 +1711,12 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     };
     bool host_grown = false;
     auto fallback = [&](DevBatch* b) {
-        if (b)
+        if (b) {
             for (u32* p : b->owned) lm_free(D.ctx, p);
+            // the abandoned batch's deferred writes may have defined image cells above the memory's length, where the uploads of a later
+            // batch (which cover [0, memory.len)) do not reach: back to None
+            if (max_addr < D.image_cap && vm_dev_fill(D.ctx, D.d_image + max_addr, VM_UNDEF, D.image_cap - max_addr) != LM_OK) return (int)DEV_ERROR;
+        }
         if (host_grown) fill_host(std::max(old_len, split_at), frames_end);  // the host batch expects its frames initialised
         if (!dev_close_windows(D, memory)) return (int)DEV_ERROR;
         memory.dev_lo = memory.dev_hi = 0;
@@ -1737,6 +1748,13 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
         }
     if (memory.lazy_failed) return fallback(nullptr);
     if (!dev_image_reserve(D, memory.len)) return DEV_ERROR;
+    // the output cells of the calls still pending go up POISONED (VM_PENDING), not as None: a segment that touches one in any way ends
+    // there (several reads tolerate None: a DEREF with an unknown result, the ADD / MUL / ExtensionOp solvers).  The arena cells hold
+    // the poison only until lazy_drain below, which writes every digest; no host read of the arena lies in between.
+    if (memory.lazy_open)
+        for (const MemBuf::LazyCall& c : memory.lazy)
+            if (!c.done && c.kind == 0)
+                for (u32 j = 0; j < c.n_out; j++) memory.p[c.res + j] = VM_PENDING;
     if (!dev_upload_host_owned(D, memory, 0, std::max(split_at, std::min(old_len, frames_end))) || !dev_upload_host_owned(D, memory, frames_end, memory.len))
         return DEV_ERROR;
     // ---- slots sized from what iteration 0 logged on the host
@@ -1766,7 +1784,9 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     for (size_t k = 0; k < cur.index.size(); k++) a.cur_index[k] = cur.index[k], a.per_iter[k] = per_iter[k];  // (kernel arguments: <= 64 names)
     a.n_instructions = (u32)bc.n_instructions, a.ending_pc = bc.ending_pc, a.n_hints = (u32)bc.hints.size();
     a.prefix_cache = (u32)std::min<u64>(split_at, VM_DEV_PREFIX_CACHE);
+#ifdef LM_VM_DEBUG  // timing experiments (tools/vm_device_probe.py): the knobs make results WRONG, so they exist in debug builds only
     if (const char* e = getenv("LM_VM_DBG")) a.dbg = (u32)strtoul(e, nullptr, 10);
+#endif
     a.wit_data = D.d_wit_data, a.wit_entry_offset = D.d_wit_off, a.wit_name_begin = D.d_wit_names;
     a.n_names = bc.n_names;
     a.image = D.d_image, a.init_len = old_len, a.split_at = split_at, a.stride = stride, a.batch_fp = batch.batch_fp, a.frame_size = batch.frame_size;
@@ -2154,6 +2174,16 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             if (how == DEV_ERROR) {
                 device_failed = true;
                 break;
+            }
+            if (how == DEV_FALLBACK && D && D->windows_open) {
+                // a host batch behind a device batch: its segments read the arena directly (SegMem, no MemBuf::guard), so the frames of the
+                // earlier device batches — current in the device image only — come back first (round-4 advisor finding: device_batch's early
+                // returns did not do this, only its fallback() lambda)
+                if (!dev_close_windows(*D, memory)) {
+                    device_failed = true;
+                    break;
+                }
+                memory.dev_lo = memory.dev_hi = 0;
             }
             const bool ok = how == DEV_DONE || handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
             t_batches += vm_now_ms() - tb;

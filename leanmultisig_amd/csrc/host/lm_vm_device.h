@@ -42,6 +42,11 @@ enum {
 };
 
 static constexpr u32 VM_UNDEF = 0xFFFFFFFFu;  // "None" (values are < p < 2^31)
+// A cell of the shared prefix whose defining Poseidon call the sequential runner has recorded but not yet executed (MemBuf, lm_vm.cpp):
+// on the host it is None + an owner; a segment must not treat it as None — DEREF with an unknown result, ADD / MUL solving for an
+// operand and the ExtensionOp solver all TOLERATE None and would go on with a memory the reference never has (round-4 advisor
+// finding).  The image carries this poison word there instead, and any read of it ends the segment (the batch moves to the host pool).
+static constexpr u32 VM_PENDING = 0xFFFFFFFEu;
 static constexpr u32 VM_DEV_MAX_ARGS = 16;    // call-frame arguments of a batch
 static constexpr u32 VM_DEV_MAX_NAMES = 64;   // named hint streams
 static constexpr u32 VM_DEV_PREFIX_CACHE = 2048;  // words of the lowest addresses every workgroup keeps in LDS
@@ -66,7 +71,7 @@ struct VmSegArgs {  // kernel argument of k_vm_segments (by value)
     u64 init_len, split_at, stride, batch_fp, frame_size;
     u32 batch_pc;
     u32 prefix_cache;  // image[0 .. prefix_cache) is also kept in LDS (<= split_at, <= VM_DEV_PREFIX_CACHE)
-    u32 dbg;           // LM_VM_DBG (timing experiments only: results are wrong): 1 skip the permutation, 2 skip the call records, 4 skip the pc / fp log
+    u32 dbg;           // builds with -DLM_VM_DEBUG only (LM_VM_DBG, timing experiments: results are wrong): 1 skip the permutation, 2 skip the call records, 4 skip the pc / fp log; else 0
     // call frames (write_call_frame, runner.rs:353-367)
     u32 return_pc_m, saved_fp_m;  // Montgomery words
     u64 start_value;

@@ -7,6 +7,7 @@
 #include <vector>
 #include <string>
 #include <map>
+#include <mutex>
 #include <utility>
 #include "../../include/leanmultisig.h"
 #include "kb.h"
@@ -77,6 +78,7 @@ struct lm_ctx {
     hipEvent_t fork_event = nullptr;
     // caching device allocator: freed blocks are kept per size class and reused (hipMalloc/hipFree synchronise the
     // device; a proof performs ~100 allocations).  Single stream => reuse is stream-ordered and safe.
+    std::mutex pool_mu;  // lm_pool_alloc / lm_pool_free may be reached from another thread (a device-resident lmh_execution released by a garbage collector)
     std::multimap<u64, void*> pool_free;
     std::map<void*, u64> pool_size;   // every block this pool owns -> its size class
     std::map<void*, bool> pool_in_use;  // handed out and not yet freed (a second lm_pool_free of the same pointer is ignored)

@@ -24,6 +24,15 @@ lm_ctx* lm_ctx_by_uid(unsigned long long uid) {
     auto it = g_ctx_live.find(uid);
     return it == g_ctx_live.end() ? nullptr : it->second;
 }
+// fn(ctx) under the registry lock when the context with that id is still alive (lm_ctx_destroy waits in ctx_unregister): a release
+// that may run on any thread cannot race with the destruction of the context whose pool it returns blocks to
+bool lm_ctx_with_live(unsigned long long uid, lm_ctx* expect, void (*fn)(lm_ctx*, void*), void* arg) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx_live.find(uid);
+    if (it == g_ctx_live.end() || it->second != expect) return false;
+    fn(expect, arg);
+    return true;
+}
 static void ctx_register(lm_ctx* c) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     c->uid = g_ctx_next_uid++;
@@ -296,6 +305,7 @@ static u64 pool_class(u64 bytes) {
 }
 hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
     const u64 cls = pool_class(bytes);
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
     auto it = ctx->pool_free.find(cls);
     if (it != ctx->pool_free.end()) {
         *out = it->second;
@@ -326,6 +336,7 @@ hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes) {
 }
 void lm_pool_free(lm_ctx* ctx, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(ctx->pool_mu);
     auto it = ctx->pool_size.find(p);
     if (it == ctx->pool_size.end()) {  // not ours
         (void)hipFree(p);

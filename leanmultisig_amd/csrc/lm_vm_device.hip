@@ -63,7 +63,7 @@ struct Machine {
     u32 fp;
     u64 ap;
     u32 n_cyc = 0, n_pos = 0, n_ext = 0, n_pend = 0, n_def = 0, n_add = 0, n_mul = 0, n_deref = 0, n_jump = 0;
-    u32 err = 0, err_aux = 0;
+    mutable u32 err = 0, err_aux = 0;  // (mutable: reading a poisoned cell fails the segment from the const read paths)
     u32 *pcs, *fps, *pos, *ext, *pend, *def;  // this segment's slots
     // hot kernel arguments as plain members behind an opaque copy (hot_args): left in the kernarg segment the compiler re-loads them
     // with scalar loads at every use under register pressure (373 s_load in the first version, a wait on each)
@@ -84,8 +84,15 @@ struct Machine {
     }
 
     __device__ __forceinline__ Machine(const VmSegArgs& a) : A(a) {}
+    __device__ __forceinline__ bool dbg_bit(u32 b) const {  // the timing knobs exist in -DLM_VM_DEBUG builds only (round-4 advisor finding)
+#ifdef LM_VM_DEBUG
+        return k_dbg & b;
+#else
+        return false;
+#endif
+    }
 
-    __device__ __forceinline__ void fail(u32 code, u64 aux) {
+    __device__ __forceinline__ void fail(u32 code, u64 aux) const {
         if (!err) err = code, err_aux = (u32)aux;
     }
     // ---- SegmentMemory (memory.rs:118-189) ------------------------------------------------------------------------------------------
@@ -96,7 +103,14 @@ struct Machine {
         if (o < k_stride) return frame[o];
         return UNDEF;
     }
-    __device__ __forceinline__ u32 peek_u(u32 a) const { return rfl(peek(a)); }  // wave-uniform address
+    __device__ __forceinline__ u32 peek_u(u32 a) const {  // wave-uniform address
+        u32 v = rfl(peek(a));
+        if (v == VM_PENDING) {  // a digest the host has not computed yet (lm_vm_device.h): not None — the segment gives up
+            fail(VM_E_UNSUPPORTED, 4);
+            v = UNDEF;
+        }
+        return v;
+    }
     // deferred write list: the lanes of `active` append (addr, value) in lane order
     __device__ __forceinline__ void defer_lanes(bool active, u32 a, u32 v) {
         const u64 m = __ballot(active);
@@ -335,8 +349,8 @@ struct Machine {
         const u32 l = lane & 15;  // the four 16-lane rows of the wave compute the same permutation
         const u32 src = l < 4 ? left_first + l : (l < 8 ? left_second + (l - 4) : arg_b + (l - 8));
         const u32 s = peek(src);
-        if (__ballot(s == UNDEF)) {
-            fail(VM_E_UNDEFINED_MEMORY, src);
+        if (__ballot(s == UNDEF || s == VM_PENDING)) {
+            fail(__ballot(s == VM_PENDING) ? VM_E_UNSUPPORTED : VM_E_UNDEFINED_MEMORY, src);
             return;
         }
         CoopRegs R;
@@ -355,11 +369,15 @@ struct Machine {
 #pragma unroll
             for (u32 i = 0; i < sizeof(CoopRegs) / 4; i++) asm volatile("" : "+v"(rw[i]));
         }
+#ifdef LM_VM_DEBUG
         const u32 o = (k_dbg & 1) ? s : (permute ? coop_permute(s, R) : coop_compress(s, R));
+#else
+        const u32 o = permute ? coop_permute(s, R) : coop_compress(s, R);
+#endif
         const u32 n_out = permute ? 16u : (half ? 4u : 8u);
         set_lanes(lane < n_out, res + lane, o);
         if (err) return;
-        if (lane == 0 && !(k_dbg & 2)) {
+        if (lane == 0 && !dbg_bit(2)) {
             u32* rec = pos + (u64)n_pos * LM_VM_POSEIDON_CALL_WORDS;
             rec[0] = arg_a, rec[1] = arg_b, rec[2] = res, rec[3] = half ? 1u : 0u, rec[4] = hard ? 1u : 0u, rec[5] = hard ? in.x1 : 0u;
             rec[6] = left_first, rec[7] = left_second, rec[8] = permute ? 1u : 0u;
@@ -642,7 +660,7 @@ struct Machine {
                 fail(VM_E_LOG_CAPACITY, 1);
                 return;
             }
-            if (lane == 0 && !(k_dbg & 4)) pcs[n_cyc] = pc, fps[n_cyc] = (u32)fp;
+            if (lane == 0 && !dbg_bit(4)) pcs[n_cyc] = pc, fps[n_cyc] = (u32)fp;
             n_cyc++;
             if (pc - win_base >= win_n) {  // refill the instruction window at pc
                 win_base = pc;

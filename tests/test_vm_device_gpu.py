@@ -42,28 +42,32 @@ def same_as_oracle(ctx, orc, bc, pi, w, expect_device=True, n_threads=2):
     return ex, run
 
 
-def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=False, head=None):
+def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=False, head=None, second_body=None, second_parallel=False):
     """main calls a PARALLEL loop over i in [0, n): frame = [ret, fp, i, end, out, perm, (extra args) | d, inv, nz, omnz, locals...];
     body(p, L) emits the iteration (L = first free frame offset); after(p) emits code behind the loop in main; second_loop: main then
     calls a second, sequential copy of the loop (one run_loop arms one batch, runner.rs:150-163: a later ParallelBatchStart is ignored);
+    second_body / second_parallel: the second loop runs second_body over i in [0, n2) (hint "n2"), as a parallel batch of its own when
+    second_parallel (handle_parallel_batch returns to a NEW run_loop, runner.rs:262-298, which arms the next ParallelBatchStart);
     head(p) emits code in main in front of the loop (main's frame grows to 200 cells, 64.. are free)."""
     p = Program()
-    N, OUT, PERM, LF, LF2 = 0, 1, 2, 3, 4
+    N, OUT, PERM, LF, LF2, N2 = 0, 1, 2, 3, 4, 5
     n_args = 4 + n_extra_args
     p.add(K(0), K(0), M(20))
     p.hint_witness("n", N)
+    if second_body:
+        p.hint_witness("n2", N2)
     p.hint_request_memory(OUT, M(N))
     p.hint_request_memory(PERM, M(N))
     p.hint_witness("perm", PERM, indirect=True)
     if head:
         head(p)
 
-    def call(lf, label, ret):
-        p.hint_request_memory(lf, K(Label("@frame")))
+    def call(lf, label, ret, n_cell=N, frame="@frame"):
+        p.hint_request_memory(lf, K(Label(frame)))
         p.deref(lf, 0, K(Label(ret)))
         p.deref(lf, 1, FP(0))
         p.deref(lf, 2, K(0))
-        p.deref(lf, 3, M(N))
+        p.deref(lf, 3, M(n_cell))
         p.deref(lf, 4, M(OUT))
         p.deref(lf, 5, M(PERM))
         for k in range(n_extra_args):
@@ -73,7 +77,7 @@ def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=Fa
 
     call(LF, "loop", "after")
     if second_loop:
-        call(LF2, "loop_b", "after2")
+        call(LF2, "loop_b", "after2", N2 if second_body else N, "@frame_b" if second_body else "@frame")
     if after:
         after(p)
     p.return_from_main(21)
@@ -82,7 +86,7 @@ def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=Fa
     d, inv, nz, omnz = 2 + n_args, 3 + n_args, 4 + n_args, 5 + n_args
     L = 6 + n_args
 
-    def emit_loop(tag, parallel):
+    def emit_loop(tag, parallel, body=body, frame_label="@frame"):
         if parallel:
             p.hint_parallel_batch_start(n_args, M(END))
         p.label("loop" + tag)
@@ -106,11 +110,11 @@ def loop_program(body, n_extra_args=0, frame_extra=0, after=None, second_loop=Fa
         for a in range(3, 2 + n_args):
             p.deref(nxt, a, M(a))
         p.jump(K(1), K(Label("loop" + tag)), M(nxt))
-        p.labels["@frame"] = frame
+        p.labels[frame_label] = frame
 
     emit_loop("", True)
     if second_loop:
-        emit_loop("_b", False)
+        emit_loop("_b", second_parallel, second_body or body, "@frame_b" if second_body else "@frame")
     return p
 
 
@@ -267,6 +271,35 @@ def test_sequential_loop_behind_the_device_batch(ctx, orc):
     assert ex.n_poseidon_calls == 4 * n
 
 
+def frame_reader_body(p, L):
+    """iteration i of the SECOND loop reads a hash word of the first loop's segment i + 1 (through main's frame pointer, saved in the
+    call frame: main's cell 3 holds the first loop's frame of iteration 0) and stores a function of it"""
+    lf, off, seg, v = L, L + 1, L + 2, L + 3
+    p.deref(1, 3, M(lf))                                   # m[main fp + 3] = frame of iteration 0 of the first loop
+    p.add(M(2), K(1), M(off))
+    p.mul(M(off), K(Label("@frame")), M(off + 10))         # (i + 1) * frame size
+    p.add(M(lf), M(off + 10), M(seg))
+    p.deref(seg, 18, M(v))                                 # first hash word of that segment (hash_and_store_body: h = L + 8 = 18)
+    p.add(M(v), K(7), M(v + 1))
+    p.poseidon16(M(seg), M(seg), FP(L + 16))               # and hashes the start of the segment's frame
+    return 24
+
+
+@pytest.mark.parametrize("n2,second_parallel", [(9, True), (9, False), (40, True)])
+def test_host_batch_behind_a_device_batch_reads_its_frames(ctx, orc, n2, second_parallel):
+    """Round-4 advisor finding: a batch that does not qualify for the device (fewer than 32 segments) behind one that ran there.  Its
+    segments read the frames of the first batch, which exist only in the device image until the window is closed: the host batch must
+    see them (csrc/host/lm_vm.cpp: execute_impl closes the windows before every host batch).  n2 = 40: both batches on the device, the
+    second one reads the first one's frames from the image."""
+    n = 64
+    rng = np.random.default_rng(5)
+    bc = loop_program(hash_and_store_body, second_loop=True, second_body=frame_reader_body, second_parallel=second_parallel).finalize()
+    h = hints_for(n, rng)
+    h["n2"] = [mont([n2])]
+    ex, run = same_as_oracle(ctx, orc, bc, PI, Witness(bc, 0, h))
+    assert ex.n_poseidon_calls == 2 * n + n2
+
+
 def chain_head(n_links, expected, read_in_body=False):
     """main hashes a chain of n_links compressions over a hinted block in front of the loop and checks the last digest against five
     expected words (copy_5): with a device context the runner records these calls and the check (csrc/host/lm_vm.cpp: MemBuf) and
@@ -315,8 +348,11 @@ def test_hash_chain_and_its_check_in_front_of_the_device_batch(ctx, orc):
     assert str(dev.value) == str(host.value)
 
 
-def test_segments_reading_a_pending_digest_send_the_batch_to_the_host(ctx, orc):
-    """iteration i reads a word of the chain's digest number which[i] through main's frame pointer (saved in its call frame).  Iteration
+@pytest.mark.parametrize("use", ["strict", "deref_only", "solve"])
+def test_segments_reading_a_pending_digest_send_the_batch_to_the_host(ctx, orc, use):
+    """(use = deref_only / solve: round-4 advisor finding — reads that TOLERATE None: a DEREF whose result nobody reads strictly, and an
+    ADD that would solve for the cell the DEREF left undefined; the image carries VM_PENDING in such cells, not None.)
+    iteration i reads a word of the chain's digest number which[i] through main's frame pointer (saved in its call frame).  Iteration
     0 — run by the host, which executes what it needs of the chain — reads link 0; the later links are still None in the image the
     segments get: they fail there, and the batch runs on the host pool — same log as the oracle's"""
     n, links = 64, 5
@@ -331,13 +367,31 @@ def test_segments_reading_a_pending_digest_send_the_batch_to_the_host(ctx, orc):
         p.mul(M(w), K(8), M(w8))
         p.add(M(1), M(w8), M(ptr))                            # main's fp + 8 * which
         p.deref(ptr, 80 + 3, M(v))                            # word 3 of that link's digest
-        p.add(M(v), K(1), M(v + 1))
-        return used + 5
+        if use == "strict":
+            p.add(M(v), K(1), M(v + 1))
+        elif use == "solve":                                  # with v None the ADD would DEFINE v = expect - 1 instead of CHECKING v + 1 == expect
+            p.hint_witness("expect", v + 1)
+            p.add(M(v), K(1), M(v + 1))
+        return used + 6
 
     hints = hints_for(n, rng)
     hints["head_block"] = [block]
     hints["which"] = [mont([0])] + [mont([int(x)]) for x in rng.integers(1, links, n - 1)]
     bc = loop_program(body, head=chain_head(links, d)).finalize()
+    if use == "solve":
+        # link k's digest word 3, + 1 — wrong in one iteration: the reference's check fails there, and so must this run (same error text)
+        digests = [chain_digest(orc, block, k + 1) for k in range(links)]
+        which = [int(from_monty(x)[0]) for x in hints["which"]]
+        hints["expect"] = [mont([(int(digests[k][3]) + 1) % P]) for k in which]
+        same_as_oracle(ctx, orc, bc, PI, Witness(bc, 0, hints), expect_device=False)
+        hints["expect"][n // 2] = mont([(int(digests[which[n // 2]][3]) + 2) % P])
+        w = Witness(bc, 0, hints)
+        with pytest.raises(lm.LmError, match="ParallelSegmentFailed") as dev:
+            execute(bc, PI, w, n_threads=2, ctx=ctx)
+        with pytest.raises(lm.LmError) as host:
+            execute(bc, PI, w, n_threads=2)
+        assert str(dev.value) == str(host.value)
+        return
     same_as_oracle(ctx, orc, bc, PI, Witness(bc, 0, hints), expect_device=False)
 
 

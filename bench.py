@@ -70,10 +70,12 @@ def build_vm_workload(ctx, rng, n_sigs, log_inv_rate, capacity, log_bytecode=19)
     n_vars = ctx.lib.lmh_stacked_n_vars(lm.capi.C.byref(tr))
     lm_builder = lm.WhirBuilder.default(log_inv_rate, prox_gaps_conjecture=capacity)
     cfg = lm.WhirConfig.new(lm_builder, n_vars)
+    # aggregate_type_1 takes the (public key, signature) pairs in ANY order (it sorts them, type_1_aggregation.rs:232): the step gets them shuffled
+    raw = vm.pack_xmss_signatures(info["sig"])[np.random.default_rng(5).permutation(n_sigs)]
     w = dict(n_sigs=n_sigs, log_rows={t: int(tr.tables[t].log_rows) for t in range(3)}, log_memory=int(tr.log_memory), log_bytecode=bc.log_size,
              ending_pc=bc.ending_pc, public_input=pi, bytecode_hash=bc.hash(), bytecode=bc.multilinear,
              counts=dict(poseidon=ex.n_poseidon_calls, extension_op=ex.n_extension_rows, cycles=ex.n_cycles, **ex.counts))
-    return dict(w=w, tr=tr, keep=[dt, ex], cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, lm_builder=lm_builder, vm=dict(bc=bc, pi=pi, wit=wit, info=info),
+    return dict(w=w, tr=tr, keep=[dt, ex], cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, lm_builder=lm_builder, vm=dict(bc=bc, pi=pi, wit=wit, info=info, raw=raw, message=info["message"], slot=info["slot"]),
                 log_inv_rate=log_inv_rate, capacity=capacity)
 
 
@@ -143,17 +145,19 @@ def pin_witness(w):
 
 
 def run_step(ctx, lm, w, whole_node=None, phases=None):
-    """One step.  whole_node (default: whenever the workload carries its program): lmh_prove_execution_vm — VM run, trace, proof;
-    else lmh_prove_execution from the trace resident in HBM.  phases: list that receives [vm_ms, trace_ms, prove_ms]."""
+    """One step.  whole_node (default: whenever the workload carries its program): lmh_aggregate_type_1 — input assembly, VM run, trace,
+    proof; else lmh_prove_execution from the trace resident in HBM.  phases: list that receives [inputs_ms, vm_ms, trace_ms, prove_ms]."""
     if whole_node is None:
         whole_node = "vm" in w
     pr = lm.Prover(ctx)
     if whole_node:
         from leanmultisig_amd import vm
         v = w["vm"]
-        t = vm.prove_execution_vm(ctx, pr, v["bc"], v["pi"], v["wit"], w["lm_builder"], n_threads=w.get("vm_threads", 0))
+        # aggregate_type_1 whole (type_1_aggregation.rs:206-377): sort + dedup, the three input hashes, the hint map, then prove_execution
+        t, info = vm.aggregate_type_1(ctx, pr, v["bc"], v["raw"], v["message"], v["slot"], w["lm_builder"], n_threads=w.get("vm_threads", 0))
         if phases is not None:
             phases.append(t)
+        w["vm_run_info"] = info.to_dict()
         return pr
     for dptr, t in w.get("pinned", ()):  # PCIe-inclusive mode: host -> HBM copies are part of the step
         ctx._check(ctx.lib.lm_upload_async(ctx.h, dptr, t.data_ptr(), t.numel()))
@@ -167,13 +171,13 @@ def step_root(pr):
     return blob[1 + 6:1 + 14]
 
 
-def cpu_baseline(orc, ob, ctx=None, witness="xmss", log_scale=2):
+def cpu_baseline(orc, ob, ctx=None, witness="xmss", log_scale=0):
     """The oracle (scalar C++ restatement of the reference algorithm; the prover's data-parallel loops — LDE, Merkle levels, sumcheck
-    rounds, folds — are OpenMP loops over the host cores, as the reference's are rayon loops) on a 1/4 sample of the same step: the
-    SAME aggregation program on 1550/4 real signatures — VM run (sequential restatement), get_execution_trace, prove_execution — i.e.
-    every table, the memory and the logup domain 4x smaller.  Scaled linearly to the metric's unit.  16 threads at most: the oracle's
-    loops are fine-grained and stop scaling there (measured on the 256-thread host of the GPU box: 8 threads 5.6 s, 16: 3.7 s, 32: 3.8 s,
-    64: 4.6 s, 256: 67 s at 1/16)."""
+    rounds, folds — are OpenMP loops over the host cores, as the reference's are rayon loops) on the SAME step at FULL size (log_scale = 0,
+    the default since round 5: the aggregation program on 1550 real signatures — VM run (sequential restatement), get_execution_trace,
+    prove_execution with 124-bit parameters; 1-2 minutes of CPU); --cpu-baseline-scale-log k takes 1550 / 2^k signatures and scales linearly.
+    16 threads at most: the oracle's loops are fine-grained and stop scaling there (measured on the 256-thread host of the GPU box: 8 threads
+    5.6 s, 16: 3.7 s, 32: 3.8 s, 64: 4.6 s, 256: 67 s at 1/16)."""
     from tests import synth_witness
     rng = np.random.default_rng(1)
     sh = log_scale
@@ -182,13 +186,14 @@ def cpu_baseline(orc, ob, ctx=None, witness="xmss", log_scale=2):
     if witness == "xmss":
         from leanmultisig_amd.programs import xmss_aggregate as xa
         n = N_SIGS >> sh
-        bc = xa.build_program()
+        bc = xa.build_program(19 if sh == 0 else None)
         signer = xa.Xmss(compress=(lambda x: ctx.poseidon16(x, compress=True)) if ctx is not None else None)
         pi, wit, _ = xa.build_witness(bc, n, rng, xmss=signer)
         t0 = time.time()
         w = ob.VmRun(orc, bc, pi, wit).trace(1)
         t_vm = time.time() - t0
-        what = f"the aggregation program on {n} real XMSS signatures (1/{1 << sh} of the step; oracle VM + get_execution_trace {t_vm:.1f} s, 1 thread)"
+        what = (f"the aggregation program on {n} real XMSS signatures ({'the full step' if sh == 0 else f'1/{1 << sh} of the step'}; "
+                f"oracle VM + get_execution_trace {t_vm:.1f} s, 1 thread)")
     else:
         w = synth_witness.build(orc, rng, n_calls=(N_SIGS * 167) >> sh, n_blocks=4096 >> sh, log_exec=20 - sh, log_pos=18 - sh, log_ext=8,
                                 log_memory=20 - sh, log_bytecode=19 - sh, fill_rows=None)
@@ -199,11 +204,11 @@ def cpu_baseline(orc, ob, ctx=None, witness="xmss", log_scale=2):
     ob.prove_execution(orc, w, synth_witness.header(w), None)
     dt = time.time() - t0
     est_full = (dt + t_vm) * (1 << sh)
-    return dict(value=N_SIGS / est_full, unit="xmss_sigs/s", cores=cores, kind="port",
+    return dict(value=N_SIGS / est_full, unit="xmss_sigs/s", cores=cores, kind="port", seconds=dt + t_vm, scale=1 << sh,
                 sample=f"oracle VM run + prove_execution (commit, logup GKR, AIR sumcheck, WHIR open; 124-bit parameters) on {what}: "
                        f"tables 2^{lr[0]}/2^{lr[2]}/2^{lr[1]}, memory 2^{w['log_memory']}, "
-                       f"prove {dt:.1f} s on {cores} OpenMP threads, scaled x{1 << sh}; the fixed-size PoW searches are "
-                       f"over-counted by the scaling")
+                       f"prove {dt:.1f} s on {cores} OpenMP threads"
+                       + ("" if sh == 0 else f", scaled x{1 << sh}; the fixed-size PoW searches are over-counted by the scaling"))
 
 
 def source_sha():
@@ -281,6 +286,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-scale-log", type=int, default=0, help="cpu_baseline on 1550 / 2^k signatures, scaled (default 0: the full step, 1-2 min)")
+    ap.add_argument("--total-signatures", type=int, default=0,
+                    help="signatures of the whole job, partitioned into one contiguous leaf per rank (signer_ranges); default 1550 x ranks = BASELINE "
+                         "configs[1] per GPU / configs[4] on 8")
     ap.add_argument("--no-whole-node", action="store_true", help="skip the whole_node leg (counter passes: only the timed region's proofs run)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="side measurement after the timed region (N = 1 only): independent proofs in flight on the GPU (one host "
@@ -338,8 +347,11 @@ def main():
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ctx = lm.Context(local_rank)
     capacity = args.soundness == "capacity"
+    # the job's signer set is cut into one contiguous leaf per rank; every rank signs its own leaf's keys (rank-seeded)
+    total = args.total_signatures or max(2, N_SIGS >> args.scale_log) * world
+    leaf_lo, leaf_hi = signer_ranges(total, world)[rank]
     if vm_path:
-        w = build_vm_workload(ctx, np.random.default_rng(1000 + rank * 64), max(2, N_SIGS >> args.scale_log), args.log_inv_rate, capacity,
+        w = build_vm_workload(ctx, np.random.default_rng(1000 + rank * 64), max(2, leaf_hi - leaf_lo), args.log_inv_rate, capacity,
                               log_bytecode=19 if args.scale_log == 0 else None)
     else:
         w = build_workload(ctx, orc, ob, np.random.default_rng(1000 + rank * 64), args.scale_log, args.log_inv_rate, args.shape, capacity, args.witness)
@@ -406,7 +418,7 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         ww = w["w"]
         sigs = ww.get("n_sigs", ((N_SIGS * 167) >> args.scale_log) // 167)  # signatures per proof (--scale-log shrinks the leaf)
-        value = sigs * world / (dt / args.steps)
+        value = (total if vm_path else sigs * world) / (dt / args.steps)  # the signatures of ALL leaves / the latency of one step
         sha = source_sha()
         # dominant kernel family: k_air_round (Poseidon16 / execution / extension_op constraint evaluation).
         # Algorithmic bytes per step: every column value of every sumcheck round is read once:
@@ -469,10 +481,12 @@ def main():
                               f"bytecode 2^{ww['log_bytecode']}, stacked 2^{w['n_vars']}, 124-bit WHIR"
                             + (" (CapacityBound: prox-gaps-conjecture)" if capacity else "")
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
-                "value_definition": "WHOLE NODE: signatures of one leaf x ranks / latency of one step from hints in host memory to the pruned "
-                                    "proof (the reference's n_xmss / mean elapsed of one aggregate_type_1); `hot_path` = the same without the VM "
+                "value_definition": "WHOLE NODE: signatures of one leaf x ranks / latency of one aggregate_type_1 — from the unsorted (public key, signature) "
+                                    "pairs in host memory (sort + dedup, hash_pubkeys, tweak table + hash, public-input buffer + hash, hint map) through "
+                                    "the VM run and the trace to the pruned proof (the reference's n_xmss / mean elapsed of one aggregate_type_1, "
+                                    "rec_aggregation/src/benchmark.rs:397-431); `hot_path` = the same without the VM "
                                     "run and the trace build; `inflight` = the throughput with several independent leaves queued on the same GPU",
-                "stages": ["leanvm_run(host head + device batch)", "trace_build(device)", "fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
+                "stages": ["aggregate_type_1 inputs(sort, hashes, hint map)", "leanvm_run(host head + device batch)", "trace_build(device)", "fiat_shamir_preamble", "memory/bytecode access counters", "stack+whir_commit(lde+merkle+ood)", "logup_fill", "logup_gkr", "column_evaluations",
                            "batched_air_sumcheck", "statement_assembly", "whir_open(weights+sumcheck+pow+queries)", "merkle_path_pruning",
                            "exchange(roots+pruned proofs)"],
                 "missing": ["the zkDSL compiler (crates/lean_compiler): the aggregation program is assembled by hand at the ISA level, raw "
@@ -549,9 +563,17 @@ def main():
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         if phases:
             ph = np.asarray(phases).mean(axis=0)
-            stages = {"Witness generation: Executing bytecode": float(ph[0]), "Witness generation: Building execution trace": float(ph[1]), **stages}
-            out["witness_ms"], out["prove_ms"] = float(ph[0] + ph[1]), float(ph[2])
+            stages = {"aggregate_type_1: inputs": float(ph[0]), "Witness generation: Executing bytecode": float(ph[1]),
+                      "Witness generation: Building execution trace": float(ph[2]), **stages}
+            out["inputs_ms"], out["witness_ms"], out["prove_ms"] = float(ph[0]), float(ph[1] + ph[2]), float(ph[3])
         out["stages_ms"] = stages
+        if vm_path:
+            # where the VM's parallel batch ran in the LAST timed step: a batch the device hands back to the host pool is correct but is not
+            # the path this line claims to measure — the default workload must not fall back
+            out.update(w.get("vm_run_info", {}))
+            if not out.get("vm_on_device") and not os.environ.get("LM_VM_HOST") and not os.environ.get("LM_BENCH_ALLOW_VM_FALLBACK"):
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: the VM's parallel batch did NOT run on the device: " + str(out.get("fallback_reason")))
         if waits.size:
             out["exchanges"] = {"per_step": waits.size / args.steps, "p50_us": float(np.percentile(waits, 50)), "p99_us": float(np.percentile(waits, 99)),
                                 "mean_us": float(waits.mean()), "waiting_ms_per_step": float(waits.sum()) / 1e3 / args.steps,
@@ -575,7 +597,7 @@ def main():
                                              "in HBM) to the pruned proof, without the VM run and the trace build (this rank, no exchange)",
                                "proof_equals_whole_node_proof": bool(np.array_equal(pr_hot.proof(), pr.proof()))}
             out["whole_node"] = {"value": value, "unit": "xmss_sigs/s", "ms_per_step": ms_per_step, "witness_ms": out.get("witness_ms"),
-                                 "vm_run_ms": float(ph[0]), "trace_ms": float(ph[1]), "prove_ms": float(ph[2]), "host_threads": w["vm_threads"],
+                                 "inputs_ms": float(ph[0]), "vm_run_ms": float(ph[1]), "trace_ms": float(ph[2]), "prove_ms": float(ph[3]), "host_threads": w["vm_threads"],
                                  "cpus_available": effective_cpus(), "definition": "= value (kept under its round-3 name)"}
         if args.shape == "recursion":  # side measurement: not the BASELINE metric
             lr = w["w"]["log_rows"]
@@ -618,7 +640,7 @@ def main():
             else:
                 out["inflight"] = measure_inflight(lm, orc, ob, local_rank, ctxs, w, C, max(3, args.steps // 2), args, sigs)
         if not args.no_cpu_baseline and world == 1 and args.shape == "xmss":  # the CPU leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(orc, ob, ctx, args.witness)
+            out["cpu_baseline"] = cpu_baseline(orc, ob, ctx, args.witness, log_scale=max(args.cpu_baseline_scale_log, args.scale_log))
         print(json.dumps(out), flush=True)
         if args.profile_all:
             ctx.profile_select("*")

@@ -302,6 +302,11 @@ void lmh_bytecode_free(lmh_bytecode* bc);
 /* Bytecode::hash = poseidon_compress_slice(instructions_multilinear, true) (lean_compiler/src/c_compile_final.rs:158,
  * utils/src/poseidon.rs:41-67); computed once, 2^(log_size + 1) sequential compressions */
 void lmh_bytecode_hash(const lmh_bytecode* bc, uint32_t out[8]);
+/* The names of the HintWitness streams by id (the keys of ExecutionWitness::hints, runner.rs:17-25): needed only by callers that
+ * build a witness by NAME (lmh_aggregate_type_1_witness); lmh_bytecode_hint_name_id: -1 when the bytecode has no such stream. */
+int lmh_bytecode_set_hint_names(lmh_bytecode* bc, const char* const* names, uint32_t n_names);
+int lmh_bytecode_hint_name_id(const lmh_bytecode* bc, const char* name);
+uint32_t lmh_bytecode_n_hint_names(const lmh_bytecode* bc);
 uint32_t lmh_bytecode_log_size(const lmh_bytecode* bc);
 uint32_t lmh_bytecode_ending_pc(const lmh_bytecode* bc);
 const uint32_t* lmh_bytecode_multilinear(const lmh_bytecode* bc);
@@ -349,6 +354,17 @@ int lmh_execute_bytecode(const lmh_bytecode* bc, const uint32_t* public_input, u
 int lmh_execute_bytecode_device(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
                                 const lm_vm_witness* witness, uint32_t n_threads, lmh_execution** out);
 int lmh_execution_on_device(const lmh_execution* e); /* 1: at least one batch ran on the device and the log is resident there */
+/* Where the parallel batches of a run executed.  A batch the device hands back to the host pool is not an error (results and errors are
+ * the same on both paths), but a node that sizes itself for the device path wants to know: bench.py reports these fields and fails
+ * when its default workload falls back. */
+typedef struct {
+    uint32_t on_device;         /* = lmh_execution_on_device */
+    uint32_t n_device_batches;  /* batches interpreted by k_vm_segments */
+    uint32_t n_host_batches;    /* batches run by the host pool (handle_parallel_batch) */
+    uint32_t run_repeated;      /* 1: the device could not decide resolve_deref_hints and the whole run was repeated on the host */
+    char host_batch_reason[256]; /* why the FIRST host batch did not run on the device ("" when none did) */
+} lm_vm_run_info;
+void lmh_execution_info(const lmh_execution* e, lm_vm_run_info* out);
 void lmh_execution_free(lmh_execution* e);
 void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* out);
 
@@ -365,6 +381,40 @@ void lmh_vm_trace_free(lm_ctx* ctx, lmh_vm_trace* t);
  * upload + column construction (until the device work is enqueued), [2] proving. */
 int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
                            const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3]);
+/* the same, also reporting where the VM's parallel batches ran (info nullable) */
+int lmh_prove_execution_vm_info(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
+                                const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3],
+                                lm_vm_run_info* info);
+
+/* ---- aggregate_type_1 (crates/rec_aggregation/src/type_1_aggregation.rs:206-377), raw signatures only -------------------------------
+ * What the reference's benchmark times per aggregation (rec_aggregation/src/benchmark.rs:397-410) is aggregate_type_1 WHOLE: before it
+ * calls prove_execution it sorts and de-duplicates the (public key, signature) pairs (:232-233), hashes the sorted public keys
+ * (hash_pubkeys :118-121), builds the tweak table of the slot and hashes it (compute_tweak_table :124-151), assembles the public-input
+ * buffer (build_type1_input_data :163-186) and hashes it onto the 8-word public input (:262), and flattens the signatures into the
+ * named hint streams of the ExecutionWitness (:264-365).  lmh_aggregate_type_1_witness is that part, lmh_aggregate_type_1 the whole
+ * function for n_recursions = 0 (children = &[]: the recursion branch needs the in-VM verifier, which this library does not assemble).
+ * The three hashes are chains of dependent compressions (n_sigs + 184 + 21 of them at 1550 signatures): they run on the calling
+ * thread with the transcript's AVX-512 permutation — a chain has no parallelism for a device kernel to use.
+ * One signature = LM_XMSS_SIG_WORDS Montgomery words: XmssPublicKey { merkle_root[4], public_param[4] }, then XmssSignature {
+ * wots_signature.randomness[6], wots_signature.chain_tips[42][4], merkle_proof[32][4] } (crates/xmss/src/{xmss.rs:19-29,wots.rs:17-25}). */
+#define LM_XMSS_V 42
+#define LM_XMSS_LOG_LIFETIME 32
+#define LM_XMSS_SIG_WORDS (4 + 4 + 6 + LM_XMSS_V * 4 + LM_XMSS_LOG_LIFETIME * 4)
+typedef struct lmh_type1_witness lmh_type1_witness;
+/* bc must carry its hint names (lmh_bytecode_set_hint_names); streams the program does not read are dropped, streams it reads and a raw
+ * aggregation leaves empty stay empty.  message: 8 words.  LM_E_INVALID: no signatures, more than MAX_XMSS_AGGREGATED = 2^15. */
+int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xmss, uint64_t n_raw, const uint32_t message[8], uint32_t slot,
+                                 lmh_type1_witness** out);
+const lm_vm_witness* lmh_type1_witness_vm(const lmh_type1_witness* w);          /* ExecutionWitness { preamble_memory_len, hints } */
+const uint32_t* lmh_type1_witness_public_input(const lmh_type1_witness* w);     /* 8 words: poseidon_compress_slice(pub_input_data, true) */
+const uint32_t* lmh_type1_witness_input_data(const lmh_type1_witness* w, uint64_t* n_words); /* pub_input_data */
+uint64_t lmh_type1_witness_n_sigs(const lmh_type1_witness* w);                  /* global_pub_keys.len() after sort + dedup */
+const uint32_t* lmh_type1_witness_pubkeys(const lmh_type1_witness* w);          /* TypeOneInfo::pubkeys, sorted, 8 words each */
+void lmh_type1_witness_free(lmh_type1_witness* w);
+/* aggregate_type_1(&[], raw_xmss, message, slot, log_inv_rate) -> proof in `p`.  times_ms (nullable): [0] the input assembly above,
+ * [1] VM run, [2] trace, [3] proving.  info (nullable): where the VM's parallel batches ran. */
+int lmh_aggregate_type_1(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* raw_xmss, uint64_t n_raw, const uint32_t message[8],
+                         uint32_t slot, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[4], lm_vm_run_info* info);
 
 /* n independent Poseidon1-16 compressions perm(x) + x of 16-word states on the host thread pool (signers, hint builders) */
 void lmh_poseidon16_compress_many(uint32_t* states, uint64_t n, uint32_t n_threads);

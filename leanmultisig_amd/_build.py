@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libleanmultisig_hip.so")
 SOURCES = ["lm_core.hip", "lm_commit.hip", "lm_whir_ops.hip", "lm_gkr.hip", "lm_air.hip", "lm_logup.hip", "lm_vm_device.hip", "host/lm_host.cpp",
            "host/lm_whir_config.cpp", "host/lm_wire.cpp", "host/lm_verify.cpp", "host/lm_poseidon_x86.cpp", "host/lm_vm.cpp",
-           "host/lm_node.cpp"]
+           "host/lm_node.cpp", "host/lm_aggregate.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("LM_PUBLISH_FENCES"):  # conservative hand-over with release fences (csrc/lm_common.h)
     FLAGS.append("-DLM_PUBLISH_FENCES=1")

@@ -164,6 +164,20 @@ _HOST_SIGS = {
     "lmh_vm_trace_view": (vp, [vp]),
     "lmh_vm_trace_free": (None, [vp, vp]),
     "lmh_prove_execution_vm": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp]),
+    "lmh_prove_execution_vm_info": (C.c_int, [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp]),
+    "lmh_execution_info": (None, [vp, vp]),
+    "lmh_bytecode_set_hint_names": (C.c_int, [vp, vp, C.c_uint32]),
+    "lmh_bytecode_hint_name_id": (C.c_int, [vp, C.c_char_p]),
+    "lmh_bytecode_n_hint_names": (C.c_uint32, [vp]),
+    # aggregate_type_1 (leanmultisig_amd/vm.py)
+    "lmh_aggregate_type_1_witness": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint32, C.POINTER(vp)]),
+    "lmh_type1_witness_vm": (vp, [vp]),
+    "lmh_type1_witness_public_input": (vp, [vp]),
+    "lmh_type1_witness_input_data": (vp, [vp, vp]),
+    "lmh_type1_witness_n_sigs": (C.c_uint64, [vp]),
+    "lmh_type1_witness_pubkeys": (vp, [vp]),
+    "lmh_type1_witness_free": (None, [vp]),
+    "lmh_aggregate_type_1": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, vp]),
     "lmh_poseidon16_compress_many": (None, [vp, C.c_uint64, C.c_uint32]),
 }
 

@@ -293,6 +293,12 @@ void lmh_vm_trace_free(lm_ctx* ctx, lmh_vm_trace* t) {
 
 int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
                            const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3]) {
+    return lmh_prove_execution_vm_info(ctx, p, bc, public_input, n_public_input, witness, builder, n_threads, times_ms, nullptr);
+}
+int lmh_prove_execution_vm_info(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, const uint32_t* public_input, uint32_t n_public_input,
+                                const lm_vm_witness* witness, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[3],
+                                lm_vm_run_info* info) {
+    if (info) memset(info, 0, sizeof *info);
     if (!ctx || !p || !bc || !builder) {
         lm_set_error("lmh_prove_execution_vm: bad arguments");
         return LM_E_INVALID;
@@ -305,6 +311,7 @@ int lmh_prove_execution_vm(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, c
     lmh_execution* ex = nullptr;
     int rc = lmh_execute_bytecode_device(ctx, bc, public_input, n_public_input, witness, n_threads, &ex);  // (LM_VM_HOST=1: all on the host pool)
     if (rc) return rc;
+    if (info) lmh_execution_info(ex, info);
     const double t1 = now_ms();
     lmh_vm_trace* tr = nullptr;
     rc = lmh_get_execution_trace(ctx, bc, ex, public_input, n_public_input, builder->starting_log_inv_rate, &tr);

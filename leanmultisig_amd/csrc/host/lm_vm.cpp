@@ -675,6 +675,7 @@ struct lmh_bytecode {
     std::vector<Instr> code;
     std::vector<u32> hint_begin;  // n_instructions + 1
     std::vector<HintRec> hints;
+    std::vector<std::string> names;  // names of the HintWitness streams by id (lmh_bytecode_set_hint_names; empty when the caller never gave them)
     mutable std::mutex hash_mu;
     mutable bool hash_done = false;
     mutable u32 hash[8];
@@ -734,6 +735,10 @@ struct lmh_execution {
     u64 public_memory_size = 0, runtime_memory_size = 0;
     lmh::DevRun* dev = nullptr;    // a run whose parallel batches executed on the device (lmh_execute_bytecode_device): the logs and the
                                    // memory image are resident in HBM; the host view is materialised on demand (lmh_execution_view)
+    // where the parallel batches of this run executed (lmh_execution_info): a batch the device hands back is not an error, but a node
+    // that expects the device path wants to know (bench.py fails when the default workload falls back)
+    u32 n_device_batches = 0, n_host_batches = 0, run_repeated = 0;
+    std::string host_batch_reason;
 };
 
 namespace lmh {
@@ -1668,7 +1673,7 @@ enum { DEV_DONE = 0, DEV_FALLBACK = 1, DEV_ERROR = 2 };
 // handle_parallel_batch with the segments on the device.  DEV_FALLBACK: nothing of the run's state has changed in a way the host
 // batch would notice — the caller runs handle_parallel_batch (which also reports every RunnerError: the device never does).
 int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp, u64& ap,
-                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D) {
+                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D, std::string& why) {
     MainMem mm{memory};
     Err scratch;
     const double t0 = vm_now_ms();
@@ -1679,19 +1684,30 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     };
     const u32 sv = get(batch.batch_fp + 2);
     const u32 ev = batch.end_mode == LM_VM_ARG_CONST ? 0 : get(batch.batch_fp + batch.end_value);
+    why = "an undefined loop bound / call frame cell";
     if (scratch.set) return DEV_FALLBACK;
     const u64 start_value = kb::from_monty(sv), end_value = batch.end_mode == LM_VM_ARG_CONST ? batch.end_value : kb::from_monty(ev);
+    why = "fewer than two iterations";
     if (end_value <= start_value + 1) return DEV_FALLBACK;
     const u64 n_iters = end_value - start_value, n_par = n_iters - 1, stride = fp - batch.batch_fp;
     const u32 return_pc = get(fp), saved_fp = get(fp + 1);
+    {
+        char buf[200];
+        snprintf(buf, sizeof buf, "batch shape outside the device limits (%llu segments [32, 2^24), frame %llu words (<= %u), %u call-frame arguments (1..%u), %u hint names (<= %u))",
+                 (unsigned long long)n_par, (unsigned long long)stride, VM_DEV_MAX_STRIDE, batch.n_args, VM_DEV_MAX_ARGS, bc.n_names, VM_DEV_MAX_NAMES);
+        why = buf;
+    }
     if (scratch.set || batch.n_args > VM_DEV_MAX_ARGS || batch.n_args == 0 || bc.n_names > VM_DEV_MAX_NAMES || stride == 0 || stride > VM_DEV_MAX_STRIDE ||
         n_par < 32 || n_par >= (1u << 24) || fp <= batch.batch_fp)
         return DEV_FALLBACK;
     u32 args[VM_DEV_MAX_ARGS];
     for (u32 i = 0; i < batch.n_args; i++) args[i] = get(batch.batch_fp + 2 + i);
+    why = "an undefined call-frame argument";
     if (scratch.set) return DEV_FALLBACK;
     const u64 max_addr = batch.batch_fp + (n_iters + 1) * stride, split_at = batch.batch_fp + stride, frames_end = batch.batch_fp + n_iters * stride;
+    why = "the batch's frames exceed the memory limit";
     if (max_addr > MAX_MEMORY) return DEV_FALLBACK;
+    why = "the call frame of the last iteration conflicts with memory / a deferred check failed";
     std::vector<u64> per_iter(cur.index.size());
     for (size_t k = 0; k < per_iter.size(); k++) per_iter[k] = cur.index[k] - batch.hint_indices_at_start[k];
     if (memory.touch_failed) return DEV_ERROR;
@@ -1815,10 +1831,12 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     }
     const double t2 = vm_now_ms();
     if (summary[0] || summary[2] || summary[3] || summary[1] > dirty_cap) {
-        if (vm_times())
-            fprintf(stderr, "[vm] device batch of %llu segments handed back to the host: %u conflicting deferred writes, %u beyond the image, first failed segment %u "
-                            "(code %u, pc %u, aux %u), %u dirty cells\n", (unsigned long long)n_par, summary[0], summary[2], summary[3], summary[4], summary[5],
-                    summary[6], summary[1]);
+        char buf[256];
+        snprintf(buf, sizeof buf, "device batch of %llu segments handed back: %u conflicting deferred writes, %u beyond the image, first failed segment %u "
+                                  "(code %u, pc %u, aux %u), %u dirty cells", (unsigned long long)n_par, summary[0], summary[2], summary[3], summary[4], summary[5],
+                 summary[6], summary[1]);
+        why = buf;
+        if (vm_times()) fprintf(stderr, "[vm] %s\n", buf);
         return fallback(&B);
     }
     // ---- success: mirror the cells outside the frames that deferred writes defined, then commit
@@ -2170,7 +2188,14 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             if (rc < 0) break;
             const double tb = vm_now_ms();
             int how = DEV_FALLBACK;
-            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D);
+            std::string why = ctx ? "LM_VM_HOST is set" : "no device context (lmh_execute_bytecode)";
+            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D, why);
+            if (how == DEV_DONE)
+                ex->n_device_batches++;
+            else if (how == DEV_FALLBACK) {
+                if (!ex->n_host_batches) ex->host_batch_reason = why;
+                ex->n_host_batches++;
+            }
             if (how == DEV_ERROR) {
                 device_failed = true;
                 break;
@@ -2233,7 +2258,9 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             if (!ok) {
                 delete ex;
                 if (!anomaly) return LM_E_DEVICE;
-                return execute_impl(nullptr, bc, public_input, n_public_input, witness, n_threads, out);
+                const int rc = execute_impl(nullptr, bc, public_input, n_public_input, witness, n_threads, out);
+                if (rc == LM_OK && *out) (*out)->run_repeated = 1, (*out)->host_batch_reason = "resolve_deref_hints met a conflict / an undefined source on the device: the run was repeated on the host";
+                return rc;
             }
             *out = ex;
             return LM_OK;
@@ -2289,6 +2316,27 @@ int lmh_execute_bytecode_device(lm_ctx* ctx, const lmh_bytecode* bc, const uint3
     return execute_impl(ctx, bc, public_input, n_public_input, witness, n_threads, out);
 }
 int lmh_execution_on_device(const lmh_execution* e) { return e && e->dev && e->dev->finalized; }
+void lmh_execution_info(const lmh_execution* e, lm_vm_run_info* out) {
+    memset(out, 0, sizeof *out);
+    if (!e) return;
+    out->on_device = e->dev && e->dev->finalized;
+    out->n_device_batches = e->n_device_batches, out->n_host_batches = e->n_host_batches, out->run_repeated = e->run_repeated;
+    snprintf(out->host_batch_reason, sizeof out->host_batch_reason, "%s", e->host_batch_reason.c_str());
+}
+int lmh_bytecode_set_hint_names(lmh_bytecode* bc, const char* const* names, uint32_t n_names) {
+    if (!bc || n_names != bc->n_names || (n_names && !names)) {
+        lm_set_error("lmh_bytecode_set_hint_names: one name per hint stream of the bytecode");
+        return LM_E_INVALID;
+    }
+    bc->names.assign(names, names + n_names);
+    return LM_OK;
+}
+int lmh_bytecode_hint_name_id(const lmh_bytecode* bc, const char* name) {
+    for (size_t k = 0; k < bc->names.size(); k++)
+        if (bc->names[k] == name) return (int)k;
+    return -1;
+}
+uint32_t lmh_bytecode_n_hint_names(const lmh_bytecode* bc) { return bc->n_names; }
 void lmh_execution_free(lmh_execution* e) { delete e; }
 void lmh_execution_view(const lmh_execution* e, lm_vm_execution_view* v) {
     memset(v, 0, sizeof *v);

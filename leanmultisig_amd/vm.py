@@ -325,6 +325,11 @@ class Bytecode:
                                                self.starting_frame_memory, C.cast(arr, C.c_void_p), len(self.hints), len(self.names))
             if not self.h:
                 raise LmError("lmh_bytecode_new: " + self.lib.lm_last_error().decode())
+            if self.names:  # the keys of ExecutionWitness::hints by id: witness builders that work by name (lmh_aggregate_type_1_witness)
+                by_id = sorted(self.names, key=self.names.get)
+                arr = (C.c_char_p * len(by_id))(*[n.encode() for n in by_id])
+                if self.lib.lmh_bytecode_set_hint_names(self.h, arr, len(by_id)) != 0:
+                    raise LmError(self.lib.lm_last_error().decode())
         return self.h
 
     def hash(self):
@@ -486,6 +491,79 @@ class DeviceTrace:
             self.close()
         except Exception:
             pass
+
+
+class VmRunInfo(C.Structure):
+    """lm_vm_run_info"""
+    _fields_ = [("on_device", C.c_uint32), ("n_device_batches", C.c_uint32), ("n_host_batches", C.c_uint32), ("run_repeated", C.c_uint32),
+                ("host_batch_reason", C.c_char * 256)]
+
+    def to_dict(self):
+        return dict(vm_on_device=bool(self.on_device) and self.n_host_batches == 0 and not self.run_repeated, device_batches=int(self.n_device_batches),
+                    host_batches=int(self.n_host_batches), run_repeated=bool(self.run_repeated), fallback_reason=self.host_batch_reason.decode() or None)
+
+
+XMSS_SIG_WORDS = 4 + 4 + 6 + 42 * 4 + 32 * 4
+
+
+def pack_xmss_signatures(sig):
+    """{root (n,4), pp (n,4), randomness (n,6), chain_tips (n,42,4), merkle_proof (n,32,4)} (leanmultisig_amd/xmss.py) -> the (n, LM_XMSS_SIG_WORDS)
+    array of (XmssPublicKey, XmssSignature) pairs lmh_aggregate_type_1 takes"""
+    n = sig["root"].shape[0]
+    return np.ascontiguousarray(np.concatenate([sig["root"], sig["pp"], sig["randomness"], sig["chain_tips"].reshape(n, -1),
+                                                sig["merkle_proof"].reshape(n, -1)], axis=1), dtype=np.uint32)
+
+
+class Type1Witness:
+    """lmh_type1_witness: what aggregate_type_1 (rec_aggregation/src/type_1_aggregation.rs:206-377) builds before prove_execution"""
+
+    def __init__(self, bytecode, raw_xmss, message, slot):
+        self.lib = capi.load()
+        raw = np.ascontiguousarray(raw_xmss, dtype=np.uint32).reshape(-1, XMSS_SIG_WORDS)
+        msg = np.ascontiguousarray(message, dtype=np.uint32)
+        out = C.c_void_p()
+        if self.lib.lmh_aggregate_type_1_witness(bytecode.handle(), raw.ctypes.data, raw.shape[0], msg.ctypes.data, int(slot), C.byref(out)) != 0:
+            raise LmError(self.lib.lm_last_error().decode())
+        self.h = out.value
+        self.c = C.cast(self.lib.lmh_type1_witness_vm(self.h), C.POINTER(VmWitness)).contents
+        self.public_input = _view(self.lib.lmh_type1_witness_public_input(self.h), 8)
+        self.n_sigs = int(self.lib.lmh_type1_witness_n_sigs(self.h))
+        nw = C.c_uint64()
+        ptr = self.lib.lmh_type1_witness_input_data(self.h, C.byref(nw))
+        self.input_data = _view(ptr, nw.value)
+        self.pubkeys = _view(self.lib.lmh_type1_witness_pubkeys(self.h), 8 * self.n_sigs).reshape(-1, 8)
+
+    def streams(self):
+        """(name_entry_begin, entry_offset, data) as arrays"""
+        n = int(self.c.n_names)
+        neb = np.ctypeslib.as_array(C.cast(self.c.name_entry_begin, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        eo = np.ctypeslib.as_array(C.cast(self.c.entry_offset, C.POINTER(C.c_uint64)), shape=(int(neb[-1]) + 1,)).copy()
+        return neb, eo, _view(self.c.data, int(eo[-1]))
+
+    def close(self):
+        if self.h:
+            self.lib.lmh_type1_witness_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def aggregate_type_1(ctx, prover, bytecode, raw_xmss, message, slot, builder, n_threads=0):
+    """aggregate_type_1(&[], raw_xmss, message, slot, log_inv_rate): input assembly + prove_execution, the proof left in `prover`.
+    Returns ([inputs_ms, vm_ms, trace_ms, prove_ms], VmRunInfo)."""
+    raw = np.ascontiguousarray(raw_xmss, dtype=np.uint32).reshape(-1, XMSS_SIG_WORDS)
+    msg = np.ascontiguousarray(message, dtype=np.uint32)
+    times = (C.c_double * 4)()
+    info = VmRunInfo()
+    rc = ctx.lib.lmh_aggregate_type_1(ctx.h, prover.h, bytecode.handle(), raw.ctypes.data, raw.shape[0], msg.ctypes.data, int(slot), C.byref(builder),
+                                      n_threads, times, C.byref(info))
+    if rc != 0:
+        raise LmError(ctx.lib.lm_last_error().decode())
+    return list(times), info
 
 
 def prove_execution_vm(ctx, prover, bytecode, public_input, witness, builder, n_threads=0):

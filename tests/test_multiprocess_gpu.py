@@ -32,4 +32,6 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["whole_node"]["value"] == j["value"] and j["whole_node"]["vm_run_ms"] > 0 and j["hot_path"]["ms_per_step"] < j["ms_per_step"]
     assert j["hot_path"]["proof_equals_whole_node_proof"] is True
     assert "Witness generation: Executing bytecode" in j["stages_ms"] and "batched AIR sumcheck" in j["stages_ms"]
+    # round 5: the step is aggregate_type_1 whole (input assembly included), and the line says where the VM's batch ran
+    assert j["stages_ms"]["aggregate_type_1: inputs"] > 0 and j["vm_on_device"] is True and j["host_batches"] == 0
     assert j["exchanges"]["per_step"] > 10 and j["node_stats"]["n_xmss"] == j["config"]["per_gpu_signatures"]

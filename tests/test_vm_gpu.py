@@ -53,6 +53,26 @@ def test_prove_execution_vm_equals_oracle(ctx, orc, program, n_sigs):
     assert np.array_equal(proof, ref)
 
 
+@pytest.mark.parametrize("n_sigs", [5, 64])
+def test_aggregate_type_1_whole_function(ctx, program, n_sigs):
+    """lmh_aggregate_type_1 (type_1_aggregation.rs:206-377: sort + dedup, input hashes, hint map, prove_execution) on shuffled pairs with a
+    duplicate = lmh_prove_execution_vm on the Python builder's witness, word for word; and it reports where the VM's batch ran"""
+    pi, w, info = xa.build_witness(program, n_sigs, np.random.default_rng(40 + n_sigs))
+    lm_builder = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    ref = lm.Prover(ctx)
+    vm.prove_execution_vm(ctx, ref, program, pi, w, lm_builder)
+    raw = vm.pack_xmss_signatures(info["sig"])
+    raw = np.concatenate([raw[np.random.default_rng(1).permutation(n_sigs)], raw[[2]]])
+    pr = lm.Prover(ctx)
+    times, run = vm.aggregate_type_1(ctx, pr, program, raw, info["message"], info["slot"], lm_builder)
+    assert len(times) == 4 and times[0] > 0 and np.array_equal(pr.proof(), ref.proof())
+    d = run.to_dict()
+    if n_sigs > 33:
+        assert d["vm_on_device"] and d["device_batches"] == 1 and d["host_batches"] == 0 and d["fallback_reason"] is None
+    else:
+        assert not d["vm_on_device"] and d["host_batches"] == 1 and "segments" in d["fallback_reason"]
+
+
 def test_runner_error_surfaces(ctx, program):
     pi, w, info = xa.build_witness(program, 3, np.random.default_rng(2))
     bad = pi.copy()

@@ -232,6 +232,32 @@ int lmh_verify_execution_bytes(const lm_verify_instance* instance, const uint8_t
 /* the proof still held by a prover object (pruned and restored on the way, like a proof that travelled) */
 int lmh_verify_execution_prover(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder);
 
+/* ---- RawProof: the input of the recursion program ------------------------------------------------------------------------------
+ * VerifierState::into_raw_proof (fiat-shamir/src/verifier.rs:21,47-60,126-195): while it verifies, the reference's verifier rebuilds
+ * the transcript in the format its in-VM verifier reads (rec_aggregation/zkdsl_implem/fiat_shamir.py) — every absorbed slice
+ * zero-padded to the rate, sumcheck polynomials with ALL their coefficients, a grinding witness as a block of its own — and
+ * aggregate_type_1 hands it to the VM as the `proof_transcript` hint (type_1_aggregation.rs:310-356); the Merkle openings travel
+ * un-pruned beside it (lmh_proof_copy has them in opening order).  lm_whir_opening_claim is what the PCS opening of that
+ * verification was asked to prove, i.e. the arguments and the expected results of `whir_open` (zkdsl_implem/whir.py:18-164,
+ * called at recursion.py:470-532, its results used at :534-654). */
+typedef struct {
+    uint64_t transcript_offset;    /* raw-transcript word WhirConfig::verify reads first (after the duplex of recursion.py:470) */
+    uint32_t challenger_state[16]; /* the sponge at that point: [capacity | rate] */
+    uint32_t num_variables, log_inv_rate, n_ood, n_statement_values;
+    uint32_t root[8];                           /* the stacked commitment (parse_commitment, recursion.py:94) */
+    uint32_t ood_points[4 * 5], ood_answers[4 * 5];
+    uint32_t combination_gen[5];                /* recursion.py:472 */
+    uint32_t statement_sum[5];     /* sum_i gen^(n_ood + i) value_i over the statement: whir_sum without its OOD part (:478-518) */
+    uint32_t statement_weights[5]; /* sum_i gen^(n_ood + i) weight_i(folding randomness): what :534-652 add to `s` */
+    uint32_t folding_randomness[32 * 5];        /* folding_randomness_global, num_variables entries */
+} lm_whir_opening_claim;
+typedef struct lmh_raw_proof lmh_raw_proof;
+/* verify_execution on the proof a prover object holds; on success *out owns the raw transcript and the claim */
+int lmh_verify_execution_raw(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder, lmh_raw_proof** out);
+const uint32_t* lmh_raw_proof_transcript(const lmh_raw_proof* r, uint64_t* n_words);
+const lm_whir_opening_claim* lmh_raw_proof_whir_claim(const lmh_raw_proof* r);
+void lmh_raw_proof_free(lmh_raw_proof* r);
+
 /* ---- pad_table (crates/lean_prover/src/trace_gen.rs:170-191) ----------------------------------------------------------------
  * lmh_table_log_rows = log2_ceil(n_rows + 1).max(MIN_LOG_N_ROWS_PER_TABLE): the height get_execution_trace gives a table.
  * lmh_pad_table fills rows [n_rows, 2^log_rows) of every committed column (device pointers in the host array d_cols; 20 / 29 /

@@ -136,6 +136,10 @@ _HOST_SIGS = {
     "lmh_verify_execution": (C.c_int, [vp, vp, vp]),
     "lmh_verify_execution_bytes": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp]),
     "lmh_verify_execution_prover": (C.c_int, [vp, vp, vp]),
+    "lmh_verify_execution_raw": (C.c_int, [vp, vp, vp, vp]),
+    "lmh_raw_proof_transcript": (vp, [vp, vp]),
+    "lmh_raw_proof_whir_claim": (vp, [vp]),
+    "lmh_raw_proof_free": (None, [vp]),
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
     "lmh_witness_root": (None, [vp, vp]),
@@ -345,6 +349,34 @@ def verify_execution(w, proof, builder=None, compressed=False):
     else:
         rc = lib.lmh_verify_execution_prover(C.byref(inst), proof.h, b)
     return rc == 0, ("" if rc == 0 else lib.lm_last_error().decode())
+
+
+class WhirOpeningClaim(C.Structure):
+    """lm_whir_opening_claim: the arguments and expected results of the recursion program's whir_open"""
+    _fields_ = [("transcript_offset", C.c_uint64), ("challenger_state", C.c_uint32 * 16), ("num_variables", C.c_uint32),
+                ("log_inv_rate", C.c_uint32), ("n_ood", C.c_uint32), ("n_statement_values", C.c_uint32), ("root", C.c_uint32 * 8),
+                ("ood_points", C.c_uint32 * 20), ("ood_answers", C.c_uint32 * 20), ("combination_gen", C.c_uint32 * 5),
+                ("statement_sum", C.c_uint32 * 5), ("statement_weights", C.c_uint32 * 5), ("folding_randomness", C.c_uint32 * 160)]
+
+
+def verify_execution_raw(w, prover, builder=None):
+    """lmh_verify_execution_raw: verify the proof `prover` holds and return (raw transcript words, WhirOpeningClaim) — the
+    RawProof::transcript the recursion program reads and what its PCS opening was asked to prove.  Raises LmError on rejection."""
+    lib = load()
+    pi = np.ascontiguousarray(w["public_input"], dtype=np.uint32)
+    bh = np.ascontiguousarray(w["bytecode_hash"], dtype=np.uint32)
+    bc = np.ascontiguousarray(w["bytecode"], dtype=np.uint32).reshape(-1)
+    inst = VerifyInstance(w["log_bytecode"], w["ending_pc"], pi.size, 0, pi.ctypes.data, bh.ctypes.data, bc.ctypes.data)
+    out = C.c_void_p()
+    rc = lib.lmh_verify_execution_raw(C.byref(inst), prover.h, C.byref(builder) if builder is not None else None, C.byref(out))
+    if rc != 0:
+        raise LmError(lib.lm_last_error().decode())
+    n = C.c_uint64()
+    ptr = lib.lmh_raw_proof_transcript(out.value, C.byref(n))
+    raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(int(n.value),)).copy()
+    claim = WhirOpeningClaim.from_buffer_copy(C.string_at(lib.lmh_raw_proof_whir_claim(out.value), C.sizeof(WhirOpeningClaim)))
+    lib.lmh_raw_proof_free(out.value)
+    return raw, claim
 
 
 class SparseStatement(C.Structure):

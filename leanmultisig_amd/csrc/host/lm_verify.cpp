@@ -27,6 +27,12 @@ using kb::ef_sub;
 using kb::ef_zero;
 using kb::to_monty;
 
+}  // namespace
+struct lmh_raw_proof {  // RawProof::transcript (fiat-shamir/src/transcript.rs:20-31) + what the PCS opening was asked to prove
+    std::vector<u32> transcript;
+    lm_whir_opening_claim claim;
+};
+namespace {
 struct Fail {  // thrown inside this file only; every entry point catches it (nothing unwinds across the ABI)
     std::string why;
 };
@@ -254,6 +260,13 @@ struct Verifier {
     size_t off = 0;
     std::vector<Opening> openings;
     size_t opening_idx = 0;
+    // VerifierState::raw_transcript (verifier.rs:21,54-60): what was absorbed, in the format the recursion program reads — every
+    // absorbed slice zero-padded to the rate, sumcheck polynomials with all their coefficients, a grinding witness as a block of its own
+    std::vector<u32> raw;
+    void record(const u32* s, size_t n) {
+        raw.insert(raw.end(), s, s + n);
+        raw.resize((raw.size() + 7) / 8 * 8, 0);
+    }
     explicit Verifier(const std::vector<u32>& t) : transcript(t) {}
     const u32* read(size_t n) {
         require(off + n <= transcript.size(), "transcript exhausted");
@@ -265,11 +278,13 @@ struct Verifier {
     std::vector<u32> next_base(size_t n) {
         const u32* p = read(n);
         ch.observe_many(p, n);
+        record(p, n);
         return std::vector<u32>(p, p + n);
     }
     std::vector<EF> next_ext(size_t n) {
         const u32* p = read(5 * n);
         ch.observe_many(p, 5 * n);
+        record(p, 5 * n);
         std::vector<EF> r(n);
         for (size_t i = 0; i < n; i++) r[i] = ef_load(p + 5 * i);
         return r;
@@ -296,6 +311,7 @@ struct Verifier {
         const u32 w = read(1)[0];
         ch.observe_many(&w, 1);
         require((kb::from_monty(ch.state[8]) & ((1u << bits) - 1)) == 0, "invalid grinding witness");
+        record(&w, 1);
     }
     // next_sumcheck_polynomial (verifier.rs:159-195): the proof carries coefficients 1.. ; the constant one follows from the sum
     std::vector<EF> next_sumcheck_poly(size_t n_coeffs, const EF& claimed, const EF* eq_alpha) {
@@ -330,6 +346,7 @@ struct Verifier {
         std::vector<u32> flat(full.size() * 5);
         for (size_t i = 0; i < full.size(); i++) memcpy(&flat[5 * i], full[i].v, 20);
         ch.observe_many(flat.data(), flat.size());
+        record(flat.data(), flat.size());
         return full;
     }
     const Opening& next_opening() {
@@ -416,7 +433,8 @@ u32 two_adic_generator(u32 bits) {
 }
 
 // WhirConfig::verify (whir/src/verify.rs:83-232).  Returns the folding randomness.
-std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCommitment& commitment, std::vector<Constraint> statement) {
+std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCommitment& commitment, std::vector<Constraint> statement,
+                            lm_whir_opening_claim* cap = nullptr) {
     const u32 n = c->num_variables;
     require(c->n_rounds <= LM_MAX_WHIR_ROUNDS && n == total_fold(c, c->n_rounds) + c->final_sumcheck_rounds, "whir: inconsistent configuration");
     require(commitment.num_variables == n, "whir: commitment size");
@@ -479,10 +497,30 @@ std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCom
     };
     WhirCommitment prev = commitment;
     vs.duplex();
+    if (cap) {  // where whir_open of the recursion program starts (recursion.py:470-532)
+        memset(cap, 0, sizeof *cap);
+        require(commitment.ood_points.size() <= 4 && n <= 32, "whir claim: more OOD samples / variables than lm_whir_opening_claim holds");
+        cap->transcript_offset = vs.raw.size();
+        memcpy(cap->challenger_state, vs.ch.state, sizeof cap->challenger_state);
+        cap->num_variables = n, cap->log_inv_rate = c->starting_log_inv_rate, cap->n_ood = (u32)commitment.ood_points.size();
+        memcpy(cap->root, commitment.root, 32);
+        for (size_t i = 0; i < commitment.ood_points.size(); i++)
+            memcpy(cap->ood_points + 5 * i, commitment.ood_points[i].v, 20), memcpy(cap->ood_answers + 5 * i, commitment.ood_answers[i].v, 20);
+    }
     {
         std::vector<Constraint> cs = oods(prev);
         cs.insert(cs.end(), statement.begin(), statement.end());
         std::vector<EF> pw = combine(cs);
+        if (cap) {
+            const size_t n_ood = commitment.ood_points.size();
+            memcpy(cap->combination_gen, (pw.size() > 1 ? pw[1] : ef_zero()).v, 20);
+            EF ssum = ef_zero();
+            size_t i = n_ood;
+            for (const Constraint& k : statement)
+                for (const auto& v : k.values) ssum = ef_add(ssum, ef_mul(pw[i++], v.second));
+            memcpy(cap->statement_sum, ssum.v, 20);
+            cap->n_statement_values = (u32)(pw.size() - n_ood);
+        }
         round_constraints.push_back({pw, cs});
     }
     round_randomness.push_back(sumcheck_rounds(fold_at(c, 0), c->starting_folding_pow_bits));
@@ -515,7 +553,7 @@ std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCom
     std::vector<EF> folding;
     for (const auto& r : round_randomness) folding.insert(folding.end(), r.begin(), r.end());
     // eval_constraints_poly :339-379
-    EF weights = ef_zero();
+    EF weights = ef_zero(), stmt_weights = ef_zero();
     {
         std::vector<EF> point = folding;
         for (size_t round = 0; round < round_constraints.size(); round++) {
@@ -531,6 +569,7 @@ std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCom
                     EF e = common;
                     for (size_t j = 0; j < sel_vars; j++)
                         e = ef_mul(e, (v.first & (1ull << (sel_vars - 1 - j))) ? point[j] : one_minus(point[j]));
+                    if (round == 0 && i >= commitment.ood_points.size()) stmt_weights = ef_add(stmt_weights, ef_mul(e, rnd[i]));
                     weights = ef_add(weights, ef_mul(e, rnd[i++]));
                 }
             }
@@ -540,6 +579,10 @@ std::vector<EF> whir_verify(const lm_whir_config* c, Verifier& vs, const WhirCom
     std::vector<EF> rev(final_rnd.rbegin(), final_rnd.rend());
     const EF final_value = eval_multilinear_coeffs(final_coeffs.data(), final_coeffs.size(), rev.data());
     require(kb::ef_eq(claimed, ef_mul(weights, final_value)), "whir: final sumcheck value does not match the constraints");
+    if (cap) {
+        memcpy(cap->statement_weights, stmt_weights.v, 20);
+        for (size_t i = 0; i < folding.size(); i++) memcpy(cap->folding_randomness + 5 * i, folding[i].v, 20);
+    }
     return folding;
 }
 
@@ -581,7 +624,7 @@ EF air_eval(int t, const std::vector<EF>& ce, const air::Extra& x) {
 }
 
 void verify_execution(const lm_verify_instance* in, const std::vector<u32>& transcript, const std::vector<PrunedBatch>& batches,
-                      const lm_whir_builder* builder_override) {
+                      const lm_whir_builder* builder_override, lmh_raw_proof* raw = nullptr) {
     Verifier vs(transcript);
     for (const PrunedBatch& b : batches) {  // VerifierState::new (verifier.rs:28-44)
         std::vector<Opening> r = restore(b);
@@ -796,18 +839,20 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         for (u32 v = 0; v < s.n_values; v++) k.values.push_back({S.sels[s.values_offset + v], ef_load(&S.vals[(s.values_offset + v) * 5])});
         statement.push_back(k);
     }
-    whir_verify(&cfg, vs, commitment, statement);
+    whir_verify(&cfg, vs, commitment, statement, raw ? &raw->claim : nullptr);
     require(vs.off == transcript.size(), "trailing transcript words");
     require(vs.opening_idx == vs.openings.size(), "unused Merkle openings");
+    if (raw) raw->transcript = std::move(vs.raw);
 }
 
-int run(const lm_verify_instance* in, const std::vector<u32>& transcript, const std::vector<PrunedBatch>& batches, const lm_whir_builder* b) {
+int run(const lm_verify_instance* in, const std::vector<u32>& transcript, const std::vector<PrunedBatch>& batches, const lm_whir_builder* b,
+        lmh_raw_proof* raw = nullptr) {
     if (!in || !in->bytecode || !in->bytecode_hash || (in->n_public_input && !in->public_input)) {
         lm_set_error("lmh_verify_execution: missing instance data");
         return LM_E_INVALID;
     }
     try {
-        verify_execution(in, transcript, batches, b);
+        verify_execution(in, transcript, batches, b, raw);
     } catch (const Fail& f) {
         lm_set_error("verify_execution: %s", f.why.c_str());
         return LM_E_INVALID;
@@ -836,5 +881,22 @@ int lmh_verify_execution_prover(const lm_verify_instance* instance, const lmh_pr
     if (!p) return LM_E_INVALID;
     return run(instance, p->transcript, lmh::prune(p), builder);
 }
+int lmh_verify_execution_raw(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder, lmh_raw_proof** out) {
+    if (!p || !out) return LM_E_INVALID;
+    lmh_raw_proof* r = new lmh_raw_proof();
+    const int rc = run(instance, p->transcript, lmh::prune(p), builder, r);
+    if (rc != LM_OK) {
+        delete r;
+        r = nullptr;
+    }
+    *out = r;
+    return rc;
+}
+const uint32_t* lmh_raw_proof_transcript(const lmh_raw_proof* r, uint64_t* n_words) {
+    if (n_words) *n_words = r ? r->transcript.size() : 0;
+    return r ? r->transcript.data() : nullptr;
+}
+const lm_whir_opening_claim* lmh_raw_proof_whir_claim(const lmh_raw_proof* r) { return r ? &r->claim : nullptr; }
+void lmh_raw_proof_free(lmh_raw_proof* r) { delete r; }
 
 }  // extern "C"

@@ -1259,8 +1259,15 @@ struct Machine {
         size_t cyc_at_arm = 0, pos_at_arm = 0, ext_at_arm = 0, pend_at_arm = 0;  // log sizes when iteration 0 started (its footprint sizes the device slots)
         bool armed = false;
     };
-    int run(bool has_stop, u64 stop_pc, Batch& batch) {
+    // skip_arm_pc: the pc of the parallel loop whose batch was just handled.  run_loop (runner.rs:120-198) restarts ON that loop's header —
+    // the last iteration, i == end — and its ParallelBatchStart hint arms a batch that can never fire (the loop returns), which makes the
+    // reference ignore every later ParallelBatchStart of the program: only the FIRST parallel loop of a run is ever batched there.  A
+    // batch is an execution strategy — the ExecutionResult equals the sequential one (tests: every run against the sequential oracle
+    // VM) — so this runner does not arm on that first instruction and later parallel loops are batched too (the recursion program's
+    // per-round query loops, programs/whir_verify.py).  ~0: the reference's arming, literally (error reports, LM_VM_REARM=0).
+    int run(bool has_stop, u64 stop_pc, Batch& batch, u64 skip_arm_pc = ~0ull) {
         batch.armed = false;
+        bool first = true;
         for (;;) {
             if (pc == bc.ending_pc) return 0;
             if (pc >= bc.n_instructions) {
@@ -1272,7 +1279,7 @@ struct Machine {
             for (u32 h = bc.hint_begin[pc]; h < bc.hint_begin[pc + 1]; h++) {
                 const HintRec& hr = bc.hints[h];
                 if (hr.kind == LM_VM_HINT_PARALLEL_BATCH_START) {
-                    if (!batch.armed) {
+                    if (!batch.armed && !(first && pc == skip_arm_pc)) {
                         batch.armed = true;
                         batch.batch_pc = pc;
                         batch.batch_fp = fp;
@@ -1290,6 +1297,7 @@ struct Machine {
                 if (err.set) return -1;
             }
             step(bc.code[pc]);
+            first = false;
             if (err.set) return -1;
             if (has_stop && pc == stop_pc) return 1;
             if (batch.armed && pc == batch.batch_pc) return 2;
@@ -1379,8 +1387,10 @@ UVec<std::pair<u64, u32>>& batch_deferred(Pool* p) {
 
 // The per-thread logs and the deferred-write list belong to the run's pool (leased to this run alone, PoolSet): concurrent runs
 // of several provers in one process do not share them.
+// trim_last_frame: this batch is one the reference would have run sequentially (Machine::run, skip_arm_pc): its run leaves the memory
+// as long as the last cell it SET, not resized to the end of the last call frame — the length is put back to that frame's arguments.
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
-                           u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err) {
+                           u64& ap, const Machine<MainMem>::Batch& batch, u32 n_threads, Err& err, bool trim_last_frame = false) {
     memory.lazy_drain();  // the segments read the arena directly
     if (memory.lazy_failed) {
         err.raise("a deferred check failed");  // (execute_impl repeats the run)
@@ -1436,6 +1446,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     }
     // memory.0.resize(max_addr, None), done BEFORE the call frames are written (the reference resizes after; Memory::set grows on demand
     // either way, so the final length is the same): the new cells are filled — and first touched — by the pool instead of one by one
+    const bool grown = max_addr > memory.len;
     if (max_addr > memory.len) {
         const u64 from = memory.len, chunk = 1u << 15;
         u32* mp = memory.p;
@@ -1531,6 +1542,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
+    if (trim_last_frame && grown && memory.len == max_addr) memory.len = fp + 2 + batch.n_args;
     if (vm_times())
         fprintf(stderr, "[vm] batch of %llu segments: resize %.2f ms, call frames %.2f ms, run %.2f ms, merge + deferred writes %.2f ms\n",
                 (unsigned long long)n_par, tp1 - tp0, tb0 - tp1, tb1 - tb0, vm_now_ms() - tb1);
@@ -1673,7 +1685,7 @@ enum { DEV_DONE = 0, DEV_FALLBACK = 1, DEV_ERROR = 2 };
 // handle_parallel_batch with the segments on the device.  DEV_FALLBACK: nothing of the run's state has changed in a way the host
 // batch would notice — the caller runs handle_parallel_batch (which also reports every RunnerError: the device never does).
 int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp, u64& ap,
-                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D, std::string& why) {
+                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D, std::string& why, bool trim_last_frame = false) {
     MainMem mm{memory};
     Err scratch;
     const double t0 = vm_now_ms();
@@ -1739,6 +1751,7 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
         return (int)DEV_FALLBACK;
     };
     fill_host(std::max(old_len, frames_end), max_addr);
+    const bool grown = max_addr > memory.len;
     if (max_addr > memory.len) memory.len = max_addr;
     host_grown = true;
     {  // write_call_frame for the last iteration (the loop comes back to the sequential runner in it)
@@ -1786,7 +1799,8 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     a.cap_ext = (u32)std::min<u64>(2 * (B.host_ext_at - batch.ext_at_arm) + 16, 1u << 20);
     a.cap_pend = (u32)std::min<u64>(2 * (B.host_pend_at - batch.pend_at_arm) + 16, 1u << 20);
     a.cap_def = 64 + 2 * batch.n_args;
-    const u32 dirty_cap = (u32)(4 * n_par + 64);
+    // cells outside the frames a segment may define (the XMSS loop: 1; a query of the recursion program: its fold, 5, and its circle value)
+    const u32 dirty_cap = (u32)(12 * n_par + 64);
     u32* d_summary = nullptr;
     if (!dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.pcs) || !dev_alloc(D, B.owned, n_par * a.cap_cyc, &a.fps) ||
         !dev_alloc(D, B.owned, n_par * a.cap_pos * LM_VM_POSEIDON_CALL_WORDS, &a.pos) ||
@@ -1854,6 +1868,7 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
+    if (trim_last_frame && grown && memory.len == max_addr) memory.len = fp + 2 + batch.n_args;  // (see handle_parallel_batch)
     if (vm_times())
         fprintf(stderr, "[vm] device batch of %llu segments: host preparation + uploads %.2f ms, segments + deferred writes + summary %.2f ms, commit %.2f ms "
                         "(%llu cycles, %llu Poseidon calls, %u dirty cells; %llu deferred host Poseidon calls executed meanwhile in %.2f ms)\n",
@@ -2181,15 +2196,20 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
         if (!allow_deferred || (memory.lazy_on && !memory.lazy_alloc())) memory.lazy_on = false;
         memory.lazy_rows = &ex->tr.ext;
         bool device_failed = false;
+        static const bool rearm_env = !(getenv("LM_VM_REARM") && getenv("LM_VM_REARM")[0] == '0');
+        const bool rearm = allow_deferred && rearm_env;  // (the repeated run that reports an error is the reference's, literally)
+        u64 skip_arm_pc = ~0ull;
+        u32 n_batches = 0;
         for (;;) {
             Machine<MainMem>::Batch batch;
-            const int rc = m.run(false, 0, batch);
+            const int rc = m.run(false, 0, batch, skip_arm_pc);
             if (rc == 0) break;
             if (rc < 0) break;
             const double tb = vm_now_ms();
             int how = DEV_FALLBACK;
             std::string why = ctx ? "LM_VM_HOST is set" : "no device context (lmh_execute_bytecode)";
-            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D, why);
+            const bool extra = n_batches > 0;  // a batch the reference runs sequentially (Machine::run, skip_arm_pc)
+            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D, why, extra);
             if (how == DEV_DONE)
                 ex->n_device_batches++;
             else if (how == DEV_FALLBACK) {
@@ -2210,12 +2230,14 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
                 }
                 memory.dev_lo = memory.dev_hi = 0;
             }
-            const bool ok = how == DEV_DONE || handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err);
+            const bool ok = how == DEV_DONE || handle_parallel_batch(*bc, w, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, m.err, extra);
             t_batches += vm_now_ms() - tb;
+            n_batches++;
+            if (rearm) skip_arm_pc = batch.batch_pc;
             if (!ok || memory.lazy_failed) break;
         }
         if (!m.err.set && !device_failed) memory.lazy_drain();
-        if (!device_failed && (memory.lazy_failed || (m.err.set && memory.lazy_checks))) {
+        if (!device_failed && allow_deferred && (memory.lazy_failed || (m.err.set && (memory.lazy_checks || n_batches > 1)))) {
             // a deferred check failed, or an error was met with checks deferred: the first error of the program is what a run
             // without deferred work reports
             if (vm_times()) fprintf(stderr, "[vm] deferred checks: the run is repeated with every instruction executed at once\n");

@@ -1,0 +1,671 @@
+"""The PCS-opening part of the recursion program — `whir_open` of the reference's in-VM verifier — assembled by hand at the ISA
+level, and the witness of one run on genuine proofs.
+
+Reference: crates/rec_aggregation/zkdsl_implem/whir.py (whir_open :18-164, whir_round :316-368, sample_stir_indexes_and_fold
+:266-313, sumcheck_verify* :167-220, parse_commitment :377-391), fiat_shamir.py (the sponge over the raw transcript: _absorb_chunks,
+fs_grinding + assert_trailing_bits_are_zeros, fs_duplex, fs_sample_chunks, fs_sample_queries, fs_receive_*), hashing.py
+(slice_hash_rtl :54-60, whir_do_{4,3,2,1}_merkle_levels :114-203), utils.py (decompose_and_verify_merkle_query :537-626, powers_const,
+compute_eq_mle_extension, expand_from_univariate_*, univariate_eval_on_base, eval_multilinear_coeffs_rev, univariate_polynomial_eval);
+the call site is recursion.py:470-532 and its results are consumed at :534-654.  The zkDSL compiler is out of scope:
+the statements are lowered by hand with leanmultisig_amd/programs/asm.py, for ONE WhirConfig (the reference's program dispatches over
+every admissible configuration with match_range; here the configuration of the child proofs is an assembly-time constant).
+
+What the program proves.  Public input = slice_hash_with_iv of a claims buffer holding, per child proof, the arguments and the
+expected results of whir_open as lm_whir_opening_claim (include/leanmultisig_host.h) has them: the sponge state at the opening, the
+commitment root, the OOD points and answers of the commitment, the statement's share of the initial sum and of the final weight, the
+folding randomness.  For every child the program replays the Fiat-Shamir transcript of WhirConfig::verify (whir/src/verify.rs:83-232)
+over the raw proof transcript, checks every sumcheck polynomial, grinding witness, Merkle opening (leaf sponge + path), folded leaf,
+the final polynomial at the final queries, recomputes the constraint weights of the OOD and STIR points at the folding randomness, and
+asserts (s + statement_weights) * final_value == end_sum and folding randomness == claim.  What stays outside is everything
+recursion.py does BEFORE the opening (GKR, logup, AIR, statement assembly): the claims buffer stands for it.
+
+MI355X-first lowering: the reference's loops over the queries of a round (decompose_and_verify_merkle_batch_const, the fold loops,
+the s6s loop of whir_open) are `range` loops run once per child; here the children advance in lock step and each such loop is ONE
+parallel loop over (child, query) pairs — 4 x 118 / 56 / 28 segments per batch at the reference's recursion configuration — which
+leanVM's runner hands to the device (csrc/lm_vm_device.hip, one wavefront per segment).  A segment finds its child's pointers
+through a jump table indexed by the iteration (match_range), verifies its opening and folds its leaf in the same iteration.
+"""
+import numpy as np
+
+from ..vm import FP, K, M, Label, Program, Witness, to_monty
+from .asm import DIM, DIGEST_LEN, Fn, absolute, at, fp, loop_epilogue, loop_prologue
+
+P = 0x7F000001
+TWO_ADICITY = 24
+ROOT_24 = 0x6AC49F88           # generator of the 2^24-th roots of unity (koala_bear.rs:50-54), canonical
+PUBLIC_INPUT_LEN = DIGEST_LEN
+ZERO_VEC_PTR, ZERO_VEC_LEN = PUBLIC_INPUT_LEN, 16
+SDS_PTR = ZERO_VEC_PTR + ZERO_VEC_LEN
+ONE_EF_PTR = SDS_PTR + DIGEST_LEN
+REPEATED_ONES_PTR, NUM_REPEATED_ONES = ONE_EF_PTR + DIM, 32
+PREAMBLE_MEMORY_LEN = ZERO_VEC_LEN + DIGEST_LEN + DIM + NUM_REPEATED_ONES
+MAIN_FP = (PUBLIC_INPUT_LEN + PREAMBLE_MEMORY_LEN + 4) // 5 * 5    # the runner's starting fp (runner.rs:253-255)
+
+
+def ceil_div(a, b):
+    return -(-a // b)
+
+
+class Shape:
+    """everything the assembly depends on, derived from a WhirConfig dict (capi.WhirConfig.to_dict)"""
+
+    def __init__(self, cfg, n_children):
+        self.cfg, self.n_children = cfg, n_children
+        self.n, self.rate, self.n_rounds = cfg["num_variables"], cfg["starting_log_inv_rate"], cfg["n_rounds"]
+        assert self.n_rounds >= 1, "a configuration without a WHIR round has base-field leaves in the final round (not assembled)"
+        self.fold = [cfg["fold_first"]] + [cfg["fold_sub"]] * self.n_rounds
+        self.n_final = cfg["final_sumcheck_rounds"]
+        assert self.n == sum(self.fold) + self.n_final
+        self.queries = [r["num_queries"] for r in cfg["rounds"]] + [cfg["final_queries"]]
+        self.oods = [cfg["commitment_ood_samples"]] + [r["ood_samples"] for r in cfg["rounds"]]
+        self.query_grinding = [r["query_pow_bits"] for r in cfg["rounds"]] + [cfg["final_query_pow_bits"]]
+        self.folding_grinding = [cfg["starting_folding_pow_bits"]] + [r["folding_pow_bits"] for r in cfg["rounds"]]
+        dom = self.n + self.rate
+        self.height, self.leaf_words = [], []
+        for r in range(self.n_rounds + 1):
+            self.height.append(dom - self.fold[r])
+            self.leaf_words.append((1 << self.fold[r]) * (1 if r == 0 else DIM))
+            dom -= cfg["rs_red"] if r == 0 else 1
+        assert all(5 <= h <= TWO_ADICITY for h in self.height) and all(1 <= o <= 4 for o in self.oods)
+        self.n_rem = [self.n - sum(self.fold[:r + 1]) for r in range(self.n_rounds + 1)]   # variables left after round r's fold
+        # claims buffer of one child (words); mirrors lm_whir_opening_claim
+        o0 = self.oods[0]
+        self.c_fs, self.c_root = 0, 16
+        self.c_ood_points = 24
+        self.c_ood_evals = self.c_ood_points + DIM * o0
+        self.c_stmt_sum = self.c_ood_evals + DIM * o0
+        self.c_stmt_weights = self.c_stmt_sum + DIM
+        self.c_rand = self.c_stmt_weights + DIM
+        self.claim_words = ceil_div(self.c_rand + DIM * self.n, DIGEST_LEN) * DIGEST_LEN
+        # raw transcript words whir_open reads (every absorbed slice padded to the rate)
+        t = 0
+        for r in range(self.n_rounds + 1):
+            t += self.fold[r] * (16 + (8 if self.folding_grinding[r] else 0))
+            if r < self.n_rounds:
+                t += 8 + ceil_div(DIM * self.oods[r + 1], 8) * 8 + (8 if self.query_grinding[r] else 0)
+        t += ceil_div(DIM << self.n_final, 8) * 8 + (8 if self.query_grinding[self.n_rounds] else 0) + 16 * self.n_final
+        self.transcript_words = t
+
+
+class Fs:
+    """fiat_shamir.py: the sponge [capacity | rate] and the transcript cursor, tracked at assembly time"""
+
+    def __init__(self, f, state, transcript_cell):
+        self.f, self.st, self.tb, self.off = f, state, transcript_cell, 0
+
+    def _absorb(self, data):
+        new = fp(self.f.alloc(16))
+        self.f.permute(self.st, data, new)   # poseidon16_permute(fs, data, chain) (_absorb_chunks :20-27)
+        self.st = new
+
+    def duplex(self):
+        self._absorb(absolute(ZERO_VEC_PTR))
+
+    def rate(self):
+        return self.st + 8
+
+    def receive_chunks(self, n):
+        loc = at(self.tb, self.off)
+        for i in range(n):
+            self._absorb(loc + DIGEST_LEN * i)
+        self.off += DIGEST_LEN * n
+        return loc
+
+    def receive_ef(self, n):
+        """fs_receive_ef_inlined :168-172: the padding of the last chunk is checked to be zero"""
+        nch = ceil_div(n * DIM, DIGEST_LEN)
+        loc = self.receive_chunks(nch)
+        for i in range(n * DIM, nch * DIGEST_LEN):
+            self.f.assert_zero(loc + i)
+        return loc
+
+    def sample_chunks(self, n):
+        """fs_sample_chunks :109-129: n x 8 squeezed words, contiguous"""
+        if n == 1:
+            return self.rate()
+        f = self.f
+        samples = fp(f.alloc(DIGEST_LEN * n))
+        f.copy8(self.rate(), samples)
+        for i in range(1, n):
+            self.duplex()
+            f.copy8(self.rate(), samples + DIGEST_LEN * i)
+        return samples
+
+    def grinding(self, bits):
+        """fs_grinding :49-60"""
+        if bits == 0:
+            return
+        self.receive_chunks(1)
+        assert self.st.kind == "fp"
+        assert_trailing_bits_are_zeros(self.f, self.st.a + 8, bits)
+
+
+def assert_trailing_bits_are_zeros(f, value, bits):
+    """fiat_shamir.py:63-96: `value` (a cell) has its `bits` low bits zero; canonical decomposition 12 + 12 + 7 bits"""
+    p = f.p
+    ch = f.alloc(2)
+    p.hint_decompose_bits_merkle_whir(FP(ch), M(value), K(12))
+    f.range_check(ch, 4095)
+    f.range_check(ch + 1, 4095)
+    t, ps, diff, top7 = f.alloc(), f.alloc(), f.alloc(), f.alloc()
+    p.mul(M(ch + 1), K(4096), M(t))
+    p.add(M(ch), M(t), M(ps))
+    p.add(M(diff), M(value), M(ps))          # diff = partial_sum - value
+    p.mul(M(diff), K(127), M(top7))          # inv(2^24) = -127
+    f.range_check(top7, 127)
+    assert_if_127_then_zero(f, top7, ps)
+    if bits < 12:
+        q = f.alloc()
+        p.mul(M(q), K(1 << bits), M(ch))     # q = chunks[0] / 2^bits
+        f.range_check(q, (1 << (12 - bits)) - 1)
+    elif bits < 24:
+        p.add(M(ch), K(0), K(0))
+        q = f.alloc()
+        p.mul(M(q), K(1 << (bits - 12)), M(ch + 1))
+        f.range_check(q, (1 << (24 - bits)) - 1)
+    else:
+        p.add(M(ch), K(0), K(0))
+        p.add(M(ch + 1), K(0), K(0))
+
+
+def assert_if_127_then_zero(f, top7, low):
+    """`if top7 == 2**7 - 1: assert low == 0` (the 31-bit decomposition is the canonical one)"""
+    p = f.p
+    t, tinv, nz, omnz = f.alloc(), f.alloc(), f.alloc(), f.alloc()
+    skip = f.fresh("canon")
+    p.add(M(t), K(127), M(top7))
+    p.hint_inverse(M(t), tinv)
+    p.mul(M(t), M(tinv), M(nz))                  # nz = (top7 != 127), a boolean a jump accepts
+    p.add(M(omnz), M(nz), K(1))
+    p.mul(M(omnz), M(t), K(0))
+    p.jump(M(nz), K(Label(skip)), FP(0))
+    p.add(M(low), K(0), K(0))
+    p.label(skip)
+    f.forget_pointers()
+
+
+def sumcheck_round(f, fs, claimed, grinding_bits, challenge_dst):
+    """one round of sumcheck_verify_with_grinding (whir.py:210-220), degree 2 -> the new claimed sum"""
+    poly = fs.receive_ef(3)
+    tmp = f.new_ef()
+    f.dot(absolute(REPEATED_ONES_PTR), poly, tmp, 3, be=True)     # sum_continuous_ef
+    f.add(tmp, poly, claimed)                                     # polynomial_sum_at_0_and_1 == claimed_sum
+    fs.grinding(grinding_bits)
+    rand = fs.rate()                                              # fs_sample_ef
+    f.copy5(rand, challenge_dst)
+    pw = f.powers(rand, 3)
+    out = f.new_ef()
+    f.dot(poly, pw, out, 3)                                       # univariate_polynomial_eval
+    return out
+
+
+def build_program(cfg, n_children=4, log_size=None):
+    """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict())"""
+    S = Shape(cfg, n_children)
+    p = Program()
+    f = Fn(p, 0, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
+    A = lambda off: MAIN_FP + off  # noqa: E731 — absolute address of a main-frame cell
+    NC, R = n_children, S.n_rounds
+
+    # ================================================================ main ================================================================
+    # build_preamble_memory (utils.py:11-29)
+    zv = f.const(ZERO_VEC_PTR)
+    for i in range(ZERO_VEC_LEN):
+        p.deref(zv, i, K(0))
+    sds = f.const(SDS_PTR)
+    p.deref(sds, 0, K(1))
+    for i in range(1, DIGEST_LEN):
+        p.deref(sds, i, K(0))
+    one = f.const(ONE_EF_PTR)
+    p.deref(one, 0, K(1))
+    for i in range(1, DIM):
+        p.deref(one, i, K(0))
+    ones = f.const(REPEATED_ONES_PTR)
+    for i in range(NUM_REPEATED_ONES):
+        p.deref(ones, i, K(1))
+    # the claims buffer and the raw proof transcripts (hinted, as main.py:38-42 / recursion.py:49-52)
+    claims = f.alloc()
+    p.hint_request_memory(claims, K(NC * S.claim_words))
+    p.hint_witness("claims", claims, indirect=True)
+    tbase = []
+    for c in range(NC):
+        t = f.alloc()
+        p.hint_request_memory(t, K(S.transcript_words))
+        p.hint_witness("proof_transcript", t, indirect=True)
+        tbase.append(t)
+    p.add(M(tbase[-1]), K(0), M(f.alloc()))    # (anchors the hints above on an instruction)
+
+    # per-round arrays shared by the children: iteration i = child * q + j of a round's loop owns entry i
+    folds_all = [f.alloc(DIM * NC * S.queries[r]) for r in range(R)]           # the folded leaves (whir.py:302-311)
+    circle_all = [f.alloc(NC * S.queries[r]) for r in range(R)]                # all_circle_values[r]
+    s6s_all = [f.alloc(DIM * NC * S.queries[r]) for r in range(R)]             # whir.py:143-147
+    # per child and round: the sampled query words (padded to whole chunks) and the descriptor its segments read
+    sampled = [[f.alloc(ceil_div(S.queries[r], 8) * 8) for r in range(R + 1)] for c in range(NC)]
+    DESC_ROOT, DESC_EQ, DESC_COEFFS, DESC_RAND = 0, 1, 2, 3
+    desc = [[f.alloc(4) for r in range(R + 1)] for c in range(NC)]
+
+    ch = []                                                                    # assembly-time state of every child
+    for c in range(NC):
+        cl = at(claims, c * S.claim_words)
+        st = dict(cl=cl, rand=fp(f.alloc(DIM * S.n)))                          # folding_randomness_global
+        st["fs"] = Fs(f, cl + S.c_fs, tbase[c])
+        # recursion.py:472-475: the combination randomness of the first constraint set; only its OOD powers are needed here
+        gen = st["fs"].rate()
+        st["pw0"] = f.powers(gen, S.oods[0])
+        ood_sum = f.new_ef()
+        f.dot(cl + S.c_ood_evals, st["pw0"], ood_sum, S.oods[0])
+        st["claimed"] = f.add(ood_sum, cl + S.c_stmt_sum)                      # whir_sum
+        st["root"] = cl + S.c_root
+        st["ood_points"], st["comb"], st["roots"] = [], [], []
+        ch.append(st)
+
+    def sumcheck_rounds(st, count, bits, first_var):
+        for k in range(count):
+            st["claimed"] = sumcheck_round(f, st["fs"], st["claimed"], bits, st["rand"] + DIM * (first_var + k))
+
+    def stir_prepare(c, st, r):
+        """sample_stir_indexes_and_fold (whir.py:266-313) up to its loops: grinding, the query words, the eq table of the folding
+        randomness, and the descriptor the (child, query) segments of round r read"""
+        fs = st["fs"]
+        fs.grinding(S.query_grinding[r])
+        nch = ceil_div(S.queries[r], 8)
+        smp = fs.sample_chunks(nch)                                            # fs_sample_queries :197-209
+        for j in range(nch):
+            f.copy8(smp + 8 * j, fp(sampled[c][r] + 8 * j))
+        var0 = sum(S.fold[:r])
+        eq = f.eq_mle(st["rand"] + DIM * var0, S.fold[r])
+        p.add(K(0), M(f.ptr(st["root"])), M(desc[c][r] + DESC_ROOT))
+        p.add(K(0), M(f.ptr(eq)), M(desc[c][r] + DESC_EQ))
+
+    # ---- whir_round x n_rounds (whir.py:316-368), children in lock step ---------------------------------------------------------------
+    var = 0
+    for r in range(R):
+        for c, st in enumerate(ch):
+            fs = st["fs"]
+            sumcheck_rounds(st, S.fold[r], S.folding_grinding[r], var)
+            new_root = fs.receive_chunks(1)                                    # parse_commitment :377-391
+            ood_points = fs.sample_chunks(ceil_div(DIM * S.oods[r + 1], 8))
+            st["ood_evals"] = fs.receive_ef(S.oods[r + 1])
+            st["ood_points"].append(ood_points)
+            stir_prepare(c, st, r)
+            st["roots"].append(new_root)
+        f.call_loop(f"merkle_loop_{r}", f"@merkle_frame_{r}", [K(NC * S.queries[r]), K(A(folds_all[r])), K(A(circle_all[r]))])
+        for c, st in enumerate(ch):
+            fs = st["fs"]
+            st["root"] = st["roots"][-1]
+            fs.duplex()
+            gen = fs.rate()
+            q, o = S.queries[r], S.oods[r + 1]
+            comb = f.powers(gen, 1 << (q + o - 1).bit_length())                # powers(): next power of two (utils.py:38-46)
+            st["comb"].append(comb)
+            s0, s1 = f.new_ef(), f.new_ef()
+            f.dot(st["ood_evals"], comb, s0, o)
+            f.dot(fp(folds_all[r] + DIM * c * q), comb + DIM * o, s1, q)
+            st["claimed"] = f.add(st["claimed"], f.add(s0, s1))
+        var += S.fold[r]
+    # ---- the final round (whir.py:71-101) --------------------------------------------------------------------------------------------------
+    for c, st in enumerate(ch):
+        fs = st["fs"]
+        sumcheck_rounds(st, S.fold[R], S.folding_grinding[R], var)
+        st["coeffs"] = fs.receive_ef(1 << S.n_final)
+        stir_prepare(c, st, R)
+        p.add(K(0), M(f.ptr(st["coeffs"])), M(desc[c][R] + DESC_COEFFS))
+    f.call_loop(f"merkle_loop_{R}", f"@merkle_frame_{R}", [K(NC * S.queries[R]), K(0), K(0)])
+    var += S.fold[R]
+    for c, st in enumerate(ch):
+        sumcheck_rounds_plain = st["fs"]
+        for k in range(S.n_final):                                             # sumcheck_verify (no grinding)
+            st["claimed"] = sumcheck_round(f, sumcheck_rounds_plain, st["claimed"], 0, st["rand"] + DIM * (var + k))
+        st["end_sum"] = st["claimed"]
+        for r in range(R):                                                     # what the s6s segments of round r read
+            p.add(K(0), FP(st["rand"].a + DIM * sum(S.fold[:r + 1])), M(desc[c][r] + DESC_RAND))
+    # ---- the constraint weights at the folding randomness (whir.py:113-156) ------------------------------------------------------------------
+    for r in range(R):
+        f.call_loop(f"s6s_loop_{r}", f"@s6s_frame_{r}", [K(NC * S.queries[r]), K(A(circle_all[r])), K(A(s6s_all[r]))])
+    for c, st in enumerate(ch):
+        cl = st["cl"]
+        rec = f.new_ef(S.oods[0])
+        for i in range(S.oods[0]):
+            ex = expand_from_univariate_ext(f, cl + S.c_ood_points + DIM * i, S.n)
+            f.poly_eq(ex, st["rand"], rec + DIM * i, S.n)
+        s = f.new_ef()
+        f.dot(rec, st["pw0"], s, S.oods[0])
+        for r in range(R):
+            my_rand = st["rand"] + DIM * sum(S.fold[:r + 1])
+            q, o, nr = S.queries[r], S.oods[r + 1], S.n_rem[r]
+            rec = f.new_ef(o)
+            for j in range(o):
+                ex = expand_from_univariate_ext(f, st["ood_points"][r] + DIM * j, nr)
+                f.poly_eq(ex, my_rand, rec + DIM * j, nr)
+            summed_ood, s7 = f.new_ef(), f.new_ef()
+            f.dot(rec, st["comb"][r], summed_ood, o)
+            f.dot(fp(s6s_all[r] + DIM * c * q), st["comb"][r] + DIM * o, s7, q)
+            s = f.add(summed_ood, f.add(s, s7))
+        # eval_multilinear_coeffs_rev (utils.py:181-192) at the final sumcheck's challenges
+        nf = S.n_final
+        basis = f.new_ef(1 << nf)
+        f.set_one(basis)
+        final_rand = st["rand"] + DIM * (S.n - nf)
+        for k in range(nf):
+            pt = f.new_ef()
+            f.copy5(final_rand + DIM * k, pt)
+            for j in range(1 << k):
+                f.mul(basis + DIM * j, pt, basis + DIM * (j + (1 << k)))
+        final_value = f.new_ef()
+        f.dot(st["coeffs"], basis, final_value, 1 << nf)
+        # recursion.py:534-654 with the statement's share taken from the claim: (s + statement_weights) * final_value == end_sum
+        total = f.add(s, cl + S.c_stmt_weights)
+        f.mul(total, final_value, st["end_sum"])
+        for k in range(S.n):
+            f.copy5(st["rand"] + DIM * k, cl + S.c_rand + DIM * k)             # folding_randomness_global == the claim's
+    # ---- slice_hash_with_iv(claims, n_chunks, public input) (hashing.py:81-89) -------------------------------------------------------------------
+    nch = NC * S.claim_words // DIGEST_LEN
+    states = f.alloc((nch - 1) * DIGEST_LEN)
+    f.compress(absolute(ZERO_VEC_PTR), at(claims, 0), fp(states))
+    for j in range(1, nch):
+        dst = absolute(0) if j == nch - 1 else fp(states + 8 * j)
+        f.compress(fp(states + 8 * (j - 1)), at(claims, 8 * j), dst)
+    p.return_from_main(f.alloc())
+    p.starting_frame_memory = f.top
+
+    # ================================================================ the loops ============================================================
+    info = dict(shape=S, frames={}, main_frame_size=f.top)
+    for r in range(R + 1):
+        info["frames"][f"merkle_{r}"] = emit_merkle_loop(p, S, r, [A(sampled[c][r]) for c in range(NC)], [A(desc[c][r]) for c in range(NC)])
+    for r in range(R):
+        info["frames"][f"s6s_{r}"] = emit_s6s_loop(p, S, r, [A(desc[c][r]) for c in range(NC)])
+    bc = p.finalize(log_size)
+    bc.info = info
+    return bc
+
+
+def expand_from_univariate_ext(f, alpha, n):
+    """expand_from_univariate_ext_const (utils.py:160-165): alpha, alpha^2, alpha^4, ..."""
+    res = f.new_ef(n)
+    f.copy5(alpha, res)
+    for i in range(n - 1):
+        f.mul(res + DIM * i, res + DIM * i, res + DIM * (i + 1))
+    return res
+
+
+def emit_child_table(p, g, S, r, label, cells):
+    """match_range over the iteration: entry i sets, for cell, per_child, per_query in cells: m[fp + cell] = per_child[c] + per_query * j
+    with (c, j) = divmod(i, q).  Entries are len(cells) + 1 instructions."""
+    q = S.queries[r]
+    block = len(cells) + 1
+    after = g.dispatch(2, block, label)      # frame cell 2 = the iteration
+    table = []
+    for i in range(S.n_children * q):
+        c, j = divmod(i, q)
+        table.append([(cell, per_child[c] + per_query * j) for cell, per_child, per_query in cells])
+    return after, table, block
+
+
+def emit_merkle_loop(p, S, r, sampled_abs, desc_abs):
+    """One (child, query) pair of round r: decompose_and_verify_merkle_query (utils.py:537-626) + the fold of the opened leaf
+    (whir.py:304-311) [+ the final polynomial at the query point, whir.py:91-99, in the last round].
+    frame: [return pc, saved fp, i, end, folds_all, circle_all, locals...]"""
+    N_ARGS = 4
+    I, FOLDS, CIRCLE = 2, 4, 5
+    final = r == S.n_rounds
+    g = Fn(p, 2 + N_ARGS, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
+    label, size_label = f"merkle_loop_{r}", f"@merkle_frame_{r}"
+    loop_prologue(p, g, label, N_ARGS)
+    DESC, APTR = g.alloc(), g.alloc()
+    after_child, child_table, child_block = emit_child_table(p, g, S, r, f"child_table_m{r}", [(DESC, desc_abs, 0), (APTR, sampled_abs, 1)])
+    root_ptr, eq_ptr = g.alloc(), g.alloc()
+    p.deref(DESC, 0, M(root_ptr))
+    p.deref(DESC, 1, M(eq_ptr))
+    a = g.alloc()
+    p.deref(APTR, 0, M(a))                                        # the sampled word
+    # nibbles of the canonical value (utils.py:539-555)
+    nib = g.alloc(6)
+    p.hint_decompose_bits_merkle_whir(FP(nib), M(a), K(4))
+    for i in range(6):
+        g.range_check(nib + i, 15)
+    ps = nib
+    for i in range(1, 6):
+        t, s = g.alloc(), g.alloc()
+        p.mul(M(nib + i), K(16 ** i), M(t))
+        p.add(M(ps), M(t), M(s))
+        ps = s
+    diff, top7 = g.alloc(), g.alloc()
+    p.add(M(diff), M(a), M(ps))
+    p.mul(M(diff), K(127), M(top7))
+    g.range_check(top7, 127)
+    assert_if_127_then_zero(g, top7, ps)
+    # the leaf and its digest (slice_hash_rtl, hashing.py:54-60)
+    n_chunks = S.leaf_words[r] // DIGEST_LEN
+    leaf = g.alloc(S.leaf_words[r])
+    states = g.alloc((n_chunks - 1) * DIGEST_LEN)
+    p.hint_witness("merkle_leaf", leaf)
+    p.poseidon16(FP(leaf + (n_chunks - 2) * 8), FP(leaf + (n_chunks - 1) * 8), FP(states))
+    for j in range(1, n_chunks - 1):
+        p.poseidon16(FP(states + (j - 1) * 8), FP(leaf + (n_chunks - 2 - j) * 8), FP(states + j * 8))
+    leaf_hash = states + (n_chunks - 2) * 8
+    # the path, four levels per nibble through 16-entry jump tables (utils.py:561-624)
+    h = S.height[r]
+    path = g.alloc(h * DIGEST_LEN)
+    n_nib = ceil_div(h, 4)
+    mstates = g.alloc((n_nib - 1) * DIGEST_LEN)
+    tables = []
+    prod = None
+    for k in range(n_nib):
+        levels = min(4, h - 4 * k)
+        temps, nibpow = g.alloc(3 * DIGEST_LEN), g.alloc()
+        state_in = leaf_hash if k == 0 else mstates + (k - 1) * 8
+        last = k == n_nib - 1
+        if k == 0:
+            p.hint_witness("merkle_path", path)
+        g.dispatch(nib + k, levels + 2, f"merkle_table_{r}_{k}")
+        tables.append(dict(k=k, levels=levels, temps=temps, nibpow=nibpow, state_in=state_in, out=None if last else mstates + k * 8))
+        if prod is None:
+            prod = nibpow
+        else:
+            t = g.alloc()
+            p.mul(M(prod), M(nibpow), M(t))
+            prod = t
+    # the fold of the leaf with eq(folding randomness) (whir.py:306-311)
+    leaf_ptr = g.alloc()
+    p.add(K(0), FP(leaf), M(leaf_ptr))
+    if not final:
+        cptr = g.alloc()
+        p.add(M(CIRCLE), M(I), M(cptr))
+        p.deref(cptr, 0, M(prod))                                 # circle_values[i]
+        i5, fptr = g.alloc(), g.alloc()
+        p.mul(M(I), K(DIM), M(i5))
+        p.add(M(FOLDS), M(i5), M(fptr))
+        p.extension_op("dot_product", M(leaf_ptr), M(eq_ptr), M(fptr), size=1 << S.fold[r], is_be=(r == 0))
+    else:
+        # whir.py:91-99: the final polynomial at the query point equals the fold (univariate_eval_on_base, utils.py:168-178)
+        fold = g.alloc(DIM)
+        p.extension_op("dot_product", M(leaf_ptr), M(eq_ptr), FP(fold), size=1 << S.fold[r], is_be=False)
+        nco = 1 << S.n_final
+        pw = g.alloc(nco)
+        p.add(K(0), K(1), M(pw))
+        for i in range(nco - 1):
+            p.mul(M(pw + i), M(prod), M(pw + i + 1))
+        co_ptr, pw_ptr = g.alloc(), g.alloc()
+        p.deref(DESC, 2, M(co_ptr))
+        p.add(K(0), FP(pw), M(pw_ptr))
+        p.extension_op("dot_product", M(pw_ptr), M(co_ptr), FP(fold), size=nco, is_be=True)
+    loop_epilogue(p, g, label, size_label, N_ARGS)
+    p.labels[size_label] = g.top
+    # ---- tables --------------------------------------------------------------------------------------------------------------------------
+    p.label(f"child_table_m{r}")
+    for entry in child_table:
+        for cell, value in entry:
+            p.add(K(0), K(value), M(cell))
+        p.jump(K(1), K(Label(after_child)), FP(0))
+    for tb in tables:
+        k, levels = tb["k"], tb["levels"]
+        shift = 1 << (TWO_ADICITY - h + 4 * k)
+        p.label(f"merkle_table_{r}_{k}")
+        for v in range(16):
+            start = p.here()
+            cur = tb["state_in"]
+            for lv in range(levels):
+                sib = path + (4 * k + lv) * 8
+                lastlv = lv == levels - 1
+                if lastlv:
+                    dst = M(root_ptr) if tb["out"] is None else FP(tb["out"])
+                else:
+                    dst = FP(tb["temps"] + 8 * lv)
+                if (v >> lv) & 1:
+                    p.poseidon16(FP(sib), FP(cur), dst)
+                else:
+                    p.poseidon16(FP(cur), FP(sib), dst)
+                cur = tb["temps"] + 8 * lv
+            p.add(K(0), K(pow(ROOT_24, shift * (v % (1 << levels)), P)), M(tb["nibpow"]))
+            p.jump(K(1), K(Label(f"merkle_table_{r}_{k}@after")), FP(0))
+            assert p.here() - start == levels + 2
+    return g.top
+
+
+def emit_s6s_loop(p, S, r, desc_abs):
+    """whir.py:143-147 for one (child, query) pair of round r: eq(expand_from_univariate_base(circle value), my_folding_randomness).
+    frame: [return pc, saved fp, i, end, circle_all, s6s_all, locals...]"""
+    N_ARGS = 4
+    I, CIRCLE, S6S = 2, 4, 5
+    g = Fn(p, 2 + N_ARGS, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
+    label, size_label = f"s6s_loop_{r}", f"@s6s_frame_{r}"
+    loop_prologue(p, g, label, N_ARGS)
+    DESC = g.alloc()
+    after_child, child_table, _ = emit_child_table(p, g, S, r, f"child_table_s{r}", [(DESC, desc_abs, 0)])
+    rand_ptr, cptr = g.alloc(), g.alloc()
+    p.deref(DESC, 3, M(rand_ptr))
+    p.add(M(CIRCLE), M(I), M(cptr))
+    nr = S.n_rem[r]
+    ex = g.alloc(nr)
+    p.deref(cptr, 0, M(ex))                                       # expand_from_univariate_base_const (utils.py:142-150)
+    for i in range(1, nr):
+        p.mul(M(ex + i - 1), M(ex + i - 1), M(ex + i))
+    ex_ptr, i5, dst = g.alloc(), g.alloc(), g.alloc()
+    p.add(K(0), FP(ex), M(ex_ptr))
+    p.mul(M(I), K(DIM), M(i5))
+    p.add(M(S6S), M(i5), M(dst))
+    p.extension_op("poly_eq", M(ex_ptr), M(rand_ptr), M(dst), size=nr, is_be=True)
+    loop_epilogue(p, g, label, size_label, N_ARGS)
+    p.labels[size_label] = g.top
+    p.label(f"child_table_s{r}")
+    for entry in child_table:
+        for cell, value in entry:
+            p.add(K(0), K(value), M(cell))
+        p.jump(K(1), K(Label(after_child)), FP(0))
+    return g.top
+
+
+# ================================================================================================================================================
+# the witness of one run
+# ================================================================================================================================================
+def parse_raw_proof(words):
+    """lmh_proof_copy blob -> (transcript, [(index, leaf, path)])  (include/leanmultisig_host.h: RawProof layout)"""
+    w = np.asarray(words, dtype=np.uint32)
+    t = int(w[0])
+    transcript = w[1:1 + t]
+    o = 1 + t
+    m = int(w[o])
+    o += 1
+    openings = []
+    for _ in range(m):
+        idx = int(w[o]) | (int(w[o + 1]) << 32)
+        ll, pl = int(w[o + 2]), int(w[o + 3])
+        o += 4
+        openings.append((idx, w[o:o + ll], w[o + ll:o + ll + pl]))
+        o += ll + pl
+    assert o == w.size
+    return transcript, openings
+
+
+def claim_words(S, claim):
+    """one child's block of the claims buffer from an lm_whir_opening_claim (capi.WhirOpeningClaim)"""
+    o0 = S.oods[0]
+    assert claim.num_variables == S.n and claim.log_inv_rate == S.rate and claim.n_ood == o0
+    out = np.zeros(S.claim_words, dtype=np.uint32)
+    out[S.c_fs:S.c_fs + 16] = np.ctypeslib.as_array(claim.challenger_state)
+    out[S.c_root:S.c_root + 8] = np.ctypeslib.as_array(claim.root)
+    out[S.c_ood_points:S.c_ood_points + DIM * o0] = np.ctypeslib.as_array(claim.ood_points)[:DIM * o0]
+    out[S.c_ood_evals:S.c_ood_evals + DIM * o0] = np.ctypeslib.as_array(claim.ood_answers)[:DIM * o0]
+    out[S.c_stmt_sum:S.c_stmt_sum + DIM] = np.ctypeslib.as_array(claim.statement_sum)
+    out[S.c_stmt_weights:S.c_stmt_weights + DIM] = np.ctypeslib.as_array(claim.statement_weights)
+    out[S.c_rand:S.c_rand + DIM * S.n] = np.ctypeslib.as_array(claim.folding_randomness)[:DIM * S.n]
+    return out
+
+
+def build_witness(bc, children):
+    """children: per child (raw transcript words, lm_whir_opening_claim, openings [(index, leaf, path)] of the WHOLE proof in opening
+    order — every opening of a proof belongs to its PCS opening).  -> (public_input, vm.Witness, info).
+    The hint streams are what type_1_aggregation.rs:310-356 builds for a recursion: `proof_transcript` per child, and the
+    `merkle_leaf` / `merkle_path` blobs of extract_merkle_hint_blobs in the order the program's segments consume them: round by
+    round, within a round child by child."""
+    from ..xmss import Xmss
+    from .xmss_aggregate import compress_slice
+    S = bc.info["shape"]
+    assert len(children) == S.n_children
+    claims, transcripts, per_child = [], [], []
+    for raw, claim, openings in children:
+        off = int(claim.transcript_offset)
+        t = np.asarray(raw, dtype=np.uint32)[off:]
+        assert t.size == S.transcript_words, (t.size, S.transcript_words)
+        transcripts.append(t)
+        claims.append(claim_words(S, claim))
+        assert len(openings) == sum(S.queries)
+        per_child.append(openings)
+    leaves, paths = [], []
+    for r in range(S.n_rounds + 1):
+        o0 = sum(S.queries[:r])
+        for c in range(S.n_children):
+            for idx, leaf, path in per_child[c][o0:o0 + S.queries[r]]:
+                assert leaf.size == S.leaf_words[r] and path.size == 8 * S.height[r]
+                leaves.append(leaf)
+                paths.append(path)
+    data = np.concatenate(claims)
+    public_input = compress_slice(Xmss(), data, use_iv=True)
+    hints = {"claims": [data], "proof_transcript": transcripts, "merkle_leaf": leaves, "merkle_path": paths}
+    return public_input, Witness(bc, PREAMBLE_MEMORY_LEN, hints), dict(claims=data)
+
+
+def expected_counts(S):
+    """Poseidon16 calls and ExtensionOp rows of one run, from the protocol parameters alone (the terms tools/recursion_shape.py counts
+    for the reference's program, here for this lowering): what a run must report (tests/test_whir_verify_program.py)."""
+    n_sumcheck = S.n
+    grind = lambda b: 1 if b else 0  # noqa: E731
+    pos = ext = 0
+    # Fiat-Shamir: one permutation per absorbed or squeezed rate block (fiat_shamir.py)
+    for r in range(S.n_rounds + 1):
+        pos += S.fold[r] * (2 + grind(S.folding_grinding[r]))
+        q = S.queries[r]
+        if r < S.n_rounds:
+            o = S.oods[r + 1]
+            pos += 1 + (ceil_div(DIM * o, 8) - 1) + ceil_div(DIM * o, 8) + 1      # root, OOD points, OOD answers, the duplex before gamma
+        else:
+            pos += ceil_div(DIM << S.n_final, 8)
+        pos += grind(S.query_grinding[r]) + ceil_div(q, 8) - 1
+        pos += q * (S.leaf_words[r] // 8 - 1 + S.height[r])                       # leaf sponge + path
+    pos += 2 * S.n_final
+    pos *= S.n_children
+    pos += S.n_children * S.claim_words // 8                                      # the public input
+    # ExtensionOp rows
+    copy8 = 2
+    powers = lambda k: 1 if k == 1 else k                                         # noqa: E731 — set_one, copy, k - 2 products
+    eq_mle = lambda k: 1 + k + 2 * ((1 << k) - 1)                                 # noqa: E731
+    ext += n_sumcheck * (3 + 1 + 1 + powers(3) + 3)
+    o0 = S.oods[0]
+    ext += powers(o0) + o0 + 1
+    for r in range(S.n_rounds + 1):
+        q = S.queries[r]
+        nq = ceil_div(q, 8)
+        ext += (copy8 * nq if nq > 1 else 0) + copy8 * nq + eq_mle(S.fold[r])
+        if r < S.n_rounds:
+            o, nr = S.oods[r + 1], S.n_rem[r]
+            no = ceil_div(DIM * o, 8)
+            ext += copy8 * no if no > 1 else 0
+            ext += powers(1 << (q + o - 1).bit_length()) + o + q + 2
+            ext += q * (1 << S.fold[r])                                           # leaf folds
+            ext += o * 2 * nr + o + q + 2 + q * nr                                # OOD / STIR constraint weights
+        else:
+            ext += q * ((1 << S.fold[r]) + (1 << S.n_final))
+    ext += o0 * 2 * S.n + o0
+    ext += 1 + S.n_final + (1 << S.n_final) - 1 + (1 << S.n_final) + 2 + S.n
+    ext *= S.n_children
+    return dict(poseidon_calls=pos, extension_rows=ext)

@@ -1,0 +1,97 @@
+"""The recursion program's PCS opening (leanmultisig_amd/programs/whir_verify.py = zkdsl_implem/whir.py `whir_open`, hand-assembled)
+on the host runner, CPU: it accepts genuine proofs (here: the ORACLE prover's, which the device prover's equal word for word), its
+run equals the oracle VM's (oracle/vm_oracle.hpp) cell for cell, its Poseidon / ExtensionOp / hint consumption equals what the
+protocol parameters predict, and it rejects what lmh_verify_execution rejects: a flipped sibling, a changed leaf, a changed
+transcript word, a wrong claim (root, sums, folding randomness), a wrong public input."""
+import numpy as np
+import pytest
+
+import leanmultisig_amd as lm
+from leanmultisig_amd import capi, vm
+from leanmultisig_amd.programs import whir_verify as wv
+from tests import oracle_binding as ob
+from tests import synth_witness
+
+N_CHILDREN = 2
+
+
+@pytest.fixture(scope="module")
+def setup(orc):
+    ob_b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
+    lm_b = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    children, cfg = [], None
+    for c in range(N_CHILDREN):
+        w = synth_witness.build(orc, np.random.default_rng(131 + c), n_calls=40)
+        cfg = lm.WhirConfig.new(lm_b, synth_witness.stacked_n_vars(w)).to_dict()
+        sizes = [r["num_queries"] for r in cfg["rounds"]] + [cfg["final_queries"]]
+        pr = lm.Prover.from_raw(ob.prove_execution(orc, w, synth_witness.header(w), ob_b), sizes)
+        raw, claim = capi.verify_execution_raw(w, pr, lm_b)
+        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1]))
+    bc = wv.build_program(cfg, N_CHILDREN)
+    return bc, children
+
+
+def test_raw_transcript_layout(setup):
+    """RawProof::transcript (fiat-shamir/src/verifier.rs:54-60,126-195): whole rate blocks, the part whir_open reads has the length the
+    configuration implies, and the claim's sponge state is reproducible from nothing but the raw transcript's words"""
+    bc, children = setup
+    S = bc.info["shape"]
+    for raw, claim, openings in children:
+        assert raw.size % 8 == 0 and raw.size - int(claim.transcript_offset) == S.transcript_words
+        assert len(openings) == sum(S.queries) and claim.n_ood == S.oods[0] and claim.num_variables == S.n
+
+
+def test_accepts_and_equals_oracle_vm(orc, setup):
+    bc, children = setup
+    S = bc.info["shape"]
+    pi, wit, _ = wv.build_witness(bc, children)
+    ex = vm.execute(bc, pi, wit, n_threads=4)
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and ex.memory_len == run.memory.size
+    assert np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+    # what the protocol parameters predict (tools/recursion_shape.py counts the same terms for the reference's configuration)
+    assert ex.n_poseidon_calls == wv.expected_counts(S)["poseidon_calls"]
+    assert ex.n_extension_rows == wv.expected_counts(S)["extension_rows"]
+    info = vm.VmRunInfo()
+    import ctypes
+    capi.load().lmh_execution_info(ex.h, ctypes.byref(info))
+    # every (child, query) loop is a parallel batch of its own: n_rounds + 1 Merkle loops and n_rounds eq-factor loops
+    assert info.n_host_batches == 2 * S.n_rounds + 1
+
+
+def _rejected(bc, children, match=None):
+    pi, wit, _ = wv.build_witness(bc, children)
+    with pytest.raises(lm.LmError, match=match):
+        vm.execute(bc, pi, wit, n_threads=4)
+
+
+def test_rejects_tampered_openings(setup):
+    bc, children = setup
+    raw, claim, ops = children[1]
+    n0 = bc.info["shape"].queries[0]
+    for k, part, word in ((3, 2, 9), (n0 + 2, 2, 37), (5, 1, 17), (n0 + 1, 1, 150)):  # (opening, 1 = leaf / 2 = path, word)
+        ops2 = [(i, leaf.copy(), path.copy()) for i, leaf, path in ops]
+        ops2[k][part][word] = (int(ops2[k][part][word]) + 1) % wv.P
+        _rejected(bc, [children[0], (raw, claim, ops2)], "MemoryAlreadySet|InvalidExtensionOp")
+
+
+def test_rejects_tampered_transcript_and_claim(setup):
+    bc, children = setup
+    raw, claim, ops = children[0]
+    off = int(claim.transcript_offset)
+    for pos in (off + 5, off + 16 * 7 + 3, raw.size - 3):
+        raw2 = raw.copy()
+        raw2[pos] ^= 2
+        _rejected(bc, [(raw2, claim, ops), children[1]])
+    for field, k in (("statement_weights", 2), ("statement_sum", 0), ("folding_randomness", 41), ("root", 1), ("ood_points", 3), ("ood_answers", 4),
+                     ("challenger_state", 2), ("challenger_state", 7)):
+        cl2 = capi.WhirOpeningClaim.from_buffer_copy(claim)
+        getattr(cl2, field)[k] ^= 1
+        _rejected(bc, [(raw, cl2, ops), children[1]])
+    pi, wit, _ = wv.build_witness(bc, children)
+    pi = pi.copy()
+    pi[3] ^= 1
+    with pytest.raises(lm.LmError, match="MemoryAlreadySet"):
+        vm.execute(bc, pi, wit)

@@ -115,6 +115,117 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss",
     return dict(w=w, tr=tr, keep=keep, cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, lm_builder=lm_builder, log_inv_rate=log_inv_rate, capacity=capacity)
 
 
+def whir_recursion_bench(ctx, lm, args, ob=None, orc=None):
+    """--shape whir-recursion: BASELINE configs[3] (`recursion --n 4 --log-inv-rate 2`, src/main.rs:91-115) as far as the recursion program
+    is assembled (leanmultisig_amd/programs/whir_verify.py: the PCS opening of the in-VM verifier, zkdsl_implem/whir.py).  Four leaves of
+    775 REAL signatures are proved by this library at rate 1/4 (untimed here; their time is reported), their raw transcripts, opening
+    claims and un-pruned Merkle openings become the hints of the root step, and ONE step = prove_execution of the root program: the VM
+    run (every (child, query) loop a batch of wavefronts on the device), the trace, the proof.  Prints one JSON line (a side measurement:
+    root proofs per second; NOT the headline metric) with the measured cycle / Poseidon / ExtensionOp counts of the run next to the
+    counts tools/recursion_shape.py derived for the same terms."""
+    from leanmultisig_amd import capi, vm
+    from leanmultisig_amd.programs import whir_verify as wv
+    from leanmultisig_amd.programs import xmss_aggregate as xa
+    n_children, child_sigs, rate = 4, max(8, 775 >> args.scale_log), args.log_inv_rate
+    capacity = args.soundness == "capacity"
+    leaf = xa.build_program(19 if args.scale_log == 0 else None)
+    builder = lm.WhirBuilder.default(rate, prox_gaps_conjecture=capacity)
+    inst = dict(log_bytecode=leaf.log_size, ending_pc=leaf.ending_pc, bytecode_hash=leaf.hash(), bytecode=leaf.multilinear)
+    signer = xa.Xmss(compress=lambda x: ctx.poseidon16(x, compress=True))
+    children, leaf_ms, n_vars = [], [], None
+    for c in range(n_children):
+        pi, wit, _ = xa.build_witness(leaf, child_sigs, np.random.default_rng(7000 + c), xmss=signer)
+        for k in range(2):  # (the second run is the warm one)
+            pr = lm.Prover(ctx)
+            t0 = time.perf_counter()
+            vm.prove_execution_vm(ctx, pr, leaf, pi, wit, builder)
+            t1 = time.perf_counter()
+        leaf_ms.append(1e3 * (t1 - t0))
+        raw, claim = capi.verify_execution_raw(dict(inst, public_input=pi), pr, builder)   # the library's verifier accepts the child
+        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1]))
+        assert n_vars in (None, claim.num_variables)
+        n_vars = claim.num_variables
+    cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
+    bc = wv.build_program(cfg, n_children, log_size=19 if args.scale_log == 0 else None)
+    S = bc.info["shape"]
+    t0 = time.perf_counter()
+    pi, wit, _ = wv.build_witness(bc, children)
+    hints_ms = 1e3 * (time.perf_counter() - t0)
+    phases, info = [], None
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            ctx.sync()
+            t0 = time.perf_counter()
+        pr = lm.Prover(ctx)
+        ph = (lm.capi.C.c_double * 3)()
+        ri = vm.VmRunInfo()
+        pia = np.ascontiguousarray(pi, dtype=np.uint32)
+        rc = ctx.lib.lmh_prove_execution_vm_info(ctx.h, pr.h, bc.handle(), pia.ctypes.data, pia.size, lm.capi.C.byref(wit.c), lm.capi.C.byref(builder), 0, ph,
+                                                 lm.capi.C.byref(ri))
+        if rc != 0:
+            raise SystemExit("whir-recursion: " + ctx.lib.lm_last_error().decode())
+        pr.proof_pruned()
+        if k >= args.warmup:
+            phases.append(list(ph))
+        info = ri.to_dict()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    ex = vm.execute(bc, pi, wit, ctx=ctx)
+    ww = dict(inst, log_bytecode=bc.log_size, ending_pc=bc.ending_pc, bytecode_hash=bc.hash(), bytecode=bc.multilinear, public_input=pi)
+    ok, err = lm.verify_execution(ww, pr.proof_bytes(compressed=True), builder, compressed=True)
+    stages = pr.stage_times()
+    ph = np.asarray(phases).mean(axis=0)
+    # the same terms as tools/recursion_shape.py counts for the reference's program (per child)
+    derived = None
+    try:
+        d = recursion_shape()["per_child"]
+        t = d["terms"]
+        derived = dict(poseidon_merkle=t["poseidon.merkle"], poseidon_pow=t["poseidon.pow"], ext_leaf_folds=t["ext.leaf_folds"], ext_eq_tables=t["ext.eq_tables"],
+                       ext_query_eq=t["ext.query_eq"], ext_final_poly_evals=t["ext.final_poly_evals"], ext_ood=t["ext.ood"],
+                       ext_combination_dots=t["ext.combination_dots"], ext_sumcheck_verify=t["ext.sumcheck_verify"],
+                       whole_verifier_poseidon_calls=d["poseidon_calls"], whole_verifier_extension_rows=d["extension_rows"], whole_verifier_cycles=d["cycles"],
+                       child_stacked_n_vars=recursion_shape()["child"]["stacked_n_vars"])
+    except Exception as e:  # noqa: BLE001 — the derivation is a side note
+        derived = {"error": repr(e)}
+    out = {
+        "metric": "recursion_root_steps_per_sec (PCS-opening part of the recursion program)", "value": 1.0 / dt, "unit": "root steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)", "data": "synthetic",
+        "config": {"workload": f"recursion --n {n_children} --log-inv-rate {rate} (BASELINE configs[3]), the root step as far as the recursion program is assembled: "
+                               f"whir_open of the in-VM verifier (zkdsl_implem/whir.py) on {n_children} GENUINE child proofs of {child_sigs} real signatures each "
+                               f"(stacked 2^{n_vars}, queries {S.queries}, Merkle heights {S.height}); GKR / logup / AIR / statement assembly of recursion.py are NOT "
+                               f"in the program (their results enter through the claims buffer)"
+                               + ("" if args.scale_log == 0 else f" [children SCALED DOWN by 2^{args.scale_log}]"),
+                   "source_sha": source_sha()},
+        "root": {"cycles": ex.n_cycles, "poseidon_calls": ex.n_poseidon_calls, "extension_rows": ex.n_extension_rows, "memory_words": ex.memory_len, **ex.counts,
+                 "bytecode_log_size": bc.log_size, "instructions": bc.info.get("n_instructions"), "frames": bc.info["frames"], "main_frame": bc.info["main_frame_size"],
+                 "per_child": {"cycles": ex.n_cycles // n_children, "poseidon_calls": ex.n_poseidon_calls // n_children, "extension_rows": ex.n_extension_rows // n_children},
+                 "expected_from_parameters": wv.expected_counts(S), "proof_accepted": bool(ok), "verifier_message": err,
+                 "proof_size_kib": pr.proof_size_fe() * 31 / 8192.0},
+        "derived_by_counting_per_child": derived,
+        "stages_ms": {"hints (host: claims, transcripts, opening blobs)": hints_ms, "Witness generation: Executing bytecode": float(ph[0]),
+                      "Witness generation: Building execution trace": float(ph[1]), "prove_execution": float(ph[2]), **stages},
+        "children": {"n": n_children, "signatures_each": child_sigs, "prove_ms_each": leaf_ms, "definition": "lmh_prove_execution_vm of one leaf at this rate (warm)"},
+        "recursion_n4": {"leaves_plus_root_ms": float(sum(leaf_ms) + 1e3 * dt),
+                         "reference": "README.md:60: 1.02 s for the 4 -> 1 step alone on an M4 Max (whole verifier in the VM; not comparable: this root verifies the "
+                                      "PCS openings only)"},
+        **info,
+    }
+    if args.equal_oracle:
+        from tests import synth_witness
+        run = ob.VmRun(orc, bc, pi, wit)
+        wo = run.trace(rate)
+        ob.set_threads(orc, min(16, len(os.sched_getaffinity(0))))
+        t0 = time.time()
+        ref = ob.prove_execution(orc, wo, synth_witness.header(wo), ob.whir_builder(log_inv_rate=rate, soundness=ob.CAPACITY if capacity else ob.JOHNSON))
+        out["config"]["proof_equals_oracle_prover"] = bool(np.array_equal(pr.proof(), ref))
+        out["config"]["oracle_vm_equals_device_vm"] = bool(ex.n_cycles == run.pcs.size and np.array_equal(ex.memory(), run.memory) and np.array_equal(ex.pcs(), run.pcs))
+        out["config"]["oracle_prover_s"] = time.time() - t0
+    print(json.dumps(out), flush=True)
+    if not ok or not out.get("vm_on_device"):
+        raise SystemExit("whir-recursion: " + (err or "the (child, query) loops did not all run on the device: " + str(out.get("fallback_reason"))))
+
+
 def oracle_builder(ob, w):
     """the workload's WHIR parameters in the oracle's format (checker only)"""
     return ob.whir_builder(log_inv_rate=w["log_inv_rate"], soundness=ob.CAPACITY if w["capacity"] else ob.JOHNSON)
@@ -311,7 +422,7 @@ def main():
                          "(tests/xmss_witness.py); synthetic: round 1's straight-line program of Poseidon calls on random inputs "
                          "(4096 operand blocks, 75 %% padding rows)")
     ap.add_argument("--scale-log", type=int, default=0, help="shrink the workload by 2^k (default 0 = config 2)")
-    ap.add_argument("--shape", choices=["xmss", "recursion"], default="xmss",
+    ap.add_argument("--shape", choices=["xmss", "recursion", "whir-recursion"], default="xmss",
                     help="xmss = BASELINE configs[1]/[2] (the metric); recursion = configs[3] stand-in: ExtensionOp table 2^19, "
                          "Poseidon 2^16, execution 2^19 — derived by tools/recursion_shape.py (side measurement, reported as proofs/s)")
     ap.add_argument("--verify", action="store_true", help="check the last proof with the oracle's verify_execution (untimed)")
@@ -347,6 +458,9 @@ def main():
     hw = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ctx = lm.Context(local_rank)
     capacity = args.soundness == "capacity"
+    if args.shape == "whir-recursion":  # side measurement with its own JSON line (N = 1)
+        assert world == 1
+        return whir_recursion_bench(ctx, lm, args, ob, orc)
     # the job's signer set is cut into one contiguous leaf per rank; every rank signs its own leaf's keys (rank-seeded)
     total = args.total_signatures or max(2, N_SIGS >> args.scale_log) * world
     leaf_lo, leaf_hi = signer_ranges(total, world)[rank]

@@ -374,6 +374,7 @@ def build_program(cfg, n_children=4, log_size=None):
         info["frames"][f"merkle_{r}"] = emit_merkle_loop(p, S, r, [A(sampled[c][r]) for c in range(NC)], [A(desc[c][r]) for c in range(NC)])
     for r in range(R):
         info["frames"][f"s6s_{r}"] = emit_s6s_loop(p, S, r, [A(desc[c][r]) for c in range(NC)])
+    info["n_instructions"] = p.here()
     bc = p.finalize(log_size)
     bc.info = info
     return bc

@@ -1387,6 +1387,13 @@ UVec<std::pair<u64, u32>>& batch_deferred(Pool* p) {
 
 // The per-thread logs and the deferred-write list belong to the run's pool (leased to this run alone, PoolSet): concurrent runs
 // of several provers in one process do not share them.
+// the length a sequential run leaves behind its last call frame: one past the highest cell anything SET (the frame's arguments, or a cell
+// an iteration defined in the next frame), not the end of the frame
+static void trim_to_defined(MemBuf& memory, u64 floor, u64 hi) {
+    while (hi > floor && memory.p[hi - 1] == UNDEF) hi--;
+    memory.len = hi;
+}
+
 // trim_last_frame: this batch is one the reference would have run sequentially (Machine::run, skip_arm_pc): its run leaves the memory
 // as long as the last cell it SET, not resized to the end of the last call frame — the length is put back to that frame's arguments.
 bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp,
@@ -1542,7 +1549,7 @@ bool handle_parallel_batch(const lmh_bytecode& bc, const Witness& w, MemBuf& mem
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
-    if (trim_last_frame && grown && memory.len == max_addr) memory.len = fp + 2 + batch.n_args;
+    if (trim_last_frame && grown && memory.len == max_addr) trim_to_defined(memory, fp + 2 + batch.n_args, max_addr);
     if (vm_times())
         fprintf(stderr, "[vm] batch of %llu segments: resize %.2f ms, call frames %.2f ms, run %.2f ms, merge + deferred writes %.2f ms\n",
                 (unsigned long long)n_par, tp1 - tp0, tb0 - tp1, tb1 - tb0, vm_now_ms() - tb1);
@@ -1868,7 +1875,7 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     pc = batch.batch_pc;
     fp = batch.batch_fp + n_iters * stride;
     ap = fp + batch.frame_size;
-    if (trim_last_frame && grown && memory.len == max_addr) memory.len = fp + 2 + batch.n_args;  // (see handle_parallel_batch)
+    if (trim_last_frame && grown && memory.len == max_addr) trim_to_defined(memory, fp + 2 + batch.n_args, max_addr);  // (see handle_parallel_batch)
     if (vm_times())
         fprintf(stderr, "[vm] device batch of %llu segments: host preparation + uploads %.2f ms, segments + deferred writes + summary %.2f ms, commit %.2f ms "
                         "(%llu cycles, %llu Poseidon calls, %u dirty cells; %llu deferred host Poseidon calls executed meanwhile in %.2f ms)\n",

@@ -57,7 +57,8 @@ class Body:
         self.small = [2]          # ... known to be < n_iter
         self.efs = []             # frame offsets of 5 defined words
         self.blocks = []          # frame offsets of 8 defined words
-        self.out_slot = 0         # next free word of this iteration's OUT row
+        self.out_slot = 0 if tag == "_a" else OUTW // 2   # next free word of this iteration's OUT row (each loop owns half a row)
+        self.out_end = OUTW // 2 if tag == "_a" else OUTW
         self.hints = {}           # per-iteration inline hint streams: name -> words per entry
         self.faults = faults
         self.tables = []
@@ -78,7 +79,7 @@ class Body:
     def out_ptr(self, n):
         """a cell holding the address of `n` fresh words of this iteration's OUT row (perm[i] * OUTW + slot)"""
         p = self.p
-        if self.out_slot + n > OUTW:
+        if self.out_slot + n > self.out_end:
             return None
         if not hasattr(self, "_row"):
             pp, pi, o, row = self.alloc(), self.alloc(), self.alloc(), self.alloc()
@@ -172,7 +173,7 @@ def op_branch(b):
     """if less_than(x, y): z = 1 + x else z = 2 * y — a conditional jump on a hinted, checked boolean"""
     p = b.p
     x, y, bit, z = b.word(), b.word(), b.alloc(), b.alloc()
-    p.hint_less_than(M(x), M(y), FP(bit))
+    p.hint_less_than(M(x), M(y), M(bit))
     p.mul(M(bit), M(bit), M(bit))                  # boolean
     then, end = b.label("then"), b.label("end")
     p.jump(M(bit), K(Label(then)), FP(0))
@@ -252,7 +253,8 @@ def op_poseidon(b):
             b.blocks.append(o)
             if n_out == 16:
                 b.blocks.append(o + 8)
-        b.efs.append(o)
+        if n_out >= 5:
+            b.efs.append(o)
         b.words.append(o)
     if variant == "compress":
         p.poseidon16(a, c, dst)
@@ -352,7 +354,7 @@ def op_hint_misc(b):
     r = int(rng.integers(0, 3))
     if r == 0:
         res = b.alloc()
-        p.hint_log2_ceil(M(int(rng.choice(b.small))), FP(res))
+        p.hint_log2_ceil(M(int(rng.choice(b.small))), M(res))
         p.add(M(res), K(0), M(b.alloc()))
         b.words.append(res)
     elif r == 1:
@@ -383,19 +385,15 @@ def op_read_digest(b):
     b.words.append(new)
 
 
-def op_write_next_frame(b):
-    """a deferred write into ANOTHER frame: a spare cell of the next iteration's frame, which that iteration reads (b.spare_in)"""
-    if b.spare_written or b.spare_in is None:
-        return
-    b.spare_written = True
-
-
 OPS = [(op_arith, 5), (op_solve, 2), (op_assert, 1), (op_load_data, 3), (op_store_out, 3), (op_frame_pointer_store_load, 2), (op_range_check, 2),
        (op_branch, 2), (op_table, 1), (op_poseidon, 5), (op_extension, 5), (op_extension_solve, 2), (op_hint_inverse, 1), (op_hint_decompose, 2),
        (op_hint_misc, 2), (op_read_digest, 1)]
 
 
-def emit_loop(p, rng, tag, n_iter, data_words, has_digest, fault, parallel=True):
+SPARE = 12
+
+
+def emit_loop(p, rng, tag, n_iter, data_words, has_digest, fault, parallel=True, chain=False):
     """a loop function `loop<tag>`; returns (frame size, inline hint streams {name: words per entry})"""
     n_args = 6                                     # i, end, OUT, DATA, PERM, DIG
     b = Body(p, rng, n_args, tag, n_iter, fault)
@@ -412,6 +410,10 @@ def emit_loop(p, rng, tag, n_iter, data_words, has_digest, fault, parallel=True)
     p.jump(M(nz), K(Label("body" + tag)), FP(0))
     p.jump(K(1), M(0), M(1))
     p.label("body" + tag)
+    spare = b.alloc()                              # cell 12 of every frame: main defines it in the first frame of a loop
+    assert spare == SPARE
+    if chain:                                      # ... and with `chain` every iteration defines the NEXT frame's from its own: a write into
+        b.words.append(spare)                      # another frame that the other frame READS — sequentially fine, impossible inside a batch
     blk = b.alloc(16)
     p.hint_witness("blk" + tag, blk)               # 16 hinted words per iteration
     b.hints["blk" + tag] = 16
@@ -429,13 +431,18 @@ def emit_loop(p, rng, tag, n_iter, data_words, has_digest, fault, parallel=True)
         fns[int(rng.choice(len(fns), p=wts))](b)
     nxt, ip1 = b.alloc(), b.alloc()
     frame = b.top
-    p.hint_request_memory(nxt, K(frame))
+    p.hint_request_memory(nxt, K(Label("@frame" + tag)))
     p.deref(nxt, 0, M(0))
     p.deref(nxt, 1, M(1))
     p.add(M(2), K(1), M(ip1))
     p.deref(nxt, 2, M(ip1))
     for a in range(3, 2 + n_args):
         p.deref(nxt, a, M(a))
+    if chain:
+        t = b.alloc()
+        frame = b.top
+        p.mul(M(spare), K(3), M(t))
+        p.deref(nxt, SPARE, M(t))
     p.jump(K(1), K(Label("loop" + tag)), M(nxt))
     for tab, after, y, consts in b.tables:
         p.label(tab)
@@ -455,11 +462,11 @@ def emit_fault(b, fault):
         p.hint_inverse(M(x), inv)
         p.mul(M(x), M(inv), K(1))
     elif fault == "conflicting_writes":             # every iteration writes i into ONE cell of main's OUT array
-        p.deref(4, OUTW - 1, M(2))
-        b.out_slot = 0
-    elif fault == "undefined_read":                 # a read of main's OUT array, which nothing defines in front of the loop
+        p.deref(4, OUTW // 2 - 1, M(2))
+        b.out_end -= 1
+    elif fault == "undefined_read":                 # a read of a cell of main's frame that nothing ever defines (cell 1 = the caller's fp)
         new, y = b.alloc(), b.alloc()
-        p.deref(4, 3, M(new))
+        p.deref(1, 140, M(new))
         p.add(M(new), K(1), M(y))
     elif fault == "extension_check":                # ones * blk == blk + (i != 0): holds in iteration 0 only
         blk = b.blocks[0]
@@ -474,7 +481,7 @@ def gen(seed, device=False):
     rng = np.random.default_rng(seed)
     n1 = int(rng.integers(33, 49)) if device else int(rng.integers(2, 10))
     two = rng.random() < 0.3
-    n2 = (int(rng.integers(33, 41)) if device and rng.random() < 0.5 else int(rng.integers(2, 9))) if two else 0
+    n2 = min(n1, int(rng.integers(33, 41)) if device and rng.random() < 0.5 else int(rng.integers(2, 9))) if two else 0
     fault = str(rng.choice(FAULTS)) if rng.random() < 0.2 else None
     head_chain = int(rng.integers(1, 5)) if rng.random() < 0.6 else 0
     data_words = int(rng.integers(64, 200))
@@ -497,10 +504,10 @@ def gen(seed, device=False):
     for k in range(head_chain):
         src = FP(HEAD_BLOCK) if k == 0 else FP(HEAD_DIG + 8 * (k - 1))
         p.poseidon16(src, FP(HEAD_BLOCK + 8), FP(HEAD_DIG + 8 * k))
-    if head_chain and rng.random() < 0.5:          # a deferred check over the last digest: copy_5 onto fresh cells
-        p.extension_op("mul", FP(HEAD_DIG + 8 * (head_chain - 1)), FP(150), FP(120))
     for k in range(5):
         p.add(K(0), K(1 if k == 0 else 0), M(150 + k))
+    if head_chain and rng.random() < 0.5:          # a deferred ExtensionOp over the last digest: copy_5 onto fresh cells
+        p.extension_op("mul", FP(HEAD_DIG + 8 * (head_chain - 1)), FP(150), FP(120))
 
     def call(lf, label, ret, n_cell, frame):
         p.hint_request_memory(lf, K(Label(frame)))
@@ -510,6 +517,7 @@ def gen(seed, device=False):
         p.deref(lf, 3, M(n_cell))
         for k, c in enumerate((OUT, DATA, PERM, DIG)):
             p.deref(lf, 4 + k, M(c))
+        p.deref(lf, SPARE, K(int(rng.integers(1, P))))
         p.jump(K(1), K(Label(label)), M(lf))
         p.label(ret)
 
@@ -527,7 +535,9 @@ def gen(seed, device=False):
     p.labels["@frame_a"] = fa
     hb = {}
     if two:
-        fb, hb = emit_loop(p, rng, "_b", n2, data_words, head_chain > 0, None, parallel=bool(rng.random() < 0.7))
+        # `chain`: loop b's iterations depend on each other through their frames; the reference runs a second parallel loop sequentially
+        # (its runner arms one batch per run), this library batches it and falls back to the literal run when a segment fails
+        fb, hb = emit_loop(p, rng, "_b", n2, data_words, head_chain > 0, None, parallel=bool(rng.random() < 0.7), chain=bool(rng.random() < 0.3))
         p.labels["@frame_b"] = fb
     bc = p.finalize()
     data = rng.integers(1, P, size=data_words)

@@ -1752,7 +1752,9 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
             // batch (which cover [0, memory.len)) do not reach: back to None
             if (max_addr < D.image_cap && vm_dev_fill(D.ctx, D.d_image + max_addr, VM_UNDEF, D.image_cap - max_addr) != LM_OK) return (int)DEV_ERROR;
         }
-        if (host_grown) fill_host(std::max(old_len, split_at), frames_end);  // the host batch expects its frames initialised
+        // the host batch grows the memory itself (and fills what it adds): back to the length this batch found, so that it also knows
+        // whether IT was the one that grew the memory (trim_last_frame)
+        if (host_grown) memory.len = old_len;
         if (!dev_close_windows(D, memory)) return (int)DEV_ERROR;
         memory.dev_lo = memory.dev_hi = 0;
         return (int)DEV_FALLBACK;

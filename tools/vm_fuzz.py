@@ -484,7 +484,7 @@ def gen(seed, device=False):
     n2 = min(n1, int(rng.integers(33, 41)) if device and rng.random() < 0.5 else int(rng.integers(2, 9))) if two else 0
     fault = str(rng.choice(FAULTS)) if rng.random() < 0.2 else None
     head_chain = int(rng.integers(1, 5)) if rng.random() < 0.6 else 0
-    data_words = int(rng.integers(64, 200))
+    data_words = max(int(rng.integers(64, 200)), 5 * n1 + 8)
     p = Program()
     N, OUT, DATA, PERM, LF, N2, LF2, DIG = 0, 1, 2, 3, 4, 5, 6, 7
     p.add(K(0), K(0), M(20))

@@ -348,11 +348,23 @@ def load_profile(name, sha):
 
 
 VALU_PEAK_T = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMD-32 units x lanes per cycle x clock = 78.6 T lane-ops/s (MI355X_MICROARCH.md)
-SPONGE_PERM_CEILING_G = VALU_PEAK_T * 1e3 / (6196 * 1.70)  # issue-bound ceiling of the one-lane permutation: 7.5 G/s
+PROFILE_TAG = "r05"  # profiles/<tag>_{pmc,valu}_bench.json, <tag>_isa_mix.json: counter / ISA summaries of the current kernel sources (sha-guarded)
+
+
+def sponge_ceiling():
+    """issue-bound ceiling of the one-lane permutation in G permutations/s and where it comes from: the static VALU count and issue weight of
+    ONE straight-line permutation (tools/ubench/one_perm.hip through tools/isa_mix.py --all) of the CURRENT sources; without such a file
+    the figure of the sources it was last measured for is used and labelled"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_isa_mix.json")))
+        k = j["kernels"]["poseidon16_permute_one_lane"]
+        stale = "" if j.get("source_sha") == source_sha() else f" [recorded for sources {j.get('source_sha')}]"
+        return VALU_PEAK_T * 1e3 / (k["valu"] * k["issue_cycle_weight"]), f"{k['valu']} VALU instructions per permutation x issue weight {k['issue_cycle_weight']} (profiles/{PROFILE_TAG}_isa_mix.json{stale})"
+    except Exception:  # noqa: BLE001
+        return VALU_PEAK_T * 1e3 / (5626 * 1.603), "5626 VALU instructions per permutation x issue weight 1.603 (static count of the round-5 sources; no ISA summary found)"
 KB_MUL_T, MAD_T = 5.65, 34.3  # measured: one Montgomery product, v_mad_u64_u32 (tools/ubench/int_rates.hip, profiles/r03_int_rates.txt)
 
 
-PROFILE_TAG = "r04"  # profiles/<tag>_{pmc,valu}_bench.json: the counter summaries of the current kernel sources (sha-guarded)
 _XBUF = {}
 
 
@@ -493,6 +505,7 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     gathered = None
     phases, stage_acc, step_s = [], {}, []
     for _ in range(args.steps):
@@ -511,8 +524,18 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
     waits = ctx.wait_log_read()
     ctx.wait_log(False)
+    # the host side of every rank (N > 1): what an 8-GPU node needs from its CPUs.  host_busy = the part of a step the prover thread is NOT
+    # waiting for the device (transcript, launch calls, the VM's sequential parts); cpu = process CPU time per step, all threads (the wait
+    # is a spin: it counts); jitter = max - min of the ranks' step times, step by step
+    rank_rows = None
+    if world > 1:
+        mine = dict(rank=rank, step_ms=[1e3 * x for x in step_s], waiting_ms_per_step=float(waits.sum()) / 1e3 / args.steps if waits.size else None,
+                    cpu_ms_per_step=1e3 * cpu_s / args.steps)
+        rank_rows = [None] * world
+        dist.all_gather_object(rank_rows, mine)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -571,7 +594,7 @@ def main():
                    # and with the family's launches serialised (the counter pass of the same sources: one kernel at a time)
                    "frac_issue_weighted_serialised": jv.get("alu_frac_issue_weighted"), "serialised_ms_per_step": jv.get("kernel_ms_under_pmc"),
                    "frac_issue_weighted_over_busy_time": (lane_ops * args.steps / (k_busy_ms * 1e-3) / 1e12 * wf / VALU_PEAK_T) if wf and k_busy_ms > 0 else None,
-                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/r04_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
+                   "source": "SQ_INSTS_VALU of k_air_round per proof (profiles/" + PROFILE_TAG + "_valu_bench.json, rocprofv3 --pmc) x 64 lanes / "
                              "HIP-event time; peak = 256 CU x 4 SIMD-32 x 2.4 GHz; issue weight = static ISA mix with "
                              "v_mul_lo/hi_u32, v_mad_u64_u32 at 4 cycles per wave64, v_lshl_add_u64 at its measured 7.4, the rest 2 "
                              "(profiles/r03_int_rates.txt)"}
@@ -616,21 +639,27 @@ def main():
             # every instruction weighted by its issue cycles); `hbm` keeps the same launches priced against HBM for reference
             "roofline": {
                 "kernel": dominant, "bound": "int-alu",
-                "achieved": alu["achieved"] * alu["issue_cycle_weight"] if alu and alu.get("issue_cycle_weight") else None,
+                # frac := the SERIALISED figure (one kernel at a time, the counter pass of the same sources): it does not move with the order in
+                # which the three AIR sessions' launches happen to overlap; the live figures (summed launch durations / busy time) are beside it
+                "achieved": (alu["frac_issue_weighted_serialised"] * VALU_PEAK_T) if alu and alu.get("frac_issue_weighted_serialised") else None,
                 "peak": VALU_PEAK_T, "unit": "T issue-weighted VALU lane-ops/s",
-                "frac": alu["frac_issue_weighted"] if alu else None,
+                "frac": alu.get("frac_issue_weighted_serialised") if alu else None,
+                "frac_definition": "issue-weighted VALU lane-instructions of the k_air_round family per proof (SQ_INSTS_VALU x 64 x issue weight) / the family's "
+                                   "kernel time with its launches serialised (the rocprofv3 counter pass) / 78.6 T lane-ops/s",
+                "frac_live_summed": alu["frac_issue_weighted"] if alu else None,
+                "frac_live_over_busy_time": alu.get("frac_issue_weighted_over_busy_time") if alu else None,
                 "traffic": traffic,
                 "launches": n_launch, "avg_launch_ms": (k_ms / n_launch) if n_launch else None,
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes * args.steps / n_launch if n_launch else None},
-                "traffic_source": "profiles/r04_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                "traffic_source": "profiles/" + PROFILE_TAG + "_pmc_bench.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                   "FETCH x2 per MI355X_MICROARCH.md); refused when recorded for other kernel sources",
                 "note": "live: HIP events on the prover's streams around every k_air_round launch of the timed region (one proof "
-                        "alone on the chip); instruction counts from profiles/r04_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
-                        "The constraint evaluation is integer-ALU bound — see DESIGN.md §3.  `frac` divides by the SUM of the launch "
+                        "alone on the chip); instruction counts from profiles/" + PROFILE_TAG + "_valu_bench.json (SQ_INSTS_VALU per proof, sha-guarded). "
+                        "The constraint evaluation is integer-ALU bound — see DESIGN.md §3.  `frac_live_summed` divides by the SUM of the launch "
                         "durations; the three AIR sessions run on three streams and their large launches overlap, so shared time is "
-                        "counted once per launch: alu.frac_issue_weighted_over_busy_time uses the time with at least one launch running, "
-                        "alu.frac_issue_weighted_serialised the counter pass (one kernel at a time)",
+                        "counted once per launch: `frac_live_over_busy_time` uses the time with at least one launch running, "
+                        "`frac` the counter pass (one kernel at a time)",
                 "alu": alu,
                 # ~20 G modular multiplications per proof for the Poseidon16 AIR sumcheck at 2^18 rows (+ ~1 G for the two
                 # small tables), scaled to the active rows of this workload: the family's algorithmic rate
@@ -657,14 +686,14 @@ def main():
         # the reference's sparse form) against the measured rate of one Montgomery product and of the 32 x 32 -> 64 multiply-add
         if sponge_ms > 0:
             perm_s = sponge_perms / (sponge_ms * 1e-3)
+            SPONGE_PERM_CEILING_G, ceiling_src = sponge_ceiling()
             out["roofline_sponge"] = {
                 "kernel": "k_leaf_sponge", "bound": "int-alu", "launches": sponge_n / args.steps, "ms_per_step": sponge_ms / args.steps,
                 "permutations_per_step": sponge_perms / args.steps, "achieved": perm_s / 1e9, "unit": "G Poseidon1-16 permutations/s",
                 "peak": SPONGE_PERM_CEILING_G, "frac": perm_s / 1e9 / SPONGE_PERM_CEILING_G,
                 "algorithmic": {"modmuls_per_permutation": 1600, "achieved_T_modmul_per_s": perm_s * 1600 / 1e12, "montgomery_product_T_per_s": KB_MUL_T,
                                 "multiply_add_T_per_s": MAD_T, "frac_of_multiply_add_rate": perm_s * 1600 / 1e12 / MAD_T},
-                "note": "live HIP events; peak = 78.6 T VALU lane-ops/s / (6196 instructions per permutation x issue weight 1.70, "
-                        "profiles/r03_isa_mix.json) = 7.5 G permutations/s; a modular multiplication inside a delayed-reduction dot product costs "
+                "note": "live HIP events; peak = 78.6 T VALU lane-ops/s / (" + ceiling_src + "); a modular multiplication inside a delayed-reduction dot product costs "
                         "one multiply-add, so the algorithmic rate is priced against the multiply-add issue rate (34.3 T/s measured, "
                         "profiles/r03_int_rates.txt), the Montgomery-product rate (5.65 T/s) is shown for scale"}
         # ---- the reference's own time breakdown (tracing spans) and its NodeStats fields (benchmark.rs:50-66)
@@ -688,6 +717,16 @@ def main():
             if not out.get("vm_on_device") and not os.environ.get("LM_VM_HOST") and not os.environ.get("LM_BENCH_ALLOW_VM_FALLBACK"):
                 print(json.dumps(out), flush=True)
                 raise SystemExit("bench.py: the VM's parallel batch did NOT run on the device: " + str(out.get("fallback_reason")))
+        if rank_rows:
+            sm = np.asarray([r["step_ms"] for r in rank_rows])          # (ranks, steps)
+            out["ranks"] = {"per_rank": [dict(rank=r["rank"], ms_per_step=float(np.mean(r["step_ms"])), waiting_ms_per_step=r["waiting_ms_per_step"],
+                                               host_busy_ms_per_step=(float(np.mean(r["step_ms"])) - r["waiting_ms_per_step"]) if r["waiting_ms_per_step"] is not None else None,
+                                               cpu_ms_per_step=r["cpu_ms_per_step"]) for r in rank_rows],
+                            "step_jitter_ms": {"mean": float((sm.max(axis=0) - sm.min(axis=0)).mean()), "max": float((sm.max(axis=0) - sm.min(axis=0)).max())},
+                            "slowest_rank_ms_per_step": float(sm.mean(axis=1).max()), "fastest_rank_ms_per_step": float(sm.mean(axis=1).min()),
+                            "cpus_available": effective_cpus(),
+                            "definition": "host side of the sharded job: host_busy = step - time spent in lm_wait_result (the prover thread's own work); cpu = "
+                                          "process CPU time per step over all threads (the wait spins); jitter = max - min over ranks of the same step"}
         if waits.size:
             out["exchanges"] = {"per_step": waits.size / args.steps, "p50_us": float(np.percentile(waits, 50)), "p99_us": float(np.percentile(waits, 99)),
                                 "mean_us": float(waits.mean()), "waiting_ms_per_step": float(waits.sum()) / 1e3 / args.steps,

@@ -6,6 +6,11 @@
 // sumcheck pair (parents 2j', 2j'+1) is 4 consecutive entries: one 16-byte load per plane.
 // During a layer's sumcheck the four multilinears (n_l, n_r, d_l, d_r) live as 4 SoA EF arrays that halve every round
 // (LSB-first folding, sumcheck_utils.rs:278-357).
+#include <errno.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include "lm_common.h"
@@ -670,11 +675,14 @@ bool gkr_tail_enabled() {
     return on;
 }
 // Resident workgroups hold their CU slots while they poll, and a tail makes progress only when ALL its workgroups are
-// resident: the tails of every prover of this process together must fit the chip (256 CUs x 2 workgroups of 1024 threads),
-// or tails could wait for each other's slots until their timeouts.  Above the cap a layer falls back to launches.
-// The counter is per PROCESS: processes that share one GPU (two ranks on one device in the tests, several provers of a node)
-// must divide the chip between them — LM_GKR_TAIL_MAX_WORKGROUPS sets this process's share (default 256 = the whole chip;
-// a tail that does not get its slots still ends by its own 3 s timeout and the layer is reported as failed, never hung).
+// resident: the tails of every prover ON ONE DEVICE together must fit the chip (256 CUs x 2 workgroups of 1024 threads), or tails
+// could wait for each other's slots until their timeouts.  Above the cap a layer falls back to launches.
+// The count is kept PER DEVICE, across processes: a small shared-memory file keyed by the device's PCI bus id
+// (/dev/shm/leanmultisig_tail_<bus id>) holds the total and one (pid, count) slot per process, so that several ranks on one GPU
+// (tests, LM_BENCH_SINGLE_DEVICE) or several provers of a node divide the chip without being told how.  A process that died with
+// workgroups reserved is noticed by the next process that attaches (its pid no longer exists) and its share is given back.  If the
+// file cannot be created the counter is per process, as before.  LM_GKR_TAIL_MAX_WORKGROUPS lowers the cap (default 256 = the whole
+// chip; a tail that does not get its slots still ends by its own 3 s timeout and the layer is reported as failed, never hung).
 int gkr_tail_max_live() {
     static const int v = [] {
         const char* e = getenv("LM_GKR_TAIL_MAX_WORKGROUPS");
@@ -683,16 +691,86 @@ int gkr_tail_max_live() {
     }();
     return v;
 }
-std::atomic<int> g_tail_workgroups{0};
-bool gkr_tail_reserve(u32 W) {
-    if (g_tail_workgroups.fetch_add((int)W, std::memory_order_acq_rel) + (int)W > gkr_tail_max_live()) {
-        g_tail_workgroups.fetch_sub((int)W, std::memory_order_acq_rel);
+struct TailShared {  // the mapped file
+    std::atomic<int> total;
+    std::atomic<int> lock;
+    struct Slot {
+        std::atomic<int> pid, count;
+    } slots[64];
+};
+struct TailCounter {
+    TailShared* sh = nullptr;  // nullptr: process-local fallback
+    int slot = -1;
+    std::atomic<int> local{0};
+};
+TailCounter* tail_counter(int device) {
+    static TailCounter counters[16];
+    static std::atomic<int> ready[16];
+    device = device < 0 || device >= 16 ? 0 : device;
+    TailCounter& c = counters[device];
+    int st = ready[device].load(std::memory_order_acquire);
+    if (st == 2) return &c;
+    int expect = 0;
+    if (!ready[device].compare_exchange_strong(expect, 1)) {
+        while (ready[device].load(std::memory_order_acquire) != 2) {
+        }
+        return &c;
+    }
+    char bus[64] = "";
+    if (!getenv("LM_GKR_TAIL_PROCESS_LOCAL") && hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
+        for (char* q = bus; *q; q++)
+            if (*q == ':' || *q == '.') *q = '_';
+        char path[128];
+        snprintf(path, sizeof path, "/leanmultisig_tail_%s", bus);
+        const int fd = shm_open(path, O_RDWR | O_CREAT, 0666);
+        if (fd >= 0) {
+            if (ftruncate(fd, sizeof(TailShared)) == 0) {  // (a new file is zero-filled: total 0, every slot free)
+                void* m = mmap(nullptr, sizeof(TailShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (m != MAP_FAILED) c.sh = (TailShared*)m;
+            }
+            close(fd);
+        }
+    }
+    if (c.sh) {
+        TailShared* sh = c.sh;
+        int z = 0;
+        for (int spins = 0; !sh->lock.compare_exchange_weak(z, 1, std::memory_order_acquire); z = 0)
+            if (++spins > (1 << 22)) break;  // (a holder that died: proceed; the worst case is a share returned twice, i.e. a cap too lax)
+        const int me = (int)getpid();
+        for (auto& sl : sh->slots) {  // shares of processes that no longer exist go back
+            const int pid = sl.pid.load();
+            if (pid && pid != me && kill(pid, 0) != 0 && errno == ESRCH) {
+                sh->total.fetch_sub(sl.count.exchange(0));
+                sl.pid.store(0);
+            }
+        }
+        for (int k = 0; k < 64 && c.slot < 0; k++) {
+            int free_pid = 0;
+            if (sh->slots[k].pid.load() == me || sh->slots[k].pid.compare_exchange_strong(free_pid, me)) c.slot = k;
+        }
+        sh->lock.store(0, std::memory_order_release);
+        if (c.slot < 0) c.sh = nullptr;  // 64 live processes on one device: count locally
+    }
+    ready[device].store(2, std::memory_order_release);
+    return &c;
+}
+bool gkr_tail_reserve(lm_ctx* ctx, u32 W) {
+    TailCounter* c = tail_counter(ctx->device);
+    std::atomic<int>& total = c->sh ? c->sh->total : c->local;
+    if (total.fetch_add((int)W, std::memory_order_acq_rel) + (int)W > gkr_tail_max_live()) {
+        total.fetch_sub((int)W, std::memory_order_acq_rel);
         return false;
     }
+    if (c->sh) c->sh->slots[c->slot].count.fetch_add((int)W, std::memory_order_acq_rel);
     return true;
 }
-void gkr_tail_release(lm_gkr* g) {
-    g_tail_workgroups.fetch_sub((int)g->tail_W, std::memory_order_acq_rel);
+void gkr_tail_unreserve(lm_ctx* ctx, int n) {
+    TailCounter* c = tail_counter(ctx->device);
+    (c->sh ? c->sh->total : c->local).fetch_sub(n, std::memory_order_acq_rel);
+    if (c->sh) c->sh->slots[c->slot].count.fetch_sub(n, std::memory_order_acq_rel);
+}
+void gkr_tail_release(lm_ctx* ctx, lm_gkr* g) {
+    gkr_tail_unreserve(ctx, (int)g->tail_W);
     g->tail_live = false;
 }
 // a resident workgroup whose layer is abandoned (error path, early free) is told to leave; it would otherwise poll until its
@@ -703,7 +781,7 @@ void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream);  // the hand-over ticket of an interrupted multi-workgroup tail
     ctx->h_cmd[11] = 0;
-    gkr_tail_release(g);
+    gkr_tail_release(ctx, g);
 }
 // a + r (b + r c)
 EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
@@ -898,15 +976,16 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             g->tail_S = Sn;
         }
     } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8 &&
-               gkr_tail_reserve((u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
+               gkr_tail_reserve(ctx, (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
         // the reservation is given back on every early return below (a leaked one would silently push later layers onto launches)
         struct TailReservation {
+            lm_ctx* ctx;
             int n;
             bool keep = false;
             ~TailReservation() {
-                if (!keep) g_tail_workgroups.fetch_sub(n, std::memory_order_acq_rel);
+                if (!keep) gkr_tail_unreserve(ctx, n);
             }
-        } reservation{(int)std::max<u64>(1, m_out / GKR_TAIL_SLICE)};
+        } reservation{ctx, (int)std::max<u64>(1, m_out / GKR_TAIL_SLICE)};
         seq = ++ctx->res_seq;
         GkrTailEq eqs;
         {
@@ -1000,7 +1079,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     const u32* h = ctx->h_res;
     if (g->tail_live) {
         g->tail_seq = seq;
-        if (m_out <= 4) gkr_tail_release(g);  // the workgroup returned after this publication
+        if (m_out <= 4) gkr_tail_release(ctx, g);  // the workgroup returned after this publication
         if (!g->tail_solo) {
             // every workgroup published its own partial sums: wait for the other flags, add the slots
             memcpy(h_sum, ctx->h_res, sizeof h_sum);

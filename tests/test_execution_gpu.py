@@ -228,11 +228,11 @@ def test_recursion_shaped_tables_verify(ctx, orc):
 def test_recursion_derived_shape_equals_oracle_prover(ctx, orc):
     """BASELINE configs[3] (`recursion --n 4 --log-inv-rate 2`) stand-in at the FULL size tools/recursion_shape.py derives by counting
     the in-VM verifier's work for four children of 775 signatures (execution 2^19, ExtensionOp 2^18 with the derived mix of leaf folds /
-    eq chains / single products, Poseidon16 2^16, memory 2^22; rate 1/4, production parameters): the device proof equals the oracle
+    eq chains / single products, Poseidon16 2^16, memory 2^21; rate 1/4, production parameters): the device proof equals the oracle
     PROVER's proof word for word (a few minutes of oracle time on 16 threads)."""
     import bench
     d = bench.recursion_shape()
-    assert d["shape"] == dict(log_exec=19, log_pos=16, log_ext=18, log_memory=22, log_bytecode=19) and d["child"]["stacked_n_vars"] == 25
+    assert d["shape"] == dict(log_exec=19, log_pos=16, log_ext=18, log_memory=21, log_bytecode=19) and d["child"]["stacked_n_vars"] == 25
     w = bench.build_workload(ctx, orc, ob, np.random.default_rng(11), 0, 2, "recursion", False, "synthetic")
     assert w["w"]["log_rows"] == {0: 19, 1: 18, 2: 16}
     proof = bench.run_step(ctx, lm, w).proof()

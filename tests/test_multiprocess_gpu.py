@@ -16,8 +16,10 @@ def test_bench_two_ranks_on_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    # two processes share the chip: each gets half of the resident GKR tail workgroups (csrc/lm_gkr.hip: the cap is per process)
-    env = dict(os.environ, LM_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", LM_GKR_TAIL_MAX_WORKGROUPS="128")
+    # two processes share the chip: the resident GKR tail workgroups of both are counted per DEVICE (csrc/lm_gkr.hip: a shared-memory
+    # counter keyed by the PCI bus id), no per-process share has to be configured
+    env = dict(os.environ, LM_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("LM_GKR_TAIL_MAX_WORKGROUPS", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--scale-log", "5", "--dist-backend", "gloo", "--no-cpu-baseline", "--verify"]
@@ -35,3 +37,7 @@ def test_bench_two_ranks_on_one_gpu():
     # round 5: the step is aggregate_type_1 whole (input assembly included), and the line says where the VM's batch ran
     assert j["stages_ms"]["aggregate_type_1: inputs"] > 0 and j["vm_on_device"] is True and j["host_batches"] == 0
     assert j["exchanges"]["per_step"] > 10 and j["node_stats"]["n_xmss"] == j["config"]["per_gpu_signatures"]
+    # the host side of every rank: own work per step, CPU time, jitter between the ranks
+    rk = j["ranks"]
+    assert len(rk["per_rank"]) == 2 and all(0 < r["host_busy_ms_per_step"] < r["ms_per_step"] and r["cpu_ms_per_step"] > 0 for r in rk["per_rank"])
+    assert rk["step_jitter_ms"]["max"] >= 0

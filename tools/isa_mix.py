@@ -58,6 +58,14 @@ def all_kernels(out_path):
             v = mx[n]
             v.pop("top")
             res[d.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]] = v
+    # one permutation per lane, straight line (tools/ubench/one_perm.hip): the issue-bound ceiling of the leaf sponge is derived from THIS
+    # count (the sponge kernel itself is a loop around it: its static count is not per permutation)
+    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               os.path.join(root, "tools", "ubench", "one_perm.hip"), "-o", tmp.name], stderr=subprocess.DEVNULL)
+        v = mixes(tmp.name)["k_one_perm"]
+        v.pop("top")
+        res["poseidon16_permute_one_lane"] = v
     json.dump({"source_sha": bench.source_sha(), "cycles_per_wave64": {**CYCLES, "other": 2}, "kernels": res}, open(out_path, "w"), indent=1)
     print("wrote", out_path, len(res), "kernels")
 

@@ -141,12 +141,12 @@ def whir_recursion_bench(ctx, lm, args, ob=None, orc=None):
             vm.prove_execution_vm(ctx, pr, leaf, pi, wit, builder)
             t1 = time.perf_counter()
         leaf_ms.append(1e3 * (t1 - t0))
-        raw, claim = capi.verify_execution_raw(dict(inst, public_input=pi), pr, builder)   # the library's verifier accepts the child
-        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1]))
+        raw, claim, stmt = capi.verify_execution_raw(dict(inst, public_input=pi), pr, builder, with_statement=True)   # the library's verifier accepts the child
+        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1], stmt, pi))
         assert n_vars in (None, claim.num_variables)
         n_vars = claim.num_variables
     cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
-    bc = wv.build_program(cfg, n_children, log_size=19 if args.scale_log == 0 else None)
+    bc = wv.build_program(cfg, n_children, log_size=19 if args.scale_log == 0 else None, statement=wv.Statement(children[0][3], children[0][1]))
     S = bc.info["shape"]
     t0 = time.perf_counter()
     pi, wit, _ = wv.build_witness(bc, children)
@@ -193,14 +193,15 @@ def whir_recursion_bench(ctx, lm, args, ob=None, orc=None):
         "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)", "data": "synthetic",
         "config": {"workload": f"recursion --n {n_children} --log-inv-rate {rate} (BASELINE configs[3]), the root step as far as the recursion program is assembled: "
                                f"whir_open of the in-VM verifier (zkdsl_implem/whir.py) on {n_children} GENUINE child proofs of {child_sigs} real signatures each "
-                               f"(stacked 2^{n_vars}, queries {S.queries}, Merkle heights {S.height}); GKR / logup / AIR / statement assembly of recursion.py are NOT "
-                               f"in the program (their results enter through the claims buffer)"
+                               f"(stacked 2^{n_vars}, queries {S.queries}, Merkle heights {S.height}) WITH the assembly of its statement ({S.statement.n_values} claimed "
+                               f"evaluations read from the children's raw transcripts, recursion.py:469-518, 534-652); GKR / logup / AIR verification of recursion.py are "
+                               f"NOT in the program (the three evaluation points they produce enter through the claims buffer)"
                                + ("" if args.scale_log == 0 else f" [children SCALED DOWN by 2^{args.scale_log}]"),
                    "source_sha": source_sha()},
         "root": {"cycles": ex.n_cycles, "poseidon_calls": ex.n_poseidon_calls, "extension_rows": ex.n_extension_rows, "memory_words": ex.memory_len, **ex.counts,
                  "bytecode_log_size": bc.log_size, "instructions": bc.info.get("n_instructions"), "frames": bc.info["frames"], "main_frame": bc.info["main_frame_size"],
                  "per_child": {"cycles": ex.n_cycles // n_children, "poseidon_calls": ex.n_poseidon_calls // n_children, "extension_rows": ex.n_extension_rows // n_children},
-                 "expected_from_parameters": wv.expected_counts(S), "proof_accepted": bool(ok), "verifier_message": err,
+                 "opening_alone_expected_from_parameters": wv.expected_counts(S), "proof_accepted": bool(ok), "verifier_message": err,
                  "proof_size_kib": pr.proof_size_fe() * 31 / 8192.0},
         "derived_by_counting_per_child": derived,
         "stages_ms": {"hints (host: claims, transcripts, opening blobs)": hints_ms, "Witness generation: Executing bytecode": float(ph[0]),

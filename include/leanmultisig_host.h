@@ -251,11 +251,28 @@ typedef struct {
     uint32_t statement_weights[5]; /* sum_i gen^(n_ood + i) weight_i(folding randomness): what :534-652 add to `s` */
     uint32_t folding_randomness[32 * 5];        /* folding_randomness_global, num_variables entries */
 } lm_whir_opening_claim;
+/* The statement the PCS opening proves, as the recursion program assembles it (recursion.py:469-518 before whir_open, :534-652 after):
+ * the three evaluation points the verifier sampled, the table heights, and WHERE in the raw transcript the claimed evaluations lie
+ * (every value the statement carries was received from the prover: value_acc / value_memory / value_bytecode_acc, the logup column
+ * evaluations of every table, the column evaluations behind the batched AIR sumcheck). */
+typedef struct {
+    uint32_t log_rows[3], log_memory, log_bytecode, gkr_n_vars, n_max, table_order[3]; /* table_order: table ids by descending height */
+    uint32_t ending_pc, log_public_memory; /* log2 of the public memory (the public input padded to a power of two) */
+    uint32_t gkr_point[32 * 5];   /* point_gkr, gkr_n_vars entries */
+    uint32_t air_point[32 * 5];   /* the batched AIR sumcheck's challenges in sumcheck order, n_max entries */
+    uint32_t pm_point[8 * 5];     /* public_memory_random_point, log2(public memory size) entries */
+    uint64_t off_value_memory_acc, off_value_memory, off_value_bytecode_acc; /* raw-transcript word offsets (5 words each) */
+    uint64_t off_inner_evals[3];  /* per table id: (n_columns + n_shift) x 5 words, flat columns first */
+    uint32_t n_logup_values[3];   /* per table id: logup column evaluations, in the order the prover sent them */
+    uint32_t logup_col[3][40];
+    uint64_t logup_off[3][40];
+} lm_pcs_statement_claim;
 typedef struct lmh_raw_proof lmh_raw_proof;
 /* verify_execution on the proof a prover object holds; on success *out owns the raw transcript and the claim */
 int lmh_verify_execution_raw(const lm_verify_instance* instance, const lmh_prover* p, const lm_whir_builder* builder, lmh_raw_proof** out);
 const uint32_t* lmh_raw_proof_transcript(const lmh_raw_proof* r, uint64_t* n_words);
 const lm_whir_opening_claim* lmh_raw_proof_whir_claim(const lmh_raw_proof* r);
+const lm_pcs_statement_claim* lmh_raw_proof_statement_claim(const lmh_raw_proof* r);
 void lmh_raw_proof_free(lmh_raw_proof* r);
 
 /* ---- pad_table (crates/lean_prover/src/trace_gen.rs:170-191) ----------------------------------------------------------------

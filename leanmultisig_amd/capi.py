@@ -139,6 +139,7 @@ _HOST_SIGS = {
     "lmh_verify_execution_raw": (C.c_int, [vp, vp, vp, vp]),
     "lmh_raw_proof_transcript": (vp, [vp, vp]),
     "lmh_raw_proof_whir_claim": (vp, [vp]),
+    "lmh_raw_proof_statement_claim": (vp, [vp]),
     "lmh_raw_proof_free": (None, [vp]),
     "lmh_whir_commit": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]),
     "lmh_witness_free": (None, [vp, vp]),
@@ -359,7 +360,17 @@ class WhirOpeningClaim(C.Structure):
                 ("statement_sum", C.c_uint32 * 5), ("statement_weights", C.c_uint32 * 5), ("folding_randomness", C.c_uint32 * 160)]
 
 
-def verify_execution_raw(w, prover, builder=None):
+class PcsStatementClaim(C.Structure):
+    """lm_pcs_statement_claim: the points of the PCS statement and where its values lie in the raw transcript"""
+    _fields_ = [("log_rows", C.c_uint32 * 3), ("log_memory", C.c_uint32), ("log_bytecode", C.c_uint32), ("gkr_n_vars", C.c_uint32),
+                ("n_max", C.c_uint32), ("table_order", C.c_uint32 * 3), ("ending_pc", C.c_uint32), ("log_public_memory", C.c_uint32),
+                ("gkr_point", C.c_uint32 * 160), ("air_point", C.c_uint32 * 160), ("pm_point", C.c_uint32 * 40),
+                ("off_value_memory_acc", C.c_uint64), ("off_value_memory", C.c_uint64), ("off_value_bytecode_acc", C.c_uint64),
+                ("off_inner_evals", C.c_uint64 * 3), ("n_logup_values", C.c_uint32 * 3), ("logup_col", (C.c_uint32 * 40) * 3),
+                ("logup_off", (C.c_uint64 * 40) * 3)]
+
+
+def verify_execution_raw(w, prover, builder=None, with_statement=False):
     """lmh_verify_execution_raw: verify the proof `prover` holds and return (raw transcript words, WhirOpeningClaim) — the
     RawProof::transcript the recursion program reads and what its PCS opening was asked to prove.  Raises LmError on rejection."""
     lib = load()
@@ -375,8 +386,9 @@ def verify_execution_raw(w, prover, builder=None):
     ptr = lib.lmh_raw_proof_transcript(out.value, C.byref(n))
     raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(int(n.value),)).copy()
     claim = WhirOpeningClaim.from_buffer_copy(C.string_at(lib.lmh_raw_proof_whir_claim(out.value), C.sizeof(WhirOpeningClaim)))
+    stmt = PcsStatementClaim.from_buffer_copy(C.string_at(lib.lmh_raw_proof_statement_claim(out.value), C.sizeof(PcsStatementClaim)))
     lib.lmh_raw_proof_free(out.value)
-    return raw, claim
+    return (raw, claim, stmt) if with_statement else (raw, claim)
 
 
 class SparseStatement(C.Structure):

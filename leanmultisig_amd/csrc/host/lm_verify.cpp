@@ -31,6 +31,7 @@ using kb::to_monty;
 struct lmh_raw_proof {  // RawProof::transcript (fiat-shamir/src/transcript.rs:20-31) + what the PCS opening was asked to prove
     std::vector<u32> transcript;
     lm_whir_opening_claim claim;
+    lm_pcs_statement_claim stmt;
 };
 namespace {
 struct Fail {  // thrown inside this file only; every entry point catches it (nothing unwinds across the ABI)
@@ -697,15 +698,20 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         for (u32 j = 0; j < miss; j++) acc = ef_mul(acc, (((offset >> log_height) >> (miss - 1 - j)) & 1) ? gp[j] : one_minus(gp[j]));
         return acc;
     };
+    lm_pcs_statement_claim scl;
+    memset(&scl, 0, sizeof scl);
     EF pref = pref_at(0, log_mem);
+    scl.off_value_memory_acc = vs.raw.size();
     const EF value_memory_acc = vs.next_ext1();
     r_num = ef_sub(r_num, ef_mul(pref, value_memory_acc));
+    scl.off_value_memory = vs.raw.size();
     const EF value_memory = vs.next_ext1();
     r_den = ef_add(r_den, ef_mul(pref, ef_sub(logup_c, finger_print(0, {value_memory, mle_of_01234567_etc(from_end(log_mem), log_mem)}, aeq))));
     u64 offset = 1ull << log_mem;
     const u32 log_bc_padded = std::max(log_bc, max_rows);
     pref = pref_at(offset, log_bc);
     const EF pref_padded = pref_at(offset, log_bc_padded);
+    scl.off_value_bytecode_acc = vs.raw.size();
     const EF value_bytecode_acc = vs.next_ext1();
     r_num = ef_sub(r_num, ef_mul(pref, value_bytecode_acc));
     {
@@ -725,11 +731,17 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         const int t = order[k];
         const VmTableDef& def = kVmTables[t];
         const u32 lr = log_rows[t];
+        auto note = [&](u32 col, u64 off) {  // where the statement's value of column `col` of table t lies in the raw transcript
+            require(scl.n_logup_values[t] < 40, "statement claim: more logup values than lm_pcs_statement_claim holds");
+            scl.logup_col[t][scl.n_logup_values[t]] = col, scl.logup_off[t][scl.n_logup_values[t]++] = off;
+        };
         if (t == 0) {
+            note(0, vs.raw.size());
             const EF on_pc = vs.next_ext1();
             columns_values[t].push_back({0, on_pc});
+            const u64 instr_off = vs.raw.size();
             std::vector<EF> instr = vs.next_ext(12);
-            for (u32 i = 0; i < 12; i++) columns_values[t].push_back({8 + i, instr[i]});
+            for (u32 i = 0; i < 12; i++) columns_values[t].push_back({8 + i, instr[i]}), note(8 + i, instr_off + 5 * i);
             pref = pref_at(offset, lr);
             r_num = ef_add(r_num, pref);
             instr.push_back(on_pc);
@@ -745,9 +757,11 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         bus_den[t] = on_data;
         offset += 1ull << lr;
         for (u32 l = 0; l < def.n_lookups; l++) {
+            note(def.lookups[l].index, vs.raw.size());
             const EF index_eval = vs.next_ext1();
             columns_values[t].push_back({def.lookups[l].index, index_eval});
             for (u32 i = 0; i < def.lookups[l].n_values; i++) {
+                note(def.lookups[l].first_value + i, vs.raw.size());
                 const EF value_eval = vs.next_ext1();
                 columns_values[t].push_back({def.lookups[l].first_value + i, value_eval});
                 pref = pref_at(offset, lr);
@@ -804,6 +818,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
     for (int k = 0; k < 3; k++) {
         const int t = order[k];
         const u32 nt = log_rows[t], n_tot = kVmTables[t].n_columns + kVmTables[t].n_shift;
+        scl.off_inner_evals[t] = vs.raw.size();
         const std::vector<EF> ce = vs.next_ext(n_tot);
         for (const EF& e : ce) col_evals_flat.insert(col_evals_flat.end(), e.v, e.v + 5);
         const EF constraint_eval = air_eval(t, ce, x);
@@ -838,6 +853,15 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         for (u32 j = 0; j < s.point_len; j++) k.point.push_back(ef_load(&S.pts[(s.point_offset + j) * 5]));
         for (u32 v = 0; v < s.n_values; v++) k.values.push_back({S.sels[s.values_offset + v], ef_load(&S.vals[(s.values_offset + v) * 5])});
         statement.push_back(k);
+    }
+    if (raw) {
+        require(gkr_n_vars <= 32 && n_max <= 32 && lpm <= 8, "statement claim: a point longer than lm_pcs_statement_claim holds");
+        for (int t = 0; t < 3; t++) scl.log_rows[t] = log_rows[t], scl.table_order[t] = (u32)order[t];
+        scl.log_memory = log_mem, scl.log_bytecode = log_bc, scl.gkr_n_vars = gkr_n_vars, scl.n_max = n_max, scl.ending_pc = in->ending_pc, scl.log_public_memory = lpm;
+        memcpy(scl.gkr_point, gp_flat.data(), gp_flat.size() * 4);
+        memcpy(scl.air_point, ap_flat.data(), ap_flat.size() * 4);
+        memcpy(scl.pm_point, pm_flat.data(), pm_flat.size() * 4);
+        raw->stmt = scl;
     }
     whir_verify(&cfg, vs, commitment, statement, raw ? &raw->claim : nullptr);
     require(vs.off == transcript.size(), "trailing transcript words");
@@ -897,6 +921,7 @@ const uint32_t* lmh_raw_proof_transcript(const lmh_raw_proof* r, uint64_t* n_wor
     return r ? r->transcript.data() : nullptr;
 }
 const lm_whir_opening_claim* lmh_raw_proof_whir_claim(const lmh_raw_proof* r) { return r ? &r->claim : nullptr; }
+const lm_pcs_statement_claim* lmh_raw_proof_statement_claim(const lmh_raw_proof* r) { return r ? &r->stmt : nullptr; }
 void lmh_raw_proof_free(lmh_raw_proof* r) { delete r; }
 
 }  // extern "C"

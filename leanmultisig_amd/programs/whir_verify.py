@@ -46,11 +46,35 @@ def ceil_div(a, b):
     return -(-a // b)
 
 
-class Shape:
-    """everything the assembly depends on, derived from a WhirConfig dict (capi.WhirConfig.to_dict)"""
+TABLE_COLUMNS = {0: (20, 2), 1: (29, 13), 2: (109, 0)}   # table id -> (n_columns, n_shift): execution, extension_op, poseidon16 (tables/*/air.rs)
 
-    def __init__(self, cfg, n_children):
-        self.cfg, self.n_children = cfg, n_children
+
+class Statement:
+    """The static layout of the PCS statement of one child shape (capi.PcsStatementClaim + WhirOpeningClaim): table heights and order,
+    where the claimed evaluations lie in the raw transcript.  Two children with equal layouts run the same program."""
+
+    def __init__(self, stmt, claim):
+        self.log_rows = [int(x) for x in stmt.log_rows]
+        self.order = [int(x) for x in stmt.table_order]
+        self.log_memory, self.log_bytecode = int(stmt.log_memory), int(stmt.log_bytecode)
+        self.gkr_n_vars, self.n_max, self.ending_pc, self.lpm = int(stmt.gkr_n_vars), int(stmt.n_max), int(stmt.ending_pc), int(stmt.log_public_memory)
+        self.off_whir = int(claim.transcript_offset)
+        self.off_value_memory_acc, self.off_value_memory = int(stmt.off_value_memory_acc), int(stmt.off_value_memory)
+        self.off_value_bytecode_acc = int(stmt.off_value_bytecode_acc)
+        self.off_inner = [int(x) for x in stmt.off_inner_evals]
+        self.logup = {t: sorted((int(stmt.logup_col[t][k]), int(stmt.logup_off[t][k])) for k in range(int(stmt.n_logup_values[t]))) for t in range(3)}
+        self.n_values = 6 + sum(len(self.logup[t]) + sum(TABLE_COLUMNS[t]) for t in range(3))
+
+    def key(self):
+        return (self.log_rows, self.order, self.log_memory, self.log_bytecode, self.gkr_n_vars, self.n_max, self.ending_pc, self.off_whir,
+                self.off_value_memory_acc, self.off_value_memory, self.off_value_bytecode_acc, self.off_inner, sorted(self.logup.items()))
+
+
+class Shape:
+    """everything the assembly depends on, derived from a WhirConfig dict (capi.WhirConfig.to_dict) and, optionally, a Statement"""
+
+    def __init__(self, cfg, n_children, statement=None):
+        self.cfg, self.n_children, self.statement = cfg, n_children, statement
         self.n, self.rate, self.n_rounds = cfg["num_variables"], cfg["starting_log_inv_rate"], cfg["n_rounds"]
         assert self.n_rounds >= 1, "a configuration without a WHIR round has base-field leaves in the final round (not assembled)"
         self.fold = [cfg["fold_first"]] + [cfg["fold_sub"]] * self.n_rounds
@@ -73,9 +97,16 @@ class Shape:
         self.c_fs, self.c_root = 0, 16
         self.c_ood_points = 24
         self.c_ood_evals = self.c_ood_points + DIM * o0
-        self.c_stmt_sum = self.c_ood_evals + DIM * o0
-        self.c_stmt_weights = self.c_stmt_sum + DIM
-        self.c_rand = self.c_stmt_weights + DIM
+        if statement is None:   # the statement's share of the initial sum and of the final weight are claims
+            self.c_stmt_sum = self.c_ood_evals + DIM * o0
+            self.c_stmt_weights = self.c_stmt_sum + DIM
+            self.c_rand = self.c_stmt_weights + DIM
+        else:                   # the statement itself: the child's public input and the three points; the values are in the transcript
+            self.c_public_input = self.c_ood_evals + DIM * o0
+            self.c_gkr_point = self.c_public_input + ceil_div(1 << statement.lpm, DIGEST_LEN) * DIGEST_LEN
+            self.c_air_point = self.c_gkr_point + DIM * statement.gkr_n_vars     # all_challenges: the LAST challenge first (recursion.py:416)
+            self.c_pm_point = self.c_air_point + DIM * statement.n_max
+            self.c_rand = self.c_pm_point + DIM * statement.lpm
         self.claim_words = ceil_div(self.c_rand + DIM * self.n, DIGEST_LEN) * DIGEST_LEN
         # raw transcript words whir_open reads (every absorbed slice padded to the rate)
         t = 0
@@ -84,7 +115,8 @@ class Shape:
             if r < self.n_rounds:
                 t += 8 + ceil_div(DIM * self.oods[r + 1], 8) * 8 + (8 if self.query_grinding[r] else 0)
         t += ceil_div(DIM << self.n_final, 8) * 8 + (8 if self.query_grinding[self.n_rounds] else 0) + 16 * self.n_final
-        self.transcript_words = t
+        self.whir_transcript_words = t
+        self.transcript_words = t + (statement.off_whir if statement else 0)   # with a statement the program is given the whole raw transcript
 
 
 class Fs:
@@ -199,9 +231,183 @@ def sumcheck_round(f, fs, claimed, grinding_bits, challenge_dst):
     return out
 
 
-def build_program(cfg, n_children=4, log_size=None):
-    """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict())"""
-    S = Shape(cfg, n_children)
+def statement_values(T):
+    """the values of the PCS statement in statement order (recursion.py:478-518 = stacked_pcs_global_statements): (kind, data) with kind
+    'at' (raw-transcript offset of one value), 'run' (offset, count: consecutive values), 'pm', 'zero', 'const' (a base constant)"""
+    out = [("at", T.off_value_memory), ("at", T.off_value_memory_acc), ("pm", None), ("at", T.off_value_bytecode_acc), ("zero", None),
+           ("const", T.ending_pc)]
+    for t in T.order:
+        n_flat, n_shift = TABLE_COLUMNS[t]
+        out += [("at", off) for _, off in T.logup[t]]
+        if n_shift:
+            out.append(("run", (T.off_inner[t] + DIM * n_flat, n_shift)))
+        out.append(("run", (T.off_inner[t], n_flat)))
+    return out
+
+
+def statement_sum(f, S, T, cl, tr, pw, acc):
+    """whir_sum (recursion.py:473-518): the OOD part `acc` + sum_i value_i * gen^(n_ood + i); consecutive values are one dot product"""
+    k = S.oods[0]
+    vals = statement_values(T)
+    i = 0
+    while i < len(vals):
+        kind, d = vals[i]
+        if kind == "at":        # merge values that lie 5 words apart into a run
+            n = 1
+            while i + n < len(vals) and vals[i + n][0] == "at" and vals[i + n][1] == d + DIM * n:
+                n += 1
+            term = f.new_ef()
+            f.dot(tr + d, pw + DIM * k, term, n)
+            acc, k, i = f.add(acc, term), k + n, i + n
+            continue
+        if kind == "run":
+            off, n = d
+            term = f.new_ef()
+            f.dot(tr + off, pw + DIM * k, term, n)
+            acc, k = f.add(acc, term), k + n
+        elif kind == "pm":      # public_memory_eval = <public input, eq(public_memory_random_point, .)> (recursion.py:464-467)
+            eq = f.eq_mle(cl + S.c_pm_point, T.lpm)
+            pm = f.new_ef()
+            f.dot(cl + S.c_public_input, eq, pm, 1 << T.lpm, be=True)
+            acc, k = f.add(acc, f.mul(pm, pw + DIM * k)), k + 1
+        elif kind == "const":   # embed_in_ef(ENDING_PC) * randomness
+            cell = f.const(d)
+            term = f.new_ef()
+            f.dot(fp(cell), pw + DIM * k, term, 1, be=True)
+            acc, k = f.add(acc, term), k + 1
+        else:                   # STARTING_PC = 0: nothing to add, the power is consumed
+            k += 1
+        i += 1
+    assert k == S.oods[0] + T.n_values
+    return acc
+
+
+def next_mle(f, x, y, n):
+    """next_mle_const (utils.py:726-767)"""
+    one = absolute(ONE_EF_PTR)
+    eq_prefix = f.new_ef(n + 1)
+    f.set_one(eq_prefix)
+    for i in range(n):
+        eq_i = f.new_ef()
+        f.poly_eq(x + DIM * i, y + DIM * i, eq_i, 1)
+        f.mul(eq_prefix + DIM * i, eq_i, eq_prefix + DIM * (i + 1))
+    low = f.new_ef(n + 1)
+    f.set_one(low + DIM * n)
+    for i in range(n):
+        idx = n - 1 - i
+        omy = f.sub(one, y + DIM * idx)
+        f.mul(low + DIM * (idx + 1), f.mul(x + DIM * idx, omy), low + DIM * idx)
+    total = absolute(ZERO_VEC_PTR)
+    for a in range(n):
+        omx = f.sub(one, x + DIM * a)
+        term = f.mul(f.mul(eq_prefix + DIM * a, f.mul(omx, y + DIM * a)), low + DIM * (a + 1))
+        total = f.add(total, term)
+    px, py = f.new_ef(), f.new_ef()
+    f.poly_eq(absolute(REPEATED_ONES_PTR), x, px, n, be=True)          # product_first_n_const
+    f.poly_eq(absolute(REPEATED_ONES_PTR), y, py, n, be=True)
+    return f.add(total, f.mul(px, py))
+
+
+def statement_weights(f, S, T, cl, rand, pw):
+    """recursion.py:534-652: sum_i gen^(n_ood + i) * weight_i(folding randomness), weight = eq(top coordinates, selector) x eq / next of the
+    statement's point at the inner coordinates.  The reference evaluates one location prefix per value (bit decomposition + poly_eq_be);
+    here the values of a statement have consecutive selectors, so their prefixes are a slice of ONE eq table over the low q <= 6 selector
+    bits, shared by the table, times a prefix over the remaining high bits per aligned block: a dot product per block."""
+    p, n = f.p, S.n
+    bits_cache, low_cache = {}, {}
+
+    def const_bits(value, nbits):
+        key = (value, nbits)
+        if key not in bits_cache:
+            c = f.alloc(max(nbits, 1))
+            for j in range(nbits):
+                p.add(K(0), K((value >> (nbits - 1 - j)) & 1), M(c + j))
+            bits_cache[key] = c
+        return bits_cache[key]
+
+    def prefix(value, nbits):
+        """eq(rand[:nbits], bits of value) (multilinear_location_prefix, recursion.py:658-661)"""
+        if nbits == 0:
+            return absolute(ONE_EF_PTR)
+        out = f.new_ef()
+        f.poly_eq(fp(const_bits(value, nbits)), rand, out, nbits, be=True)
+        return out
+
+    def run_weight(k, sel0, m, n_top):
+        """sum_{j < m} pw[k + j] * eq(rand[:n_top], sel0 + j)"""
+        q = min(6, n_top)
+        if (n_top, q) not in low_cache:
+            low_cache[(n_top, q)] = f.eq_mle(rand + DIM * (n_top - q), q)
+        low = low_cache[(n_top, q)]
+        acc, j = None, 0
+        while j < m:
+            blk, lo = (sel0 + j) >> q, (sel0 + j) & ((1 << q) - 1)
+            ln = min(m - j, (1 << q) - lo)
+            d = f.new_ef()
+            f.dot(pw + DIM * (k + j), low + DIM * lo, d, ln)
+            term = f.mul(d, prefix(blk, n_top - q)) if n_top > q else d
+            acc = term if acc is None else f.add(acc, term)
+            j += ln
+        return acc
+
+    k = S.oods[0]
+    mem = 1 << T.log_memory
+    gkr_tail = lambda nv: cl + S.c_gkr_point + DIM * (T.gkr_n_vars - nv)  # noqa: E731 — from_end(point_gkr, nv)
+    inner = lambda nv: rand + DIM * (n - nv)                               # noqa: E731
+    # memory and its accumulator (selectors 0, 1), the public memory, the bytecode accumulator
+    eqf = f.new_ef()
+    f.poly_eq(inner(T.log_memory), gkr_tail(T.log_memory), eqf, T.log_memory)
+    s = f.mul(run_weight(k, 0, 2, n - T.log_memory), eqf)
+    k += 2
+    eqf = f.new_ef()
+    f.poly_eq(inner(T.lpm), cl + S.c_pm_point, eqf, T.lpm)
+    s = f.add(s, f.mul(f.mul(pw + DIM * k, prefix(0, n - T.lpm)), eqf))
+    k += 1
+    eqf = f.new_ef()
+    f.poly_eq(inner(T.log_bytecode), gkr_tail(T.log_bytecode), eqf, T.log_bytecode)
+    s = f.add(s, f.mul(f.mul(pw + DIM * k, prefix((2 * mem) >> T.log_bytecode, n - T.log_bytecode)), eqf))
+    k += 1
+    soff = 2 * mem + (1 << max(T.log_bytecode, T.log_rows[T.order[0]]))
+    for t in T.order:
+        nv = T.log_rows[t]
+        n_flat, n_shift = TABLE_COLUMNS[t]
+        if t == 0:              # pc at the first and at the last row of the execution table: full-index prefixes
+            s = f.add(s, f.mul(pw + DIM * k, prefix(soff, n)))
+            s = f.add(s, f.mul(pw + DIM * (k + 1), prefix(soff + (1 << nv) - 1, n)))
+            k += 2
+        base = soff >> nv
+        # the logup column evaluations at from_end(point_gkr, nv): runs of consecutive columns
+        eqf = f.new_ef()
+        f.poly_eq(gkr_tail(nv), inner(nv), eqf, nv)
+        cols = [c for c, _ in T.logup[t]]
+        w, i = None, 0
+        while i < len(cols):
+            m = 1
+            while i + m < len(cols) and cols[i + m] == cols[i] + m:
+                m += 1
+            rw = run_weight(k, base + cols[i], m, n - nv)
+            w = rw if w is None else f.add(w, rw)
+            k, i = k + m, i + m
+        s = f.add(s, f.mul(w, eqf))
+        # the column evaluations behind the AIR sumcheck at all_challenges[:nv]: shifted columns (next_mle), then all flat columns
+        point = cl + S.c_air_point
+        if n_shift:
+            s = f.add(s, f.mul(run_weight(k, base, n_shift, n - nv), next_mle(f, point, inner(nv), nv)))
+            k += n_shift
+        eqf = f.new_ef()
+        f.poly_eq(point, inner(nv), eqf, nv)
+        s = f.add(s, f.mul(run_weight(k, base, n_flat, n - nv), eqf))
+        k += n_flat
+        soff += n_flat << nv
+    assert k == S.oods[0] + T.n_values
+    return s
+
+
+def build_program(cfg, n_children=4, log_size=None, statement=None):
+    """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict()).  statement (a Statement): the
+    program also assembles the PCS statement (recursion.py:469-518, 534-652) instead of taking its two sums from the claims."""
+    S = Shape(cfg, n_children, statement)
+    T = statement
     p = Program()
     f = Fn(p, 0, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
     A = lambda off: MAIN_FP + off  # noqa: E731 — absolute address of a main-frame cell
@@ -227,13 +433,17 @@ def build_program(cfg, n_children=4, log_size=None):
     claims = f.alloc()
     p.hint_request_memory(claims, K(NC * S.claim_words))
     p.hint_witness("claims", claims, indirect=True)
-    tbase = []
+    tfull = []
     for c in range(NC):
         t = f.alloc()
         p.hint_request_memory(t, K(S.transcript_words))
         p.hint_witness("proof_transcript", t, indirect=True)
+        tfull.append(t)
+    tbase = []                                   # where whir_open starts reading
+    for c in range(NC):
+        t = f.alloc()
+        p.add(M(tfull[c]), K(T.off_whir if T else 0), M(t))
         tbase.append(t)
-    p.add(M(tbase[-1]), K(0), M(f.alloc()))    # (anchors the hints above on an instruction)
 
     # per-round arrays shared by the children: iteration i = child * q + j of a round's loop owns entry i
     folds_all = [f.alloc(DIM * NC * S.queries[r]) for r in range(R)]           # the folded leaves (whir.py:302-311)
@@ -251,10 +461,13 @@ def build_program(cfg, n_children=4, log_size=None):
         st["fs"] = Fs(f, cl + S.c_fs, tbase[c])
         # recursion.py:472-475: the combination randomness of the first constraint set; only its OOD powers are needed here
         gen = st["fs"].rate()
-        st["pw0"] = f.powers(gen, S.oods[0])
+        st["pw0"] = f.powers(gen, S.oods[0] if T is None else 1 << (S.oods[0] + T.n_values - 1).bit_length())
         ood_sum = f.new_ef()
         f.dot(cl + S.c_ood_evals, st["pw0"], ood_sum, S.oods[0])
-        st["claimed"] = f.add(ood_sum, cl + S.c_stmt_sum)                      # whir_sum
+        if T is None:
+            st["claimed"] = f.add(ood_sum, cl + S.c_stmt_sum)                  # whir_sum
+        else:
+            st["claimed"] = statement_sum(f, S, T, cl, at(tfull[c], 0), st["pw0"], ood_sum)
         st["root"] = cl + S.c_root
         st["ood_points"], st["comb"], st["roots"] = [], [], []
         ch.append(st)
@@ -354,7 +567,7 @@ def build_program(cfg, n_children=4, log_size=None):
         final_value = f.new_ef()
         f.dot(st["coeffs"], basis, final_value, 1 << nf)
         # recursion.py:534-654 with the statement's share taken from the claim: (s + statement_weights) * final_value == end_sum
-        total = f.add(s, cl + S.c_stmt_weights)
+        total = f.add(s, cl + S.c_stmt_weights) if T is None else f.add(s, statement_weights(f, S, T, cl, st["rand"], st["pw0"]))
         f.mul(total, final_value, st["end_sum"])
         for k in range(S.n):
             f.copy5(st["rand"] + DIM * k, cl + S.c_rand + DIM * k)             # folding_randomness_global == the claim's
@@ -578,8 +791,8 @@ def parse_raw_proof(words):
     return transcript, openings
 
 
-def claim_words(S, claim):
-    """one child's block of the claims buffer from an lm_whir_opening_claim (capi.WhirOpeningClaim)"""
+def claim_words(S, claim, stmt=None, public_input=None):
+    """one child's block of the claims buffer from an lm_whir_opening_claim (capi.WhirOpeningClaim) [+ lm_pcs_statement_claim]"""
     o0 = S.oods[0]
     assert claim.num_variables == S.n and claim.log_inv_rate == S.rate and claim.n_ood == o0
     out = np.zeros(S.claim_words, dtype=np.uint32)
@@ -587,15 +800,26 @@ def claim_words(S, claim):
     out[S.c_root:S.c_root + 8] = np.ctypeslib.as_array(claim.root)
     out[S.c_ood_points:S.c_ood_points + DIM * o0] = np.ctypeslib.as_array(claim.ood_points)[:DIM * o0]
     out[S.c_ood_evals:S.c_ood_evals + DIM * o0] = np.ctypeslib.as_array(claim.ood_answers)[:DIM * o0]
-    out[S.c_stmt_sum:S.c_stmt_sum + DIM] = np.ctypeslib.as_array(claim.statement_sum)
-    out[S.c_stmt_weights:S.c_stmt_weights + DIM] = np.ctypeslib.as_array(claim.statement_weights)
+    if S.statement is None:
+        out[S.c_stmt_sum:S.c_stmt_sum + DIM] = np.ctypeslib.as_array(claim.statement_sum)
+        out[S.c_stmt_weights:S.c_stmt_weights + DIM] = np.ctypeslib.as_array(claim.statement_weights)
+    else:
+        T = S.statement
+        assert Statement(stmt, claim).key() == T.key(), "a child proof of another shape than the program was assembled for"
+        pi = np.asarray(public_input, dtype=np.uint32)
+        out[S.c_public_input:S.c_public_input + pi.size] = pi                   # (zero padded to the public memory's power of two)
+        out[S.c_gkr_point:S.c_gkr_point + DIM * T.gkr_n_vars] = np.ctypeslib.as_array(stmt.gkr_point)[:DIM * T.gkr_n_vars]
+        ap = np.ctypeslib.as_array(stmt.air_point)[:DIM * T.n_max].reshape(T.n_max, DIM)
+        out[S.c_air_point:S.c_air_point + DIM * T.n_max] = ap[::-1].reshape(-1)
+        out[S.c_pm_point:S.c_pm_point + DIM * T.lpm] = np.ctypeslib.as_array(stmt.pm_point)[:DIM * T.lpm]
     out[S.c_rand:S.c_rand + DIM * S.n] = np.ctypeslib.as_array(claim.folding_randomness)[:DIM * S.n]
     return out
 
 
 def build_witness(bc, children):
     """children: per child (raw transcript words, lm_whir_opening_claim, openings [(index, leaf, path)] of the WHOLE proof in opening
-    order — every opening of a proof belongs to its PCS opening).  -> (public_input, vm.Witness, info).
+    order — every opening of a proof belongs to its PCS opening [, lm_pcs_statement_claim, the child's public input: programs assembled
+    with a Statement]).  -> (public_input, vm.Witness, info).
     The hint streams are what type_1_aggregation.rs:310-356 builds for a recursion: `proof_transcript` per child, and the
     `merkle_leaf` / `merkle_path` blobs of extract_merkle_hint_blobs in the order the program's segments consume them: round by
     round, within a round child by child."""
@@ -604,12 +828,13 @@ def build_witness(bc, children):
     S = bc.info["shape"]
     assert len(children) == S.n_children
     claims, transcripts, per_child = [], [], []
-    for raw, claim, openings in children:
-        off = int(claim.transcript_offset)
+    for child in children:
+        raw, claim, openings = child[:3]
+        off = int(claim.transcript_offset) if S.statement is None else 0
         t = np.asarray(raw, dtype=np.uint32)[off:]
         assert t.size == S.transcript_words, (t.size, S.transcript_words)
         transcripts.append(t)
-        claims.append(claim_words(S, claim))
+        claims.append(claim_words(S, claim, *child[3:5]))
         assert len(openings) == sum(S.queries)
         per_child.append(openings)
     leaves, paths = [], []

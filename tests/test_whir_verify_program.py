@@ -15,8 +15,7 @@ from tests import synth_witness
 N_CHILDREN = 2
 
 
-@pytest.fixture(scope="module")
-def setup(orc):
+def _children(orc):
     ob_b = ob.whir_builder(log_inv_rate=1, pow_bits=6, security=60)
     lm_b = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
     children, cfg = [], None
@@ -25,10 +24,25 @@ def setup(orc):
         cfg = lm.WhirConfig.new(lm_b, synth_witness.stacked_n_vars(w)).to_dict()
         sizes = [r["num_queries"] for r in cfg["rounds"]] + [cfg["final_queries"]]
         pr = lm.Prover.from_raw(ob.prove_execution(orc, w, synth_witness.header(w), ob_b), sizes)
-        raw, claim = capi.verify_execution_raw(w, pr, lm_b)
-        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1]))
-    bc = wv.build_program(cfg, N_CHILDREN)
-    return bc, children
+        raw, claim, stmt = capi.verify_execution_raw(w, pr, lm_b, with_statement=True)
+        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1], stmt, w["public_input"]))
+    return cfg, children
+
+
+@pytest.fixture(scope="module")
+def setup(orc):
+    """the opening alone: the statement's two sums are claims"""
+    cfg, children = _children(orc)
+    return wv.build_program(cfg, N_CHILDREN), [ch[:3] for ch in children]
+
+
+@pytest.fixture(scope="module")
+def setup_stmt(orc):
+    """the opening WITH its statement (recursion.py:469-518, 534-652): points in the claims, values read from the raw transcript"""
+    cfg, children = _children(orc)
+    T = wv.Statement(children[0][3], children[0][1])
+    assert T.n_values == children[0][1].n_statement_values == 252
+    return wv.build_program(cfg, N_CHILDREN, statement=T), children
 
 
 def test_raw_transcript_layout(setup):
@@ -95,3 +109,38 @@ def test_rejects_tampered_transcript_and_claim(setup):
     pi[3] ^= 1
     with pytest.raises(lm.LmError, match="MemoryAlreadySet"):
         vm.execute(bc, pi, wit)
+
+
+def test_with_statement_accepts_and_equals_oracle_vm(orc, setup_stmt):
+    bc, children = setup_stmt
+    pi, wit, _ = wv.build_witness(bc, children)
+    ex = vm.execute(bc, pi, wit, n_threads=4)
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+
+
+def test_with_statement_rejects_a_wrong_statement(setup_stmt):
+    """every ingredient of the PCS statement is bound: a claimed evaluation in the part of the transcript in front of the opening (a
+    logup column value, a column evaluation behind the AIR sumcheck, value_memory), each of the three points, the child's public input"""
+    bc, children = setup_stmt
+    raw, claim, ops, stmt, pub = children[0]
+    T = bc.info["shape"].statement
+    for off in (T.off_value_memory + 1, T.off_value_bytecode_acc, T.logup[0][3][1] + 2, T.logup[2][-1][1], T.off_inner[2] + 5 * 50 + 1, T.off_inner[1] + 5 * 30,
+                T.off_inner[0] + 3):
+        raw2 = raw.copy()
+        raw2[off] ^= 1
+        _rejected(bc, [(raw2, claim, ops, stmt, pub), children[1]], "InvalidExtensionOp")
+    for field, k in (("gkr_point", 7), ("gkr_point", 5 * (T.gkr_n_vars - 1)), ("air_point", 2), ("air_point", 5 * (T.n_max - 1) + 4), ("pm_point", 6)):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        getattr(st2, field)[k] ^= 1
+        _rejected(bc, [(raw, claim, ops, st2, pub), children[1]], "InvalidExtensionOp")
+    pub2 = np.asarray(pub).copy()
+    pub2[5] ^= 1
+    _rejected(bc, [(raw, claim, ops, stmt, pub2), children[1]], "InvalidExtensionOp")
+    # a child of another shape than the program was assembled for is refused when the witness is built
+    st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+    st2.log_rows[1] += 1
+    with pytest.raises(AssertionError, match="another shape"):
+        wv.build_witness(bc, [(raw, claim, ops, st2, pub), children[1]])

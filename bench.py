@@ -146,7 +146,7 @@ def whir_recursion_bench(ctx, lm, args, ob=None, orc=None):
         assert n_vars in (None, claim.num_variables)
         n_vars = claim.num_variables
     cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
-    bc = wv.build_program(cfg, n_children, log_size=19 if args.scale_log == 0 else None, statement=wv.Statement(children[0][3], children[0][1]))
+    bc = wv.build_program(cfg, n_children, log_size=19 if args.scale_log == 0 else None, statement=wv.Statement(children[0][3], children[0][1]), air=True)
     S = bc.info["shape"]
     t0 = time.perf_counter()
     pi, wit, _ = wv.build_witness(bc, children)
@@ -192,10 +192,10 @@ def whir_recursion_bench(ctx, lm, args, ob=None, orc=None):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32 (KoalaBear Montgomery, 31-bit modular)", "data": "synthetic",
         "config": {"workload": f"recursion --n {n_children} --log-inv-rate {rate} (BASELINE configs[3]), the root step as far as the recursion program is assembled: "
-                               f"whir_open of the in-VM verifier (zkdsl_implem/whir.py) on {n_children} GENUINE child proofs of {child_sigs} real signatures each "
+                               f"the in-VM verifier from the batched AIR sumcheck on (recursion.py:383-654 + zkdsl_implem/whir.py whir_open) on {n_children} GENUINE child proofs of {child_sigs} real signatures each "
                                f"(stacked 2^{n_vars}, queries {S.queries}, Merkle heights {S.height}) WITH the assembly of its statement ({S.statement.n_values} claimed "
-                               f"evaluations read from the children's raw transcripts, recursion.py:469-518, 534-652); GKR / logup / AIR verification of recursion.py are "
-                               f"NOT in the program (the three evaluation points they produce enter through the claims buffer)"
+                               f"evaluations read from the children's raw transcripts, recursion.py:469-518, 534-652); the head of recursion.py (GKR, logup statement) and the AIR "
+                               f"constraint evaluators are NOT in the program (GKR point, logup_c and the three constraint evaluations enter through the claims buffer)"
                                + ("" if args.scale_log == 0 else f" [children SCALED DOWN by 2^{args.scale_log}]"),
                    "source_sha": source_sha()},
         "root": {"cycles": ex.n_cycles, "poseidon_calls": ex.n_poseidon_calls, "extension_rows": ex.n_extension_rows, "memory_words": ex.memory_len, **ex.counts,

@@ -266,6 +266,13 @@ typedef struct {
     uint32_t n_logup_values[3];   /* per table id: logup column evaluations, in the order the prover sent them */
     uint32_t logup_col[3][40];
     uint64_t logup_off[3][40];
+    /* the batched AIR sumcheck in front of the statement (recursion.py:383-467): where it starts, and what it needs from before */
+    uint64_t air_offset;               /* raw-transcript word of the first round polynomial */
+    uint32_t air_challenger_state[16]; /* the sponge when bus_beta is sampled (:385) */
+    uint32_t air_degree, reserved2;    /* MAX_AIR_FULL_DEGREE: a round polynomial has air_degree + 1 coefficients */
+    uint32_t logup_c[5];
+    uint64_t off_bus_selector[3], off_bus_data[3]; /* per table id: eval_on_selector / eval_on_data (:331-339) */
+    uint32_t air_constraint_evals[3][5];           /* per table id: evaluate_air_constraints at the column evaluations (:434) */
 } lm_pcs_statement_claim;
 typedef struct lmh_raw_proof lmh_raw_proof;
 /* verify_execution on the proof a prover object holds; on success *out owns the raw transcript and the claim */

@@ -748,9 +748,11 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
             r_den = ef_add(r_den, ef_mul(pref, ef_sub(logup_c, finger_print(2, instr, aeq))));
             offset += 1ull << lr;
         }
+        scl.off_bus_selector[t] = vs.raw.size();
         const EF on_selector = vs.next_ext1();
         pref = pref_at(offset, lr);
         r_num = ef_add(r_num, ef_mul(pref, on_selector));
+        scl.off_bus_data[t] = vs.raw.size();
         const EF on_data = vs.next_ext1();
         r_den = ef_add(r_den, ef_mul(pref, on_data));
         bus_num[t] = on_selector;
@@ -776,6 +778,9 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
     require(kb::ef_eq(r_den, den_value), "logup: denominator claim does not match the column evaluations");
 
     // ---- AIR (verify_execution.rs:100-186) ----
+    scl.air_offset = vs.raw.size();
+    memcpy(scl.air_challenger_state, vs.ch.state, sizeof scl.air_challenger_state);
+    memcpy(scl.logup_c, logup_c.v, 20);
     const EF bus_beta = vs.sample();
     vs.duplex();
     const EF air_alpha = vs.sample();
@@ -822,6 +827,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         const std::vector<EF> ce = vs.next_ext(n_tot);
         for (const EF& e : ce) col_evals_flat.insert(col_evals_flat.end(), e.v, e.v + 5);
         const EF constraint_eval = air_eval(t, ce, x);
+        memcpy(scl.air_constraint_evals[t], constraint_eval.v, 20);
         // back_loaded_table_contribution (verify_execution.rs:233-251)
         std::vector<EF> nat(nt);
         for (u32 j = 0; j < nt; j++) nat[j] = air_point[n_max - 1 - j];
@@ -857,7 +863,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
     if (raw) {
         require(gkr_n_vars <= 32 && n_max <= 32 && lpm <= 8, "statement claim: a point longer than lm_pcs_statement_claim holds");
         for (int t = 0; t < 3; t++) scl.log_rows[t] = log_rows[t], scl.table_order[t] = (u32)order[t];
-        scl.log_memory = log_mem, scl.log_bytecode = log_bc, scl.gkr_n_vars = gkr_n_vars, scl.n_max = n_max, scl.ending_pc = in->ending_pc, scl.log_public_memory = lpm;
+        scl.log_memory = log_mem, scl.log_bytecode = log_bc, scl.gkr_n_vars = gkr_n_vars, scl.n_max = n_max, scl.ending_pc = in->ending_pc, scl.log_public_memory = lpm, scl.air_degree = max_full_degree;
         memcpy(scl.gkr_point, gp_flat.data(), gp_flat.size() * 4);
         memcpy(scl.air_point, ap_flat.data(), ap_flat.size() * 4);
         memcpy(scl.pm_point, pm_flat.data(), pm_flat.size() * 4);

@@ -64,17 +64,22 @@ class Statement:
         self.off_inner = [int(x) for x in stmt.off_inner_evals]
         self.logup = {t: sorted((int(stmt.logup_col[t][k]), int(stmt.logup_off[t][k])) for k in range(int(stmt.n_logup_values[t]))) for t in range(3)}
         self.n_values = 6 + sum(len(self.logup[t]) + sum(TABLE_COLUMNS[t]) for t in range(3))
+        # the batched AIR sumcheck in front of the statement
+        self.air_off, self.air_degree = int(stmt.air_offset), int(stmt.air_degree)
+        self.off_bus_selector, self.off_bus_data = [int(x) for x in stmt.off_bus_selector], [int(x) for x in stmt.off_bus_data]
 
     def key(self):
         return (self.log_rows, self.order, self.log_memory, self.log_bytecode, self.gkr_n_vars, self.n_max, self.ending_pc, self.off_whir,
-                self.off_value_memory_acc, self.off_value_memory, self.off_value_bytecode_acc, self.off_inner, sorted(self.logup.items()))
+                self.off_value_memory_acc, self.off_value_memory, self.off_value_bytecode_acc, self.off_inner, sorted(self.logup.items()),
+                self.air_off, self.air_degree, self.off_bus_selector, self.off_bus_data, self.lpm)
 
 
 class Shape:
     """everything the assembly depends on, derived from a WhirConfig dict (capi.WhirConfig.to_dict) and, optionally, a Statement"""
 
-    def __init__(self, cfg, n_children, statement=None):
-        self.cfg, self.n_children, self.statement = cfg, n_children, statement
+    def __init__(self, cfg, n_children, statement=None, air=False):
+        assert statement is not None or not air
+        self.cfg, self.n_children, self.statement, self.air = cfg, n_children, statement, air
         self.n, self.rate, self.n_rounds = cfg["num_variables"], cfg["starting_log_inv_rate"], cfg["n_rounds"]
         assert self.n_rounds >= 1, "a configuration without a WHIR round has base-field leaves in the final round (not assembled)"
         self.fold = [cfg["fold_first"]] + [cfg["fold_sub"]] * self.n_rounds
@@ -101,12 +106,18 @@ class Shape:
             self.c_stmt_sum = self.c_ood_evals + DIM * o0
             self.c_stmt_weights = self.c_stmt_sum + DIM
             self.c_rand = self.c_stmt_weights + DIM
-        else:                   # the statement itself: the child's public input and the three points; the values are in the transcript
+        elif not air:           # the statement itself: the child's public input and the three points; the values are in the transcript
             self.c_public_input = self.c_ood_evals + DIM * o0
             self.c_gkr_point = self.c_public_input + ceil_div(1 << statement.lpm, DIGEST_LEN) * DIGEST_LEN
             self.c_air_point = self.c_gkr_point + DIM * statement.gkr_n_vars     # all_challenges: the LAST challenge first (recursion.py:416)
             self.c_pm_point = self.c_air_point + DIM * statement.n_max
             self.c_rand = self.c_pm_point + DIM * statement.lpm
+        else:                   # + the batched AIR sumcheck: c_fs is the sponge when bus_beta is sampled; the sumcheck's challenges and the
+            self.c_public_input = self.c_ood_evals + DIM * o0      # public-memory point are SAMPLED by the program; what is left of the
+            self.c_gkr_point = self.c_public_input + ceil_div(1 << statement.lpm, DIGEST_LEN) * DIGEST_LEN   # verifier's earlier work: the GKR
+            self.c_logup_c = self.c_gkr_point + DIM * statement.gkr_n_vars                                   # point, logup_c, and the three
+            self.c_air_evals = self.c_logup_c + DIM                                                          # AIR constraint evaluations
+            self.c_rand = self.c_air_evals + 3 * DIM
         self.claim_words = ceil_div(self.c_rand + DIM * self.n, DIGEST_LEN) * DIGEST_LEN
         # raw transcript words whir_open reads (every absorbed slice padded to the rate)
         t = 0
@@ -117,6 +128,10 @@ class Shape:
         t += ceil_div(DIM << self.n_final, 8) * 8 + (8 if self.query_grinding[self.n_rounds] else 0) + 16 * self.n_final
         self.whir_transcript_words = t
         self.transcript_words = t + (statement.off_whir if statement else 0)   # with a statement the program is given the whole raw transcript
+        if air:   # what the AIR part reads in front of the opening: round polynomials and the tables' column evaluations
+            T = statement
+            a = T.n_max * ceil_div(DIM * (T.air_degree + 1), 8) * 8 + sum(ceil_div(DIM * sum(TABLE_COLUMNS[t]), 8) * 8 for t in range(3))
+            assert T.air_off + a == T.off_whir, (T.air_off, a, T.off_whir)
 
 
 class Fs:
@@ -245,7 +260,7 @@ def statement_values(T):
     return out
 
 
-def statement_sum(f, S, T, cl, tr, pw, acc):
+def statement_sum(f, S, T, cl, tr, pw, acc, pm_point):
     """whir_sum (recursion.py:473-518): the OOD part `acc` + sum_i value_i * gen^(n_ood + i); consecutive values are one dot product"""
     k = S.oods[0]
     vals = statement_values(T)
@@ -266,7 +281,7 @@ def statement_sum(f, S, T, cl, tr, pw, acc):
             f.dot(tr + off, pw + DIM * k, term, n)
             acc, k = f.add(acc, term), k + n
         elif kind == "pm":      # public_memory_eval = <public input, eq(public_memory_random_point, .)> (recursion.py:464-467)
-            eq = f.eq_mle(cl + S.c_pm_point, T.lpm)
+            eq = f.eq_mle(pm_point, T.lpm)
             pm = f.new_ef()
             f.dot(cl + S.c_public_input, eq, pm, 1 << T.lpm, be=True)
             acc, k = f.add(acc, f.mul(pm, pw + DIM * k)), k + 1
@@ -308,7 +323,7 @@ def next_mle(f, x, y, n):
     return f.add(total, f.mul(px, py))
 
 
-def statement_weights(f, S, T, cl, rand, pw):
+def statement_weights(f, S, T, cl, rand, pw, air_point, pm_point):
     """recursion.py:534-652: sum_i gen^(n_ood + i) * weight_i(folding randomness), weight = eq(top coordinates, selector) x eq / next of the
     statement's point at the inner coordinates.  The reference evaluates one location prefix per value (bit decomposition + poly_eq_be);
     here the values of a statement have consecutive selectors, so their prefixes are a slice of ONE eq table over the low q <= 6 selector
@@ -360,7 +375,7 @@ def statement_weights(f, S, T, cl, rand, pw):
     s = f.mul(run_weight(k, 0, 2, n - T.log_memory), eqf)
     k += 2
     eqf = f.new_ef()
-    f.poly_eq(inner(T.lpm), cl + S.c_pm_point, eqf, T.lpm)
+    f.poly_eq(inner(T.lpm), pm_point, eqf, T.lpm)
     s = f.add(s, f.mul(f.mul(pw + DIM * k, prefix(0, n - T.lpm)), eqf))
     k += 1
     eqf = f.new_ef()
@@ -390,7 +405,7 @@ def statement_weights(f, S, T, cl, rand, pw):
             k, i = k + m, i + m
         s = f.add(s, f.mul(w, eqf))
         # the column evaluations behind the AIR sumcheck at all_challenges[:nv]: shifted columns (next_mle), then all flat columns
-        point = cl + S.c_air_point
+        point = air_point
         if n_shift:
             s = f.add(s, f.mul(run_weight(k, base, n_shift, n - nv), next_mle(f, point, inner(nv), nv)))
             k += n_shift
@@ -403,10 +418,59 @@ def statement_weights(f, S, T, cl, rand, pw):
     return s
 
 
-def build_program(cfg, n_children=4, log_size=None, statement=None):
+def air_sumcheck_verify(f, S, T, cl, tr, fs):
+    """recursion.py:383-467: bus_beta / air_alpha / eta, the initial sum from the bus evaluations, the batched AIR sumcheck
+    (sumcheck_verify_reversed, whir.py:184-207), the tables' column evaluations and the back-loaded check against the claimed constraint
+    evaluations, then the public-memory point.  -> (all_challenges, public_memory_random_point)"""
+    zero = absolute(ZERO_VEC_PTR)
+    bus_beta = fs.rate()
+    fs.duplex()                     # air_alpha = fs.rate(): its powers only enter evaluate_air_constraints, whose results are claims here
+    fs.duplex()
+    eta_pw = f.powers(fs.rate(), 3)
+    claimed = zero
+    for k, t in enumerate(T.order):
+        num, den = tr + T.off_bus_selector[t], tr + T.off_bus_data[t]
+        bfv = num if t == 0 else f.sub(zero, num)                              # opposite_extension_ret for the tables that pull
+        bfv = f.add(bfv, f.mul(bus_beta, f.sub(den, cl + S.c_logup_c)))
+        claimed = f.add(claimed, f.mul(eta_pw + DIM * k, bfv))
+    n_co = T.air_degree + 1
+    all_ch = f.new_ef(T.n_max)
+    for r in range(T.n_max):
+        poly = fs.receive_ef(n_co)
+        tmp = f.new_ef()
+        f.dot(absolute(REPEATED_ONES_PTR), poly, tmp, n_co, be=True)
+        f.add(tmp, poly, claimed)                                               # p(0) + p(1) == the running claim
+        rand = fs.rate()
+        f.copy5(rand, all_ch + DIM * (T.n_max - 1 - r))
+        nxt = f.new_ef()
+        f.dot(poly, f.powers(rand, n_co), nxt, n_co)
+        claimed = nxt
+    check = None
+    for k, t in enumerate(T.order):
+        nv = T.log_rows[t]
+        inner = fs.receive_ef(sum(TABLE_COLUMNS[t]))
+        assert inner.kind == "at" and inner.k == T.off_inner[t] - T.air_off
+        eq_val = f.new_ef()
+        f.poly_eq(cl + S.c_gkr_point + DIM * (T.gkr_n_vars - nv), all_ch, eq_val, nv)
+        if T.n_max > nv:            # product_first_n (utils.py:70-83)
+            k_t = f.new_ef()
+            f.poly_eq(absolute(REPEATED_ONES_PTR), all_ch + DIM * nv, k_t, T.n_max - nv, be=True)
+            lhs = f.mul(eta_pw + DIM * k, k_t)
+        else:
+            lhs = f.mul(eta_pw + DIM * k, absolute(ONE_EF_PTR))
+        term = f.mul(lhs, f.mul(eq_val, cl + S.c_air_evals + DIM * t))
+        check = term if check is None else f.add(check, term)
+    f.copy5(check, claimed)                                                     # the sumcheck's final value is what the tables give
+    pm_point = fs.sample_chunks(ceil_div(DIM * T.lpm, 8))                       # fs_sample_many_ef(INNER_PUBLIC_MEMORY_LOG_SIZE)
+    return all_ch, pm_point
+
+
+def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
     """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict()).  statement (a Statement): the
-    program also assembles the PCS statement (recursion.py:469-518, 534-652) instead of taking its two sums from the claims."""
-    S = Shape(cfg, n_children, statement)
+    program also assembles the PCS statement (recursion.py:469-518, 534-652) instead of taking its two sums from the claims; air: it
+    starts in front of the batched AIR sumcheck (recursion.py:383-467) and samples that sumcheck's challenges and the public-memory point
+    itself."""
+    S = Shape(cfg, n_children, statement, air)
     T = statement
     p = Program()
     f = Fn(p, 0, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
@@ -442,7 +506,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None):
     tbase = []                                   # where whir_open starts reading
     for c in range(NC):
         t = f.alloc()
-        p.add(M(tfull[c]), K(T.off_whir if T else 0), M(t))
+        p.add(M(tfull[c]), K((T.air_off if air else T.off_whir) if T else 0), M(t))
         tbase.append(t)
 
     # per-round arrays shared by the children: iteration i = child * q + j of a round's loop owns entry i
@@ -459,6 +523,11 @@ def build_program(cfg, n_children=4, log_size=None, statement=None):
         cl = at(claims, c * S.claim_words)
         st = dict(cl=cl, rand=fp(f.alloc(DIM * S.n)))                          # folding_randomness_global
         st["fs"] = Fs(f, cl + S.c_fs, tbase[c])
+        st["air_point"], st["pm_point"] = (cl + S.c_air_point, cl + S.c_pm_point) if T is not None and not air else (None, None)
+        if air:
+            st["air_point"], st["pm_point"] = air_sumcheck_verify(f, S, T, cl, at(tfull[c], 0), st["fs"])
+            assert st["fs"].off == T.off_whir - T.air_off
+            st["fs"].duplex()                                                  # recursion.py:470
         # recursion.py:472-475: the combination randomness of the first constraint set; only its OOD powers are needed here
         gen = st["fs"].rate()
         st["pw0"] = f.powers(gen, S.oods[0] if T is None else 1 << (S.oods[0] + T.n_values - 1).bit_length())
@@ -467,7 +536,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None):
         if T is None:
             st["claimed"] = f.add(ood_sum, cl + S.c_stmt_sum)                  # whir_sum
         else:
-            st["claimed"] = statement_sum(f, S, T, cl, at(tfull[c], 0), st["pw0"], ood_sum)
+            st["claimed"] = statement_sum(f, S, T, cl, at(tfull[c], 0), st["pw0"], ood_sum, st["pm_point"])
         st["root"] = cl + S.c_root
         st["ood_points"], st["comb"], st["roots"] = [], [], []
         ch.append(st)
@@ -567,7 +636,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None):
         final_value = f.new_ef()
         f.dot(st["coeffs"], basis, final_value, 1 << nf)
         # recursion.py:534-654 with the statement's share taken from the claim: (s + statement_weights) * final_value == end_sum
-        total = f.add(s, cl + S.c_stmt_weights) if T is None else f.add(s, statement_weights(f, S, T, cl, st["rand"], st["pw0"]))
+        total = f.add(s, cl + S.c_stmt_weights) if T is None else f.add(s, statement_weights(f, S, T, cl, st["rand"], st["pw0"], st["air_point"], st["pm_point"]))
         f.mul(total, final_value, st["end_sum"])
         for k in range(S.n):
             f.copy5(st["rand"] + DIM * k, cl + S.c_rand + DIM * k)             # folding_randomness_global == the claim's
@@ -809,9 +878,14 @@ def claim_words(S, claim, stmt=None, public_input=None):
         pi = np.asarray(public_input, dtype=np.uint32)
         out[S.c_public_input:S.c_public_input + pi.size] = pi                   # (zero padded to the public memory's power of two)
         out[S.c_gkr_point:S.c_gkr_point + DIM * T.gkr_n_vars] = np.ctypeslib.as_array(stmt.gkr_point)[:DIM * T.gkr_n_vars]
-        ap = np.ctypeslib.as_array(stmt.air_point)[:DIM * T.n_max].reshape(T.n_max, DIM)
-        out[S.c_air_point:S.c_air_point + DIM * T.n_max] = ap[::-1].reshape(-1)
-        out[S.c_pm_point:S.c_pm_point + DIM * T.lpm] = np.ctypeslib.as_array(stmt.pm_point)[:DIM * T.lpm]
+        if S.air:
+            out[S.c_fs:S.c_fs + 16] = np.ctypeslib.as_array(stmt.air_challenger_state)
+            out[S.c_logup_c:S.c_logup_c + DIM] = np.ctypeslib.as_array(stmt.logup_c)
+            out[S.c_air_evals:S.c_air_evals + 3 * DIM] = np.ctypeslib.as_array(stmt.air_constraint_evals).reshape(-1)
+        else:
+            ap = np.ctypeslib.as_array(stmt.air_point)[:DIM * T.n_max].reshape(T.n_max, DIM)
+            out[S.c_air_point:S.c_air_point + DIM * T.n_max] = ap[::-1].reshape(-1)
+            out[S.c_pm_point:S.c_pm_point + DIM * T.lpm] = np.ctypeslib.as_array(stmt.pm_point)[:DIM * T.lpm]
     out[S.c_rand:S.c_rand + DIM * S.n] = np.ctypeslib.as_array(claim.folding_randomness)[:DIM * S.n]
     return out
 

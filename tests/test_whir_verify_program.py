@@ -45,6 +45,13 @@ def setup_stmt(orc):
     return wv.build_program(cfg, N_CHILDREN, statement=T), children
 
 
+@pytest.fixture(scope="module")
+def setup_air(orc):
+    """from the batched AIR sumcheck on (recursion.py:383-654): the sumcheck's challenges and the public-memory point are sampled in the VM"""
+    cfg, children = _children(orc)
+    return wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1]), air=True), children
+
+
 def test_raw_transcript_layout(setup):
     """RawProof::transcript (fiat-shamir/src/verifier.rs:54-60,126-195): whole rate blocks, the part whir_open reads has the length the
     configuration implies, and the claim's sponge state is reproducible from nothing but the raw transcript's words"""
@@ -144,3 +151,34 @@ def test_with_statement_rejects_a_wrong_statement(setup_stmt):
     st2.log_rows[1] += 1
     with pytest.raises(AssertionError, match="another shape"):
         wv.build_witness(bc, [(raw, claim, ops, st2, pub), children[1]])
+
+
+def test_from_the_air_sumcheck_accepts_and_equals_oracle_vm(orc, setup_air):
+    bc, children = setup_air
+    pi, wit, _ = wv.build_witness(bc, children)
+    ex = vm.execute(bc, pi, wit, n_threads=4)
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+
+
+def test_from_the_air_sumcheck_rejects(setup_air):
+    """a round polynomial of the AIR sumcheck, a column evaluation behind it (absorbed: the transcript diverges), a bus evaluation, and
+    every claim that is left (logup_c, the three constraint evaluations, the GKR point, the sponge state)"""
+    bc, children = setup_air
+    raw, claim, ops, stmt, pub = children[1]
+    T = bc.info["shape"].statement
+    for off in (T.air_off + 2, T.air_off + 56 * 3 + 11, T.off_inner[0] + 7, T.off_inner[2] + 5 * 100, T.off_bus_selector[1] + 1, T.off_bus_data[2] + 4,
+                T.off_value_memory):
+        raw2 = raw.copy()
+        raw2[off] ^= 1
+        _rejected(bc, [children[0], (raw2, claim, ops, stmt, pub)], "InvalidExtensionOp|NotEqual")
+    for field, k in (("logup_c", 1), ("gkr_point", 11), ("air_challenger_state", 3), ("air_challenger_state", 9)):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        getattr(st2, field)[k] ^= 1
+        _rejected(bc, [children[0], (raw, claim, ops, st2, pub)], "InvalidExtensionOp|NotEqual")
+    for t in range(3):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        st2.air_constraint_evals[t][2] ^= 1
+        _rejected(bc, [children[0], (raw, claim, ops, st2, pub)], "InvalidExtensionOp|NotEqual")

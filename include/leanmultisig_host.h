@@ -273,6 +273,10 @@ typedef struct {
     uint32_t logup_c[5];
     uint64_t off_bus_selector[3], off_bus_data[3]; /* per table id: eval_on_selector / eval_on_data (:331-339) */
     uint32_t air_constraint_evals[3][5];           /* per table id: evaluate_air_constraints at the column evaluations (:434) */
+    /* the head of the verifier (recursion.py:48-378): what it does not derive itself */
+    uint32_t bytecode_hash_domsep[8];              /* compress(bytecode hash | SNARK_DOMAIN_SEP), observed at :56 */
+    uint32_t bytecode_value[5];                    /* the `bytecode_value_hint` of :138: the bytecode table at (point, alphas) */
+    uint32_t reserved3;
 } lm_pcs_statement_claim;
 typedef struct lmh_raw_proof lmh_raw_proof;
 /* verify_execution on the proof a prover object holds; on success *out owns the raw transcript and the claim */

@@ -369,7 +369,8 @@ class PcsStatementClaim(C.Structure):
                 ("off_inner_evals", C.c_uint64 * 3), ("n_logup_values", C.c_uint32 * 3), ("logup_col", (C.c_uint32 * 40) * 3),
                 ("logup_off", (C.c_uint64 * 40) * 3), ("air_offset", C.c_uint64), ("air_challenger_state", C.c_uint32 * 16), ("air_degree", C.c_uint32),
                 ("reserved2", C.c_uint32), ("logup_c", C.c_uint32 * 5), ("off_bus_selector", C.c_uint64 * 3), ("off_bus_data", C.c_uint64 * 3),
-                ("air_constraint_evals", (C.c_uint32 * 5) * 3)]
+                ("air_constraint_evals", (C.c_uint32 * 5) * 3), ("bytecode_hash_domsep", C.c_uint32 * 8), ("bytecode_value", C.c_uint32 * 5),
+                ("reserved3", C.c_uint32)]
 
 
 def verify_execution_raw(w, prover, builder=None, with_statement=False):

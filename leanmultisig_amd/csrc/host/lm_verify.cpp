@@ -638,6 +638,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         for (int i = 0; i < 8; i++) st[8 + i] = to_monty(kSnarkDomainSep[i]);
         lmh::host_compress(st);
         vs.observe(st, 8);
+        if (raw) memcpy(raw->stmt.bytecode_hash_domsep, st, 32);
     }
     const std::vector<u32> dims_m = vs.next_base(6);
     u32 dims[6];
@@ -719,6 +720,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         std::vector<EF> bp(from_end(log_bc), from_end(log_bc) + log_bc);
         bp.insert(bp.end(), alphas.begin(), alphas.end());  // from_end(alphas, log2_ceil(12) = 4): all four
         const EF bytecode_value = mle_eval_base_big(in->bytecode, bp.data(), log_bc + 4);
+        memcpy(scl.bytecode_value, bytecode_value.v, 20);
         // (alphas[..len - 4] is empty: the corrective product is 1)
         const EF d = ef_add(ef_add(bytecode_value, ef_mul(index_value, aeq[12])), ef_mul_base(aeq[15], to_monty(2)));
         r_den = ef_add(r_den, ef_mul(pref, ef_sub(logup_c, d)));
@@ -867,6 +869,7 @@ void verify_execution(const lm_verify_instance* in, const std::vector<u32>& tran
         memcpy(scl.gkr_point, gp_flat.data(), gp_flat.size() * 4);
         memcpy(scl.air_point, ap_flat.data(), ap_flat.size() * 4);
         memcpy(scl.pm_point, pm_flat.data(), pm_flat.size() * 4);
+        memcpy(scl.bytecode_hash_domsep, raw->stmt.bytecode_hash_domsep, 32);
         raw->stmt = scl;
     }
     whir_verify(&cfg, vs, commitment, statement, raw ? &raw->claim : nullptr);

@@ -53,7 +53,8 @@ class Statement:
     """The static layout of the PCS statement of one child shape (capi.PcsStatementClaim + WhirOpeningClaim): table heights and order,
     where the claimed evaluations lie in the raw transcript.  Two children with equal layouts run the same program."""
 
-    def __init__(self, stmt, claim):
+    def __init__(self, stmt, claim, public_input_len=None):
+        self.public_input_len = public_input_len if public_input_len is not None else 1 << int(stmt.log_public_memory)
         self.log_rows = [int(x) for x in stmt.log_rows]
         self.order = [int(x) for x in stmt.table_order]
         self.log_memory, self.log_bytecode = int(stmt.log_memory), int(stmt.log_bytecode)
@@ -64,6 +65,7 @@ class Statement:
         self.off_inner = [int(x) for x in stmt.off_inner_evals]
         self.logup = {t: sorted((int(stmt.logup_col[t][k]), int(stmt.logup_off[t][k])) for k in range(int(stmt.n_logup_values[t]))) for t in range(3)}
         self.n_values = 6 + sum(len(self.logup[t]) + sum(TABLE_COLUMNS[t]) for t in range(3))
+        self.rate, self.n_ood = int(claim.log_inv_rate), int(claim.n_ood)
         # the batched AIR sumcheck in front of the statement
         self.air_off, self.air_degree = int(stmt.air_offset), int(stmt.air_degree)
         self.off_bus_selector, self.off_bus_data = [int(x) for x in stmt.off_bus_selector], [int(x) for x in stmt.off_bus_data]
@@ -77,9 +79,9 @@ class Statement:
 class Shape:
     """everything the assembly depends on, derived from a WhirConfig dict (capi.WhirConfig.to_dict) and, optionally, a Statement"""
 
-    def __init__(self, cfg, n_children, statement=None, air=False):
-        assert statement is not None or not air
-        self.cfg, self.n_children, self.statement, self.air = cfg, n_children, statement, air
+    def __init__(self, cfg, n_children, statement=None, air=False, head=False):
+        assert (statement is not None or not air) and (air or not head)
+        self.cfg, self.n_children, self.statement, self.air, self.head = cfg, n_children, statement, air, head
         self.n, self.rate, self.n_rounds = cfg["num_variables"], cfg["starting_log_inv_rate"], cfg["n_rounds"]
         assert self.n_rounds >= 1, "a configuration without a WHIR round has base-field leaves in the final round (not assembled)"
         self.fold = [cfg["fold_first"]] + [cfg["fold_sub"]] * self.n_rounds
@@ -112,6 +114,12 @@ class Shape:
             self.c_air_point = self.c_gkr_point + DIM * statement.gkr_n_vars     # all_challenges: the LAST challenge first (recursion.py:416)
             self.c_pm_point = self.c_air_point + DIM * statement.n_max
             self.c_rand = self.c_pm_point + DIM * statement.lpm
+        elif head:              # the whole of recursion.py but evaluate_air_constraints: the transcript is replayed from its first word;
+            self.c_public_input = 0                                                    # claims: the child's public input, the digest of
+            self.c_domsep = ceil_div(1 << statement.lpm, DIGEST_LEN) * DIGEST_LEN      # (bytecode hash, domain separator), the three AIR
+            self.c_air_evals = self.c_domsep + DIGEST_LEN                              # constraint evaluations and the bytecode value
+            self.c_bytecode_value = self.c_air_evals + 3 * DIM                         # (a hint in the reference too, recursion.py:138)
+            self.c_rand = self.c_bytecode_value + DIM
         else:                   # + the batched AIR sumcheck: c_fs is the sponge when bus_beta is sampled; the sumcheck's challenges and the
             self.c_public_input = self.c_ood_evals + DIM * o0      # public-memory point are SAMPLED by the program; what is left of the
             self.c_gkr_point = self.c_public_input + ceil_div(1 << statement.lpm, DIGEST_LEN) * DIGEST_LEN   # verifier's earlier work: the GKR
@@ -323,7 +331,7 @@ def next_mle(f, x, y, n):
     return f.add(total, f.mul(px, py))
 
 
-def statement_weights(f, S, T, cl, rand, pw, air_point, pm_point):
+def statement_weights(f, S, T, cl, rand, pw, air_point, pm_point, gkr_point):
     """recursion.py:534-652: sum_i gen^(n_ood + i) * weight_i(folding randomness), weight = eq(top coordinates, selector) x eq / next of the
     statement's point at the inner coordinates.  The reference evaluates one location prefix per value (bit decomposition + poly_eq_be);
     here the values of a statement have consecutive selectors, so their prefixes are a slice of ONE eq table over the low q <= 6 selector
@@ -367,7 +375,7 @@ def statement_weights(f, S, T, cl, rand, pw, air_point, pm_point):
 
     k = S.oods[0]
     mem = 1 << T.log_memory
-    gkr_tail = lambda nv: cl + S.c_gkr_point + DIM * (T.gkr_n_vars - nv)  # noqa: E731 — from_end(point_gkr, nv)
+    gkr_tail = lambda nv: gkr_point + DIM * (T.gkr_n_vars - nv)  # noqa: E731 — from_end(point_gkr, nv)
     inner = lambda nv: rand + DIM * (n - nv)                               # noqa: E731
     # memory and its accumulator (selectors 0, 1), the public memory, the bytecode accumulator
     eqf = f.new_ef()
@@ -418,7 +426,186 @@ def statement_weights(f, S, T, cl, rand, pw, air_point, pm_point):
     return s
 
 
-def air_sumcheck_verify(f, S, T, cl, tr, fs):
+LOOKUPS = {0: [(2, 5, 1), (3, 6, 1), (4, 7, 1)], 1: [(6, 14, 5), (7, 19, 5), (13, 24, 5)], 2: [(6, 9, 4), (7, 13, 4), (1, 17, 8), (2, 93, 16)]}
+# (index column, first value column, number of value columns) per lookup into memory and table (LOOKUPS_INDEXES / LOOKUPS_VALUES)
+N_INSTRUCTION_COLUMNS, LOGUP_BYTECODE_DOMAINSEP = 12, 2
+
+
+def sumcheck_reversed(f, fs, claimed, n_rounds, degree, challenges):
+    """sumcheck_verify_reversed_helper_const (whir.py:199-207): the challenge of round r lands on challenges[n_rounds - 1 - r]"""
+    n_co = degree + 1
+    for r in range(n_rounds):
+        poly = fs.receive_ef(n_co)
+        tmp = f.new_ef()
+        f.dot(absolute(REPEATED_ONES_PTR), poly, tmp, n_co, be=True)
+        f.add(tmp, poly, claimed)
+        rand = fs.rate()
+        f.copy5(rand, challenges + DIM * (n_rounds - 1 - r))
+        nxt = f.new_ef()
+        f.dot(poly, f.powers(rand, n_co), nxt, n_co)
+        claimed = nxt
+    return claimed
+
+
+def head_verify(f, S, T, cl, fs):
+    """recursion.py:48-378: the transcript from its first word — public input and domain separator observed, the dimensions checked
+    against the ones this program is assembled for, the stacked commitment, logup_c and the alphas, verify_gkr_quotient, and the logup
+    statement (the GKR claims rebuilt from the column evaluations the prover sends).
+    -> dict(root, ood_points, ood_evals, logup_c, gkr_point)"""
+    p = f.p
+    one, zero = absolute(ONE_EF_PTR), absolute(ZERO_VEC_PTR)
+    n_pi_chunks = ceil_div(1 << T.lpm, DIGEST_LEN)
+    for j in range(n_pi_chunks):                        # fs_observe(inner_public_memory), fs_observe(bytecode_hash_domsep)
+        fs._absorb(cl + S.c_public_input + DIGEST_LEN * j)
+    fs._absorb(cl + S.c_domsep)
+    dims = fs.receive_chunks(1)
+    for i, want in enumerate([T.rate, T.log_memory, T.public_input_len] + T.log_rows + [0, 0]):
+        f.store(dims + i, K(want))                      # the dimensions are assembly-time constants of this program: asserted
+    root = fs.receive_chunks(1)                         # parse_commitment
+    ood_points = fs.sample_chunks(ceil_div(DIM * T.n_ood, 8))
+    ood_evals = fs.receive_ef(T.n_ood)
+    logup_c = fs.rate()
+    fs.duplex()
+    alphas = fs.sample_chunks(ceil_div(DIM * 4, 8))
+    aeq = f.eq_mle(alphas, 4)                           # logup_alphas_eq_poly: 16 values
+    # ---- verify_gkr_quotient (recursion.py:684-749)
+    ng = T.gkr_n_vars
+    nums, dens = fs.receive_ef(32), fs.receive_ef(32)
+    quots = f.new_ef(32)
+    for k in range(32):
+        f.ext("mul", dens + DIM * k, quots + DIM * k, nums + DIM * k)      # div_extension: the unknown factor is solved for
+    f.dot(absolute(REPEATED_ONES_PTR), quots, zero, 32, be=True)          # the quotient sum is zero (set_to_5_zeros(quotient_gkr), :108)
+    point = fs.sample_chunks(ceil_div(DIM * 5, 8))
+    eq32 = f.eq_mle(point, 5)
+    cnum, cden = f.new_ef(), f.new_ef()
+    f.dot(nums, eq32, cnum, 32)
+    f.dot(dens, eq32, cden, 32)
+    for i in range(5, ng):                              # verify_gkr_quotient_step
+        fs.duplex()
+        alpha = fs.rate()
+        target = f.add(cnum, f.mul(alpha, cden))
+        pp = f.new_ef(i + 1)
+        value = sumcheck_reversed(f, fs, target, i, 3, pp)
+        ie = fs.receive_ef(4)
+        a_num, b_num, a_den, b_den = ie, ie + DIM, ie + 2 * DIM, ie + 3 * DIM
+        sum_num = f.add(f.mul(a_num, b_den), f.mul(b_num, a_den))
+        sum_den = f.mul(a_den, b_den)
+        eqf = f.new_ef()
+        f.poly_eq(point, pp, eqf, i)
+        f.mul(f.add(sum_num, f.mul(sum_den, alpha)), eqf, value)
+        beta = fs.rate()
+        eqb = f.eq_mle(beta, 1)
+        cnum, cden = f.new_ef(), f.new_ef()
+        f.dot(ie, eqb, cnum, 2)
+        f.dot(ie + 2 * DIM, eqb, cden, 2)
+        f.copy5(beta, pp + DIM * i)
+        point = pp
+    gp = point
+    # ---- the logup statement (recursion.py:110-378)
+    bits_cache = {}
+
+    def prefix(value, nbits):
+        if nbits == 0:
+            return one
+        key = (value, nbits)
+        if key not in bits_cache:
+            c = f.alloc(nbits)
+            for j in range(nbits):
+                p.add(K(0), K((value >> (nbits - 1 - j)) & 1), M(c + j))
+            bits_cache[key] = c
+        out = f.new_ef()
+        f.poly_eq(fp(bits_cache[key]), gp, out, nbits, be=True)
+        return out
+
+    def mle_of_index(pt, n):                            # mle_of_01234567_etc (utils.py:206-217), from the last coordinate up
+        e = zero
+        for k in range(n - 1, -1, -1):
+            x = pt + DIM * k
+            c = f.new_ef()
+            f.ext("add", fp(f.const(1 << (n - 1 - k))), e, c, be=True)
+            e = f.add(f.mul(f.sub(one, x), e), f.mul(x, c))
+        return e
+
+    def base_times(value, x):                           # mul_base_extension_ret
+        out = f.new_ef()
+        f.dot(fp(f.const(value)), x, out, 1, be=True)
+        return out
+
+    tail = lambda nv: gp + DIM * (ng - nv)              # noqa: E731
+    mem_prefix = prefix(0, ng - T.log_memory)
+    value_acc, value_memory = fs.receive_ef(1), fs.receive_ef(1)
+    assert value_acc.k == T.off_value_memory_acc and value_memory.k == T.off_value_memory
+    r_num = f.sub(zero, f.mul(mem_prefix, value_acc))
+    buf = f.new_ef(2)
+    f.copy5(value_memory, buf)
+    f.copy5(mle_of_index(tail(T.log_memory), T.log_memory), buf + DIM)
+    fp_mem = f.new_ef()
+    f.dot(buf, aeq, fp_mem, 2)                          # fingerprint_2 with the memory domain separator 0
+    r_den = f.mul(mem_prefix, f.sub(logup_c, fp_mem))
+    offset = 1 << T.log_memory
+    lb, n_cycles_log = T.log_bytecode, T.log_rows[0]
+    lbp = max(lb, n_cycles_log)
+    bc_prefix, bcp_prefix = prefix(offset >> lb, ng - lb), prefix(offset >> lbp, ng - lbp)
+    value_bc_acc = fs.receive_ef(1)
+    assert value_bc_acc.k == T.off_value_bytecode_acc
+    r_num = f.sub(r_num, f.mul(bc_prefix, value_bc_acc))
+    dom = base_times(LOGUP_BYTECODE_DOMAINSEP, aeq + DIM * 15)
+    inner = f.add(cl + S.c_bytecode_value, f.add(f.mul(mle_of_index(tail(lb), lb), aeq + DIM * N_INSTRUCTION_COLUMNS), dom))
+    r_den = f.add(r_den, f.mul(bc_prefix, f.sub(logup_c, inner)))
+    if lbp > lb:                                        # mle_of_zeros_then_ones_pow2 (utils.py:700-709)
+        pt = tail(lbp)
+        prod = f.sub(one, pt)
+        for k in range(1, lbp - lb):
+            prod = f.mul(prod, f.sub(one, pt + DIM * k))
+        r_den = f.add(r_den, f.mul(bcp_prefix, f.sub(one, prod)))
+    offset += 1 << lbp
+    for t in T.order:
+        nv = T.log_rows[t]
+        if t == 0:
+            pre = prefix(offset >> nv, ng - nv)
+            on_pc, instr = fs.receive_ef(1), fs.receive_ef(N_INSTRUCTION_COLUMNS)
+            r_num = f.add(r_num, pre)
+            fpb = f.new_ef()
+            f.dot(instr, aeq, fpb, N_INSTRUCTION_COLUMNS)                 # fingerprint_bytecode (:674-681)
+            fpb = f.add(f.add(fpb, f.mul(on_pc, aeq + DIM * N_INSTRUCTION_COLUMNS)), dom)
+            r_den = f.add(r_den, f.mul(pre, f.sub(logup_c, fpb)))
+            offset += 1 << nv
+        pre = prefix(offset >> nv, ng - nv)
+        on_sel, on_data = fs.receive_ef(1), fs.receive_ef(1)
+        assert on_sel.k == T.off_bus_selector[t] and on_data.k == T.off_bus_data[t]
+        r_num = f.add(r_num, f.mul(pre, on_sel))
+        r_den = f.add(r_den, f.mul(pre, on_data))
+        offset += 1 << nv
+        for _, _, n_val in LOOKUPS[t]:
+            index_eval = fs.receive_ef(1)
+            for i in range(n_val):
+                value_eval = fs.receive_ef(1)
+                pre = prefix(offset >> nv, ng - nv)
+                r_num = f.add(r_num, pre)
+                buf = f.new_ef(2)
+                f.copy5(value_eval, buf)
+                if i == 0:
+                    f.copy5(index_eval, buf + DIM)
+                else:
+                    f.ext("add", fp(f.const(i)), index_eval, buf + DIM, be=True)   # add_base_extension_ret(i, index_eval)
+                fpv = f.new_ef()
+                f.dot(buf, aeq, fpv, 2)
+                r_den = f.add(r_den, f.mul(pre, f.sub(logup_c, fpv)))
+                offset += 1 << nv
+    # + mle_of_zeros_then_ones(point_gkr, offset, n_vars) (utils.py:670-697): the padding of the logup vector
+    assert offset < (1 << ng)
+    res = one
+    for i in range(ng):
+        x = gp + DIM * (ng - 1 - i)
+        res = f.mul(x, res) if (offset >> i) & 1 else f.add(f.mul(f.sub(one, x), res), x)
+    r_den = f.add(r_den, res)
+    f.copy5(r_num, cnum)                                # the GKR claims are what the column evaluations give (:376-377)
+    f.copy5(r_den, cden)
+    assert fs.off == T.air_off
+    return dict(root=root, ood_points=ood_points, ood_evals=ood_evals, logup_c=logup_c, gkr_point=gp)
+
+
+def air_sumcheck_verify(f, S, T, cl, tr, fs, logup_c, gkr_point):
     """recursion.py:383-467: bus_beta / air_alpha / eta, the initial sum from the bus evaluations, the batched AIR sumcheck
     (sumcheck_verify_reversed, whir.py:184-207), the tables' column evaluations and the back-loaded check against the claimed constraint
     evaluations, then the public-memory point.  -> (all_challenges, public_memory_random_point)"""
@@ -431,7 +618,7 @@ def air_sumcheck_verify(f, S, T, cl, tr, fs):
     for k, t in enumerate(T.order):
         num, den = tr + T.off_bus_selector[t], tr + T.off_bus_data[t]
         bfv = num if t == 0 else f.sub(zero, num)                              # opposite_extension_ret for the tables that pull
-        bfv = f.add(bfv, f.mul(bus_beta, f.sub(den, cl + S.c_logup_c)))
+        bfv = f.add(bfv, f.mul(bus_beta, f.sub(den, logup_c)))
         claimed = f.add(claimed, f.mul(eta_pw + DIM * k, bfv))
     n_co = T.air_degree + 1
     all_ch = f.new_ef(T.n_max)
@@ -449,9 +636,9 @@ def air_sumcheck_verify(f, S, T, cl, tr, fs):
     for k, t in enumerate(T.order):
         nv = T.log_rows[t]
         inner = fs.receive_ef(sum(TABLE_COLUMNS[t]))
-        assert inner.kind == "at" and inner.k == T.off_inner[t] - T.air_off
+        assert inner.kind == "at" and inner.k in (T.off_inner[t] - T.air_off, T.off_inner[t])
         eq_val = f.new_ef()
-        f.poly_eq(cl + S.c_gkr_point + DIM * (T.gkr_n_vars - nv), all_ch, eq_val, nv)
+        f.poly_eq(gkr_point + DIM * (T.gkr_n_vars - nv), all_ch, eq_val, nv)
         if T.n_max > nv:            # product_first_n (utils.py:70-83)
             k_t = f.new_ef()
             f.poly_eq(absolute(REPEATED_ONES_PTR), all_ch + DIM * nv, k_t, T.n_max - nv, be=True)
@@ -465,12 +652,13 @@ def air_sumcheck_verify(f, S, T, cl, tr, fs):
     return all_ch, pm_point
 
 
-def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
+def build_program(cfg, n_children=4, log_size=None, statement=None, air=False, head=False):
     """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict()).  statement (a Statement): the
     program also assembles the PCS statement (recursion.py:469-518, 534-652) instead of taking its two sums from the claims; air: it
     starts in front of the batched AIR sumcheck (recursion.py:383-467) and samples that sumcheck's challenges and the public-memory point
-    itself."""
-    S = Shape(cfg, n_children, statement, air)
+    itself; head: it replays the transcript from its first word (recursion.py:48-378: GKR quotient, logup statement) — the whole verifier
+    of one child except evaluate_air_constraints, whose three results stay claims."""
+    S = Shape(cfg, n_children, statement, air, head)
     T = statement
     p = Program()
     f = Fn(p, 0, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
@@ -506,7 +694,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
     tbase = []                                   # where whir_open starts reading
     for c in range(NC):
         t = f.alloc()
-        p.add(M(tfull[c]), K((T.air_off if air else T.off_whir) if T else 0), M(t))
+        p.add(M(tfull[c]), K((0 if head else T.air_off if air else T.off_whir) if T else 0), M(t))
         tbase.append(t)
 
     # per-round arrays shared by the children: iteration i = child * q + j of a round's loop owns entry i
@@ -522,22 +710,30 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
     for c in range(NC):
         cl = at(claims, c * S.claim_words)
         st = dict(cl=cl, rand=fp(f.alloc(DIM * S.n)))                          # folding_randomness_global
-        st["fs"] = Fs(f, cl + S.c_fs, tbase[c])
+        st["fs"] = Fs(f, absolute(ZERO_VEC_PTR) if head else cl + S.c_fs, tbase[c])     # (fs_new: the zero state)
         st["air_point"], st["pm_point"] = (cl + S.c_air_point, cl + S.c_pm_point) if T is not None and not air else (None, None)
+        hd = dict(root=cl + S.c_root, ood_points=cl + S.c_ood_points, ood_evals=cl + S.c_ood_evals) if not head else None
+        if head:
+            hd = head_verify(f, S, T, cl, st["fs"])
+        elif air:
+            hd.update(logup_c=cl + S.c_logup_c, gkr_point=cl + S.c_gkr_point)
+        elif T is not None:
+            hd.update(gkr_point=cl + S.c_gkr_point)
+        st["hd"] = hd
         if air:
-            st["air_point"], st["pm_point"] = air_sumcheck_verify(f, S, T, cl, at(tfull[c], 0), st["fs"])
-            assert st["fs"].off == T.off_whir - T.air_off
+            st["air_point"], st["pm_point"] = air_sumcheck_verify(f, S, T, cl, at(tfull[c], 0), st["fs"], hd["logup_c"], hd["gkr_point"])
+            assert st["fs"].off == T.off_whir - (0 if head else T.air_off)
             st["fs"].duplex()                                                  # recursion.py:470
         # recursion.py:472-475: the combination randomness of the first constraint set; only its OOD powers are needed here
         gen = st["fs"].rate()
         st["pw0"] = f.powers(gen, S.oods[0] if T is None else 1 << (S.oods[0] + T.n_values - 1).bit_length())
         ood_sum = f.new_ef()
-        f.dot(cl + S.c_ood_evals, st["pw0"], ood_sum, S.oods[0])
+        f.dot(hd["ood_evals"], st["pw0"], ood_sum, S.oods[0])
         if T is None:
             st["claimed"] = f.add(ood_sum, cl + S.c_stmt_sum)                  # whir_sum
         else:
             st["claimed"] = statement_sum(f, S, T, cl, at(tfull[c], 0), st["pw0"], ood_sum, st["pm_point"])
-        st["root"] = cl + S.c_root
+        st["root"] = hd["root"]
         st["ood_points"], st["comb"], st["roots"] = [], [], []
         ch.append(st)
 
@@ -608,7 +804,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
         cl = st["cl"]
         rec = f.new_ef(S.oods[0])
         for i in range(S.oods[0]):
-            ex = expand_from_univariate_ext(f, cl + S.c_ood_points + DIM * i, S.n)
+            ex = expand_from_univariate_ext(f, st["hd"]["ood_points"] + DIM * i, S.n)
             f.poly_eq(ex, st["rand"], rec + DIM * i, S.n)
         s = f.new_ef()
         f.dot(rec, st["pw0"], s, S.oods[0])
@@ -636,7 +832,7 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False):
         final_value = f.new_ef()
         f.dot(st["coeffs"], basis, final_value, 1 << nf)
         # recursion.py:534-654 with the statement's share taken from the claim: (s + statement_weights) * final_value == end_sum
-        total = f.add(s, cl + S.c_stmt_weights) if T is None else f.add(s, statement_weights(f, S, T, cl, st["rand"], st["pw0"], st["air_point"], st["pm_point"]))
+        total = f.add(s, cl + S.c_stmt_weights) if T is None else f.add(s, statement_weights(f, S, T, cl, st["rand"], st["pw0"], st["air_point"], st["pm_point"], st["hd"]["gkr_point"]))
         f.mul(total, final_value, st["end_sum"])
         for k in range(S.n):
             f.copy5(st["rand"] + DIM * k, cl + S.c_rand + DIM * k)             # folding_randomness_global == the claim's
@@ -877,6 +1073,14 @@ def claim_words(S, claim, stmt=None, public_input=None):
         assert Statement(stmt, claim).key() == T.key(), "a child proof of another shape than the program was assembled for"
         pi = np.asarray(public_input, dtype=np.uint32)
         out[S.c_public_input:S.c_public_input + pi.size] = pi                   # (zero padded to the public memory's power of two)
+        if S.head:
+            out[:] = 0
+            out[S.c_public_input:S.c_public_input + pi.size] = pi
+            out[S.c_domsep:S.c_domsep + 8] = np.ctypeslib.as_array(stmt.bytecode_hash_domsep)
+            out[S.c_air_evals:S.c_air_evals + 3 * DIM] = np.ctypeslib.as_array(stmt.air_constraint_evals).reshape(-1)
+            out[S.c_bytecode_value:S.c_bytecode_value + DIM] = np.ctypeslib.as_array(stmt.bytecode_value)
+            out[S.c_rand:S.c_rand + DIM * S.n] = np.ctypeslib.as_array(claim.folding_randomness)[:DIM * S.n]
+            return out
         out[S.c_gkr_point:S.c_gkr_point + DIM * T.gkr_n_vars] = np.ctypeslib.as_array(stmt.gkr_point)[:DIM * T.gkr_n_vars]
         if S.air:
             out[S.c_fs:S.c_fs + 16] = np.ctypeslib.as_array(stmt.air_challenger_state)

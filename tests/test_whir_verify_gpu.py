@@ -3,9 +3,9 @@ signatures proved by this library (lmh_prove_execution_vm, rate 1/4, the referen
 their raw transcripts / opening claims / un-pruned Merkle openings fed to the in-VM verifier, whose (child, query) loops run as
 device batches (csrc/lm_vm_device.hip).  The run must equal the oracle VM's cell for cell, every parallel loop must have run on the
 device, the proof of THAT execution must equal the oracle prover's word for word and be accepted by both verifiers, and a flipped
-sibling must be rejected with the host runner's error.  The program starts in front of the batched AIR sumcheck (recursion.py:383-654): it verifies
-that sumcheck against claimed constraint evaluations, samples the public-memory point and assembles the PCS statement (252 claimed
-evaluations read from the children's raw transcripts)."""
+sibling must be rejected with the host runner's error.  The program is the whole verifier of one child (recursion.py:48-654 + whir.py) except
+evaluate_air_constraints: GKR quotient, logup statement, batched AIR sumcheck against claimed constraint evaluations, public-memory
+point, PCS statement (252 evaluations), whir_open."""
 import ctypes
 
 import numpy as np
@@ -38,9 +38,10 @@ def recursion(ctx):
         assert n_vars in (None, claim.num_variables)
         n_vars = claim.num_variables
     cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
-    # from the batched AIR sumcheck on: its challenges and the public-memory point are sampled in the VM, the 252 claimed evaluations of
-    # the PCS statement are read from the children's raw transcripts
-    bc = wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1]), air=True)
+    # the whole verifier of recursion.py except evaluate_air_constraints: the transcript replayed from its first word (GKR quotient, logup
+    # statement, batched AIR sumcheck, public-memory point, PCS statement, whir_open); claims: the three constraint evaluations, the
+    # bytecode value (a hint in the reference too), the domain-separator digest
+    bc = wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1], public_input_len=8), air=True, head=True)
     pi, wit, _ = wv.build_witness(bc, children)
     return bc, children, pi, wit
 

@@ -52,6 +52,14 @@ def setup_air(orc):
     return wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1]), air=True), children
 
 
+@pytest.fixture(scope="module")
+def setup_head(orc):
+    """the whole verifier of recursion.py except evaluate_air_constraints: the transcript is replayed from its first word"""
+    cfg, children = _children(orc)
+    T = wv.Statement(children[0][3], children[0][1], public_input_len=len(children[0][4]))
+    return wv.build_program(cfg, N_CHILDREN, statement=T, air=True, head=True), children
+
+
 def test_raw_transcript_layout(setup):
     """RawProof::transcript (fiat-shamir/src/verifier.rs:54-60,126-195): whole rate blocks, the part whir_open reads has the length the
     configuration implies, and the claim's sponge state is reproducible from nothing but the raw transcript's words"""
@@ -182,3 +190,40 @@ def test_from_the_air_sumcheck_rejects(setup_air):
         st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
         st2.air_constraint_evals[t][2] ^= 1
         _rejected(bc, [children[0], (raw, claim, ops, st2, pub)], "InvalidExtensionOp|NotEqual")
+
+
+def test_whole_verifier_accepts_and_equals_oracle_vm(orc, setup_head):
+    bc, children = setup_head
+    pi, wit, _ = wv.build_witness(bc, children)
+    ex = vm.execute(bc, pi, wit, n_threads=4)
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+
+
+def test_whole_verifier_rejects_any_changed_word(setup_head):
+    """recursion.py without evaluate_air_constraints: every word of the raw transcript is either absorbed by the sponge or checked to be
+    zero padding, and every claim that is left (public input, domain-separator digest, the three constraint evaluations, the bytecode
+    value) enters an equation: 40 random positions of the transcript and every claim field, one word each"""
+    bc, children = setup_head
+    raw, claim, ops, stmt, pub = children[0]
+    rng = np.random.default_rng(77)
+    for pos in list(rng.integers(0, raw.size, size=40)) + [0, 7, raw.size - 1]:
+        raw2 = raw.copy()
+        raw2[pos] ^= 1
+        _rejected(bc, [(raw2, claim, ops, stmt, pub), children[1]])
+    for field, k in (("bytecode_hash_domsep", 3), ("bytecode_value", 0), ("bytecode_value", 4)):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        getattr(st2, field)[k] ^= 1
+        _rejected(bc, [(raw, claim, ops, st2, pub), children[1]])
+    for t in range(3):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        st2.air_constraint_evals[t][t] ^= 1
+        _rejected(bc, [(raw, claim, ops, st2, pub), children[1]])
+    pub2 = np.asarray(pub).copy()
+    pub2[2] ^= 1
+    _rejected(bc, [(raw, claim, ops, stmt, pub2), children[1]])
+    cl2 = capi.WhirOpeningClaim.from_buffer_copy(claim)
+    cl2.folding_randomness[3] ^= 1
+    _rejected(bc, [(raw, cl2, ops, stmt, pub), children[1]])

@@ -602,16 +602,17 @@ def head_verify(f, S, T, cl, fs):
     f.copy5(r_num, cnum)                                # the GKR claims are what the column evaluations give (:376-377)
     f.copy5(r_den, cden)
     assert fs.off == T.air_off
-    return dict(root=root, ood_points=ood_points, ood_evals=ood_evals, logup_c=logup_c, gkr_point=gp)
+    return dict(root=root, ood_points=ood_points, ood_evals=ood_evals, logup_c=logup_c, gkr_point=gp, aeq=aeq)
 
 
-def air_sumcheck_verify(f, S, T, cl, tr, fs, logup_c, gkr_point):
+def air_sumcheck_verify(f, S, T, cl, tr, fs, logup_c, gkr_point, evaluators=None):
     """recursion.py:383-467: bus_beta / air_alpha / eta, the initial sum from the bus evaluations, the batched AIR sumcheck
     (sumcheck_verify_reversed, whir.py:184-207), the tables' column evaluations and the back-loaded check against the claimed constraint
     evaluations, then the public-memory point.  -> (all_challenges, public_memory_random_point)"""
     zero = absolute(ZERO_VEC_PTR)
     bus_beta = fs.rate()
-    fs.duplex()                     # air_alpha = fs.rate(): its powers only enter evaluate_air_constraints, whose results are claims here
+    fs.duplex()
+    air_alpha = fs.rate()           # (its powers only enter evaluate_air_constraints)
     fs.duplex()
     eta_pw = f.powers(fs.rate(), 3)
     claimed = zero
@@ -645,20 +646,37 @@ def air_sumcheck_verify(f, S, T, cl, tr, fs, logup_c, gkr_point):
             lhs = f.mul(eta_pw + DIM * k, k_t)
         else:
             lhs = f.mul(eta_pw + DIM * k, absolute(ONE_EF_PTR))
-        term = f.mul(lhs, f.mul(eq_val, cl + S.c_air_evals + DIM * t))
+        if evaluators is None:      # the constraint evaluation is a claim
+            air_eval = cl + S.c_air_evals + DIM * t
+        else:                       # evaluate_air_constraints (recursion.py:434, 777-787)
+            from . import air_eval as ae
+            if "apw" not in evaluators:
+                evaluators.update(apw=f.powers(air_alpha, ae.MAX_ALPHA), bus_beta=bus_beta)
+            A = ae.Alg(f, absolute(ONE_EF_PTR), zero)
+            n_flat = TABLE_COLUMNS[t][0]
+            if t == 0:
+                air_eval = ae.eval_execution(A, inner, inner + DIM * n_flat, evaluators)
+            elif t == 1:
+                air_eval = ae.eval_extension_op(A, inner, inner + DIM * n_flat, evaluators)
+            else:
+                air_eval = ae.eval_poseidon16(A, inner, evaluators, evaluators["mds_window"])
+        term = f.mul(lhs, f.mul(eq_val, air_eval))
         check = term if check is None else f.add(check, term)
     f.copy5(check, claimed)                                                     # the sumcheck's final value is what the tables give
     pm_point = fs.sample_chunks(ceil_div(DIM * T.lpm, 8))                       # fs_sample_many_ef(INNER_PUBLIC_MEMORY_LOG_SIZE)
     return all_ch, pm_point
 
 
-def build_program(cfg, n_children=4, log_size=None, statement=None, air=False, head=False):
+def build_program(cfg, n_children=4, log_size=None, statement=None, air=False, head=False, evaluators=False):
     """-> vm.Bytecode for `n_children` proofs of the WhirConfig `cfg` (a dict, capi.WhirConfig.to_dict()).  statement (a Statement): the
     program also assembles the PCS statement (recursion.py:469-518, 534-652) instead of taking its two sums from the claims; air: it
     starts in front of the batched AIR sumcheck (recursion.py:383-467) and samples that sumcheck's challenges and the public-memory point
     itself; head: it replays the transcript from its first word (recursion.py:48-378: GKR quotient, logup statement) — the whole verifier
-    of one child except evaluate_air_constraints, whose three results stay claims."""
+    of one child except evaluate_air_constraints, whose three results stay claims — unless evaluators: then the three constraint
+    polynomials are evaluated in the VM as well (programs/air_eval.py) and the program is the reference's `recursion()` whole."""
+    assert head or not evaluators
     S = Shape(cfg, n_children, statement, air, head)
+    S.evaluators = evaluators
     T = statement
     p = Program()
     f = Fn(p, 0, ZERO_VEC_PTR, ONE_EF_PTR, REPEATED_ONES_PTR)
@@ -706,6 +724,10 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False, h
     DESC_ROOT, DESC_EQ, DESC_COEFFS, DESC_RAND = 0, 1, 2, 3
     desc = [[f.alloc(4) for r in range(R + 1)] for c in range(NC)]
 
+    mds_window = None
+    if evaluators:
+        from .air_eval import write_mds_window
+        mds_window = write_mds_window(f)
     ch = []                                                                    # assembly-time state of every child
     for c in range(NC):
         cl = at(claims, c * S.claim_words)
@@ -721,7 +743,8 @@ def build_program(cfg, n_children=4, log_size=None, statement=None, air=False, h
             hd.update(gkr_point=cl + S.c_gkr_point)
         st["hd"] = hd
         if air:
-            st["air_point"], st["pm_point"] = air_sumcheck_verify(f, S, T, cl, at(tfull[c], 0), st["fs"], hd["logup_c"], hd["gkr_point"])
+            ev = dict(aeq=hd["aeq"], mds_window=mds_window) if evaluators else None
+            st["air_point"], st["pm_point"] = air_sumcheck_verify(f, S, T, cl, at(tfull[c], 0), st["fs"], hd["logup_c"], hd["gkr_point"], ev)
             assert st["fs"].off == T.off_whir - (0 if head else T.air_off)
             st["fs"].duplex()                                                  # recursion.py:470
         # recursion.py:472-475: the combination randomness of the first constraint set; only its OOD powers are needed here

@@ -3,9 +3,8 @@ signatures proved by this library (lmh_prove_execution_vm, rate 1/4, the referen
 their raw transcripts / opening claims / un-pruned Merkle openings fed to the in-VM verifier, whose (child, query) loops run as
 device batches (csrc/lm_vm_device.hip).  The run must equal the oracle VM's cell for cell, every parallel loop must have run on the
 device, the proof of THAT execution must equal the oracle prover's word for word and be accepted by both verifiers, and a flipped
-sibling must be rejected with the host runner's error.  The program is the whole verifier of one child (recursion.py:48-654 + whir.py) except
-evaluate_air_constraints: GKR quotient, logup statement, batched AIR sumcheck against claimed constraint evaluations, public-memory
-point, PCS statement (252 evaluations), whir_open."""
+sibling must be rejected with the host runner's error.  The program is the reference's `recursion()` whole (recursion.py:48-787 + whir.py): GKR quotient,
+logup statement, batched AIR sumcheck with evaluate_air_constraints in the VM, public-memory point, PCS statement, whir_open."""
 import ctypes
 
 import numpy as np
@@ -38,10 +37,10 @@ def recursion(ctx):
         assert n_vars in (None, claim.num_variables)
         n_vars = claim.num_variables
     cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
-    # the whole verifier of recursion.py except evaluate_air_constraints: the transcript replayed from its first word (GKR quotient, logup
-    # statement, batched AIR sumcheck, public-memory point, PCS statement, whir_open); claims: the three constraint evaluations, the
-    # bytecode value (a hint in the reference too), the domain-separator digest
-    bc = wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1], public_input_len=8), air=True, head=True)
+    # `recursion()` of the reference whole: the transcript replayed from its first word (GKR quotient, logup statement, batched AIR
+    # sumcheck with the three constraint polynomials evaluated in the VM, public-memory point, PCS statement, whir_open); what is
+    # taken as given: the bytecode value (a hint in the reference too) and the domain-separator digest
+    bc = wv.build_program(cfg, N_CHILDREN, statement=wv.Statement(children[0][3], children[0][1], public_input_len=8), air=True, head=True, evaluators=True)
     pi, wit, _ = wv.build_witness(bc, children)
     return bc, children, pi, wit
 

@@ -60,6 +60,14 @@ def setup_head(orc):
     return wv.build_program(cfg, N_CHILDREN, statement=T, air=True, head=True), children
 
 
+@pytest.fixture(scope="module")
+def setup_full(orc):
+    """the reference's `recursion()` whole: as setup_head, and the three AIR constraint polynomials evaluated in the VM (programs/air_eval.py)"""
+    cfg, children = _children(orc)
+    T = wv.Statement(children[0][3], children[0][1], public_input_len=len(children[0][4]))
+    return wv.build_program(cfg, N_CHILDREN, statement=T, air=True, head=True, evaluators=True), children
+
+
 def test_raw_transcript_layout(setup):
     """RawProof::transcript (fiat-shamir/src/verifier.rs:54-60,126-195): whole rate blocks, the part whir_open reads has the length the
     configuration implies, and the claim's sponge state is reproducible from nothing but the raw transcript's words"""
@@ -227,3 +235,36 @@ def test_whole_verifier_rejects_any_changed_word(setup_head):
     cl2 = capi.WhirOpeningClaim.from_buffer_copy(claim)
     cl2.folding_randomness[3] ^= 1
     _rejected(bc, [(raw, cl2, ops, stmt, pub), children[1]])
+
+
+def test_recursion_whole_accepts_and_equals_oracle_vm(orc, setup_full):
+    """`recursion()` of zkdsl_implem/recursion.py, every line of it: nothing about the child proof is taken on trust but the bytecode
+    value (a hint in the reference too, reduced by main.py's bytecode-claim sumcheck)"""
+    bc, children = setup_full
+    pi, wit, _ = wv.build_witness(bc, children)
+    ex = vm.execute(bc, pi, wit, n_threads=4)
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+
+
+def test_recursion_whole_rejects(setup_full):
+    """with the constraint polynomials evaluated in the VM the three claimed evaluations are ignored (changing them changes nothing but
+    the public input, which is recomputed); every transcript word and the remaining claims still decide acceptance"""
+    bc, children = setup_full
+    raw, claim, ops, stmt, pub = children[1]
+    T = bc.info["shape"].statement
+    rng = np.random.default_rng(78)
+    for pos in list(rng.integers(0, raw.size, size=25)) + [T.off_inner[2] + 5 * 60, T.off_inner[1] + 9, T.off_inner[0] + 40]:
+        raw2 = raw.copy()
+        raw2[pos] ^= 1
+        _rejected(bc, [children[0], (raw2, claim, ops, stmt, pub)])
+    for field, k in (("bytecode_hash_domsep", 0), ("bytecode_value", 2)):
+        st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+        getattr(st2, field)[k] ^= 1
+        _rejected(bc, [children[0], (raw, claim, ops, st2, pub)])
+    st2 = capi.PcsStatementClaim.from_buffer_copy(stmt)
+    st2.air_constraint_evals[2][0] ^= 1          # no longer an input of any equation
+    pi, wit, _ = wv.build_witness(bc, [children[0], (raw, claim, ops, st2, pub)])
+    vm.execute(bc, pi, wit, n_threads=4)

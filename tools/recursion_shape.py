@@ -124,7 +124,11 @@ def derive():
     memory_words = hint_words + 4 * cycles
     per_child = dict(poseidon_calls=poseidon, extension_rows=ext_rows, extension_calls=ext_calls, cycles=cycles, memory_words=memory_words, terms=terms,
                      trees=trees, whir_cycles=whir_cycles, whir_cycles_round4_rules=whir_cycles_round4_rules,
-                     measured_whir_part=dict(cycles=43285, poseidon_calls=7412, extension_rows=29931, source="profiles/r05_bench_whir_recursion.json"))
+                     measured_whir_part=dict(cycles=43285, poseidon_calls=7412, extension_rows=29931, source="whir_open alone, round 5"),
+                     # recursion() whole as assembled by hand (programs/whir_verify.py + air_eval.py), per child of the same shape: the
+                     # counted ExtensionOp rows were 25 % low for THIS lowering (textbook MDS layers as 16-term dot products in the AIR
+                     # evaluator: 8.8 k rows where the count assumed 3.5 k), the counted cycles 36 % high
+                     measured_whole_recursion=dict(cycles=58148, poseidon_calls=8681, extension_rows=47215, source="profiles/r05_bench_whir_recursion.json"))
     root = dict(poseidon_calls=N_CHILDREN * poseidon + 400, extension_rows=N_CHILDREN * ext_rows + 2000, cycles=N_CHILDREN * cycles + 10000,
                 memory_words=N_CHILDREN * memory_words + 50000)
     shape = dict(log_exec=log2_ceil(root["cycles"]), log_pos=max(8, log2_ceil(root["poseidon_calls"])), log_ext=max(8, log2_ceil(root["extension_rows"])),

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "../../leanmultisig_amd/csrc/poseidon16.h"
 using namespace kb;
-extern "C" __global__ __launch_bounds__(256) void k_one_perm(u32* io) {
+__global__ __launch_bounds__(256) void k_one_perm(u32* io) {
     u32 s[16];
     const u32 t = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll

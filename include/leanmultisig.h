@@ -160,6 +160,12 @@ uint32_t lm_tree_leaf_words(const lm_tree* tree);
  * flatten_to_base); siblings: n_idx x log_height x 8, bottom-up. */
 int lm_tree_open(lm_ctx* ctx, const lm_tree* tree, const uint64_t* indices, uint32_t n_idx, uint32_t* leaves,
                  uint32_t* siblings);
+/* The same opening as two calls: _begin enqueues the kernel, _end waits for it and copies leaves and paths out (it consumes the
+ * handle, also on failure; leaves = NULL abandons the opening).  Between the two the caller may enqueue other work on the context
+ * (it is ordered behind the opening kernel): WHIR's weight kernels of a round depend on the query indices only (open.rs:337-382). */
+typedef struct lm_tree_opening lm_tree_opening;
+int lm_tree_open_begin(lm_ctx* ctx, const lm_tree* tree, const uint64_t* indices, uint32_t n_idx, lm_tree_opening** out);
+int lm_tree_open_end(lm_ctx* ctx, lm_tree_opening* opening, uint32_t* leaves, uint32_t* siblings);
 /* test/debug access: copy the device-resident LDE matrix out in the reference's row-major order (h x leaf_words) */
 int lm_tree_download_matrix(lm_ctx* ctx, const lm_tree* tree, uint32_t* rows);
 /* test/debug access: all digest layers bottom-up, (2h - 1) x 8 words */
@@ -172,6 +178,15 @@ int lm_tree_download_digests(lm_ctx* ctx, const lm_tree* tree, uint32_t* digests
  * out: n_polys x 5 host words. */
 int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
                 uint64_t stride_words, const uint32_t* point, uint32_t* out);
+/* Evaluations that no transcript step separates (the column evaluations behind the GKR, logup.rs:224-308) need not wait for each other:
+ * between _begin and _end, lm_mle_eval (pinned results) and lm_mle_eval_cols enqueue their kernels, return at once and leave `out`
+ * untouched; _end waits for the last one and fills every `out`.  No other call that publishes a result may be made in between. */
+int lm_results_defer_begin(lm_ctx* ctx);
+int lm_results_defer_end(lm_ctx* ctx);
+/* ONE polynomial at n_points points (points: n_points x n_vars x 5 words, out: n_points x 5): the OOD samples of a commitment
+ * (whir/src/utils.rs:30-57) are drawn together; the device reads the polynomial once per pair of points. */
+int lm_mle_eval_points(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_points, const uint32_t* points,
+                       uint32_t* out);
 /* Same for n_cols base columns given by a host array of DEVICE pointers (the 91 column evaluations that follow the GKR,
  * crates/sub_protocols/src/logup.rs:224-308, are batches of this form). */
 int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t n_vars, const uint32_t* point,

@@ -58,6 +58,11 @@ _SIGS = {
     "lm_tree_log_height": (C.c_uint32, [vp]),
     "lm_tree_leaf_words": (C.c_uint32, [vp]),
     "lm_tree_open": (C.c_int, [vp, vp, vp, C.c_uint32, vp, vp]),
+    "lm_tree_open_begin": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(vp)]),
+    "lm_tree_open_end": (C.c_int, [vp, vp, vp, vp]),
+    "lm_mle_eval_points": (C.c_int, [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]),
+    "lm_results_defer_begin": (C.c_int, [vp]),
+    "lm_results_defer_end": (C.c_int, [vp]),
     "lm_tree_download_matrix": (C.c_int, [vp, vp, vp]),
     "lm_tree_download_digests": (C.c_int, [vp, vp, vp]),
     "lm_mle_eval_cols": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
@@ -518,6 +523,20 @@ class Tree:
         self.ctx._check(self.ctx.lib.lm_tree_open(self.ctx.h, self.h, _ptr(idx), n, _ptr(leaves), _ptr(sib)))
         return leaves, sib
 
+    def open_begin(self, indices):
+        """lm_tree_open_begin: the opening kernel is enqueued; the returned closure waits for it and returns (leaves, siblings)"""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        n = idx.size
+        h = vp()
+        self.ctx._check(self.ctx.lib.lm_tree_open_begin(self.ctx.h, self.h, _ptr(idx), n, C.byref(h)))
+
+        def end():
+            leaves = np.empty((n, self.leaf_words), dtype=np.uint32)
+            sib = np.empty((n, self.log_height, 8), dtype=np.uint32)
+            self.ctx._check(self.ctx.lib.lm_tree_open_end(self.ctx.h, h, _ptr(leaves), _ptr(sib)))
+            return leaves, sib
+        return end
+
     def matrix(self):
         out = np.empty((1 << self.log_height, self.leaf_words), dtype=np.uint32)
         self.ctx._check(self.ctx.lib.lm_tree_download_matrix(self.ctx.h, self.h, _ptr(out)))
@@ -671,6 +690,32 @@ class Context:
                                          _ptr(pt) if pt.size else None, _ptr(out)))
         return out
 
+
+    def mle_eval_points(self, d_evals, is_ext, n_vars, points):
+        """one polynomial at several points (points: n_points x n_vars x 5) -> n_points x 5"""
+        pts = _u32(points).reshape(-1)
+        n_points = pts.size // max(1, n_vars * 5) if n_vars else int(np.asarray(points).shape[0])
+        assert n_vars == 0 or pts.size == n_points * n_vars * 5
+        out = np.empty((n_points, 5), dtype=np.uint32)
+        ptr = d_evals.ptr if isinstance(d_evals, DeviceBuffer) else int(d_evals)
+        self._check(self.lib.lm_mle_eval_points(self.h, ptr, int(bool(is_ext)), n_vars, n_points, _ptr(pts) if pts.size else None, _ptr(out)))
+        return out
+
+    def mle_eval_deferred(self, jobs):
+        """jobs: list of (d_evals, is_ext, n_vars, point) evaluated between lm_results_defer_begin / _end -> list of 5-word results"""
+        outs = [np.zeros((1, 5), dtype=np.uint32) for _ in jobs]
+        keep = []
+        self._check(self.lib.lm_results_defer_begin(self.h))
+        try:
+            for (d_evals, is_ext, n_vars, point), out in zip(jobs, outs):
+                pt = _u32(point).reshape(-1)
+                keep.append(pt)
+                ptr = d_evals.ptr if isinstance(d_evals, DeviceBuffer) else int(d_evals)
+                self._check(self.lib.lm_mle_eval(self.h, ptr, int(bool(is_ext)), n_vars, 1, (5 if is_ext else 1) << n_vars,
+                                                 _ptr(pt) if pt.size else None, _ptr(out)))
+        finally:
+            self._check(self.lib.lm_results_defer_end(self.h))
+        return [o[0] for o in outs]
 
     def access_counts(self, length, jobs):
         """jobs: list of (DeviceBuffer index column, n_rows, n_values) -> DeviceBuffer of `length` field elements"""

@@ -269,6 +269,26 @@ int open_and_hint(lm_ctx* ctx, lmh_prover* p, const lm_tree* tree, const std::ve
     return LM_OK;
 }
 
+// the second half of open_and_hint for an opening begun with lm_tree_open_begin (consumes the handle)
+int collect_opening(lm_ctx* ctx, lmh_prover* p, const lm_tree* tree, lm_tree_opening* opening, const std::vector<u64>& idx,
+                    std::vector<u32>& leaves, u32& leaf_words) {
+    leaf_words = lm_tree_leaf_words(tree);
+    const u32 log_h = lm_tree_log_height(tree);
+    leaves.resize((u64)idx.size() * leaf_words);
+    std::vector<u32> sib((u64)idx.size() * log_h * 8 + 1);
+    int rc = lm_tree_open_end(ctx, opening, leaves.data(), sib.data());
+    if (rc) return rc;
+    p->batch_sizes.push_back((u32)idx.size());
+    for (size_t q = 0; q < idx.size(); q++) {
+        Opening o;
+        o.index = idx[q];
+        o.leaf.assign(leaves.begin() + q * leaf_words, leaves.begin() + (q + 1) * leaf_words);
+        o.path.assign(sib.begin() + q * log_h * 8, sib.begin() + (q + 1) * log_h * 8);
+        p->openings.push_back(std::move(o));
+    }
+    return LM_OK;
+}
+
 u32 fold_at(const lm_whir_config* c, u32 round) { return round == 0 ? c->folding_factor_first : c->folding_factor_subsequent; }
 u32 total_fold(const lm_whir_config* c, u32 n_rounds) { return c->folding_factor_first + c->folding_factor_subsequent * n_rounds; }
 
@@ -279,13 +299,14 @@ int sample_ood(lm_ctx* ctx, lmh_prover* p, u32 n_samples, u32 num_variables, con
     ans.clear();
     if (!n_samples) return LM_OK;
     if (!sample_vec(p, n_samples, pts)) return LM_E_INVALID;
-    for (EF z : pts) {
-        std::vector<EF> pt = expand_from_univariate(z, num_variables);
-        EF a;
-        int rc = lm_mle_eval(ctx, d_poly, is_ext, num_variables, 1, 0, num_variables ? pt[0].v : nullptr, a.v);
-        if (rc) return rc;
-        ans.push_back(a);
-    }
+    // all samples in one call: the polynomial is read once per PAIR of points (lm_mle_eval_points)
+    std::vector<u32> coords;
+    coords.reserve((size_t)n_samples * num_variables * 5);
+    for (EF z : pts)
+        for (const EF& e : expand_from_univariate(z, num_variables)) coords.insert(coords.end(), e.v, e.v + 5);
+    ans.resize(n_samples);
+    int rc = lm_mle_eval_points(ctx, d_poly, is_ext, num_variables, n_samples, num_variables ? coords.data() : nullptr, ans[0].v);
+    if (rc) return rc;
     add_ext(p, ans);
     return LM_OK;
 }
@@ -689,19 +710,75 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
         wclk.mark("round.pow");
         std::vector<u64> idx;
         if (!rc && !sample_in_range(p, ilog2(domain_size >> fold_at(c, round)), c->rounds[round].num_queries, idx)) rc = LM_E_INVALID;
-        std::vector<u32> leaves;
-        u32 lw = 0;
-        if (!rc) rc = open_and_hint(ctx, p, tree, idx, leaves, lw);
+        // The openings are hints: they do not enter the challenger, so nothing up to the next sumcheck depends on the opened LEAVES
+        // except the claimed sum.  The opening kernel is enqueued, the combination randomness is sampled and the weight kernels —
+        // which depend on the query INDICES only — are enqueued behind it; leaves and paths are collected, and the STIR evaluations
+        // computed, while those run (open.rs:92-181 in transcript order: hint_merkle_paths, then sample gamma).
+        lm_tree_opening* opening = nullptr;
+        if (!rc && !idx.empty()) rc = lm_tree_open_begin(ctx, tree, idx.data(), (u32)idx.size(), &opening);
         if (rc) {
             lm_tree_free(ctx, new_tree);
             return fail(rc);
         }
-        wclk.mark("round.open_queries");
+        auto drop = [&](int code) {
+            (void)lm_tree_open_end(ctx, opening, nullptr, nullptr);
+            lm_tree_free(ctx, new_tree);
+            return fail(code);
+        };
+        wclk.mark("round.open_queries(launch)");
+        p->ch.duplex();
+        std::vector<EF> g1;
+        if (!sample_vec(p, 1, g1)) return drop(LM_E_INVALID);
+        const EF g = g1[0];
+        // add_new_equality + add_new_base_equality (open.rs:337-382)
+        items.clear();
+        pts.clear();
+        scalars.clear();
+        EF gpw = kb::ef_one();
+        for (size_t i = 0; i < ood_points.size(); i++) {
+            std::vector<EF> pt = expand_from_univariate(ood_points[i], num_variables);
+            u64 off = pts.size() / 5;
+            for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
+            push_item(0, num_variables, 0, off, gpw);
+            sc.sum = kb::ef_add(sc.sum, kb::ef_mul(gpw, ood_answers[i]));
+            gpw = kb::ef_mul(gpw, g);
+        }
+        const u32 dom_gen = two_adic_generator(next_domain_gen_log);
+        std::vector<EF> stir_scalar(idx.size());
+        {
+            // the query points z, z^2, z^4, .. are base-field: squarings in the base field, embedded (expand_from_univariate on
+            // ef_from_base(z) computes the same words with 19 extension-field squarings per query)
+            const size_t at = pts.size();
+            pts.resize(at + idx.size() * (size_t)num_variables * 5, 0u);
+            u32* w = pts.data() + at;
+            for (size_t q = 0; q < idx.size(); q++) {
+                u32 z = kb::pow(dom_gen, idx[q]);
+                const u64 off = (at + q * (size_t)num_variables * 5) / 5;
+                for (u32 j = 0; j < num_variables; j++, w += 5) {
+                    w[0] = z;
+                    z = kb::sqr(z);
+                }
+                push_item(0, num_variables, 0, off, gpw);
+                stir_scalar[q] = gpw;
+                gpw = kb::ef_mul(gpw, g);
+            }
+        }
+        wclk.mark("round.items(host)");
+        rc = lm_weights_accumulate(ctx, sc.W, num_variables, items.data(), (u32)items.size(), pts.data(), pts.size() / 5,
+                                   scalars.data());
+        if (rc) return drop(rc);
+        wclk.mark("round.weights(launch)");
+        std::vector<u32> leaves;
+        u32 lw = 0;
+        if ((rc = collect_opening(ctx, p, tree, opening, idx, leaves, lw))) {
+            lm_tree_free(ctx, new_tree);
+            return fail(rc);
+        }
+        wclk.mark("round.open_queries(collect)");
         const u32 ff = fold_at(c, round);
         const EF* folding_randomness = randomness.data() + (randomness.size() - ff);
         // leaf value at the folding randomness = <leaf, eq(randomness, .)>: the eq table is shared by all queries (a base
         // leaf then costs 5 multiplications per word instead of a chain of EF folds; same field element either way)
-        std::vector<EF> stir_evals(idx.size());
         {
             const u64 m = 1ull << ff;
             std::vector<EF> eq(m);
@@ -733,43 +810,10 @@ int lmh_whir_prove(lm_ctx* ctx, lmh_prover* p, const lm_whir_config* c, const lm
                     }
                     for (int k = 0; k < 5; k++) acc.v[k] = kb::reduce(kb::fold32(a64[k]));
                 }
-                stir_evals[q] = acc;
+                sc.sum = kb::ef_add(sc.sum, kb::ef_mul(stir_scalar[q], acc));
             }
         }
         wclk.mark("round.stir_evals(host)");
-        p->ch.duplex();
-        std::vector<EF> g1;
-        if (!sample_vec(p, 1, g1)) {
-            lm_tree_free(ctx, new_tree);
-            return fail(LM_E_INVALID);
-        }
-        const EF g = g1[0];
-        // add_new_equality + add_new_base_equality (open.rs:337-382)
-        items.clear();
-        pts.clear();
-        scalars.clear();
-        EF gpw = kb::ef_one();
-        for (size_t i = 0; i < ood_points.size(); i++) {
-            std::vector<EF> pt = expand_from_univariate(ood_points[i], num_variables);
-            u64 off = pts.size() / 5;
-            for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
-            push_item(0, num_variables, 0, off, gpw);
-            sc.sum = kb::ef_add(sc.sum, kb::ef_mul(gpw, ood_answers[i]));
-            gpw = kb::ef_mul(gpw, g);
-        }
-        const u32 dom_gen = two_adic_generator(next_domain_gen_log);
-        for (size_t q = 0; q < idx.size(); q++) {
-            u32 z = kb::pow(dom_gen, idx[q]);
-            std::vector<EF> pt = expand_from_univariate(kb::ef_from_base(z), num_variables);
-            u64 off = pts.size() / 5;
-            for (const EF& e : pt) pts.insert(pts.end(), e.v, e.v + 5);
-            push_item(0, num_variables, 0, off, gpw);
-            sc.sum = kb::ef_add(sc.sum, kb::ef_mul(gpw, stir_evals[q]));
-            gpw = kb::ef_mul(gpw, g);
-        }
-        rc = lm_weights_accumulate(ctx, sc.W, num_variables, items.data(), (u32)items.size(), pts.data(), pts.size() / 5,
-                                   scalars.data());
-        wclk.mark("round.weights");
         if (!rc) rc = sumcheck_rounds(ctx, p, sc, fnext, c->rounds[round].folding_pow_bits, randomness);
         wclk.mark("round.sumcheck");
         if (rc) {
@@ -1345,38 +1389,55 @@ int lmh_prove_execution(lm_ctx* ctx, lmh_prover* p, const lm_execution_trace* tr
     }
     auto from_end = [&](u32 n) { return gkr_pt.data() + (size_t)(gkr_n_vars - n) * 5; };
     // column evaluations (logup.rs:224-308)
+    // All of them are evaluations at suffixes of the GKR point and nothing is sampled in between: the six device evaluations are
+    // enqueued back to back (lm_results_defer_begin: results at increasing offsets of the pinned buffer, no wait per call), collected
+    // once, and then observed in the reference's order.
     EF value_memory_acc, value_memory, value_bytecode_acc;
-    if ((rc = lm_mle_eval(ctx, d_memory_acc, 0, log_mem, 1, 0, from_end(log_mem), value_memory_acc.v))) return fail(rc);
-    add_base(p, value_memory_acc.v, 5);
-    if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, log_mem, 1, 0, from_end(log_mem), value_memory.v))) return fail(rc);
-    add_base(p, value_memory.v, 5);
-    if ((rc = lm_mle_eval(ctx, d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail(rc);
-    add_base(p, value_bytecode_acc.v, 5);
-    std::vector<ColVal> columns_values[3];
-    EF bus_num[3], bus_den[3];
+    std::vector<u32> want_of[3], ev_of[3];
+    size_t i_sel_of[3], i_lk_of[3];
+    if ((rc = lm_results_defer_begin(ctx))) return fail(rc);
+    auto fail_deferred = [&](int code) {
+        (void)lm_results_defer_end(ctx);
+        return fail(code);
+    };
+    if ((rc = lm_mle_eval(ctx, d_memory_acc, 0, log_mem, 1, 0, from_end(log_mem), value_memory_acc.v))) return fail_deferred(rc);
+    if ((rc = lm_mle_eval(ctx, tr->d_memory, 0, log_mem, 1, 0, from_end(log_mem), value_memory.v))) return fail_deferred(rc);
+    if ((rc = lm_mle_eval(ctx, d_bytecode_acc, 0, log_bc, 1, 0, from_end(log_bc), value_bytecode_acc.v))) return fail_deferred(rc);
     for (int k = 0; k < 3; k++) {
         const int t = order[k];
         const VmTableDef& def = kVmTables[t];
         const u32 lr = tr->tables[t].log_rows;
         const u32* const* cols = tr->tables[t].d_cols;
         // gather the column list in transcript order, evaluate them in one batch
-        std::vector<u32> want;
+        std::vector<u32>& want = want_of[t];
         if (t == 0) {
             want.push_back(0);
             for (u32 c = 0; c < 12; c++) want.push_back(8 + c);
         }
-        const size_t i_sel = want.size();
+        i_sel_of[t] = want.size();
         want.push_back(def.selector);
         for (u32 c = 0; c < 4; c++) want.push_back(def.bus_data[c]);
-        const size_t i_lk = want.size();
+        i_lk_of[t] = want.size();
         for (u32 l = 0; l < def.n_lookups; l++) {
             want.push_back(def.lookups[l].index);
             for (u32 i = 0; i < def.lookups[l].n_values; i++) want.push_back(def.lookups[l].first_value + i);
         }
         std::vector<const u32*> ptrs;
         for (u32 c : want) ptrs.push_back(cols[c]);
-        std::vector<u32> ev(want.size() * 5);
-        if ((rc = lm_mle_eval_cols(ctx, ptrs.data(), (u32)ptrs.size(), lr, from_end(lr), ev.data()))) return fail(rc);
+        ev_of[t].resize(want.size() * 5);
+        if ((rc = lm_mle_eval_cols(ctx, ptrs.data(), (u32)ptrs.size(), lr, from_end(lr), ev_of[t].data()))) return fail_deferred(rc);
+    }
+    if ((rc = lm_results_defer_end(ctx))) return fail(rc);
+    add_base(p, value_memory_acc.v, 5);
+    add_base(p, value_memory.v, 5);
+    add_base(p, value_bytecode_acc.v, 5);
+    std::vector<ColVal> columns_values[3];
+    EF bus_num[3], bus_den[3];
+    for (int k = 0; k < 3; k++) {
+        const int t = order[k];
+        const VmTableDef& def = kVmTables[t];
+        const std::vector<u32>&want = want_of[t], &ev = ev_of[t];
+        const size_t i_sel = i_sel_of[t], i_lk = i_lk_of[t];
         auto E = [&](size_t i) { return ef_load(&ev[5 * i]); };
         if (t == 0) {
             add_base(p, &ev[0], 5);       // eval_on_pc

@@ -6,6 +6,8 @@
 // the gather is a replicate-on-load, every NTT pass streams whole columns, and the leaf sponge (one row per lane)
 // reads 64 consecutive rows of a column per wave instruction: fully coalesced.  An EF matrix of C columns is stored
 // as 5*C base columns in plane-major order (k*C + c); the reference's leaf word 5c+k maps to that column.
+#include <memory>
+#include <vector>
 #include "lm_common.h"
 #include "poseidon16_coop.h"
 #include "poseidon16_quad.h"
@@ -467,6 +469,38 @@ __global__ __launch_bounds__(256) void k_compress_layer_coop(const u32* __restri
     const u32 d = coop_compress(prev[g * 16 + l], R);
     if (l < 8) next[g * 8 + l] = d;
 }
+// up to five Merkle levels in one launch, node i on lanes 16i .. 16i+15: a workgroup owns 32 consecutive nodes of the input level
+// and everything above them — 16, 8, 4, 2, 1 nodes — which it stores at their places in the (contiguous, bottom-up) digest layers and
+// keeps in LDS for its next pass.  The levels of <= 2^14 nodes are latency: one launch per level was 6 us each whatever the size.
+static constexpr u32 MID_SPAN = 32;
+static bool merkle_mid_enabled() {  // LM_MERKLE_NO_MID=1: one launch per level (A/B measurements)
+    static const bool on = getenv("LM_MERKLE_NO_MID") == nullptr;
+    return on;
+}
+__global__ __launch_bounds__(256) void k_merkle_mid_coop(u32* __restrict__ lvl, u64 n_in, u32 levels, const u32* __restrict__ tab) {
+    __shared__ u32 buf[2][MID_SPAN / 2 * 8];
+    CoopRegs R;
+    coop_load(R, tab);
+    const u32 l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const u64 b = blockIdx.x;
+    const u32* in = lvl + b * MID_SPAN * 8;
+    u32* out = lvl + n_in * 8;  // the level being produced
+    u64 n_out = n_in >> 1;
+    for (u32 k = 0; k < levels; k++) {
+        const u32 cnt = MID_SPAN >> (k + 1);  // nodes this workgroup produces at this level
+        if (grp < cnt) {
+            const u32 x = k == 0 ? in[grp * 16 + l] : buf[(k - 1) & 1][grp * 16 + l];
+            const u32 d = coop_compress(x, R);
+            if (l < 8) {
+                out[(b * cnt + grp) * 8 + l] = d;
+                buf[k & 1][grp * 8 + l] = d;
+            }
+        }
+        __syncthreads();
+        out += n_out * 8;
+        n_out >>= 1;
+    }
+}
 // the last levels of a tree in ONE workgroup of 256 lanes (16 nodes per pass): level sizes n0 >= n0/2 >= .. >= 1 nodes,
 // level k read at lvl and written right behind it (digest layers are contiguous, bottom-up)
 // The root is published through the pinned result buffer (sequence flag), so lm_commit needs no copy command.
@@ -745,6 +779,17 @@ int lm_commit(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars,
             LM_LAUNCH(ctx, k_merkle_top_coop, dim3(1), dim3(256), 0, t->d_digests + off * 8, n, coop, ctx->h_res, root_seq);
             break;
         }
+        if (next_n <= COOP_MAX_PERMS && n >= 2 * MID_SPAN && merkle_mid_enabled()) {
+            // several levels per launch while the last one keeps >= 128 nodes for the single-workgroup top
+            u32 levels = 0;
+            while (levels < 4 && (n >> (levels + 1)) >= 128) levels++;
+            if (levels) {
+                LM_LAUNCH(ctx, k_merkle_mid_coop, dim3((unsigned)(n / MID_SPAN)), dim3(256), 0, t->d_digests + off * 8, n, levels, coop);
+                for (u32 k = 0; k + 1 < levels; k++) off += n, n >>= 1;  // (the loop's own step accounts for the last level)
+                off += n;
+                continue;
+            }
+        }
         if (next_n <= COOP_MAX_PERMS)
             LM_LAUNCH(ctx, k_compress_layer_coop, dim3((unsigned)((next_n * 16 + 255) / 256)), dim3(256), 0,
                       (const u32*)(t->d_digests + off * 8), t->d_digests + (off + n) * 8, next_n, coop);
@@ -779,10 +824,18 @@ void lm_tree_free(lm_ctx* ctx, lm_tree* t) {
 uint32_t lm_tree_log_height(const lm_tree* t) { return t ? t->log_h : 0; }
 uint32_t lm_tree_leaf_words(const lm_tree* t) { return t ? t->leaf_words : 0; }
 
-int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_t n_idx, uint32_t* leaves,
-                 uint32_t* siblings) {
-    LM_REQUIRE(ctx && t && indices && leaves && siblings);
-    if (n_idx == 0) return LM_OK;
+// The opening as two calls: the kernel is enqueued with its results going into pinned host memory behind a published sequence
+// number, the caller does other work — WHIR enqueues the weight kernels of the same round, which depend on the query INDICES only —
+// and collects leaves and paths afterwards.  Work enqueued on the context's stream in between is ordered behind the opening kernel
+// (the scratch buffer both use is reused in stream order).  Without room in the staging ring the opening completes inside _begin.
+struct lm_tree_opening {
+    u32 seq = 0;
+    u64 leaf_total = 0, sib_total = 0;
+    const u32 *p_leaves = nullptr, *p_sib = nullptr;  // pinned (seq != 0)
+    std::vector<u32> done;                            // leaves | siblings, already on the host (seq == 0)
+};
+int lm_tree_open_begin(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_t n_idx, lm_tree_opening** out) {
+    LM_REQUIRE(ctx && t && indices && out && n_idx >= 1);
     const u64 h = 1ull << t->log_h;
     for (u32 i = 0; i < n_idx; i++) LM_REQUIRE(indices[i] < h);
     const u64 leaf_total = (u64)n_idx * t->leaf_words, sib_total = (u64)n_idx * t->log_h * 8;
@@ -795,25 +848,51 @@ int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_
     if ((rc = lm_stage_upload(ctx, d_idx, indices, (size_t)n_idx * 8))) return rc;
     void* pinned;
     if ((rc = lm_stage_alloc(ctx, (leaf_total + sib_total) * 4, &pinned))) return rc;
+    std::unique_ptr<lm_tree_opening> o(new lm_tree_opening());
+    o->leaf_total = leaf_total, o->sib_total = sib_total;
     if (pinned) {  // results straight into pinned host memory
         u32* p_leaves = static_cast<u32*>(pinned);
         u32* p_sib = p_leaves + leaf_total;
-        const u32 seq = ++ctx->res_seq;
+        o->seq = ++ctx->res_seq;
+        o->p_leaves = p_leaves, o->p_sib = p_sib;
         LM_LAUNCH(ctx, k_tree_open<true>, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, p_leaves, p_sib, h, t->log_h,
-                  t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, ctx->d_sync + 1, ctx->h_res, seq);
+                  t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, ctx->d_sync + 1, ctx->h_res, o->seq);
         LM_HIP(hipGetLastError());
-        if ((rc = lm_wait_result(ctx, seq))) return rc;
-        memcpy(leaves, p_leaves, leaf_total * 4);
-        if (sib_total) memcpy(siblings, p_sib, sib_total * 4);
-        return LM_OK;
+    } else {
+        LM_LAUNCH(ctx, k_tree_open<false>, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, d_leaves, d_sib, h, t->log_h,
+                  t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, (u32*)nullptr, (u32*)nullptr, 0u);
+        LM_HIP(hipGetLastError());
+        o->done.resize(leaf_total + sib_total);
+        LM_HIP(hipMemcpyAsync(o->done.data(), d_leaves, (leaf_total + sib_total) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    LM_LAUNCH(ctx, k_tree_open<false>, dim3(n_idx), dim3(256), 0, t->d_matrix, t->d_digests, d_idx, d_leaves, d_sib, h, t->log_h,
-              t->is_ext, t->eff_cols, t->stored_words, t->leaf_words, (u32*)nullptr, (u32*)nullptr, 0u);
-    LM_HIP(hipGetLastError());
-    LM_HIP(hipMemcpyAsync(leaves, d_leaves, leaf_total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (sib_total) LM_HIP(hipMemcpyAsync(siblings, d_sib, sib_total * 4, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = o.release();
     return LM_OK;
+}
+// consumes the handle (also on failure; leaves = NULL abandons the opening)
+int lm_tree_open_end(lm_ctx* ctx, lm_tree_opening* opening, uint32_t* leaves, uint32_t* siblings) {
+    if (!opening) return LM_OK;
+    std::unique_ptr<lm_tree_opening> o(opening);
+    LM_REQUIRE(ctx);
+    if (o->seq) {  // (an abandoned opening still writes into the staging ring: let it finish)
+        int rc = lm_wait_result(ctx, o->seq);
+        if (rc) return rc;
+    }
+    if (!leaves || !siblings) return LM_OK;
+    const u32* src_l = o->seq ? o->p_leaves : o->done.data();
+    const u32* src_s = o->seq ? o->p_sib : o->done.data() + o->leaf_total;
+    memcpy(leaves, src_l, o->leaf_total * 4);
+    if (o->sib_total) memcpy(siblings, src_s, o->sib_total * 4);
+    return LM_OK;
+}
+int lm_tree_open(lm_ctx* ctx, const lm_tree* t, const uint64_t* indices, uint32_t n_idx, uint32_t* leaves,
+                 uint32_t* siblings) {
+    LM_REQUIRE(ctx && t && indices && leaves && siblings);
+    if (n_idx == 0) return LM_OK;
+    lm_tree_opening* o = nullptr;
+    int rc = lm_tree_open_begin(ctx, t, indices, n_idx, &o);
+    if (rc) return rc;
+    return lm_tree_open_end(ctx, o, leaves, siblings);
 }
 
 int lm_tree_download_matrix(lm_ctx* ctx, const lm_tree* t, uint32_t* rows) {

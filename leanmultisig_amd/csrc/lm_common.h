@@ -45,6 +45,7 @@ void lm_set_error(const char* fmt, ...);
 struct lm_ctx {
     unsigned long long uid = 0;  // process-unique: objects that outlive a context (a device-resident lmh_execution) find out through lm_ctx_by_uid
     int device = 0;
+    int n_cus = 256;  // compute units of the device (occupancy-aware launch shapes)
     hipStream_t stream = nullptr;
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words
@@ -57,10 +58,19 @@ struct lm_ctx {
     // pinned, device-visible result buffer: final reduction kernels store round results here directly, the host
     // reads them after a stream synchronise (no D2H copy command per sumcheck round)
     u32* h_res = nullptr;
-    static constexpr u64 RES_WORDS = 4096;
+    static constexpr u64 RES_WORDS = 8192;  // (the resident GKR tail: 1024 + 64 slots of 64 words)
     static constexpr u64 RES_FLAG = RES_WORDS;  // one extra word after the payload: sequence number of the last result
     static constexpr u64 ERR_WORD = 8;          // h_res[RES_FLAG + ERR_WORD]: sticky count of data errors seen by kernels (lm_access_errors)
     u32 res_seq = 0;                            // host side counter; a publishing kernel stores it to h_res[RES_FLAG]
+    // deferred results (lm_results_defer_begin / _end): evaluations that no transcript step separates are enqueued back to back, each
+    // publishing at the next free offset of h_res; _end waits for the last sequence number and hands every result to its caller's buffer
+    struct Deferred {
+        u32* out;
+        u32 offset, words;
+    };
+    bool defer_on = false;
+    u32 defer_off = 0, defer_seq = 0;
+    std::vector<Deferred> deferred;
     // pinned, device-visible mailbox lines (host -> resident kernel): line 0 belongs to `stream`, line 1 + k to aux_stream[k].
     // A resident kernel (k_gkr_tail) polls its line for the next message instead of ending and being relaunched.
     u32* h_cmd = nullptr;

@@ -107,6 +107,32 @@ __global__ void k_eq_table_small(EqSmallArg point, u32 n, u32* __restrict__ out)
     for (int k = 0; k < 5; k++) out[(u64)k * len + i] = acc.v[k];
 }
 
+// up to four such tables in one launch (the hi and lo tables of an evaluation, or of two evaluation points): table t takes the blocks
+// [first_block[t], first_block[t + 1]) and is written at out + off[t]
+struct EqMultiArg {
+    EqSmallArg point[4];
+    u32 n[4], first_block[5];
+    u64 off[4];
+};
+__global__ __launch_bounds__(256) void k_eq_table_multi(EqMultiArg a, u32 n_tables, u32* __restrict__ out) {
+    u32 t = 0;
+    while (t + 1 < n_tables && blockIdx.x >= a.first_block[t + 1]) t++;
+    const u32 n = a.n[t], len = 1u << n;
+    const u32 i = (blockIdx.x - a.first_block[t]) * 256 + threadIdx.x;
+    if (i >= len) return;
+    EF acc = ef_one();
+    for (u32 j = 0; j < n; j++) {
+        EF p;
+#pragma unroll
+        for (int k = 0; k < 5; k++) p.v[k] = a.point[t].v[j * 5 + k];
+        const u32 bit = (i >> (n - 1 - j)) & 1;
+        acc = ef_mul(acc, bit ? p : ef_sub(ef_one(), p));
+    }
+    u32* o = out + a.off[t];
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[(u64)k * len + i] = acc.v[k];
+}
+
 __device__ __forceinline__ EF wave_reduce_ef(EF v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -262,6 +288,66 @@ __global__ __launch_bounds__(256) void k_mle_partial_ext(const u32* __restrict__
         r = ef_mul(r, e);
 #pragma unroll
         for (int k = 0; k < 5; k++) partial[((u64)poly * n_hi + hi) * 5 + k] = r.v[k];
+    }
+}
+// ONE polynomial at NP points in one pass over its values (the OOD samples of a commitment are drawn together, whir/src/utils.rs:30-57):
+// eq tables of point q at eq_lo + q * 5 * 2^k_lo and eq_hi + q * 5 * n_hi; partial[(q * n_hi + hi)] as above
+template <u32 NP, bool EXT>
+__global__ __launch_bounds__(256) void k_mle_partial_pts(const u32* __restrict__ evals, u64 plane, u32 k_lo, const u32* __restrict__ eq_lo,
+                                                         const u32* __restrict__ eq_hi, u32 n_hi, u32* __restrict__ partial) {
+    __shared__ u32 red[32];
+    const u32 hi = blockIdx.x;
+    const u32 len_lo = 1u << k_lo;
+    const u32* v = evals + (u64)hi * len_lo;
+    EF s[NP];
+    if constexpr (EXT) {
+#pragma unroll
+        for (u32 q = 0; q < NP; q++) s[q] = ef_zero();
+        for (u32 i = threadIdx.x; i < len_lo; i += 256) {
+            EF x;
+#pragma unroll
+            for (int k = 0; k < 5; k++) x.v[k] = v[(u64)k * plane + i];
+#pragma unroll
+            for (u32 q = 0; q < NP; q++) {
+                EF e;
+#pragma unroll
+                for (int k = 0; k < 5; k++) e.v[k] = eq_lo[((u64)q * 5 + k) * len_lo + i];
+                s[q] = ef_add(s[q], ef_mul(x, e));
+            }
+        }
+    } else {
+        u64 acc[NP][5];
+#pragma unroll
+        for (u32 q = 0; q < NP; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[q][k] = 0;
+        for (u32 i = threadIdx.x; i < len_lo; i += 256) {
+            const u32 x = v[i];
+#pragma unroll
+            for (u32 q = 0; q < NP; q++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const u64 t = acc[q][k] + (u64)x * eq_lo[((u64)q * 5 + k) * len_lo + i];
+                    const u64 y = t - P_SHL32;
+                    acc[q][k] = t >= P_SHL32 ? y : t;
+                }
+        }
+#pragma unroll
+        for (u32 q = 0; q < NP; q++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) s[q].v[k] = reduce(acc[q][k]);
+    }
+#pragma unroll
+    for (u32 q = 0; q < NP; q++) {
+        EF r = block_reduce_ef(s[q], red);
+        if (threadIdx.x == 0) {
+            EF e;
+#pragma unroll
+            for (int k = 0; k < 5; k++) e.v[k] = eq_hi[((u64)q * 5 + k) * n_hi + hi];
+            r = ef_mul(r, e);
+#pragma unroll
+            for (int k = 0; k < 5; k++) partial[((u64)q * n_hi + hi) * 5 + k] = r.v[k];
+        }
     }
 }
 // out[poly] = sum_hi partial[poly][hi]   (AoS EF)
@@ -604,6 +690,10 @@ int lm_ctx_create(int device, lm_ctx** out) {
 }
 static int ctx_create_impl(int device, lm_ctx* c) {
     c->device = device;
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->n_cus = n;
+    }
     LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
@@ -847,6 +937,99 @@ int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64
     return LM_OK;
 }
 
+// offset of the next result in the pinned buffer: 0 unless results are being deferred (then the slot is recorded for _end; a result
+// that no longer fits ends the deferral for this call: the earlier ones are collected first)
+static u32 defer_slot(lm_ctx* ctx, u32* out, u32 words) {
+    if (!ctx->defer_on) return 0;
+    if (ctx->defer_off + words > lm_ctx::RES_WORDS) {
+        (void)lm_results_defer_end(ctx);
+        ctx->defer_on = true;
+    }
+    const u32 at = ctx->defer_off;
+    ctx->deferred.push_back({out, at, words});
+    ctx->defer_off += words;
+    return at;
+}
+int lm_results_defer_begin(lm_ctx* ctx) {
+    LM_REQUIRE(ctx && !ctx->defer_on);
+    ctx->defer_on = true;
+    ctx->defer_off = 0;
+    ctx->defer_seq = 0;
+    ctx->deferred.clear();
+    return LM_OK;
+}
+int lm_results_defer_end(lm_ctx* ctx) {
+    LM_REQUIRE(ctx);
+    if (!ctx->defer_on) return LM_OK;
+    ctx->defer_on = false;
+    int rc = ctx->defer_seq ? lm_wait_result(ctx, ctx->defer_seq) : LM_OK;
+    if (!rc)
+        for (const lm_ctx::Deferred& d : ctx->deferred) memcpy(d.out, ctx->h_res + d.offset, (size_t)d.words * 4);
+    ctx->deferred.clear();
+    ctx->defer_off = 0;
+    ctx->defer_seq = 0;
+    return rc;
+}
+
+// hi and lo eq tables of up to two points in ONE launch: table (q, hi) at base + q * 5 * n_hi (hi block) resp. the lo block
+static int launch_eq_tables(lm_ctx* ctx, const uint32_t* points, u32 n_points, u32 n_vars, u32 k_hi, u32 k_lo, u32* d_eq_lo, u32* d_eq_hi,
+                            u32* base) {
+    EqMultiArg a;
+    memset(&a, 0, sizeof a);
+    const u32 n_hi = 1u << k_hi, len_lo = 1u << k_lo;
+    u32 t = 0, blocks = 0;
+    for (u32 q = 0; q < n_points; q++) {
+        const u32* pt = points + (size_t)q * n_vars * 5;
+        if (k_hi) memcpy(a.point[t].v, pt, (size_t)k_hi * 20);
+        a.n[t] = k_hi, a.first_block[t] = blocks, a.off[t] = (u64)(d_eq_hi - base) + (u64)q * 5 * n_hi;
+        blocks += (n_hi + 255) / 256, t++;
+        if (k_lo) memcpy(a.point[t].v, pt + (size_t)k_hi * 5, (size_t)k_lo * 20);
+        a.n[t] = k_lo, a.first_block[t] = blocks, a.off[t] = (u64)(d_eq_lo - base) + (u64)q * 5 * len_lo;
+        blocks += (len_lo + 255) / 256, t++;
+    }
+    a.first_block[t] = blocks;
+    LM_LAUNCH(ctx, k_eq_table_multi, dim3(blocks), dim3(256), 0, a, t, base);
+    return LM_OK;
+}
+
+int lm_mle_eval_points(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_points, const uint32_t* points,
+                       uint32_t* out) {
+    LM_REQUIRE(ctx && d_evals && out && n_points >= 1 && n_vars <= 32 && (n_vars == 0 || points));
+    const u32 k_lo = n_vars < 12 ? n_vars : 12;
+    const u32 k_hi = n_vars - k_lo;
+    LM_REQUIRE(k_hi <= 20);
+    const u32 n_hi = 1u << k_hi, len_lo = 1u << k_lo;
+    for (u32 q0 = 0; q0 < n_points; q0 += 2) {  // two points per pass over the polynomial
+        const u32 np = n_points - q0 < 2 ? n_points - q0 : 2;
+        const u64 need = 2 * (5ull * len_lo + 5ull * n_hi) + 2ull * n_hi * 5 + 64;
+        u32* s;
+        int rc = lm_scratch(ctx, need, &s);
+        if (rc) return rc;
+        u32* d_eq_lo = s;
+        u32* d_eq_hi = d_eq_lo + 2 * 5ull * len_lo;
+        u32* d_partial = d_eq_hi + 2 * 5ull * n_hi;
+        if ((rc = launch_eq_tables(ctx, points + (size_t)q0 * n_vars * 5, np, n_vars, k_hi, k_lo, d_eq_lo, d_eq_hi, s))) return rc;
+        const u64 plane = 1ull << n_vars;
+        if (np == 2) {
+            if (is_ext)
+                LM_LAUNCH(ctx, (k_mle_partial_pts<2, true>), dim3(n_hi), dim3(256), 0, d_evals, plane, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+            else
+                LM_LAUNCH(ctx, (k_mle_partial_pts<2, false>), dim3(n_hi), dim3(256), 0, d_evals, plane, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+        } else {
+            if (is_ext)
+                LM_LAUNCH(ctx, (k_mle_partial_pts<1, true>), dim3(n_hi), dim3(256), 0, d_evals, plane, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+            else
+                LM_LAUNCH(ctx, (k_mle_partial_pts<1, false>), dim3(n_hi), dim3(256), 0, d_evals, plane, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
+        }
+        const u32 seq = ++ctx->res_seq;
+        LM_LAUNCH(ctx, k_sum_partials, dim3(np), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res, seq);
+        LM_HIP(hipGetLastError());
+        if ((rc = lm_wait_result(ctx, seq))) return rc;
+        memcpy(out + (size_t)q0 * 5, ctx->h_res, (size_t)np * 20);
+    }
+    return LM_OK;
+}
+
 int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_vars, uint32_t n_polys,
                 uint64_t stride_words, const uint32_t* point, uint32_t* out) {
     LM_REQUIRE(ctx && d_evals && out && n_polys >= 1 && n_vars <= 40);
@@ -865,11 +1048,7 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     u32* d_partial = d_eq_hi + 5ull * n_hi;
     u32* d_out = d_partial + (u64)n_polys * n_hi * 5;
     // point = (hi part: first k_hi coordinates) ++ (lo part: last k_lo coordinates)
-    EqSmallArg p_hi, p_lo;
-    if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
-    if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
+    if ((rc = launch_eq_tables(ctx, point, 1, n_vars, k_hi, k_lo, d_eq_lo, d_eq_hi, s))) return rc;
     if (!is_ext) {
         if (n_polys >= MLE_POLYS_MAX)
             LM_LAUNCH(ctx, k_mle_partial_base<MLE_POLYS_MAX>, dim3(n_hi, (n_polys + MLE_POLYS_MAX - 1) / MLE_POLYS_MAX), dim3(256), 0, d_evals,
@@ -883,10 +1062,15 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     }
     const bool pinned = (u64)n_polys * 5 <= lm_ctx::RES_WORDS;
     if (pinned) {
+        const u32 at = defer_slot(ctx, out, n_polys * 5);
         const u32 seq = ++ctx->res_seq;
-        LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res,
+        LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res + at, ctx->d_sync + 1, ctx->h_res,
                   seq);
         LM_HIP(hipGetLastError());
+        if (ctx->defer_on) {
+            ctx->defer_seq = seq;
+            return LM_OK;
+        }
         if ((rc = lm_wait_result(ctx, seq))) return rc;
         memcpy(out, ctx->h_res, (u64)n_polys * 20);
     } else {
@@ -916,20 +1100,21 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     u32* d_eq_hi = d_eq_lo + 5ull * len_lo;
     u32* d_partial = d_eq_hi + 5ull * n_hi;
     if ((rc = lm_stage_upload(ctx, (void*)d_ptrs, d_cols, (size_t)n_cols * 8))) return rc;
-    EqSmallArg p_hi, p_lo;
-    if (k_hi) memcpy(p_hi.v, point, (size_t)k_hi * 20);
-    if (k_lo) memcpy(p_lo.v, point + (size_t)k_hi * 5, (size_t)k_lo * 20);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((n_hi + 255) / 256), dim3(256), 0, p_hi, k_hi, d_eq_hi);
-    LM_LAUNCH(ctx, k_eq_table_small, dim3((len_lo + 255) / 256), dim3(256), 0, p_lo, k_lo, d_eq_lo);
+    if ((rc = launch_eq_tables(ctx, point, 1, n_vars, k_hi, k_lo, d_eq_lo, d_eq_hi, s))) return rc;
     if (n_cols >= MLE_POLYS_MAX)
         LM_LAUNCH(ctx, k_mle_partial_cols<MLE_POLYS_MAX>, dim3(n_hi, (n_cols + MLE_POLYS_MAX - 1) / MLE_POLYS_MAX), dim3(256), 0,
                   (const u32* const*)d_ptrs, n_cols, k_lo, d_eq_lo, d_eq_hi, n_hi, d_partial);
     else
         LM_LAUNCH(ctx, k_mle_partial_cols<1>, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, n_cols, k_lo, d_eq_lo, d_eq_hi, n_hi,
                   d_partial);
+    const u32 at = defer_slot(ctx, out, n_cols * 5);
     const u32 seq = ++ctx->res_seq;
-    LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res, ctx->d_sync + 1, ctx->h_res, seq);
+    LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res + at, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());
+    if (ctx->defer_on) {
+        ctx->defer_seq = seq;
+        return LM_OK;
+    }
     if ((rc = lm_wait_result(ctx, seq))) return rc;
     memcpy(out, ctx->h_res, (u64)n_cols * 20);
     return LM_OK;

@@ -423,12 +423,13 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
 // them) and polls the same mailbox line; no workgroup talks to another until a slice is down to one quad or two, when the
 // others hand their folded entries to workgroup 0 through device memory (agent-scope stores + a ticket) and leave.
 static constexpr u32 GKR_TAIL_SLICE = 256;                 // entries per workgroup
-static constexpr u32 GKR_TAIL_MAX_W = 16;
+static constexpr u32 GKR_TAIL_MAX_W = 64;  // round 5 (was 16): the launches on 2^13 / 2^14 entries were 14 us of kernel + 13 us until the next one started
 static constexpr u32 GKR_TAIL_MAX = GKR_TAIL_SLICE * GKR_TAIL_MAX_W;
 static constexpr u32 GKR_TAIL_THREADS = 4 * GKR_TAIL_SLICE;
 static constexpr u32 GKR_TAIL_STEPS = 7;  // entries: 4096, 1024, 256, 64, 16, 4  /  2048, 512, 128, 32, 8, 2
 static constexpr u32 GKR_TAIL_SLOT_AT = 1024, GKR_TAIL_SLOT_WORDS = 64;  // h_res: partial sums of workgroup w > 0 (+ 63: its flag)
 static constexpr u32 GKR_TAIL_MERGE_WORDS = GKR_TAIL_MAX_W * 2 * 20;       // device scratch of the hand-over
+static_assert(GKR_TAIL_SLOT_AT + GKR_TAIL_MAX_W * GKR_TAIL_SLOT_WORDS <= lm_ctx::RES_WORDS, "tail slots fit the pinned result buffer");
 static constexpr u32 GKR_TAIL_ABORT = 0xdead0001u;
 static constexpr unsigned long long GKR_TAIL_TIMEOUT = 300000000ull;  // wall_clock64 ticks (100 MHz): 3 s without an answer = abandoned
 struct GkrTailEq {
@@ -558,8 +559,8 @@ __global__ __launch_bounds__(GKR_TAIL_THREADS) void k_gkr_tail(const u32* __rest
 #pragma unroll
                     for (int k = 0; k < 5; k++) arr[(role * 5 + k) * stride + i] = xa.v[k];
                 }
-                if (threadIdx.x < 20 * stride) {
-                    const u32 qk = threadIdx.x / stride, e = threadIdx.x % stride;
+                for (u32 t = threadIdx.x; t < 20 * stride; t += GKR_TAIL_THREADS) {  // (up to 20 x 128 words with 64 workgroups)
+                    const u32 qk = t / stride, e = t % stride;
                     if (e >= Sn) {
                         const u32 src_w = e / Sn, src_i = e % Sn;
                         arr[qk * stride + e] = e < Sm ? lm_load_agent(merge_buf + ((src_w * 2 + src_i) * 4 + qk / 5) * 5 + qk % 5) : 0;
@@ -683,6 +684,18 @@ bool gkr_tail_enabled() {
 // workgroups reserved is noticed by the next process that attaches (its pid no longer exists) and its share is given back.  If the
 // file cannot be created the counter is per process, as before.  LM_GKR_TAIL_MAX_WORKGROUPS lowers the cap (default 256 = the whole
 // chip; a tail that does not get its slots still ends by its own 3 s timeout and the layer is reported as failed, never hung).
+// LM_GKR_TAIL_W: workgroups of ONE tail (default GKR_TAIL_MAX_W = 64, i.e. layers enter the tail at 2^14 entries per array;
+// 16 = round 4's behaviour, A/B measurements)
+u64 gkr_tail_max_entries() {
+    static const u64 v = [] {
+        const char* e = getenv("LM_GKR_TAIL_W");
+        u32 w = e ? (u32)atoi(e) : GKR_TAIL_MAX_W;
+        if (w < 1) w = 1;
+        if (w > GKR_TAIL_MAX_W) w = GKR_TAIL_MAX_W;
+        return (u64)GKR_TAIL_SLICE * w;
+    }();
+    return v;
+}
 int gkr_tail_max_live() {
     static const int v = [] {
         const char* e = getenv("LM_GKR_TAIL_MAX_WORKGROUPS");
@@ -975,7 +988,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         } else {
             g->tail_S = Sn;
         }
-    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= GKR_TAIL_MAX && m_out >= 8 &&
+    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= gkr_tail_max_entries() && m_out >= 8 &&
                gkr_tail_reserve(ctx, (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
         // the reservation is given back on every early return below (a leaked one would silently push later layers onto launches)
         struct TailReservation {

@@ -105,6 +105,50 @@ def test_mle_eval_matches_oracle(ctx, orc, n_vars):
     assert list(got[0]) == list(orc.mle_eval_ext(ev, pt))
 
 
+@pytest.mark.parametrize("n_vars,n_points", [(0, 2), (3, 1), (11, 2), (13, 3), (18, 2), (16, 5)])
+def test_mle_eval_points_matches_oracle(ctx, orc, n_vars, n_points):
+    """lm_mle_eval_points (the OOD samples of a commitment in one pass per pair of points): every point against the oracle, base and
+    extension-field polynomials; and the same evaluations through the deferred-result window (lm_results_defer_begin / _end)"""
+    rng = np.random.default_rng(1000 + n_vars * 10 + n_points)
+    n = 1 << n_vars
+    pts = rand_field(rng, (n_points, n_vars, 5))
+    poly = rand_field(rng, n)
+    d = ctx.to_device(poly)
+    got = ctx.mle_eval_points(d, False, n_vars, pts)
+    for q in range(n_points):
+        assert list(got[q]) == list(orc.mle_eval_base(poly, pts[q]))
+    ev = rand_field(rng, (n, 5))
+    de = ctx.ef_to_device_soa(ev)
+    got = ctx.mle_eval_points(de, True, n_vars, pts)
+    for q in range(n_points):
+        assert list(got[q]) == list(orc.mle_eval_ext(ev, pts[q]))
+    jobs = [(d, False, n_vars, pts[q]) for q in range(n_points)] + [(de, True, n_vars, pts[q]) for q in range(n_points)]
+    res = ctx.mle_eval_deferred(jobs)
+    for q in range(n_points):
+        assert list(res[q]) == list(orc.mle_eval_base(poly, pts[q]))
+        assert list(res[n_points + q]) == list(orc.mle_eval_ext(ev, pts[q]))
+
+
+def test_tree_open_in_two_calls(ctx, orc):
+    """lm_tree_open_begin / _end with other work enqueued in between (WHIR enqueues the round's weight kernels there) == lm_tree_open"""
+    rng = np.random.default_rng(77)
+    n_vars, fold, rate = 16, 7, 1
+    evals = rand_field(rng, 1 << n_vars)
+    d = ctx.to_device(evals)
+    tree = ctx.commit(d, False, n_vars, fold, rate)
+    h = 1 << tree.log_height
+    idx = rng.integers(0, h, size=40)
+    end = tree.open_begin(idx)
+    pt = rand_field(rng, (n_vars, 5))
+    val = ctx.mle_eval(d, False, n_vars, pt)  # uses the context's scratch and publishes a later sequence number
+    leaves, sib = end()
+    ref_leaves, ref_sib = tree.open(idx)
+    assert np.array_equal(leaves, ref_leaves) and np.array_equal(sib, ref_sib)
+    assert list(val[0]) == list(orc.mle_eval_base(evals, pt))
+    for k, i in enumerate(idx):
+        assert orc.merkle_verify(tree.root, tree.log_height, int(i), leaves[k], sib[k])
+
+
 def test_ood_point_is_dft_consistent(ctx, orc):
     """size-independent property at a larger size: LDE row i of a column == MLE of the (replicated) column at
     expand_from_univariate(g^i) (whir/src/dft.rs:583-603), evaluated entirely on the device."""

@@ -99,8 +99,10 @@ def build_workload(ctx, orc, ob, rng, scale_log=0, log_inv_rate=1, shape="xmss",
         sp, root = d["shape"], d["root"]
         ext = [(op, be, size, max(1, cnt >> sh)) for op, be, size, cnt in d["ext_calls"]]
         n_pos_calls, n_ext_calls = root["poseidon_calls"] >> sh, sum(c for _, _, _, c in ext)
+        # (the synthetic generator gives every ExtensionOp call fresh operands: its memory needs one more doubling than the executed
+        # program's 2^21 words — the stand-in runs at 2^22, as it did before the derived memory size was corrected)
         w = synth_witness.build(orc, rng, n_calls=n_pos_calls, n_blocks=4096 >> min(sh, 6), log_exec=sp["log_exec"] - sh, log_pos=sp["log_pos"] - sh,
-                                log_ext=sp["log_ext"] - sh, log_memory=max(sp["log_memory"] - sh, 16), log_bytecode=sp["log_bytecode"] - sh,
+                                log_ext=sp["log_ext"] - sh, log_memory=max(sp["log_memory"] + 1 - sh, 16), log_bytecode=sp["log_bytecode"] - sh,
                                 fill_rows=fill_rows, n_arith=max(0, (root["cycles"] >> sh) - n_pos_calls - n_ext_calls), ext_calls=ext)
     else:
         w = synth_witness.build(orc, rng, n_calls=n_calls, n_blocks=4096 >> min(sh, 6), log_exec=20 - sh, log_pos=18 - sh,

@@ -779,6 +779,12 @@ class Context:
                                             d_dens.ptr))
         return d_nums, d_dens
 
+    def prod_round2(self, d_f, f_is_ext, d_W, n_vars):
+        """the eight sums of a two-round pass (40 words: p00, p01, p10, q0, q1, t0, t2, t3)"""
+        out = np.empty(40, dtype=np.uint32)
+        self._check(self.lib.lm_prod_round2(self.h, d_f.ptr, int(bool(f_is_ext)), d_W.ptr, n_vars, _ptr(out)))
+        return out
+
     def prod_round(self, d_f, f_is_ext, d_W, n_vars):
         out = np.empty(10, dtype=np.uint32)
         self._check(self.lib.lm_prod_round(self.h, d_f.ptr, int(bool(f_is_ext)), d_W.ptr, n_vars, _ptr(out)))

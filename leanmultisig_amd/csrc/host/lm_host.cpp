@@ -1006,7 +1006,7 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     struct Session {
         lm_air* h = nullptr;
         u32 n_vars = 0, deg = 0;
-        std::vector<EF> eq_factor;
+        std::vector<EF> eq_factor, inv_eq_factor;
         EF sum, mmf;
     };
     std::vector<Session> ss(n_tables);
@@ -1031,6 +1031,25 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
         ss[i].deg = lm_air_degree(ss[i].h);
         ss[i].eq_factor.resize(t.log_rows);
         for (u32 j = 0; j < t.log_rows; j++) ss[i].eq_factor[j] = ef_load(t.eq_point + 5 * j);
+        // 1 / eq_factor[j] for every round of the session with ONE inversion (the per-round inverse sat between two device exchanges)
+        {
+            const u32 n = t.log_rows;
+            std::vector<EF> pre(n + 1);
+            pre[0] = kb::ef_one();
+            for (u32 j = 0; j < n; j++) pre[j + 1] = kb::ef_mul(pre[j], ss[i].eq_factor[j]);
+            ss[i].inv_eq_factor.resize(n);
+            bool zero = true;
+            for (int k = 0; k < 5; k++) zero = zero && pre[n].v[k] == 0;
+            if (zero) {
+                for (u32 j = 0; j < n; j++) ss[i].inv_eq_factor[j] = kb::ef_inv(ss[i].eq_factor[j]);
+            } else {
+                EF run = kb::ef_inv(pre[n]);
+                for (u32 j = n; j-- > 0;) {
+                    ss[i].inv_eq_factor[j] = kb::ef_mul(run, pre[j]);
+                    run = kb::ef_mul(run, ss[i].eq_factor[j]);
+                }
+            }
+        }
         ss[i].sum = ef_load(t.sum);
         ss[i].mmf = kb::ef_one();
         n_rounds = std::max(n_rounds, t.log_rows);
@@ -1084,7 +1103,7 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             ev[0] = kb::ef_mul(ef_load(&raw[0]), s.mmf);
             for (u32 z = 2; z <= d; z++) ev[z] = kb::ef_mul(ef_load(&raw[(size_t)(z - 1) * 5]), s.mmf);
             const EF eq_alpha = s.eq_factor.back();
-            ev[1] = kb::ef_mul(kb::ef_sub(s.sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), ev[0])), kb::ef_inv(eq_alpha));
+            ev[1] = kb::ef_mul(kb::ef_sub(s.sum, kb::ef_mul(kb::ef_sub(kb::ef_one(), eq_alpha), ev[0])), s.inv_eq_factor[s.eq_factor.size() - 1]);
             // DensePolynomial::lagrange_interpolation on the points 0..d: the basis polynomials depend on d only (lagrange_basis)
             std::vector<EF> coeffs(d + 1, kb::ef_zero());
             {

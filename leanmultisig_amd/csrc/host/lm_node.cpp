@@ -206,10 +206,9 @@ int lmh_get_execution_trace(lm_ctx* ctx, const lmh_bytecode* bc, const lmh_execu
                 memcpy(w + 16, st, 32);
             }
         } tail;
-        if ((rc = vm_dev_image_export(ctx, d_memory, dv.image, L, nullptr)) || (rc = lm_upload_async(ctx, d_memory + L, tail.w, 24))) return fail(rc);
-    } else if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24)))
+        if ((rc = vm_dev_image_export(ctx, d_memory, dv.image, L, nullptr, padded, tail.w))) return fail(rc);  // (image | tail | zeros: one launch)
+    } else if ((rc = lm_upload_async(ctx, d_memory, v.memory, L + 24)) || (rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24)))
         return fail(rc);  // image + [0 x 16 | poseidon16(0)] (written by the runner)
-    if ((rc = lm_memset_zero(ctx, d_memory + L + 24, padded - L - 24))) return fail(rc);
     mark("alloc + memory upload");
     // ---- bytecode table: device copy cached in the CONTEXT under the bytecode's unique id --------------------------------------
     u32* d_bytecode = (u32*)lm_ctx_cache_get(ctx, vm_bytecode_uid(bc) << 4);

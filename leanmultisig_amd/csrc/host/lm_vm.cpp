@@ -1925,14 +1925,13 @@ bool device_finalize(lmh_execution* ex, DevRun& D, bool& anomaly) {
     bool ok = true;
     u64 h_cyc = 0, h_pos = 0, h_ext = 0, h_pend = 0;  // host entries consumed so far
     u64 o_cyc = 0, o_pos = 0, o_ext = 0, o_pend = 0;  // positions in the final arrays
+    std::vector<VmPart> parts;  // every host piece and the resolver's zeroed scratch: one launch (vm_dev_place)
     auto host_part = [&](u64 cyc_to, u64 pos_to, u64 ext_to, u64 pend_to) {
-        ok = ok && vm_dev_upload(D.ctx, D.d_pcs + o_cyc, tr.pcs.data() + h_cyc, (cyc_to - h_cyc) * 4) == LM_OK &&
-             vm_dev_upload(D.ctx, D.d_fps + o_cyc, tr.fps.data() + h_cyc, (cyc_to - h_cyc) * 4) == LM_OK &&
-             vm_dev_upload(D.ctx, D.d_pos + o_pos * LM_VM_POSEIDON_CALL_WORDS, tr.pos.data() + h_pos * LM_VM_POSEIDON_CALL_WORDS,
-                           (pos_to - h_pos) * LM_VM_POSEIDON_CALL_WORDS * 4) == LM_OK &&
-             vm_dev_upload(D.ctx, D.d_ext + o_ext * LM_VM_EXTENSION_ROW_WORDS, tr.ext.data() + h_ext * LM_VM_EXTENSION_ROW_WORDS,
-                           (ext_to - h_ext) * LM_VM_EXTENSION_ROW_WORDS * 4) == LM_OK &&
-             vm_dev_upload(D.ctx, d_pend + o_pend * 2, hp.data() + h_pend * 2, (pend_to - h_pend) * 8) == LM_OK;
+        parts.push_back({D.d_pcs + o_cyc, tr.pcs.data() + h_cyc, cyc_to - h_cyc});
+        parts.push_back({D.d_fps + o_cyc, tr.fps.data() + h_cyc, cyc_to - h_cyc});
+        parts.push_back({D.d_pos + o_pos * LM_VM_POSEIDON_CALL_WORDS, tr.pos.data() + h_pos * LM_VM_POSEIDON_CALL_WORDS, (pos_to - h_pos) * LM_VM_POSEIDON_CALL_WORDS});
+        parts.push_back({D.d_ext + o_ext * LM_VM_EXTENSION_ROW_WORDS, tr.ext.data() + h_ext * LM_VM_EXTENSION_ROW_WORDS, (ext_to - h_ext) * LM_VM_EXTENSION_ROW_WORDS});
+        parts.push_back({d_pend + o_pend * 2, hp.data() + h_pend * 2, (pend_to - h_pend) * 2});
         o_cyc += cyc_to - h_cyc, o_pos += pos_to - h_pos, o_ext += ext_to - h_ext, o_pend += pend_to - h_pend;
         h_cyc = cyc_to, h_pos = pos_to, h_ext = ext_to, h_pend = pend_to;
     };
@@ -1944,7 +1943,9 @@ bool device_finalize(lmh_execution* ex, DevRun& D, bool& anomaly) {
     }
     host_part(tr.pcs.size(), tr.pos.size() / LM_VM_POSEIDON_CALL_WORDS, tr.ext.size() / LM_VM_EXTENSION_ROW_WORDS, tr.pending.size());
     // resolve_deref_hints on the assembled image
-    ok = ok && lm_memset_zero(D.ctx, (u32*)d_status, (n_pend + 3) / 4 ? (n_pend + 3) / 4 : 1) == LM_OK && lm_memset_zero(D.ctx, d_info, VM_RESOLVE_INFO_WORDS) == LM_OK;
+    parts.push_back({(u32*)d_status, nullptr, (n_pend + 3) / 4 ? (n_pend + 3) / 4 : 1});
+    parts.push_back({d_info, nullptr, (u64)VM_RESOLVE_INFO_WORDS});
+    ok = ok && vm_dev_place(D.ctx, parts.data(), (u32)parts.size()) == LM_OK;
     u32 info[VM_RESOLVE_INFO_WORDS] = {0};
     for (u32 first = 0; ok && n_pend;) {
         const u32 rounds = 3;

@@ -100,6 +100,14 @@ int vm_dev_splice(lm_ctx* ctx, const VmSegArgs& a, u64 n_par, const u64* d_offse
 // resolve_deref_hints (runner.rs:206-236) over n entries (target, src): n_rounds rounds numbered from first_round, then the zero
 // fill of what is left — which acts only if the last of these rounds resolved nothing.  d_info: VM_RESOLVE_INFO_WORDS words.
 int vm_dev_resolve(lm_ctx* ctx, u32* image, u64 image_len, const u32* pend, u64 n, uint8_t* status, u32* d_info, u32 first_round, u32 n_rounds);
+// host pieces -> device destinations in one launch (src == nullptr: zero fill); the sources are copied before the call returns
+static constexpr u32 VM_PLACE_MAX = 16;
+struct VmPart {
+    u32* dst;
+    const u32* src;
+    u64 n_words;
+};
+int vm_dev_place(lm_ctx* ctx, const VmPart* parts, u32 n_parts);
 int vm_dev_fill(lm_ctx* ctx, u32* d, u32 word, u64 n);
 int vm_dev_download(lm_ctx* ctx, void* dst, const void* d_src, size_t bytes);  // synchronises the stream
 int vm_dev_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);    // asynchronous: src must stay valid until the next synchronisation
@@ -108,5 +116,5 @@ int vm_dev_mark(lm_ctx* ctx);
 int vm_dev_wait_mark(lm_ctx* ctx);
 const u32* vm_dev_coop_table(lm_ctx* ctx);
 // dst[i] = src[i] == VM_UNDEF ? 0 : src[i]; optional defined mask
-int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined);
+int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined, u64 n_total = 0, const u32* tail24 = nullptr);  // dst[n .. n_total) = tail24, then zeros
 }  // namespace lmh

@@ -75,6 +75,14 @@ struct lm_ctx {
     // A resident kernel (k_gkr_tail) polls its line for the next message instead of ending and being relaunched.
     u32* h_cmd = nullptr;
     static constexpr u64 CMD_LINE_WORDS = 16;
+    // Late-bound challenges ("launch ahead", lm_mail_*): a kernel whose only unknown arguments are the next two challenges is enqueued
+    // BEHIND the kernel whose result they are derived from and waits for them on the device — line MAIL_LINE of h_cmd, relayed to the
+    // other workgroups through d_relay — so the exchange costs the two posted writes instead of a launch (~13 -> ~7 us).  Messages are
+    // numbered 1, 2, ..: consecutive numbers alternate the parity tag of the payload words, a kernel is told its number at launch.
+    static constexpr u64 MAIL_LINE = 1 + 3;   // (= 1 + N_AUX: behind the lines of the resident GKR tails)
+    static constexpr u64 CMD_LINES = 2 + 3;
+    u32* d_relay = nullptr;                   // CMD_LINE_WORDS device words
+    u32 mail_reserved = 0, mail_posted = 0;   // numbers handed to enqueued kernels / written to the line
     // pinned staging ring for small host -> device tables (pointer lists, job lists, evaluation points): the host image is
     // written here and copied with ONE asynchronous command — no synchronisation to keep a caller's vector alive, no
     // pageable-memory staging inside the runtime.  A region stays valid until the ring wraps; wrapping synchronises.
@@ -208,6 +216,53 @@ __device__ __forceinline__ void lm_publish_flag_word(kb::u32* flag_word, kb::u32
 }
 __device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) { lm_publish_flag_word(h_res + lm_ctx::RES_FLAG, seq); }
 #endif
+#if defined(__HIPCC__)
+static constexpr kb::u32 LM_MAIL_ABORT = 0xdead0002u;
+static constexpr unsigned long long LM_MAIL_TIMEOUT = 300000000ull;  // wall_clock64 ticks (100 MHz): 3 s without the message = abandoned
+// Wait for message `no` (two challenges).  Every thread of the workgroup calls it; workgroup 0 polls the pinned line and relays the
+// eleven tagged words to d_relay with agent-scope stores, the others poll the relay (a message is accepted when its ten payload words
+// carry the parity of `no` and word 10 equals `no` in ONE wave-wide load: no ordering between the stores is assumed, a stale or
+// half-written line is refused).  lds: 16 words.  Returns false when the kernel was dismissed (word 11) or nothing came for 3 s.
+__device__ __forceinline__ bool lm_mail_receive(const kb::u32* __restrict__ h_line, kb::u32* __restrict__ d_relay, kb::u32 no,
+                                                kb::u32* lds, kb::EF& r0, kb::EF& r1) {
+    if (threadIdx.x < 64) {
+        const kb::u32 lane = threadIdx.x;
+        const bool first = blockIdx.x == 0;
+        const unsigned long long t0 = wall_clock64();
+        kb::u32 v = 0;
+        bool done = false, dismissed = false;
+        while (!done) {
+            v = 0;
+            if (lane < 16)
+                v = first ? __hip_atomic_load(h_line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                          : __hip_atomic_load(d_relay + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = lane < 10 ? (v >> 31) == (no & 1) : lane == 10 ? v == no : true;
+            done = __ballot(ok) == ~0ull;
+            dismissed = __ballot(lane == 11 && v == LM_MAIL_ABORT) != 0 || wall_clock64() - t0 > LM_MAIL_TIMEOUT;
+            if (dismissed) break;
+            if (!done && !first) __builtin_amdgcn_s_sleep(4);
+        }
+        if (first && lane < 12) {  // (an abort is relayed as well: word 11)
+            __hip_atomic_store(d_relay + lane, dismissed && lane == 11 ? LM_MAIL_ABORT : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane < 16) lds[lane] = dismissed ? LM_MAIL_ABORT : (v & 0x7fffffffu);
+    }
+    __syncthreads();
+    if (lds[11] == LM_MAIL_ABORT) return false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        r0.v[k] = __builtin_amdgcn_readfirstlane(lds[k]);
+        r1.v[k] = __builtin_amdgcn_readfirstlane(lds[5 + k]);
+    }
+    return true;
+}
+#endif
+// host side (lm_core.hip): the number the next enqueued kernel will wait for; the message; dismissal of kernels whose message
+// will never come (error paths: synchronises the stream)
+kb::u32 lm_mail_reserve(lm_ctx* ctx);
+void lm_mail_post(lm_ctx* ctx, kb::u32 no, const kb::u32 r0[5], const kb::u32 r1[5]);
+int lm_mail_abort(lm_ctx* ctx);
+static inline const kb::u32* lm_mail_line(const lm_ctx* ctx) { return ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE; }
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 // the same on flag word h_res[RES_FLAG + 1 + aux] (aux >= 0), published by work on aux_stream[aux]
 int lm_wait_result_aux(lm_ctx* ctx, int aux, kb::u32 seq);

@@ -541,6 +541,33 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
     return LM_OK;
 }
 
+// ---- late-bound challenges (lm_common.h) ----
+kb::u32 lm_mail_reserve(lm_ctx* ctx) { return ++ctx->mail_reserved; }
+void lm_mail_post(lm_ctx* ctx, kb::u32 no, const kb::u32 r0[5], const kb::u32 r1[5]) {
+    // (numbers are posted in the order they were reserved: the kernels wait in stream order)
+    volatile u32* line = ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE;
+    const u32 tag = (no & 1) << 31;
+    for (int k = 0; k < 5; k++) line[k] = r0[k] | tag, line[5 + k] = r1[k] | tag;
+    line[10] = no;
+    ctx->mail_posted = no;
+}
+int lm_mail_abort(lm_ctx* ctx) {
+    if (ctx->mail_posted == ctx->mail_reserved) return LM_OK;
+    volatile u32* line = ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE;
+    line[11] = LM_MAIL_ABORT;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < lm_ctx::N_AUX; i++)  // (AIR sessions wait on their own streams)
+        if (ctx->aux_stream[i]) (void)hipStreamSynchronize(ctx->aux_stream[i]);
+    // the numbers skipped here never appear on the line: restart it so that the next message differs in parity from what is there
+    const u32 last = ctx->mail_reserved, tag = (last & 1) << 31;
+    u32 img[lm_ctx::CMD_LINE_WORDS];
+    for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) img[i] = i < 10 ? tag : i == 10 ? last : 0;
+    for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) line[i] = img[i];
+    ctx->mail_posted = last;
+    LM_HIP(hipMemcpy(ctx->d_relay, img, sizeof img, hipMemcpyHostToDevice));
+    return LM_OK;
+}
+
 int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out) {
     *out = nullptr;
     bytes = (bytes + 63) & ~(size_t)63;
@@ -699,8 +726,11 @@ static int ctx_create_impl(int device, lm_ctx* c) {
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));
     LM_HIP(hipHostMalloc((void**)&c->h_res, (lm_ctx::RES_WORDS + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
     for (int i = 0; i < 16; i++) c->h_res[lm_ctx::RES_FLAG + i] = 0;
-    LM_HIP(hipHostMalloc((void**)&c->h_cmd, lm_ctx::CMD_LINE_WORDS * (1 + lm_ctx::N_AUX) * 4, hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_cmd, 0, lm_ctx::CMD_LINE_WORDS * (1 + lm_ctx::N_AUX) * 4);
+    static_assert(lm_ctx::MAIL_LINE == 1 + lm_ctx::N_AUX && lm_ctx::CMD_LINES == 2 + lm_ctx::N_AUX, "mailbox lines");
+    LM_HIP(hipHostMalloc((void**)&c->h_cmd, lm_ctx::CMD_LINE_WORDS * lm_ctx::CMD_LINES * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_cmd, 0, lm_ctx::CMD_LINE_WORDS * lm_ctx::CMD_LINES * 4);
+    LM_HIP(hipMalloc(&c->d_relay, lm_ctx::CMD_LINE_WORDS * 4));
+    LM_HIP(hipMemset(c->d_relay, 0, lm_ctx::CMD_LINE_WORDS * 4));
     LM_HIP(hipHostMalloc((void**)&c->h_stage, lm_ctx::STAGE_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     LM_HIP(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     const u64 n = 1ull << (LM_TW_LOG - 1);
@@ -758,6 +788,7 @@ void lm_ctx_destroy(lm_ctx* c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_cmd) (void)hipHostFree(c->h_cmd);
+    if (c->d_relay) (void)hipFree(c->d_relay);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& kv : c->pool_size) (void)hipFree(kv.first);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -50,7 +50,18 @@ struct lm_gkr {
     u32 tail_W = 1, tail_S = 0;  // its workgroups and the length of a workgroup's slice (the host mirrors the kernel's schedule)
     bool tail_solo = true;       // only workgroup 0 is left (always true for tail_W == 1)
     u32* d_merge = nullptr;      // hand-over scratch of a multi-workgroup tail
+    // the next launch of the layer, enqueued ahead of its two challenges (gkr_shoot with a mail number)
+    bool ahead = false;
+    struct GkrShotT {
+        u32 t, F, p, seq, mail_no;
+        u64 m_out, n_threads;
+        bool la, tail;
+        int dst;
+        u32 tail_W, tail_S;
+        bool tail_solo;
+    } ahead_shot;
 };
+using GkrShot = lm_gkr::GkrShotT;
 
 // ---- layer construction (layers.rs:124-189): (n0 d1 + n1 d0, d0 d1) ------------------------------------------------
 template <bool BASE>
@@ -352,9 +363,14 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
                                                   const u32* __restrict__ arr_in, u64 m_out, u64 n_threads, u64 valid_in, EF r0, EF r1, EF alpha,
                                                   EqSplit eq,
                                                   u32* __restrict__ out, unsigned long long* __restrict__ acc, u32* __restrict__ done_counter,
-                                                  u32* __restrict__ h_res, u32 seq) {
+                                                  u32* __restrict__ h_res, u32 seq, const u32* __restrict__ h_mail, u32* __restrict__ d_relay,
+                                                  u32 mail_no) {
     __shared__ u32 lds[4 * GKR_SUM_WORDS];
     __shared__ u32 tot[GKR_SUM_WORDS];
+    if constexpr (F > 0) {
+        // enqueued ahead of its challenges (lm_gkr_round): they arrive as message mail_no; a dismissed kernel publishes nothing
+        if (mail_no && !lm_mail_receive(h_mail, d_relay, mail_no, lds, r0, r1)) return;
+    }
     const u64 m_in = m_out << F;
     const u32 cls = threadIdx.x & 3;
     EF acc_e = ef_zero(), acc_x = ef_zero(), acc_y = ef_zero();
@@ -423,7 +439,9 @@ __global__ __launch_bounds__(256) void k_gkr_step(const u32* __restrict__ n_in, 
 // them) and polls the same mailbox line; no workgroup talks to another until a slice is down to one quad or two, when the
 // others hand their folded entries to workgroup 0 through device memory (agent-scope stores + a ticket) and leave.
 static constexpr u32 GKR_TAIL_SLICE = 256;                 // entries per workgroup
-static constexpr u32 GKR_TAIL_MAX_W = 64;  // round 5 (was 16): the launches on 2^13 / 2^14 entries were 14 us of kernel + 13 us until the next one started
+static constexpr u32 GKR_TAIL_MAX_W = 64;      // what the buffers are sized for (LM_GKR_TAIL_W)
+static constexpr u32 GKR_TAIL_DEFAULT_W = 16;  // measured (round 5, GKR stage): 16 workgroups 4.40 - 4.42 ms, 32: 4.44 - 4.57, 64: 4.81 - 4.82 — every
+                                               // exchange of a wider tail waits for all its workgroups' polls and publications
 static constexpr u32 GKR_TAIL_MAX = GKR_TAIL_SLICE * GKR_TAIL_MAX_W;
 static constexpr u32 GKR_TAIL_THREADS = 4 * GKR_TAIL_SLICE;
 static constexpr u32 GKR_TAIL_STEPS = 7;  // entries: 4096, 1024, 256, 64, 16, 4  /  2048, 512, 128, 32, 8, 2
@@ -484,10 +502,18 @@ template <int MODE, int F>
 __global__ __launch_bounds__(GKR_TAIL_THREADS) void k_gkr_tail(const u32* __restrict__ n_in, const u32* __restrict__ d_in,
                                                                const u32* __restrict__ arr_in, u32 m_out0, u64 valid_in, EF r0, EF r1, EF alpha,
                                                                GkrTailEq eqs, u32* __restrict__ h_res, u32 seq0, const u32* __restrict__ h_cmd,
-                                                               u32* __restrict__ merge_buf, u32* __restrict__ merge_counter) {
+                                                               u32* __restrict__ merge_buf, u32* __restrict__ merge_counter,
+                                                               const u32* __restrict__ h_mail, u32* __restrict__ d_relay, u32 mail_no) {
     __shared__ __attribute__((aligned(16))) u32 arr[20 * GKR_TAIL_SLICE];  // [(array * 5 + k) * stride + i], stride = max(local length, 4)
     __shared__ u32 red[(GKR_TAIL_THREADS / 64) * 20];                      // per wave: [class][5]
     __shared__ u32 msg[16];
+    if constexpr (F > 0) {
+        // enqueued ahead of the two challenges of its first fold (lm_gkr_round): they arrive as message mail_no of the launch-ahead line
+        if (mail_no) {
+            if (!lm_mail_receive(h_mail, d_relay, mail_no, msg, r0, r1)) return;
+            __syncthreads();
+        }
+    }
     const u32 lane = threadIdx.x & 63;
     const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u32 role = wv & 3, grp = wv >> 2;  // phase A: array `role`; phase B: operand pair / form `role`
@@ -684,12 +710,12 @@ bool gkr_tail_enabled() {
 // workgroups reserved is noticed by the next process that attaches (its pid no longer exists) and its share is given back.  If the
 // file cannot be created the counter is per process, as before.  LM_GKR_TAIL_MAX_WORKGROUPS lowers the cap (default 256 = the whole
 // chip; a tail that does not get its slots still ends by its own 3 s timeout and the layer is reported as failed, never hung).
-// LM_GKR_TAIL_W: workgroups of ONE tail (default GKR_TAIL_MAX_W = 64, i.e. layers enter the tail at 2^14 entries per array;
-// 16 = round 4's behaviour, A/B measurements)
+// LM_GKR_TAIL_W: workgroups of ONE tail (default 16: layers enter the tail at 2^12 entries per array; up to GKR_TAIL_MAX_W = 64 for
+// A/B measurements)
 u64 gkr_tail_max_entries() {
     static const u64 v = [] {
         const char* e = getenv("LM_GKR_TAIL_W");
-        u32 w = e ? (u32)atoi(e) : GKR_TAIL_MAX_W;
+        u32 w = e ? (u32)atoi(e) : GKR_TAIL_DEFAULT_W;
         if (w < 1) w = 1;
         if (w > GKR_TAIL_MAX_W) w = GKR_TAIL_MAX_W;
         return (u64)GKR_TAIL_SLICE * w;
@@ -799,11 +825,13 @@ void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
 // a + r (b + r c)
 EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
 }  // namespace
+static void gkr_ahead_drop(lm_ctx* ctx, lm_gkr* g);
 
 extern "C" {
 
 void lm_gkr_free(lm_ctx* ctx, lm_gkr* g) {
     if (!g) return;
+    gkr_ahead_drop(ctx, g);
     gkr_tail_dismiss(ctx, g);
     for (u32* p : g->nums) lm_pool_free(ctx, p);
     for (u32* p : g->dens) lm_pool_free(ctx, p);
@@ -915,6 +943,7 @@ int lm_gkr_top(lm_ctx* ctx, const lm_gkr* g, uint32_t* nums32, uint32_t* dens32)
 // Start the sumcheck of the layer with 2^(K+1) entries (K = number of coordinates of the claim point, 5 <= K < n_vars).
 int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point, const uint32_t alpha[5]) {
     LM_REQUIRE(ctx && g && point && alpha && K >= 5 && K < g->n_vars);
+    gkr_ahead_drop(ctx, g);
     gkr_tail_dismiss(ctx, g);
     g->K = K;
     g->round = 0;
@@ -935,61 +964,36 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
 // out = (c0_raw, c2_raw) of finalize_round (sumcheck_utils.rs:90-109), padding included because the vectors are fully
 // materialised.  Every other call is answered on the host from the look-ahead sums of the previous launch (see k_gkr_step);
 // the challenges are folded into the arrays two at a time by the next launch.
-int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
-    LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
-    LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
-    if (prev_r) g->pending.push_back(host_ef(prev_r));
-    if (g->la_valid) {
-        const EF& r = g->pending.back();
-        const EF c0 = quad_at(g->la[0], g->la[1], g->la[2], r), c2 = quad_at(g->la[3], g->la[4], g->la[5], r);
-        memcpy(out_c0_c2, c0.v, 20);
-        memcpy(out_c0_c2 + 5, c2.v, 20);
-        g->la_valid = false;
-        g->round++;
-        return LM_OK;
-    }
-    const u32 t = g->round;
-    const u32 F = (u32)g->pending.size();
+// One launch of a layer's schedule (a step over the arrays, or the first launch of a resident tail): everything but the two challenges
+// it folds is known one launch earlier — the state the previous launch leaves (cur, m, arr_valid) and the round index —, so it can be
+// enqueued AHEAD, behind that launch, and receive (r0, r1) as a message (lm_mail_*; mail_no != 0).
+static int gkr_shoot(lm_ctx* ctx, lm_gkr* g, u32 t, u32 F, int cur, u64 m, u64 arr_valid, const EF& r0, const EF& r1, u32 mail_no, GkrShot* out) {
     LM_REQUIRE(F == 0 || F == 2);  // the schedule: first launch of a layer has nothing to fold, later ones two challenges
-    const u64 m_out = g->m >> F;
+    LM_REQUIRE(mail_no == 0 || F == 2);
+    const u64 m_out = m >> F;
     LM_REQUIRE(m_out >= 2 && m_out == (2ull << (g->K - 1 - t)));
     const bool la = m_out >= 4;
     const u32 p = g->K - 1 - t;  // round t: 2^p pairs, eq over point[0..p)
     const EqSplit eq = g->eqt.at(la ? p - 1 : p);
     // valid inputs: storage entries of the layer (array index y <-> entries 2y, 2y + 1) or entries of the work arrays
-    const bool input_layer0 = g->K == g->n_vars - 1;
-    const u64 valid_in = g->cur < 0 ? (input_layer0 ? g->valid0 : g->valid[g->n_vars - g->K - 2]) : g->arr_valid;
-    const u64 arr_in_valid = g->cur < 0 ? valid_in / 2 : valid_in;                      // in array entries
+    const bool input_layer = g->K == g->n_vars - 1;
+    const u64 valid_in = cur < 0 ? (input_layer ? g->valid0 : g->valid[g->n_vars - g->K - 2]) : arr_valid;
+    const u64 arr_in_valid = cur < 0 ? valid_in / 2 : valid_in;                      // in array entries
     u64 n_threads = round_up8((arr_in_valid + (1ull << F) - 1) >> F, m_out);     // outputs that are computed (rest: closed form)
-    int rc;
-    const int dst = g->cur < 0 ? 0 : 1 - g->cur;
-    const bool input_layer = input_layer0;
+    const int dst = cur < 0 ? 0 : 1 - cur;
     // the layer being proven has 2^(K+1) entries: the caller's input when K + 1 == n_vars, else owned layer
     // nums[i] (2^(n_vars-1-i) entries) with i = n_vars - K - 2
     const u32* n_st = input_layer ? g->d_nums0 : g->nums[g->n_vars - g->K - 2];
     const u32* d_st = input_layer ? g->d_dens0 : g->dens[g->n_vars - g->K - 2];
-    const EF r0 = F ? g->pending[0] : ef_zero(), r1 = F ? g->pending[1] : ef_zero();
     const u32* nul = nullptr;
+    const u32* h_mail = lm_mail_line(ctx);
+    u32* d_relay = ctx->d_relay;
+    GkrShot sh;
+    sh.t = t, sh.F = F, sh.m_out = m_out, sh.la = la, sh.p = p, sh.dst = dst, sh.tail = false, sh.mail_no = mail_no;
+    sh.tail_W = 1, sh.tail_S = 0, sh.tail_solo = true;
     u32 seq;
-    if (g->tail_live) {
-        // the resident workgroup holds the arrays in LDS: hand it the two challenges (bit 31 = parity of the sequence number
-        // of its next publication, see k_gkr_tail) and wait for that publication
-        LM_REQUIRE(F == 2 && ctx->res_seq == g->tail_seq);
-        seq = ++ctx->res_seq;
-        volatile u32* cmd = ctx->h_cmd;
-        const u32 tag = (seq & 1) << 31;
-        for (int k = 0; k < 5; k++) cmd[k] = r0.v[k] | tag, cmd[5 + k] = r1.v[k] | tag;
-        cmd[10] = seq;
-        n_threads = m_out;  // the resident workgroup materialises every entry (padding included)
-        const u32 Sn = g->tail_S >> 2;
-        if (!g->tail_solo && Sn < 4) {
-            g->tail_solo = true;
-            g->tail_S = g->tail_W * Sn;
-        } else {
-            g->tail_S = Sn;
-        }
-    } else if (gkr_tail_enabled() && ctx->h_cmd && m_out <= gkr_tail_max_entries() && m_out >= 8 &&
-               gkr_tail_reserve(ctx, (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
+    if (gkr_tail_enabled() && ctx->h_cmd && m_out <= gkr_tail_max_entries() && m_out >= 8 &&
+        gkr_tail_reserve(ctx, (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
         // the reservation is given back on every early return below (a leaked one would silently push later layers onto launches)
         struct TailReservation {
             lm_ctx* ctx;
@@ -1013,14 +1017,15 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         }
         // no stale message, no stale dismissal; the payload words carry the parity the FIRST message will NOT have (that of this
         // launch's own sequence number), so a poll that sees part of the line before and part after the host's stores is refused
+        // (enqueued ahead, this happens while the previous launch — a step, never a tail — is still running: nothing polls line 0 then)
         for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) ((volatile u32*)ctx->h_cmd)[i] = i < 10 ? (seq & 1) << 31 : 0;
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
-        g->tail_W = (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE);
-        g->tail_S = (u32)(m_out / g->tail_W);
-        g->tail_solo = g->tail_W == 1;
+        sh.tail_W = (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE);
+        sh.tail_S = (u32)(m_out / sh.tail_W);
+        sh.tail_solo = sh.tail_W == 1;
 #define GKR_TAIL(MODE, FF, NI, DI, AI) \
-    LM_LAUNCH(ctx, (k_gkr_tail<MODE, FF>), dim3(g->tail_W), dim3(GKR_TAIL_THREADS), 0, NI, DI, AI, (u32)m_out, valid_in, r0, r1, g->alpha, eqs, ctx->h_res, seq, (const u32*)ctx->h_cmd, g->d_merge, ctx->d_sync + 1)
-        if (g->cur < 0) {
+    LM_LAUNCH(ctx, (k_gkr_tail<MODE, FF>), dim3(sh.tail_W), dim3(GKR_TAIL_THREADS), 0, NI, DI, AI, (u32)m_out, valid_in, r0, r1, g->alpha, eqs, ctx->h_res, seq, (const u32*)ctx->h_cmd, g->d_merge, ctx->d_sync + 1, h_mail, d_relay, mail_no)
+        if (cur < 0) {
             if (F == 0) {
                 if (input_layer)
                     GKR_TAIL(0, 0, n_st, d_st, nul);
@@ -1034,13 +1039,13 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             }
         } else {
             LM_REQUIRE(F == 2);
-            GKR_TAIL(2, 2, nul, nul, (const u32*)g->work[g->cur]);
+            GKR_TAIL(2, 2, nul, nul, (const u32*)g->work[cur]);
         }
 #undef GKR_TAIL
         LM_HIP(hipGetLastError());
-        reservation.keep = true;  // from here gkr_tail_release / gkr_tail_dismiss give it back
-        g->tail_live = true;
-        n_threads = m_out;
+        reservation.keep = true;  // from here gkr_tail_release / gkr_tail_dismiss / gkr_ahead_drop give it back
+        sh.tail = true;
+        n_threads = m_out;  // the resident workgroups materialise every entry (padding included)
     } else {
     const u32 blocks = (u32)std::min<u64>((n_threads + 255) / 256, 1024);
     seq = ++ctx->res_seq;
@@ -1049,18 +1054,18 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     // the valid inputs read once (input layer: 4 + 20 bytes per entry, owned layer: 20 + 20, work arrays: 4 x 20 per array entry) + the
     // four folded arrays written once
     const bool big = n_threads >= (1ull << 20);
-    const u64 alg_bytes = (g->cur < 0 ? (input_layer ? 24ull : 40ull) * valid_in : 80ull * std::min<u64>(arr_in_valid, m_out << F)) + (F ? 80ull * n_threads : 0);
+    const u64 alg_bytes = (cur < 0 ? (input_layer ? 24ull : 40ull) * valid_in : 80ull * std::min<u64>(arr_in_valid, m_out << F)) + (F ? 80ull * n_threads : 0);
 #define k_gkr_step_big k_gkr_step
 #define GKR_STEP(MODE, FF, LL, NI, DI, AI)                                                                                                                     \
     do {                                                                                                                                                      \
         if (big) {                                                                                                                                            \
             /* (LM_LAUNCH_ON directly: one more macro level would expand the alias before it is stringified) */                                            \
-            LM_LAUNCH_ON(ctx, (ctx)->stream, (k_gkr_step_big<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq); \
+            LM_LAUNCH_ON(ctx, (ctx)->stream, (k_gkr_step_big<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq, h_mail, d_relay, mail_no); \
             LM_PROF_BYTES(ctx, k_gkr_step_big, alg_bytes);                                                                                                    \
         } else                                                                                                                                                \
-            LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq); \
+            LM_LAUNCH(ctx, (k_gkr_step<MODE, FF, LL>), dim3(blocks), dim3(256), 0, NI, DI, AI, m_out, n_threads, valid_in, r0, r1, g->alpha, eq, g->work[dst], ctx->d_acc, counter, ctx->h_res, seq, h_mail, d_relay, mail_no); \
     } while (0)
-    if (g->cur < 0) {
+    if (cur < 0) {
         LM_REQUIRE(la);  // K >= 5: the launches that read layer storage always cover two rounds
         if (F == 0) {
             if (input_layer)
@@ -1076,15 +1081,112 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     } else {
         LM_REQUIRE(F == 2);
         if (la)
-            GKR_STEP(2, 2, true, nul, nul, (const u32*)g->work[g->cur]);
+            GKR_STEP(2, 2, true, nul, nul, (const u32*)g->work[cur]);
         else
-            GKR_STEP(2, 2, false, nul, nul, (const u32*)g->work[g->cur]);
+            GKR_STEP(2, 2, false, nul, nul, (const u32*)g->work[cur]);
     }
 #undef GKR_STEP
 #undef k_gkr_step_big
-    }
     LM_HIP(hipGetLastError());
+    }
+    sh.seq = seq;
+    sh.n_threads = n_threads;
+    *out = sh;
+    return LM_OK;
+}
+// a launch enqueued ahead whose challenges will never be posted (error paths, an abandoned layer): dismiss it, give its tail slots back
+static void gkr_ahead_drop(lm_ctx* ctx, lm_gkr* g) {
+    if (!g->ahead) return;
+    (void)lm_mail_abort(ctx);
+    if (g->ahead_shot.tail) {
+        (void)hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream);
+        gkr_tail_unreserve(ctx, (int)g->ahead_shot.tail_W);
+    }
+    g->ahead = false;
+}
+static bool gkr_launch_ahead_enabled() {  // LM_GKR_NO_AHEAD=1: every launch waits for its challenges on the host (A/B measurements)
+    static const bool on = getenv("LM_GKR_NO_AHEAD") == nullptr;
+    return on;
+}
+
+int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
+    LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
+    LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
+    if (prev_r) g->pending.push_back(host_ef(prev_r));
+    if (g->la_valid) {
+        const EF& r = g->pending.back();
+        const EF c0 = quad_at(g->la[0], g->la[1], g->la[2], r), c2 = quad_at(g->la[3], g->la[4], g->la[5], r);
+        memcpy(out_c0_c2, c0.v, 20);
+        memcpy(out_c0_c2 + 5, c2.v, 20);
+        g->la_valid = false;
+        g->round++;
+        return LM_OK;
+    }
+    const u32 t = g->round;
+    const u32 F = (u32)g->pending.size();
+    LM_REQUIRE(F == 0 || F == 2);
+    const EF r0 = F ? g->pending[0] : ef_zero(), r1 = F ? g->pending[1] : ef_zero();
+    int rc;
+    GkrShot sh;
+    if (g->tail_live) {
+        // the resident workgroup holds the arrays in LDS: hand it the two challenges (bit 31 = parity of the sequence number
+        // of its next publication, see k_gkr_tail) and wait for that publication
+        LM_REQUIRE(F == 2 && ctx->res_seq == g->tail_seq && !g->ahead);
+        sh.t = t, sh.F = F, sh.m_out = g->m >> F, sh.la = sh.m_out >= 4, sh.p = g->K - 1 - t, sh.dst = g->cur < 0 ? 0 : 1 - g->cur;
+        sh.tail = true, sh.mail_no = 0;
+        LM_REQUIRE(sh.m_out >= 2 && sh.m_out == (2ull << (g->K - 1 - t)));
+        sh.seq = ++ctx->res_seq;
+        volatile u32* cmd = ctx->h_cmd;
+        const u32 tag = (sh.seq & 1) << 31;
+        for (int k = 0; k < 5; k++) cmd[k] = r0.v[k] | tag, cmd[5 + k] = r1.v[k] | tag;
+        cmd[10] = sh.seq;
+        sh.n_threads = sh.m_out;  // the resident workgroup materialises every entry (padding included)
+        const u32 Sn = g->tail_S >> 2;
+        if (!g->tail_solo && Sn < 4) {
+            g->tail_solo = true;
+            g->tail_S = g->tail_W * Sn;
+        } else {
+            g->tail_S = Sn;
+        }
+    } else if (g->ahead) {
+        // this launch is already on the stream, behind the previous one: its two challenges go out as a message
+        sh = g->ahead_shot;
+        g->ahead = false;
+        if (sh.t != t || sh.F != F) {
+            g->ahead = true;
+            gkr_ahead_drop(ctx, g);
+            lm_set_error("lm_gkr_round: the launch enqueued ahead does not match the round being asked for");
+            return LM_E_INVALID;
+        }
+        lm_mail_post(ctx, sh.mail_no, r0.v, r1.v);
+        if (sh.tail) {
+            g->tail_live = true;
+            g->tail_W = sh.tail_W, g->tail_S = sh.tail_S, g->tail_solo = sh.tail_solo;
+        }
+    } else {
+        if ((rc = gkr_shoot(ctx, g, t, F, g->cur, g->m, g->arr_valid, r0, r1, 0, &sh))) return rc;
+        if (sh.tail) {
+            g->tail_live = true;
+            g->tail_W = sh.tail_W, g->tail_S = sh.tail_S, g->tail_solo = sh.tail_solo;
+        }
+    }
+    // The launch after this one (two rounds on: F = 2) reads what this one leaves; enqueue it now, behind this one, when this one is a
+    // launch (a live tail takes messages instead) and the layer has rounds left for it
+    if (!sh.tail && t + 2 < g->K && gkr_launch_ahead_enabled()) {
+        const u32 no = lm_mail_reserve(ctx);
+        rc = gkr_shoot(ctx, g, t + 2, 2, F ? sh.dst : g->cur, sh.m_out, F ? sh.n_threads : g->arr_valid, ef_zero(), ef_zero(), no, &g->ahead_shot);
+        if (rc) {
+            (void)lm_mail_abort(ctx);
+            return rc;
+        }
+        g->ahead = true;
+    }
+    const u32 seq = sh.seq, p = sh.p;
+    const u64 m_out = sh.m_out, n_threads = sh.n_threads;
+    const bool la = sh.la;
+    const int dst = sh.dst;
     if ((rc = lm_wait_result(ctx, seq))) {
+        gkr_ahead_drop(ctx, g);
         gkr_tail_dismiss(ctx, g);
         return rc;
     }

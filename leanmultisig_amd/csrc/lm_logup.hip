@@ -283,8 +283,9 @@ extern "C" int lm_access_counts(lm_ctx* ctx, uint32_t* d_acc, uint64_t len, uint
     u32* d_cursor = d_offsets + nb + 1;
     u32* d_boundary = d_cursor + nb;
     u32* d_items = d_boundary + (u64)nb * ACC_MAX_RUN;
-    LM_HIP(hipMemsetAsync(d_totals, 0, ((u64)nb + 1) * 4, ctx->stream));
-    LM_HIP(hipMemsetAsync(d_boundary, 0, (u64)nb * ACC_MAX_RUN * 4, ctx->stream));  // split windows add into these two
+    // totals and boundary counts start from zero (split windows add into the boundary counts and into d_acc); the offsets and cursors
+    // between them in the scratch block are written by k_acc_scan before anything reads them: one fill for the whole block
+    LM_HIP(hipMemsetAsync(d_totals, 0, (size_t)((d_boundary + (u64)nb * ACC_MAX_RUN) - d_totals) * 4, ctx->stream));
     LM_HIP(hipMemsetAsync(d_acc, 0, len * 4, ctx->stream));
     LM_LAUNCH(ctx, (k_acc_pass<0>), dim3(tiles), dim3(256), (size_t)nb * 4, jobs, len, nb, d_totals, d_cursor, d_items);
     LM_LAUNCH(ctx, k_acc_scan, dim3(1), dim3(1024), 0, (const u32*)d_totals, nb, d_offsets, d_cursor);

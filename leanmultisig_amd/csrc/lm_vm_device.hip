@@ -901,11 +901,21 @@ __global__ __launch_bounds__(256) void k_vm_resolve_finish(u32* __restrict__ ima
     if (old != UNDEF && old != 0u) atomicAdd(info, 1u);
 }
 
-__global__ __launch_bounds__(256) void k_vm_image_export(u32* __restrict__ dst, const u32* __restrict__ src, u64 n, uint8_t* __restrict__ defined) {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const u32 v = src[i];
-        dst[i] = v == UNDEF ? 0u : v;
-        if (defined) defined[i] = v != UNDEF;
+// (n_total > n: the committed memory column — the image, then `tail` (24 words: [0 x 16 | poseidon16(0)], trace_gen.rs:106-110), then
+// zeros up to the padded length — in one launch instead of a kernel, a copy and a fill)
+struct VmTail {
+    u32 w[24];
+};
+__global__ __launch_bounds__(256) void k_vm_image_export(u32* __restrict__ dst, const u32* __restrict__ src, u64 n, uint8_t* __restrict__ defined,
+                                                         u64 n_total, VmTail tail) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n_total; i += (u64)gridDim.x * 256) {
+        if (i < n) {
+            const u32 v = src[i];
+            dst[i] = v == UNDEF ? 0u : v;
+            if (defined) defined[i] = v != UNDEF;
+        } else {
+            dst[i] = i - n < 24 ? tail.w[i - n] : 0u;
+        }
     }
 }
 }  // namespace
@@ -952,6 +962,67 @@ int vm_dev_resolve(lm_ctx* ctx, u32* image, u64 image_len, const u32* pend, u64 
     LM_HIP(hipGetLastError());
     return LM_OK;
 }
+// The host's parts of a run's log (sequential head and tail: a few thousand cycles, their precompile calls, the pending list) go up in
+// ONE step: the pieces are packed into the pinned staging ring and a kernel reads them from there and stores each at its place between
+// the spliced segment logs; the same launch zeroes the resolver's status bytes and counters (ten copy / fill commands before).
+struct VmPlaceArgs {
+    u32 n;
+    u32* dst[VM_PLACE_MAX];
+    u64 src_off[VM_PLACE_MAX], n_words[VM_PLACE_MAX];  // (src_off = ~0: zero fill)
+};
+__global__ __launch_bounds__(256) void k_vm_place(const u32* __restrict__ src, VmPlaceArgs a) {
+    const u32 part = blockIdx.y;
+    if (part >= a.n) return;
+    u32* __restrict__ dst = a.dst[part];
+    const u64 n = a.n_words[part], off = a.src_off[part];
+    const bool zero = off == ~0ull;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) dst[i] = zero ? 0u : src[off + i];
+}
+int vm_dev_place(lm_ctx* ctx, const VmPart* parts, u32 n_parts) {
+    u64 total = 0;
+    for (u32 i = 0; i < n_parts; i++)
+        if (parts[i].src) total += (parts[i].n_words + 15) & ~15ull;
+    void* st = nullptr;
+    if (total) {
+        int rc = lm_stage_alloc(ctx, total * 4, &st);
+        if (rc) return rc;
+    }
+    if (total && !st) {  // no room in the ring: plain copies (synchronous semantics of the sources are the caller's: they stay alive)
+        for (u32 i = 0; i < n_parts; i++) {
+            if (!parts[i].n_words) continue;
+            if (parts[i].src)
+                LM_HIP(hipMemcpyAsync(parts[i].dst, parts[i].src, parts[i].n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+            else
+                LM_HIP(hipMemsetAsync(parts[i].dst, 0, parts[i].n_words * 4, ctx->stream));
+        }
+        return LM_OK;
+    }
+    u32* img = static_cast<u32*>(st);
+    u64 at = 0;
+    for (u32 p0 = 0; p0 < n_parts; p0 += VM_PLACE_MAX) {
+        VmPlaceArgs a;
+        a.n = 0;
+        u64 longest = 0;
+        for (u32 i = p0; i < n_parts && i < p0 + VM_PLACE_MAX; i++) {
+            if (!parts[i].n_words) continue;
+            a.dst[a.n] = parts[i].dst, a.n_words[a.n] = parts[i].n_words;
+            if (parts[i].src) {
+                memcpy(img + at, parts[i].src, parts[i].n_words * 4);
+                a.src_off[a.n] = at;
+                at += (parts[i].n_words + 15) & ~15ull;
+            } else {
+                a.src_off[a.n] = ~0ull;
+            }
+            longest = std::max<u64>(longest, parts[i].n_words);
+            a.n++;
+        }
+        if (!a.n) continue;
+        const unsigned bx = (unsigned)std::min<u64>((longest + 255) / 256, 64);
+        LM_LAUNCH(ctx, k_vm_place, dim3(bx, a.n), dim3(256), 0, (const u32*)img, a);
+    }
+    LM_HIP(hipGetLastError());
+    return LM_OK;
+}
 int vm_dev_fill(lm_ctx* ctx, u32* d, u32 word, u64 n) {
     if (n == 0) return LM_OK;
     LM_HIP(hipMemsetD32Async((hipDeviceptr_t)d, (int)word, n, ctx->stream));
@@ -976,10 +1047,14 @@ int vm_dev_wait_mark(lm_ctx* ctx) {
     return LM_OK;
 }
 const u32* vm_dev_coop_table(lm_ctx* ctx) { return ctx->d_coop; }
-int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined) {
-    if (n == 0) return LM_OK;
-    const unsigned blocks = (unsigned)std::min<u64>((n + 255) / 256, 8192);
-    LM_LAUNCH(ctx, k_vm_image_export, dim3(blocks), dim3(256), 0, dst, src, n, defined);
+int vm_dev_image_export(lm_ctx* ctx, u32* dst, const u32* src, u64 n, uint8_t* defined, u64 n_total, const u32* tail24) {
+    if (n_total < n) n_total = n;
+    if (n_total == 0) return LM_OK;
+    VmTail t;
+    memset(&t, 0, sizeof t);
+    if (tail24) memcpy(t.w, tail24, sizeof t.w);
+    const unsigned blocks = (unsigned)std::min<u64>((n_total + 255) / 256, 8192);
+    LM_LAUNCH(ctx, k_vm_image_export, dim3(blocks), dim3(256), 0, dst, src, n, defined, n_total, t);
     LM_HIP(hipGetLastError());
     return LM_OK;
 }

@@ -106,3 +106,21 @@ def test_gkr_launch_per_round_pair_schedule_matches_oracle():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "16 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("env_name,env_value", [("LM_GKR_NO_AHEAD", "1"), ("LM_GKR_TAIL_W", "64"), ("LM_GKR_TAIL_W", "2")])
+def test_gkr_schedule_variants_match_oracle(env_name, env_value):
+    """The launches of a layer are enqueued AHEAD of their challenges by default (k_gkr_step / k_gkr_tail wait for message n of the
+    launch-ahead line, lm_mail_*): LM_GKR_NO_AHEAD=1 restores one launch per exchange.  LM_GKR_TAIL_W sets the workgroups of a resident
+    tail (default 16; 64: layers enter it at 2^14 entries and the hand-over gathers 64 slices; 2: almost every round pair is a launch).
+    Same transcripts either way (the switches are read once per process: the parity tests are re-run in a child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{env_name: env_value})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gkr_gpu.py", "-k",
+                        "test_gkr_matches_oracle or test_gkr_active_prefix_matches_oracle or test_gkr_abandoned_layer or test_gkr_large"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

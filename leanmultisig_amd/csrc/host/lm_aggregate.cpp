@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "lm_host_internal.h"
+#include "lm_vm_internal.h"
 
 using namespace lmh;
 
@@ -70,12 +71,26 @@ struct lmh_type1_witness {
     std::unique_ptr<u32[]> data;
     u64 n_sigs = 0;
     lm_vm_witness c;
+    // late mode (lmh_aggregate_type_1): hash_pubkeys — the long chain — and what hangs on it (the digest inside `input_data`, the public
+    // input) are computed by `hasher` while the VM already runs; `late` tells the runner which words are not final yet (lmh::VmLate)
+    std::thread hasher;
+    lmh::VmLate late;
+    void finish() {
+        if (hasher.joinable()) hasher.join();
+    }
+    ~lmh_type1_witness() { finish(); }
 };
 
 extern "C" {
 
+static int type1_witness_build(const lmh_bytecode* bc, const uint32_t* raw_xmss, uint64_t n_raw, const uint32_t message[8], uint32_t slot,
+                               bool late_mode, lmh_type1_witness** out);
 int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xmss, uint64_t n_raw, const uint32_t message[8], uint32_t slot,
                                  lmh_type1_witness** out) {
+    return type1_witness_build(bc, raw_xmss, n_raw, message, slot, false, out);
+}
+static int type1_witness_build(const lmh_bytecode* bc, const uint32_t* raw_xmss, uint64_t n_raw, const uint32_t message[8], uint32_t slot,
+                               bool late_mode, lmh_type1_witness** out) {
     if (!bc || !raw_xmss || !message || !out || n_raw == 0) {
         lm_set_error("lmh_aggregate_type_1_witness: bad arguments (at least one signature)");
         return LM_E_INVALID;
@@ -88,6 +103,8 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
     }
     try {
         std::unique_ptr<lmh_type1_witness> w(new lmh_type1_witness());
+        const bool times = getenv("LM_INPUT_TIMES") != nullptr;
+        double tm[6] = {now_ms(), 0, 0, 0, 0, 0};
         // raw_xmss.sort_by(pk); dedup_by(pk) (:232-233): Ord of XmssPublicKey = merkle_root then public_param, canonical values
         std::vector<u32> key(n_raw * PUB_KEY_FLAT_SIZE);
         for (u64 i = 0; i < n_raw; i++)
@@ -104,6 +121,7 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
             return LM_E_INVALID;
         }
         w->n_sigs = n;
+        tm[1] = now_ms();
         // ---- the hint map (:317-365), flattened in name-id order: layout first, so that the streams can be filled while the hashes run -----
         const u32 log_size = lmh_bytecode_log_size(bc), n_vars = log_size + N_INSTRUCTION_COLUMNS_LOG;
         const u32 claim_size = (n_vars + 1) * DIMENSION, claim_padded = (claim_size + DIGEST_LEN - 1) / DIGEST_LEN * DIGEST_LEN;
@@ -143,6 +161,13 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
         std::vector<u32> tw(TWEAK_TABLE_SIZE_FE_PADDED, 0u);
         u32 pubkeys_hash[8], tweaks_hash[8];
         const u32* ord = order.data();
+        const bool threaded = n >= 64;  // (a thread costs ~30 us: not for a handful of signatures)
+        const bool late = late_mode && threaded;  // hash_pubkeys runs beside the VM: its digest is a late word of the run (below)
+        const bool main_copies_wots = late;       // (this thread has nothing to hash then: it takes the largest copy)
+        auto copy_wots = [&]() {
+            if (u32* dst = streams[S_WOTS].dst)  // encode_wots_signature (:188-194): randomness | chain_tips
+                for (u64 i = 0; i < n; i++) memcpy(dst + i * WOTS_SIG_SIZE_FE, raw_xmss + (u64)ord[i] * LM_XMSS_SIG_WORDS + PUB_KEY_FLAT_SIZE, WOTS_SIG_SIZE_FE * 4);
+        };
         auto side = [&]() {
             // compute_tweak_table(slot) (:124-151) and its hash (TWEAKS_HASHING_USE_IV = false)
             u32 at = 0;
@@ -153,8 +178,7 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
                 make_tweak(TWEAK_TYPE_MERKLE, level + 1, (u32)((u64)slot >> (level + 1)), &tw[at]), at += TWEAK_SLOT_SIZE;
             compress_slice(tw.data(), tw.size(), false, tweaks_hash);
             if (u32* dst = streams[S_TWEAKS].dst) memcpy(dst, tw.data(), tw.size() * 4);
-            if (u32* dst = streams[S_WOTS].dst)  // encode_wots_signature (:188-194): randomness | chain_tips
-                for (u64 i = 0; i < n; i++) memcpy(dst + i * WOTS_SIG_SIZE_FE, raw_xmss + (u64)ord[i] * LM_XMSS_SIG_WORDS + PUB_KEY_FLAT_SIZE, WOTS_SIG_SIZE_FE * 4);
+            if (!main_copies_wots) copy_wots();
             if (u32* dst = streams[S_MERKLE].dst)
                 for (u64 i = 0; i < n; i++)
                     memcpy(dst + i * LOG_LIFETIME * XMSS_DIGEST_LEN, raw_xmss + (u64)ord[i] * LM_XMSS_SIG_WORDS + PUB_KEY_FLAT_SIZE + WOTS_SIG_SIZE_FE,
@@ -162,8 +186,8 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
             if (u32* dst = streams[S_RAW_INDICES].dst)
                 for (u64 i = 0; i < n; i++) dst[i] = kb::to_monty((u32)i);  // global_pub_keys.binary_search(pk): the raw keys ARE the global list
         };
+        tm[2] = now_ms();
         std::thread helper;
-        const bool threaded = n >= 64;  // (a thread costs ~30 us: not for a handful of signatures)
         if (threaded)
             helper = std::thread(side);
         else
@@ -171,9 +195,15 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
         // global_pub_keys (= the raw keys: no children) and hash_pubkeys
         w->pubkeys.resize(n * PUB_KEY_FLAT_SIZE);
         for (u64 i = 0; i < n; i++) memcpy(&w->pubkeys[i * 8], raw_xmss + (u64)order[i] * LM_XMSS_SIG_WORDS, 32);
-        compress_slice(w->pubkeys.data(), w->pubkeys.size(), true, pubkeys_hash);
+        if (late) {
+            memset(pubkeys_hash, 0, sizeof pubkeys_hash);
+            copy_wots();
+        } else
+            compress_slice(w->pubkeys.data(), w->pubkeys.size(), true, pubkeys_hash);
         if (u32* dst = streams[S_PUBKEYS].dst) memcpy(dst, w->pubkeys.data(), w->pubkeys.size() * 4);
+        tm[3] = now_ms();
         if (threaded) helper.join();
+        tm[4] = now_ms();
         // build_type1_input_data (:163-186) with the bytecode claim of a run without children: (0^n_vars, bytecode[0]) (bytecode_claims.rs:38-45)
         std::vector<u32>& d = w->input_data;
         d.assign(d_size, 0u);
@@ -187,20 +217,43 @@ int lmh_aggregate_type_1_witness(const lmh_bytecode* bc, const uint32_t* raw_xms
             host_compress(st);  // poseidon16_compress_pair(bytecode_hash, SNARK_DOMAIN_SEP)
             memcpy(&d[at], st, 32), at += 8;
         }
+        const u32 at_pubkeys_hash = at;
         memcpy(&d[at], pubkeys_hash, 32), at += 8;
         memcpy(&d[at], message, 32), at += 8;
         for (u32 c = 0; c < N_MERKLE_CHUNKS_FOR_SLOT; c++) d[at + c] = kb::to_monty((~(slot >> (4 * c))) & 0xF);
         at += 8;
         memcpy(&d[at], tweaks_hash, 32);
-        compress_slice(d.data(), d.size(), true, w->public_input);
+        if (!late) compress_slice(d.data(), d.size(), true, w->public_input);
         if (u32* dst = streams[S_NUM_CHUNKS].dst) dst[0] = kb::to_monty((u32)(d.size() / DIGEST_LEN));
         if (u32* dst = streams[S_INPUT_DATA].dst) memcpy(dst, d.data(), d.size() * 4);
+        if (late) {
+            // hash_pubkeys, its place in the input data (buffer and hint stream), the public input: on a thread of their own; the runner
+            // is told which words it must not read yet (everything else of the witness is final when this function returns)
+            lmh_type1_witness* wp = w.get();
+            u32* hint_words = streams[S_INPUT_DATA].dst ? streams[S_INPUT_DATA].dst + at_pubkeys_hash : nullptr;
+            memset(wp->public_input, 0, sizeof wp->public_input);
+            wp->hasher = std::thread([wp, hint_words, at_pubkeys_hash]() {
+                u32 h[8];
+                compress_slice(wp->pubkeys.data(), wp->pubkeys.size(), true, h);
+                memcpy(&wp->input_data[at_pubkeys_hash], h, 32);
+                if (hint_words) memcpy(hint_words, h, 32);
+                compress_slice(wp->input_data.data(), wp->input_data.size(), true, wp->public_input);
+            });
+            wp->late.n_ranges = hint_words ? 1 : 0;
+            wp->late.first_word[0] = hint_words ? (u64)(hint_words - wp->data.get()) : 0;
+            wp->late.n_words[0] = 8;
+            wp->late.public_input = true;
+            wp->late.wait = [wp]() { wp->finish(); };
+        }
         if (u32* dst = streams[S_META].dst) dst[0] = 0, dst[1] = 0, dst[2] = kb::to_monty((u32)n);  // [n_recursions, n_dup, raw_count]
         if (u32* dst = streams[S_IS_SPLIT].dst) dst[0] = 0;
         w->name_entry_begin[n_names] = e;
         w->entry_offset[e] = o;
         w->c.preamble_memory_len = PREAMBLE_MEMORY_LEN, w->c.n_names = n_names;
         w->c.name_entry_begin = w->name_entry_begin.data(), w->c.entry_offset = w->entry_offset.data(), w->c.data = w->data.get();
+        if (times)
+            fprintf(stderr, "# aggregate_type_1 inputs: sort + dedup %.3f ms, hint map layout %.3f, hash_pubkeys (helper: tweak table, blobs) %.3f, join %.3f, input data + hash %.3f\n",
+                    tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], now_ms() - tm[4]);
         *out = w.release();
     } catch (const std::bad_alloc&) {
         lm_set_error("lmh_aggregate_type_1_witness: out of memory");
@@ -222,11 +275,16 @@ int lmh_aggregate_type_1(lm_ctx* ctx, lmh_prover* p, const lmh_bytecode* bc, con
                          uint32_t slot, const lm_whir_builder* builder, uint32_t n_threads, double times_ms[4], lm_vm_run_info* info) {
     const double t0 = now_ms();
     lmh_type1_witness* w = nullptr;
-    int rc = lmh_aggregate_type_1_witness(bc, raw_xmss, n_raw, message, slot, &w);
+    // LM_INPUTS_EAGER=1: hash_pubkeys before the VM starts (the reference's order; A/B measurements)
+    static const bool late_ok = getenv("LM_INPUTS_EAGER") == nullptr;
+    int rc = type1_witness_build(bc, raw_xmss, n_raw, message, slot, late_ok, &w);
     if (rc) return rc;
     const double t1 = now_ms();
     double t[3] = {0, 0, 0};
+    if (w->late.wait) lmh::vm_set_late(&w->late);  // (consumed by the run that follows on this thread)
     rc = lmh_prove_execution_vm_info(ctx, p, bc, w->public_input, 8, &w->c, builder, n_threads, t, info);
+    lmh::vm_set_late(nullptr);
+    w->finish();
     lmh_type1_witness_free(w);
     if (times_ms) times_ms[0] = t1 - t0, times_ms[1] = t[0], times_ms[2] = t[1], times_ms[3] = t[2];
     return rc;

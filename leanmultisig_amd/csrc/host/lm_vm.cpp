@@ -37,6 +37,7 @@
 #include "lm_vm_device.h"
 
 namespace lmh {
+static thread_local const VmLate* g_vm_late = nullptr;  // vm_set_late: inputs of the next run on this thread that are not final yet
 
 // ---------------------------------------------------------------------------------------------------------------------
 // thread pool: parallel_for(n, f) runs f(i) for i < n on the calling thread + the workers, dynamic scheduling
@@ -373,8 +374,22 @@ struct MemBuf {
         owner = (u32*)q;
         return true;
     }
+    std::function<void()> late_wait;  // kind 2 (late input words, VmLate): blocks until the words at left_first (a host pointer) are final
     void lazy_execute_check(LazyCall& c);
     void lazy_execute(LazyCall& c) {  // all inputs are defined by now
+        if (c.kind == 2) {
+            if (late_wait) {
+                const double t0 = vm_now_ms();
+                late_wait();
+                if (vm_times() && vm_now_ms() - t0 > 0.01)
+                    fprintf(stderr, "[vm] late input words (cells %llu..): the run waited %.2f ms for them\n", (unsigned long long)c.res, vm_now_ms() - t0);
+            }
+            memcpy(p + c.res, reinterpret_cast<const u32*>((uintptr_t)c.left_first), 4u * c.n_out);
+            memset(owner + c.res, 0, 4u * c.n_out);
+            c.done = 1;
+            lazy_open--;
+            return;
+        }
         if (c.kind == 1) {
             lazy_execute_check(c);
             c.done = 1;
@@ -407,8 +422,9 @@ struct MemBuf {
             };
             if (c.kind == 0)
                 scan(c.left_first, 4), scan(c.left_second, 4), scan(c.arg_b, 8);
-            else
+            else if (c.kind == 1)
                 scan(c.left_first, c.is_be ? c.size : 5 * c.size), scan(c.arg_b, 5 * c.size), scan(c.res, 5);
+            // (kind 2, late input words: no inputs in memory)
             if (dep)
                 stack.push_back(dep - 1);
             else {
@@ -431,9 +447,27 @@ struct MemBuf {
     }
     void lazy_reset() {  // an aborted run: forget the pending calls
         for (LazyCall& c : lazy)
-            if (!c.done && c.kind == 0) memset(owner + c.res, 0, 4u * c.n_out);
+            if (!c.done && c.kind != 1) memset(owner + c.res, 0, 4u * c.n_out);
         lazy.clear();
         lazy_drained = 0, lazy_open = 0;
+    }
+    // cells [at, at + n) will hold the n words at src once late_wait() has returned: pending, owned by a call of kind 2.  false: not
+    // possible (deferral off, a cell already defined or owned, n > 64) — the caller waits and writes the words as usual.
+    bool lazy_late(u64 at, const u32* src, u32 n) {
+        if (!lazy_on || !owner || n == 0 || n > 64 || at + n > MAX_MEMORY) return false;
+        guard(at), guard(at + n - 1);
+        for (u32 j = 0; j < n; j++)
+            if (at + j < len && (p[at + j] != 0xFFFFFFFFu || owner[at + j])) return false;
+        if (at + n > len) grow(at + n);
+        if (!lazy_open && !lazy.empty()) lazy.clear(), lazy_drained = 0;
+        LazyCall c;
+        memset(&c, 0, sizeof c);
+        c.kind = 2, c.left_first = (u64)(uintptr_t)src, c.res = at, c.n_out = (u8)n;
+        lazy.push_back(c);
+        const u32 tag = (u32)lazy.size();
+        for (u32 j = 0; j < n; j++) owner[at + j] = tag;
+        lazy_open++, lazy_total++;
+        return true;
     }
     MemBuf() {
         {  // an arena released by an earlier run: its pages are already resident
@@ -595,6 +629,24 @@ struct MainMem {  // Memory: grows on write, write-once cells
         if (__builtin_expect(v == UNDEF && m.lazy_open, 0)) return m.lazy_cell(i);  // (a deferred Poseidon call defines it: MemBuf)
         return v;
     }
+    // the pointee of a DEREF whose result is unknown: a cell that holds a LATE input word (MemBuf kind 2) reads as None — the
+    // instruction then does nothing and resolve_deref_hints fills the result at the end of the run, exactly as for a cell that is not
+    // defined yet (a range check on a small value lands on the public input: it must not wait for it).  Counted as a deferred check:
+    // an error met afterwards repeats the run with everything executed at once.
+    u32 peek_pointee(u64 i) const {
+        m.guard(i);
+        if (i >= m.len) return UNDEF;
+        const u32 v = m.p[i];
+        if (__builtin_expect(v == UNDEF && m.lazy_open, 0)) {
+            const u32 o = m.owner[i];
+            if (o && m.lazy[o - 1].kind == 2 && !m.lazy[o - 1].done) {
+                m.lazy_checks++;
+                return UNDEF;
+            }
+            return m.lazy_cell(i);
+        }
+        return v;
+    }
     bool set(u64 i, u32 v, Err& e) {
         m.guard(i);
         if (i >= m.len) {
@@ -616,6 +668,10 @@ struct MainMem {  // Memory: grows on write, write-once cells
         return true;
     }
 };
+// late words of a hint entry (Witness::late): MainMem keeps the cells pending, anything else waits for the words
+inline bool mem_set_late(MainMem& mm, u64 at, const u32* src, u32 n) { return mm.m.lazy_late(at, src, n); }
+struct SegMem;
+inline bool mem_set_late(SegMem&, u64, const u32*, u32) { return false; }
 struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, own slice writable, other writes deferred
     const u32* shared;
     u64 shared_len;
@@ -627,6 +683,7 @@ struct SegMem {  // SegmentMemory (memory.rs:118-189): shared prefix read-only, 
         const u64 o = i - seg_start;
         return o < seg_len ? seg[o] : UNDEF;
     }
+    u32 peek_pointee(u64 i) const { return peek(i); }
     bool set(u64 i, u32 v, Err& e) {
         if (i < seg_start || i - seg_start >= seg_len) {
             deferred->push_back(std::pair<u64, u32>(i, v));
@@ -750,6 +807,7 @@ struct Witness {
     const u64* name_begin;
     const u64* entry_offset;
     const u32* data;
+    const VmLate* late = nullptr;  // words of `data` that are not final yet (the sequential runner only: MainMem::set_late)
 };
 
 template <class Mem>
@@ -891,8 +949,25 @@ struct Machine {
                     if (err.set) return;
                     dest = usize(p);
                 }
-                for (u64 k = w.entry_offset[e]; k < w.entry_offset[e + 1]; k++)
+                for (u64 k = w.entry_offset[e]; k < w.entry_offset[e + 1]; k++) {
+                    if (__builtin_expect(w.late != nullptr, 0)) {  // words still being computed: their cells stay pending (VmLate)
+                        u32 r = 0;
+                        while (r < w.late->n_ranges && w.late->first_word[r] != k) r++;
+                        if (r < w.late->n_ranges && k + w.late->n_words[r] <= w.entry_offset[e + 1]) {
+                            const u32 n = w.late->n_words[r];
+                            if (mem_set_late(mem, dest, w.data + k, n)) {
+                                dest += n, k += n - 1;
+                                continue;
+                            }
+                            if (vm_times()) fprintf(stderr, "[vm] late hint words written to cell %llu could not stay pending: waiting\n", (unsigned long long)dest);
+                            w.late->wait();  // (not deferrable here: the words are needed now)
+                        } else {
+                            for (u32 q = 0; q < w.late->n_ranges; q++)
+                                if (k > w.late->first_word[q] && k < w.late->first_word[q] + w.late->n_words[q]) w.late->wait();
+                        }
+                    }
                     if (!mem.set(dest++, w.data[k], err)) return;
+                }
                 break;
             }
             case LM_VM_HINT_DEBUG_ASSERT: {
@@ -1202,7 +1277,7 @@ struct Machine {
                     }
                     const u32 p = need_mem(fp + in.a);
                     if (err.set) return;
-                    const u32 v = mem.peek(usize(p) + in.b);
+                    const u32 v = mem.peek_pointee(usize(p) + in.b);
                     if (v != UNDEF && !mem.set(fp + in.c, v, err)) return;
                     // else: a range check, resolved by resolve_deref_hints
                 } else {
@@ -2067,6 +2142,7 @@ bool decode_instruction(const u32* row, Instr& in, std::string& why) {
 }  // namespace lmh
 
 namespace lmh {
+void vm_set_late(const VmLate* late) { g_vm_late = late; }
 void vm_execution_regions(const lmh_execution* e, VmRegion out[5]) {
     out[0] = {(void*)e->memory.data(), (size_t)MAX_MEMORY * 4};
     out[1] = {(void*)e->tr.pcs.data(), e->tr.pcs.cap * sizeof(u32)};
@@ -2169,6 +2245,14 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
         ex = new lmh_execution();
         PoolSession session(n_threads);  // the pool stays hot from here to the end of the run
         Witness w{witness->preamble_memory_len, witness->name_entry_begin, witness->entry_offset, witness->data};
+        const VmLate* late = g_vm_late;  // (vm_set_late: this run's inputs are not all final yet)
+        g_vm_late = nullptr;
+        struct LateGuard {  // whatever way the run ends, its caller reads the inputs afterwards: they are final by then
+            const VmLate* l;
+            ~LateGuard() {
+                if (l && l->wait) l->wait();
+            }
+        } late_guard{late};
         // execute_bytecode_helper (runner.rs:238-343)
         u64 pub = 1;
         while (pub < n_public_input) pub <<= 1;  // padd_with_zero_to_next_power_of_two (0usize.next_power_of_two() == 1: one zero word)
@@ -2205,6 +2289,25 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             memory.lazy_on = D != nullptr;
         if (!allow_deferred || (memory.lazy_on && !memory.lazy_alloc())) memory.lazy_on = false;
         memory.lazy_rows = &ex->tr.ext;
+        if (late) {
+            if (!memory.lazy_on || !late->wait) {  // nothing is deferred in this run: the inputs are awaited here
+                if (late->wait) late->wait();
+                if (n_public_input) memcpy(memory.p, public_input, 4ull * n_public_input);
+            } else {
+                memory.late_wait = late->wait;
+                w.late = late;
+                if (late->public_input && n_public_input) {
+                    for (u32 i = 0; i < n_public_input; i++) memory.p[i] = UNDEF;
+                    bool ok = true;
+                    for (u32 at = 0; at < n_public_input && ok; at += 64) ok = memory.lazy_late(at, public_input + at, std::min<u32>(64, n_public_input - at));
+                    if (!ok) {
+                        late->wait();
+                        memory.lazy_drain();
+                        memcpy(memory.p, public_input, 4ull * n_public_input);
+                    }
+                }
+            }
+        }
         bool device_failed = false;
         static const bool rearm_env = !(getenv("LM_VM_REARM") && getenv("LM_VM_REARM")[0] == '0');
         const bool rearm = allow_deferred && rearm_env;  // (the repeated run that reports an error is the reference's, literally)
@@ -2252,6 +2355,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             // without deferred work reports
             if (vm_times()) fprintf(stderr, "[vm] deferred checks: the run is repeated with every instruction executed at once\n");
             delete ex;
+            if (late && late->wait) late->wait();  // (the repeated run reads the inputs as they are)
             return execute_impl(ctx, bc, public_input, n_public_input, witness, n_threads, out, false);
         }
         if (memory.touch_failed) device_failed = true;
@@ -2290,6 +2394,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             if (!ok) {
                 delete ex;
                 if (!anomaly) return LM_E_DEVICE;
+                if (late && late->wait) late->wait();
                 const int rc = execute_impl(nullptr, bc, public_input, n_public_input, witness, n_threads, out);
                 if (rc == LM_OK && *out) (*out)->run_repeated = 1, (*out)->host_batch_reason = "resolve_deref_hints met a conflict / an undefined source on the device: the run was repeated on the host";
                 return rc;

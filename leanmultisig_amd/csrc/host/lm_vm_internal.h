@@ -35,6 +35,20 @@ struct VmDeviceView {
     u64 public_memory_size;
 };
 bool vm_execution_device(const lmh_execution* e, VmDeviceView* out);
+// Words of a run's inputs that are still being computed when the run starts (lmh_aggregate_type_1: the hash of the public keys inside
+// the `input_data` hint and the public input, a 0.65 ms hash chain that nothing in the program reads before its last instructions).
+// The sequential runner treats them like the outputs of a deferred Poseidon call (MemBuf): the cells they are written to stay None
+// with an owner, whatever depends on them is deferred behind them, and the first real access — normally the drain under the device
+// batch — calls wait().  A run that does not defer (LM_VM_LAZY=0, no device, the repeated run after an error) waits before it starts.
+struct VmLate {
+    u32 n_ranges = 0;
+    u64 first_word[4] = {0, 0, 0, 0};  // index into the witness's data words (a range lies inside one hint entry)
+    u32 n_words[4] = {0, 0, 0, 0};     // 1 .. 64
+    bool public_input = false;         // the public-input buffer handed to the run is late as a whole
+    std::function<void()> wait;        // returns once every late word holds its final value (idempotent, called on the run's thread)
+};
+// applies to the NEXT run started on the calling thread (lmh_execute_bytecode{,_device}); cleared by that run
+void vm_set_late(const VmLate* late);
 // called with a buffer's base address right before the runner frees or moves it (lm_node.cpp unpins it there)
 void vm_set_release_hook(void (*hook)(void* base));
 }  // namespace lmh

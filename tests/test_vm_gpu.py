@@ -73,6 +73,27 @@ def test_aggregate_type_1_whole_function(ctx, program, n_sigs):
         assert not d["vm_on_device"] and d["host_batches"] == 1 and "segments" in d["fallback_reason"]
 
 
+def test_aggregate_type_1_late_inputs_error_paths(ctx, program):
+    """lmh_aggregate_type_1 starts the VM while hash_pubkeys is still running (the digest inside `input_data` and the public input are
+    late words of the run, lmh::VmLate).  A forged signature makes a segment fail, the batch moves to the host pool and the run is
+    repeated with everything executed at once — all of which read the late words: the error must be the runner's, and the same
+    context must prove the honest set afterwards (proof == the witness-first path's)."""
+    n = 70
+    pi, w, info = xa.build_witness(program, n, np.random.default_rng(4321))
+    lm_builder = lm.WhirBuilder.default(1, security_level=60, pow_bits=6)
+    raw = vm.pack_xmss_signatures(info["sig"])
+    bad = raw.copy()
+    bad[17, 8 + 6 + 3] ^= 1  # a chain tip of signature 17 (behind the public key and the randomness)
+    pr = lm.Prover(ctx)
+    with pytest.raises(lm.LmError, match="lmh_execute_bytecode"):
+        vm.aggregate_type_1(ctx, pr, program, bad, info["message"], info["slot"], lm_builder)
+    ref = lm.Prover(ctx)
+    vm.prove_execution_vm(ctx, ref, program, pi, w, lm_builder)
+    pr = lm.Prover(ctx)
+    times, run = vm.aggregate_type_1(ctx, pr, program, raw[::-1].copy(), info["message"], info["slot"], lm_builder)
+    assert np.array_equal(pr.proof(), ref.proof()) and run.to_dict()["vm_on_device"]
+
+
 def test_runner_error_surfaces(ctx, program):
     pi, w, info = xa.build_witness(program, 3, np.random.default_rng(2))
     bad = pi.copy()

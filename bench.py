@@ -622,7 +622,8 @@ def main():
                             + (" (CapacityBound: prox-gaps-conjecture)" if capacity else "")
                             + ("" if args.scale_log == 0 else f" [SCALED DOWN by 2^{args.scale_log}]"),
                 "value_definition": "WHOLE NODE: signatures of one leaf x ranks / latency of one aggregate_type_1 — from the unsorted (public key, signature) "
-                                    "pairs in host memory (sort + dedup, hash_pubkeys, tweak table + hash, public-input buffer + hash, hint map) through "
+                                    "pairs in host memory (sort + dedup, hash_pubkeys, tweak table + hash, public-input buffer + hash, hint map; since round 5 hash_pubkeys "
+                                    "and the public-input hash run on a helper thread BESIDE the VM, which takes their 16 words as late inputs: LM_INPUTS_EAGER=1 restores hashes-then-VM) through "
                                     "the VM run and the trace to the pruned proof (the reference's n_xmss / mean elapsed of one aggregate_type_1, "
                                     "rec_aggregation/src/benchmark.rs:397-431); `hot_path` = the same without the VM "
                                     "run and the trace build; `inflight` = the throughput with several independent leaves queued on the same GPU",

@@ -303,7 +303,10 @@ int lm_logup_build_active(lm_ctx* ctx, const lm_logup_section* sections, uint32_
  * being relaunched, so any other call that launches work on the same context would queue behind it — it
  * fails after the resident kernel's 3 s timeout and the layer is lost.  Use another lm_ctx for concurrent work (the
  * reference's prove_gkr_quotient does nothing else between the rounds of a layer either).  lm_gkr_free / a new
- * lm_gkr_layer_begin dismiss a resident kernel at once.  LM_GKR_NO_TAIL=1 (environment) restores one launch per round pair. */
+ * lm_gkr_layer_begin dismiss a resident kernel at once.  LM_GKR_NO_TAIL=1 (environment) restores one launch per round pair.
+ * Before the arrays are that small, the NEXT launch of the layer is enqueued behind the current one ahead of its two challenges and
+ * receives them as a message on the device (csrc/lm_common.h: lm_mail_*); it is dismissed the same way when the layer is abandoned
+ * (lm_gkr_free / lm_gkr_layer_begin) and gives up by itself after 3 s.  LM_GKR_NO_AHEAD=1 launches only when the challenges exist. */
 typedef struct lm_gkr lm_gkr;
 int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, lm_gkr** out);
 /* Same with an ACTIVE PREFIX: entries [active_len, 2^n_vars) are the neutral pair (0, 1) and are never read (they need not

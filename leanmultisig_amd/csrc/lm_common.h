@@ -45,7 +45,6 @@ void lm_set_error(const char* fmt, ...);
 struct lm_ctx {
     unsigned long long uid = 0;  // process-unique: objects that outlive a context (a device-resident lmh_execution) find out through lm_ctx_by_uid
     int device = 0;
-    int n_cus = 256;  // compute units of the device (occupancy-aware launch shapes)
     hipStream_t stream = nullptr;
     u32* d_tw = nullptr;        // 2^(LM_TW_LOG-1) words
     u32* d_tw_small = nullptr;  // 2^LM_TW_SMALL_LOG words

@@ -717,10 +717,6 @@ int lm_ctx_create(int device, lm_ctx** out) {
 }
 static int ctx_create_impl(int device, lm_ctx* c) {
     c->device = device;
-    {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->n_cus = n;
-    }
     LM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LM_HIP(hipMalloc(&c->d_tw, (1ull << (LM_TW_LOG - 1)) * 4));
     LM_HIP(hipMalloc(&c->d_tw_small, (1ull << LM_TW_SMALL_LOG) * 4));

@@ -5,6 +5,8 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <csignal>
+#include <unistd.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef uint32_t u32;
 
@@ -84,11 +86,34 @@ int main() {
         auto t1 = std::chrono::steady_clock::now();
         printf("launch per exchange: %.2f us per exchange\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / n);
     }
-    // the same with the down mailbox in fine-grained DEVICE memory written by the host through the BAR (if the runtime allows it)
+    // the same with the down mailbox in fine-grained DEVICE memory written by the host through the BAR (if the runtime allows it):
+    // the kernel then polls its own HBM instead of reading host memory over PCIe, the host's message is a posted write
     u32* dmb = nullptr;
     if (hipExtMallocWithFlags((void**)&dmb, 4096, hipDeviceMallocFinegrained) == hipSuccess && dmb) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, dmb) == hipSuccess) printf("fine-grained device memory: host pointer %p device pointer %p\n", a.hostPointer, a.devicePointer);
+        CHECK(hipMemset(dmb, 0, 4096));
+        CHECK(hipDeviceSynchronize());
+        signal(SIGSEGV, [](int) { const char m[] = "host write to fine-grained device memory: SIGSEGV (not host-accessible)\n"; (void)!write(1, m, sizeof m - 1); _exit(0); });
+        signal(SIGBUS, [](int) { const char m[] = "host write to fine-grained device memory: SIGBUS\n"; (void)!write(1, m, sizeof m - 1); _exit(0); });
+        volatile u32* d = dmb;
+        d[64] = 7;  // probe
+        printf("host write to fine-grained device memory works (read back %u)\n", d[64]);
+        for (int rep = 0; rep < 3; rep++) {
+            *up_flag = 0;
+            d[256] = 0;
+            auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(k_resident, dim3(1), dim3(1024), 0, s, h, h + 128, (const u32*)dmb + 192, (const u32*)dmb + 256, n, h + 320);
+            for (u32 it = 1; it <= n; it++) {
+                while (*up_flag != it) __builtin_ia32_pause();
+                for (int i = 0; i < 16; i++) d[192 + i] = h[i] ^ it;
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                d[256] = it;
+            }
+            CHECK(hipStreamSynchronize(s));
+            auto t1 = std::chrono::steady_clock::now();
+            printf("resident, mailbox in device memory: %.2f us per exchange (err %u)\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / n, h[320]);
+        }
     } else {
         printf("hipExtMallocWithFlags(finegrained) failed\n");
     }

@@ -2277,10 +2277,12 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             D->ctx_uid = lm_ctx_uid(ctx);
             ex->dev = D;
             memory.on_touch = [D, &memory] { return dev_close_windows(*D, memory); };
+            const double tw0 = vm_now_ms();
             if (!dev_witness(*D, witness)) {  // the hint streams travel while the sequential head of the program runs
                 delete ex;
                 return LM_E_DEVICE;
             }
+            if (vm_times()) fprintf(stderr, "[vm] hint streams: upload enqueued in %.3f ms\n", vm_now_ms() - tw0);
         }
         // deferred Poseidon calls (MemBuf) pay off when a batch runs on the device; LM_VM_LAZY=1 / 0 forces them on (host runs too) / off
         if (const char* e = getenv("LM_VM_LAZY"))
@@ -2319,6 +2321,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             if (rc == 0) break;
             if (rc < 0) break;
             const double tb = vm_now_ms();
+            if (vm_times() && n_batches == 0) fprintf(stderr, "[vm] sequential head: %.3f ms until the first batch\n", tb - t_start);
             int how = DEV_FALLBACK;
             std::string why = ctx ? "LM_VM_HOST is set" : "no device context (lmh_execute_bytecode)";
             const bool extra = n_batches > 0;  // a batch the reference runs sequentially (Machine::run, skip_arm_pc)

@@ -576,7 +576,8 @@ struct UVec {
 // a deferred ExtensionOp check (exec_multi_row, exec.rs:106-190, with every operand defined): the values of its rows, result == c
 inline void MemBuf::lazy_execute_check(LazyCall& c) {
     const u64 size = c.size, a_stride = c.is_be ? 1 : 5;
-    std::vector<EF> elems(size), vbs(size), comp(size);
+    static thread_local std::vector<EF> elems, vbs, comp;  // (size <= 256 for a deferred check)
+    elems.resize(size), vbs.resize(size), comp.resize(size);
     for (u64 i = 0; i < size; i++) {
         EF a, b;
         if (c.is_be)
@@ -1181,7 +1182,11 @@ struct Machine {
         const u64 a_stride = is_be ? 1 : 5;
         // `size` comes from the bytecode (< 2^25): the operand vectors grow as the operands are read, so a size that runs off the
         // defined memory fails with UndefinedMemory before anything of its order is allocated
-        std::vector<EF> elems, vbs;
+        // (scratch kept per thread: the recursion program runs tens of thousands of short calls on the host, three heap
+        // allocations each were a third of their cost)
+        static thread_local std::vector<EF> elems, vbs, comp;
+        if (elems.capacity() > (1u << 16)) elems = std::vector<EF>(), vbs = std::vector<EF>(), comp = std::vector<EF>();  // (after a rare long call)
+        elems.clear(), vbs.clear();
         elems.reserve(std::min<u64>(size, 1u << 12)), vbs.reserve(std::min<u64>(size, 1u << 12));
         for (u64 i = 0; i < size; i++) {
             EF a, b;
@@ -1195,7 +1200,7 @@ struct Machine {
             elems.push_back(compute_elem(a, b, op));
             vbs.push_back(b);
         }
-        std::vector<EF> comp(size);
+        comp.resize(size);
         comp[size - 1] = elems[size - 1];
         for (u64 i = size - 1; i-- > 0;) comp[i] = op == OP_POLY_EQ ? kb::ef_mul(elems[i], comp[i + 1]) : kb::ef_add(elems[i], comp[i + 1]);
         if (!set_ef(pr, comp[0])) return;

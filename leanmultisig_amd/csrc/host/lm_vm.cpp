@@ -37,7 +37,21 @@
 #include "lm_vm_device.h"
 
 namespace lmh {
-static thread_local const VmLate* g_vm_late = nullptr;  // vm_set_late: inputs of the next run on this thread that are not final yet
+static thread_local const VmLate* g_vm_late = nullptr;
+static thread_local unsigned long long g_vm_prof[4] = {0, 0, 0, 0};  // rdtsc ticks / calls: Poseidon16, ExtensionOp (LM_VM_TIMES)
+static bool g_vm_prof_on = getenv("LM_VM_TIMES") != nullptr;
+static void vm_prof_report() {
+    static const double ticks_per_ms = [] {
+        const auto t0 = std::chrono::steady_clock::now();
+        const unsigned long long c0 = __builtin_ia32_rdtsc();
+        while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
+        }
+        return (double)(__builtin_ia32_rdtsc() - c0) / std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }();
+    fprintf(stderr, "[vm] this thread's precompile calls: Poseidon16 %llu in %.3f ms, ExtensionOp %llu in %.3f ms\n", g_vm_prof[1], g_vm_prof[0] / ticks_per_ms,
+            g_vm_prof[3], g_vm_prof[2] / ticks_per_ms);
+    g_vm_prof[0] = g_vm_prof[1] = g_vm_prof[2] = g_vm_prof[3] = 0;
+}  // vm_set_late: inputs of the next run on this thread that are not final yet
 
 // ---------------------------------------------------------------------------------------------------------------------
 // thread pool: parallel_for(n, f) runs f(i) for i < n on the calling thread + the workers, dynamic scheduling
@@ -1320,7 +1334,13 @@ struct Machine {
                 if (err.set) return;
                 const u32 c = need(in.mc, in.c, in.cm);
                 if (err.set) return;
-                if (in.kind == K_POSEIDON)
+                if (__builtin_expect(g_vm_prof_on, 0)) {  // LM_VM_TIMES: where the sequential runner's time goes (the calling thread's totals)
+                    const unsigned long long t0 = __builtin_ia32_rdtsc();
+                    if (in.kind == K_POSEIDON)
+                        poseidon(in, a, b, c), g_vm_prof[0] += __builtin_ia32_rdtsc() - t0, g_vm_prof[1]++;
+                    else
+                        extension_op(in, a, b, c), g_vm_prof[2] += __builtin_ia32_rdtsc() - t0, g_vm_prof[3]++;
+                } else if (in.kind == K_POSEIDON)
                     poseidon(in, a, b, c);
                 else
                     extension_op(in, a, b, c);
@@ -2397,7 +2417,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             bool anomaly = false;
             const bool ok = device_finalize(ex, *D, anomaly);
             if (vm_times())
-                fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, device assembly + resolve_deref_hints %.2f ms%s\n", t_loop - t_start - t_batches,
+                vm_prof_report(), fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, device assembly + resolve_deref_hints %.2f ms%s\n", t_loop - t_start - t_batches,
                         t_batches, vm_now_ms() - t_resolve, anomaly ? " (anomaly: the run is repeated on the host)" : "");
             if (!ok) {
                 delete ex;
@@ -2438,7 +2458,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             memcpy(mem + n + 16, st, 32);
         }
         if (vm_times())
-            fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, resolve_deref_hints %.2f ms, defined mask %.2f ms\n",
+            vm_prof_report(), fprintf(stderr, "[vm] sequential parts %.2f ms, batches %.2f ms, resolve_deref_hints %.2f ms, defined mask %.2f ms\n",
                     t_loop - t_start - t_batches, t_batches, t_resolve - t_loop, vm_now_ms() - t_resolve);
     } catch (const std::bad_alloc&) {
         delete ex;

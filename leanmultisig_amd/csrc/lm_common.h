@@ -262,6 +262,7 @@ kb::u32 lm_mail_reserve(lm_ctx* ctx);
 void lm_mail_post(lm_ctx* ctx, kb::u32 no, const kb::u32 r0[5], const kb::u32 r1[5]);
 int lm_mail_abort(lm_ctx* ctx);
 static inline const kb::u32* lm_mail_line(const lm_ctx* ctx) { return ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE; }
+size_t lm_ctx_live_count();  // contexts alive in this process
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 // the same on flag word h_res[RES_FLAG + 1 + aux] (aux >= 0), published by work on aux_stream[aux]
 int lm_wait_result_aux(lm_ctx* ctx, int aux, kb::u32 seq);

@@ -38,6 +38,11 @@ static void ctx_register(lm_ctx* c) {
     c->uid = g_ctx_next_uid++;
     g_ctx_live[c->uid] = c;
 }
+// contexts alive in this process (launch-ahead, lm_gkr.hip, is for a prover that has the device to itself)
+size_t lm_ctx_live_count() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    return g_ctx_live.size();
+}
 static void ctx_unregister(lm_ctx* c) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     g_ctx_live.erase(c->uid);

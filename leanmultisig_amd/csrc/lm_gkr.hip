@@ -52,6 +52,7 @@ struct lm_gkr {
     u32* d_merge = nullptr;      // hand-over scratch of a multi-workgroup tail
     // the next launch of the layer, enqueued ahead of its two challenges (gkr_shoot with a mail number)
     bool ahead = false;
+    bool ahead_ok = false;  // decided per layer (lm_gkr_layer_begin): this prover has the device to itself
     struct GkrShotT {
         u32 t, F, p, seq, mail_no;
         u64 m_out, n_threads;
@@ -826,6 +827,7 @@ void gkr_tail_dismiss(lm_ctx* ctx, lm_gkr* g) {
 EF quad_at(const EF& a, const EF& b, const EF& c, const EF& r) { return ef_add(a, ef_mul(r, ef_add(b, ef_mul(r, c)))); }
 }  // namespace
 static void gkr_ahead_drop(lm_ctx* ctx, lm_gkr* g);
+static bool gkr_launch_ahead_enabled(lm_ctx* ctx);
 
 extern "C" {
 
@@ -945,6 +947,7 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
     LM_REQUIRE(ctx && g && point && alpha && K >= 5 && K < g->n_vars);
     gkr_ahead_drop(ctx, g);
     gkr_tail_dismiss(ctx, g);
+    g->ahead_ok = gkr_launch_ahead_enabled(ctx);
     g->K = K;
     g->round = 0;
     g->cur = -1;
@@ -1104,9 +1107,24 @@ static void gkr_ahead_drop(lm_ctx* ctx, lm_gkr* g) {
     }
     g->ahead = false;
 }
-static bool gkr_launch_ahead_enabled() {  // LM_GKR_NO_AHEAD=1: every launch waits for its challenges on the host (A/B measurements)
+// Launch-ahead is for a prover that has the device to itself.  A launch that waits for its message holds its wave slots while it
+// waits; with ten provers in flight the chip never drains, and a 1024-thread workgroup of a resident tail — which needs sixteen free
+// wave slots on ONE compute unit — can be starved of a slot until the rest of its tail gives up (seen once in 1200 proofs of ten
+// concurrent provers: "sequence never published", after the 3 s timeout; never with one launch per exchange).  So: only when this is
+// the process's only context and no other process is registered on the device (the tails' shared counter knows them).
+// LM_GKR_NO_AHEAD=1 switches it off altogether (A/B measurements).
+static bool gkr_launch_ahead_enabled(lm_ctx* ctx) {
     static const bool on = getenv("LM_GKR_NO_AHEAD") == nullptr;
-    return on;
+    if (!on || lm_ctx_live_count() != 1) return false;
+    TailCounter* c = tail_counter(ctx->device);
+    if (c->sh) {
+        const int me = (int)getpid();
+        for (auto& sl : c->sh->slots) {
+            const int pid = sl.pid.load(std::memory_order_relaxed);
+            if (pid && pid != me && !(kill(pid, 0) != 0 && errno == ESRCH)) return false;  // (a slot of a process that is gone does not count)
+        }
+    }
+    return true;
 }
 
 int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
@@ -1172,7 +1190,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     }
     // The launch after this one (two rounds on: F = 2) reads what this one leaves; enqueue it now, behind this one, when this one is a
     // launch (a live tail takes messages instead) and the layer has rounds left for it
-    if (!sh.tail && t + 2 < g->K && gkr_launch_ahead_enabled()) {
+    if (!sh.tail && t + 2 < g->K && g->ahead_ok) {
         const u32 no = lm_mail_reserve(ctx);
         rc = gkr_shoot(ctx, g, t + 2, 2, F ? sh.dst : g->cur, sh.m_out, F ? sh.n_threads : g->arr_valid, ef_zero(), ef_zero(), no, &g->ahead_shot);
         if (rc) {

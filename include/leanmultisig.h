@@ -70,6 +70,10 @@ uint64_t lm_profile_names(lm_ctx* ctx, char* buf, uint64_t cap);
  * lm_wait_log_read copies up to `cap` entries and returns how many there are. */
 int lm_wait_log(lm_ctx* ctx, int on);
 uint64_t lm_wait_log_read(lm_ctx* ctx, float* out_us, uint64_t cap);
+/* How often this context re-ran a GKR layer with one launch per exchange because a resident kernel (the tail of a layer, a launch
+ * enqueued ahead of its challenges) never got its wave slots on a shared device: an internal scheduling event, not a prover error —
+ * the proof is unchanged (lm_gkr_round). */
+uint32_t lm_soft_fallbacks(const lm_ctx* ctx);
 
 int lm_malloc(lm_ctx* ctx, uint64_t n_words, uint32_t** d_out);
 int lm_free(lm_ctx* ctx, uint32_t* d_ptr);

@@ -32,6 +32,7 @@ _SIGS = {
     "lm_profile_names": (C.c_uint64, [vp, vp, C.c_uint64]),
     "lm_wait_log": (C.c_int, [vp, C.c_int]),
     "lm_wait_log_read": (C.c_uint64, [vp, vp, C.c_uint64]),
+    "lm_soft_fallbacks": (C.c_uint32, [vp]),
     "lm_profile_read": (C.c_int, [vp, C.c_char_p, u64p, C.POINTER(C.c_double)]),
     "lm_profile_busy_ms": (C.c_double, [vp]),
     "lm_profile_read_bytes": (C.c_uint64, [vp, C.c_char_p]),
@@ -616,6 +617,10 @@ class Context:
         if n:
             self.lib.lm_wait_log_read(self.h, out.ctypes.data, n)
         return out
+
+    def soft_fallbacks(self):
+        """GKR layers this context re-ran with one launch per exchange (a resident kernel never got its slots): lm_soft_fallbacks"""
+        return int(self.lib.lm_soft_fallbacks(self.h))
 
     # ---- memory -------------------------------------------------------------------------------------
     def alloc(self, n_words):

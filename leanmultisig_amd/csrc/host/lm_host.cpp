@@ -1070,6 +1070,21 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     std::vector<u32> launch_order(n_tables);
     for (u32 i = 0; i < n_tables; i++) launch_order[i] = i;
     std::stable_sort(launch_order.begin(), launch_order.end(), [&](u32 a, u32 b) { return tables[a].table > tables[b].table; });
+    // A session's FIRST round depends on no challenge of the batch (its eq point and alpha are known before round 0), only its later
+    // ones do: the base-field rounds of the tables that join late (Poseidon16: five launches, 0.42 ms on the default workload) are
+    // enqueued at once, tallest table first, and run beside the rounds the tallest table does alone; their sums wait in the session's
+    // slice of the pinned buffer until the session joins.  (LM_AIR_NO_EARLY_FIRST=1: launch when the session joins, for A/B.)
+    static const bool early_first = getenv("LM_AIR_NO_EARLY_FIRST") == nullptr;
+    if (early_first) {
+        std::vector<u32> by_height(n_tables);
+        for (u32 i = 0; i < n_tables; i++) by_height[i] = i;
+        std::stable_sort(by_height.begin(), by_height.end(), [&](u32 a, u32 b) { return ss[a].n_vars > ss[b].n_vars; });
+        for (u32 i : by_height) {
+            int rc = lm_air_round_launch(ctx, ss[i].h);
+            if (rc) return cleanup(rc);
+            launched[i] = true;
+        }
+    }
     for (u32 round = 0; round < n_rounds; round++) {
         std::vector<EF> combined(max_full_degree + 1, kb::ef_zero());
         std::vector<std::vector<EF>> bare(n_tables);
@@ -1133,11 +1148,11 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
             const u32 i = launch_order[oi];
             Session& s = ss[i];
             const u32 join = n_rounds - s.n_vars;
-            launched[i] = false;
-            if (round < join) {
+            if (round < join) {  // (not joined yet: its first round may already be in flight)
                 k[i] = kb::ef_mul(k[i], ch);
                 continue;
             }
+            launched[i] = false;
             // process_challenge
             const EF a = s.eq_factor.back();
             const EF eq_eval = kb::ef_add(kb::ef_mul(kb::ef_sub(kb::ef_one(), a), kb::ef_sub(kb::ef_one(), ch)), kb::ef_mul(a, ch));

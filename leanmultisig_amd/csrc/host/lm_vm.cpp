@@ -1792,7 +1792,8 @@ enum { DEV_DONE = 0, DEV_FALLBACK = 1, DEV_ERROR = 2 };
 // handle_parallel_batch with the segments on the device.  DEV_FALLBACK: nothing of the run's state has changed in a way the host
 // batch would notice — the caller runs handle_parallel_batch (which also reports every RunnerError: the device never does).
 int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& memory, Trace& trace, Cursors& cur, u64& pc, u64& fp, u64& ap,
-                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D, std::string& why, bool trim_last_frame = false) {
+                 const Machine<MainMem>::Batch& batch, u32 n_threads, DevRun& D, std::string& why, bool trim_last_frame = false,
+                 const VmLate* late = nullptr) {
     MainMem mm{memory};
     Err scratch;
     const double t0 = vm_now_ms();
@@ -1831,6 +1832,24 @@ int device_batch(const lmh_bytecode& bc, const lm_vm_witness* witness, MemBuf& m
     for (size_t k = 0; k < per_iter.size(); k++) per_iter[k] = cur.index[k] - batch.hint_indices_at_start[k];
     if (memory.touch_failed) return DEV_ERROR;
     if (!dev_program(D, bc) || !dev_witness(D, witness)) return DEV_ERROR;
+    // Late input words (VmLate): the device copy of the hint streams went up while a helper thread may still have been writing them
+    // (round-5 advisor finding: only the sequential runner honoured the late ranges).  A batch whose segments CONSUME entries of a stream
+    // that holds a late range must read the final words: wait for the helper and send the range again, stream-ordered in front of the
+    // segment kernels.  (The aggregation program reads its late words in its sequential head: per_iter is 0 for that stream.)
+    if (late && late->n_ranges) {
+        bool waited = false;
+        for (u32 r = 0; r < late->n_ranges; r++) {
+            const u64 w0 = late->first_word[r];
+            for (u32 k = 0; k < witness->n_names; k++) {
+                if (!per_iter[k]) continue;
+                const u64 e0 = witness->name_entry_begin[k], e1 = witness->name_entry_begin[k + 1];
+                if (e0 == e1 || w0 < witness->entry_offset[e0] || w0 >= witness->entry_offset[e1]) continue;
+                if (!waited && late->wait) late->wait();
+                waited = true;
+                if (vm_dev_upload(D.ctx, D.d_wit_data + w0, witness->data + w0, 4ull * late->n_words[r]) != LM_OK) return DEV_ERROR;
+            }
+        }
+    }
 
     // ---- host side of the batch: the memory grows to max_addr, the frame the sequential runner continues in gets its call frame.
     // The frames of the segments are NOT touched here: they exist in the device image only (window) until something reads them.
@@ -2350,7 +2369,7 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             int how = DEV_FALLBACK;
             std::string why = ctx ? "LM_VM_HOST is set" : "no device context (lmh_execute_bytecode)";
             const bool extra = n_batches > 0;  // a batch the reference runs sequentially (Machine::run, skip_arm_pc)
-            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D, why, extra);
+            if (D) how = device_batch(*bc, witness, memory, ex->tr, cur, m.pc, m.fp, m.ap, batch, n_threads, *D, why, extra, late);
             if (how == DEV_DONE)
                 ex->n_device_batches++;
             else if (how == DEV_FALLBACK) {

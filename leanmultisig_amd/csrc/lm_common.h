@@ -113,6 +113,8 @@ struct lm_ctx {
     // host <-> device exchanges (lm_wait_log): how long each lm_wait_result of the prover thread waited, in microseconds
     bool wait_log_on = false;
     std::vector<float> wait_us;
+    // GKR layers that were re-run with one launch per exchange because a resident kernel never got its wave slots (lm_gkr_round)
+    u32 soft_fallbacks = 0;
 };
 
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)
@@ -217,6 +219,7 @@ __device__ __forceinline__ void lm_publish_flag(kb::u32* h_res, kb::u32 seq) { l
 #endif
 #if defined(__HIPCC__)
 static constexpr kb::u32 LM_MAIL_ABORT = 0xdead0002u;
+static constexpr kb::u32 LM_MAIL_DISMISSED_BIT = 0x80000000u;
 static constexpr unsigned long long LM_MAIL_TIMEOUT = 300000000ull;  // wall_clock64 ticks (100 MHz): 3 s without the message = abandoned
 // Wait for message `no` (two challenges).  Every thread of the workgroup calls it; workgroup 0 polls the pinned line and relays the
 // eleven tagged words to d_relay with agent-scope stores, the others poll the relay (a message is accepted when its ten payload words
@@ -224,6 +227,9 @@ static constexpr unsigned long long LM_MAIL_TIMEOUT = 300000000ull;  // wall_clo
 // half-written line is refused).  lds: 16 words.  Returns false when the kernel was dismissed (word 11) or nothing came for 3 s.
 __device__ __forceinline__ bool lm_mail_receive(const kb::u32* __restrict__ h_line, kb::u32* __restrict__ d_relay, kb::u32 no,
                                                 kb::u32* lds, kb::EF& r0, kb::EF& r1) {
+    // A dismissal travels to the other workgroups in relay word 10 itself, as `no | LM_MAIL_DISMISSED_BIT` (message numbers stay below
+    // 2^31): ONE word, tied to the number this kernel waits for — a dismissal left behind by an earlier kernel names another number and is
+    // not honoured (round-5 advisor finding: a sticky abort word made every later launch leave without publishing).
     if (threadIdx.x < 64) {
         const kb::u32 lane = threadIdx.x;
         const bool first = blockIdx.x == 0;
@@ -237,12 +243,18 @@ __device__ __forceinline__ bool lm_mail_receive(const kb::u32* __restrict__ h_li
                           : __hip_atomic_load(d_relay + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool ok = lane < 10 ? (v >> 31) == (no & 1) : lane == 10 ? v == no : true;
             done = __ballot(ok) == ~0ull;
-            dismissed = __ballot(lane == 11 && v == LM_MAIL_ABORT) != 0 || wall_clock64() - t0 > LM_MAIL_TIMEOUT;
+            // (the clock is read by the scalar unit: the timeout decision is the same in every lane)
+            const bool late = (unsigned long long)__builtin_amdgcn_readfirstlane((int)((wall_clock64() - t0) > LM_MAIL_TIMEOUT)) != 0;
+            dismissed = __ballot(first ? (lane == 11 && v == LM_MAIL_ABORT) : (lane == 10 && v == (no | LM_MAIL_DISMISSED_BIT))) != 0 || late;
             if (dismissed) break;
             if (!done && !first) __builtin_amdgcn_s_sleep(4);
         }
-        if (first && lane < 12) {  // (an abort is relayed as well: word 11)
-            __hip_atomic_store(d_relay + lane, dismissed && lane == 11 ? LM_MAIL_ABORT : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (first) {
+            if (dismissed) {
+                if (lane == 10) __hip_atomic_store(d_relay + 10, no | LM_MAIL_DISMISSED_BIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane < 11) {
+                __hip_atomic_store(d_relay + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (lane < 16) lds[lane] = dismissed ? LM_MAIL_ABORT : (v & 0x7fffffffu);
     }
@@ -261,8 +273,10 @@ __device__ __forceinline__ bool lm_mail_receive(const kb::u32* __restrict__ h_li
 kb::u32 lm_mail_reserve(lm_ctx* ctx);
 void lm_mail_post(lm_ctx* ctx, kb::u32 no, const kb::u32 r0[5], const kb::u32 r1[5]);
 int lm_mail_abort(lm_ctx* ctx);
+void lm_mail_reset(lm_ctx* ctx);  // line and relay back to "no message, no dismissal" whatever the counters say (the stream must be idle)
 static inline const kb::u32* lm_mail_line(const lm_ctx* ctx) { return ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE; }
 size_t lm_ctx_live_count();  // contexts alive in this process
+void lm_gkr_register_process(int device);  // lm_gkr.hip: take this process's slot in the device's shared counter (lm_ctx_create)
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 // the same on flag word h_res[RES_FLAG + 1 + aux] (aux >= 0), published by work on aux_stream[aux]
 int lm_wait_result_aux(lm_ctx* ctx, int aux, kb::u32 seq);

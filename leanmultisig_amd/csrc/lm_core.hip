@@ -463,6 +463,13 @@ extern "C" uint64_t lm_wait_log_read(lm_ctx* ctx, float* out_us, uint64_t cap) {
 }
 int lm_wait_result(lm_ctx* ctx, u32 seq) { return lm_wait_result_aux(ctx, -1, seq); }
 int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
+    // While results are being deferred (lm_results_defer_begin) the head of the pinned buffer belongs to them: a call that publishes
+    // there and waits — every round kernel, lm_mle_eval_points, lm_tree_open, ... — would overwrite the first deferred result.  The
+    // header says "do not"; this makes a slip loud instead of a wrong transcript (lm_results_defer_end clears the flag before it waits).
+    if (aux < 0 && ctx->defer_on) {
+        lm_set_error("lm_wait_result: a result was published and awaited on the main flag while results are being deferred (lm_results_defer_begin .. _end)");
+        return LM_E_INVALID;
+    }
     volatile u32* flag = ctx->h_res + lm_ctx::RES_FLAG + (aux + 1);
     hipStream_t stream = aux < 0 ? ctx->stream : ctx->aux_stream[aux];
     // several publishers may be in flight on the stream (their sequence numbers increase): "at least seq" is the condition
@@ -572,6 +579,17 @@ int lm_mail_abort(lm_ctx* ctx) {
     LM_HIP(hipMemcpy(ctx->d_relay, img, sizeof img, hipMemcpyHostToDevice));
     return LM_OK;
 }
+
+void lm_mail_reset(lm_ctx* ctx) {
+    volatile u32* line = ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE;
+    const u32 last = ctx->mail_reserved, tag = (last & 1) << 31;
+    u32 img[lm_ctx::CMD_LINE_WORDS];
+    for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) img[i] = i < 10 ? tag : i == 10 ? last : 0;
+    for (u32 i = 0; i < lm_ctx::CMD_LINE_WORDS; i++) line[i] = img[i];
+    ctx->mail_posted = last;
+    (void)hipMemcpy(ctx->d_relay, img, sizeof img, hipMemcpyHostToDevice);
+}
+extern "C" uint32_t lm_soft_fallbacks(const lm_ctx* ctx) { return ctx ? ctx->soft_fallbacks : 0; }
 
 int lm_stage_alloc(lm_ctx* ctx, size_t bytes, void** out) {
     *out = nullptr;
@@ -767,6 +785,7 @@ static int ctx_create_impl(int device, lm_ctx* c) {
         LM_HIP(hipMalloc(&c->d_quad, QUAD_TAB_WORDS * 4));
         LM_HIP(hipMemcpy(c->d_quad, qt.data(), QUAD_TAB_WORDS * 4, hipMemcpyHostToDevice));
     }
+    lm_gkr_register_process(device);  // this process is on the device from now on (launch-ahead gate of the other provers, lm_gkr.hip)
     return LM_OK;
 }
 void lm_ctx_destroy(lm_ctx* c) {
@@ -971,16 +990,20 @@ int lm_ef_soa_to_aos(lm_ctx* ctx, const uint32_t* d_soa, uint32_t* d_aos, uint64
 
 // offset of the next result in the pinned buffer: 0 unless results are being deferred (then the slot is recorded for _end; a result
 // that no longer fits ends the deferral for this call: the earlier ones are collected first)
-static u32 defer_slot(lm_ctx* ctx, u32* out, u32 words) {
-    if (!ctx->defer_on) return 0;
+// (a failed collection of the earlier results fails this call too: their callers' buffers were not filled — round-5 advisor finding)
+static int defer_slot(lm_ctx* ctx, u32* out, u32 words, u32* at_out) {
+    *at_out = 0;
+    if (!ctx->defer_on) return LM_OK;
     if (ctx->defer_off + words > lm_ctx::RES_WORDS) {
-        (void)lm_results_defer_end(ctx);
+        const int rc = lm_results_defer_end(ctx);
+        if (rc) return rc;  // (deferral is off now: the caller's lm_results_defer_end is a no-op)
         ctx->defer_on = true;
     }
     const u32 at = ctx->defer_off;
     ctx->deferred.push_back({out, at, words});
     ctx->defer_off += words;
-    return at;
+    *at_out = at;
+    return LM_OK;
 }
 int lm_results_defer_begin(lm_ctx* ctx) {
     LM_REQUIRE(ctx && !ctx->defer_on);
@@ -1094,7 +1117,8 @@ int lm_mle_eval(lm_ctx* ctx, const uint32_t* d_evals, int is_ext, uint32_t n_var
     }
     const bool pinned = (u64)n_polys * 5 <= lm_ctx::RES_WORDS;
     if (pinned) {
-        const u32 at = defer_slot(ctx, out, n_polys * 5);
+        u32 at;
+        if ((rc = defer_slot(ctx, out, n_polys * 5, &at))) return rc;
         const u32 seq = ++ctx->res_seq;
         LM_LAUNCH(ctx, k_sum_partials, dim3(n_polys), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res + at, ctx->d_sync + 1, ctx->h_res,
                   seq);
@@ -1139,7 +1163,8 @@ int lm_mle_eval_cols(lm_ctx* ctx, const uint32_t* const* d_cols, uint32_t n_cols
     else
         LM_LAUNCH(ctx, k_mle_partial_cols<1>, dim3(n_hi, n_cols), dim3(256), 0, (const u32* const*)d_ptrs, n_cols, k_lo, d_eq_lo, d_eq_hi, n_hi,
                   d_partial);
-    const u32 at = defer_slot(ctx, out, n_cols * 5);
+    u32 at;
+    if ((rc = defer_slot(ctx, out, n_cols * 5, &at))) return rc;
     const u32 seq = ++ctx->res_seq;
     LM_LAUNCH(ctx, k_sum_partials, dim3(n_cols), dim3(256), 0, (const u32*)d_partial, n_hi, ctx->h_res + at, ctx->d_sync + 1, ctx->h_res, seq);
     LM_HIP(hipGetLastError());

@@ -10,6 +10,7 @@
 #include <fcntl.h>
 #include <signal.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -52,7 +53,13 @@ struct lm_gkr {
     u32* d_merge = nullptr;      // hand-over scratch of a multi-workgroup tail
     // the next launch of the layer, enqueued ahead of its two challenges (gkr_shoot with a mail number)
     bool ahead = false;
-    bool ahead_ok = false;  // decided per layer (lm_gkr_layer_begin): this prover has the device to itself
+    bool ahead_ok = false;  // decided per layer (lm_gkr_layer_begin) and re-checked per launch: this prover has the device to itself
+    // Fail soft (lm_gkr_round): the challenges of the layer in progress, so that the layer can be re-run from its storage with one launch
+    // per exchange when a resident kernel (a tail, a launch enqueued ahead) never got its wave slots; no_resident: this object has
+    // fallen back once and uses neither for the rest of its life.
+    std::vector<EF> history;
+    bool no_resident = false;
+    u32 exchanges_tail = 0, exchanges_ahead = 0;  // counted for the fault injection of the tests (LM_GKR_FAULT)
     struct GkrShotT {
         u32 t, F, p, seq, mail_no;
         u64 m_out, n_threads;
@@ -760,10 +767,16 @@ TailCounter* tail_counter(int device) {
     if (!getenv("LM_GKR_TAIL_PROCESS_LOCAL") && hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
         for (char* q = bus; *q; q++)
             if (*q == ':' || *q == '.') *q = '_';
-        char path[128];
-        snprintf(path, sizeof path, "/leanmultisig_tail_%s", bus);
-        const int fd = shm_open(path, O_RDWR | O_CREAT, 0666);
-        if (fd >= 0) {
+        // one file per user and device, readable and writable by that user only (the counts steer scheduling decisions: another
+        // local user must not be able to edit them; provers of different users do not see each other and are "foreign" to each
+        // other, which the launch-ahead gate below treats like any other tenant: the layer falls back if a resident kernel starves)
+        char path[160];
+        snprintf(path, sizeof path, "/leanmultisig_tail_%u_%s", (unsigned)geteuid(), bus);
+        const int fd = shm_open(path, O_RDWR | O_CREAT | O_NOFOLLOW, 0600);
+        struct stat st;
+        if (fd >= 0 && (fstat(fd, &st) != 0 || st.st_uid != geteuid() || (st.st_mode & 077) != 0)) {
+            close(fd);  // not ours alone: count per process
+        } else if (fd >= 0) {
             if (ftruncate(fd, sizeof(TailShared)) == 0) {  // (a new file is zero-filled: total 0, every slot free)
                 void* m = mmap(nullptr, sizeof(TailShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
                 if (m != MAP_FAILED) c.sh = (TailShared*)m;
@@ -777,13 +790,19 @@ TailCounter* tail_counter(int device) {
         for (int spins = 0; !sh->lock.compare_exchange_weak(z, 1, std::memory_order_acquire); z = 0)
             if (++spins > (1 << 22)) break;  // (a holder that died: proceed; the worst case is a share returned twice, i.e. a cap too lax)
         const int me = (int)getpid();
+        int live_sum = 0;
         for (auto& sl : sh->slots) {  // shares of processes that no longer exist go back
             const int pid = sl.pid.load();
             if (pid && pid != me && kill(pid, 0) != 0 && errno == ESRCH) {
                 sh->total.fetch_sub(sl.count.exchange(0));
                 sl.pid.store(0);
             }
+            const int cnt = sl.count.load();
+            if (cnt < 0 || cnt > 65536 || (cnt && !sl.pid.load())) sl.count.store(0);  // (nonsense left by a crash: a count without an owner)
+            live_sum += sl.count.load();
         }
+        // the total is what the slots add up to (checked whenever a process attaches: a file damaged by a crash heals here)
+        if (sh->total.load() != live_sum) sh->total.store(live_sum);
         for (int k = 0; k < 64 && c.slot < 0; k++) {
             int free_pid = 0;
             if (sh->slots[k].pid.load() == me || sh->slots[k].pid.compare_exchange_strong(free_pid, me)) c.slot = k;
@@ -956,6 +975,7 @@ int lm_gkr_layer_begin(lm_ctx* ctx, lm_gkr* g, uint32_t K, const uint32_t* point
     g->point.resize(K);
     for (u32 j = 0; j < K; j++) memcpy(g->point[j].v, point + 5 * j, 20);
     g->pending.clear();
+    g->history.clear();
     g->la_valid = false;
     g->fin_m = 0;
     // round t uses eq over point[0 .. p), p = K-1-t
@@ -995,7 +1015,7 @@ static int gkr_shoot(lm_ctx* ctx, lm_gkr* g, u32 t, u32 F, int cur, u64 m, u64 a
     sh.t = t, sh.F = F, sh.m_out = m_out, sh.la = la, sh.p = p, sh.dst = dst, sh.tail = false, sh.mail_no = mail_no;
     sh.tail_W = 1, sh.tail_S = 0, sh.tail_solo = true;
     u32 seq;
-    if (gkr_tail_enabled() && ctx->h_cmd && m_out <= gkr_tail_max_entries() && m_out >= 8 &&
+    if (gkr_tail_enabled() && !g->no_resident && ctx->h_cmd && m_out <= gkr_tail_max_entries() && m_out >= 8 &&
         gkr_tail_reserve(ctx, (u32)std::max<u64>(1, m_out / GKR_TAIL_SLICE))) {
         // the reservation is given back on every early return below (a leaked one would silently push later layers onto launches)
         struct TailReservation {
@@ -1116,18 +1136,36 @@ static void gkr_ahead_drop(lm_ctx* ctx, lm_gkr* g) {
 static bool gkr_launch_ahead_enabled(lm_ctx* ctx) {
     static const bool on = getenv("LM_GKR_NO_AHEAD") == nullptr;
     if (!on || lm_ctx_live_count() != 1) return false;
+    // LM_GKR_AHEAD_ASSUME_ALONE=1: the operator's word that no other prover process shares the device (also what the tests use to
+    // exercise launch-ahead from a child process while the parent holds a context)
+    static const bool assume = getenv("LM_GKR_AHEAD_ASSUME_ALONE") != nullptr;
+    if (assume) return true;
     TailCounter* c = tail_counter(ctx->device);
-    if (c->sh) {
-        const int me = (int)getpid();
-        for (auto& sl : c->sh->slots) {
-            const int pid = sl.pid.load(std::memory_order_relaxed);
-            if (pid && pid != me && !(kill(pid, 0) != 0 && errno == ESRCH)) return false;  // (a slot of a process that is gone does not count)
-        }
+    // No shared counter (shm unavailable or not private to this user, LM_GKR_TAIL_PROCESS_LOCAL): other provers cannot be seen, so this
+    // one does not assume it is alone (round-5 advisor finding).
+    if (!c->sh) return false;
+    const int me = (int)getpid();
+    for (auto& sl : c->sh->slots) {
+        const int pid = sl.pid.load(std::memory_order_relaxed);
+        if (pid && pid != me && !(kill(pid, 0) != 0 && errno == ESRCH)) return false;  // (a slot of a process that is gone does not count)
     }
     return true;
 }
+// lm_ctx_create: a process takes its slot when it creates its first context on the device, not at its first GKR layer — another prover's
+// gate sees it from then on.  (The gate is evaluated per layer AND before every launch that is enqueued ahead.)
+}  // extern "C"
+void lm_gkr_register_process(int device) { (void)tail_counter(device); }
+extern "C" {
 
-int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
+// LM_GKR_FAULT=tail:<n> / ahead:<n> (tests): the n-th message of that kind of this object is NOT sent — the resident kernel that waits for
+// it gives up after its 3 s, exactly what a kernel that never got its wave slots looks like to the host
+static bool gkr_fault(const char* kind, u32 count) {
+    static const char* e = getenv("LM_GKR_FAULT");
+    if (!e) return false;
+    const size_t n = strlen(kind);
+    return strncmp(e, kind, n) == 0 && e[n] == ':' && (u32)atoi(e + n + 1) == count;
+}
+static int gkr_round_impl(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
     LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
     LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
     if (prev_r) g->pending.push_back(host_ef(prev_r));
@@ -1157,7 +1195,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
         volatile u32* cmd = ctx->h_cmd;
         const u32 tag = (sh.seq & 1) << 31;
         for (int k = 0; k < 5; k++) cmd[k] = r0.v[k] | tag, cmd[5 + k] = r1.v[k] | tag;
-        cmd[10] = sh.seq;
+        if (!gkr_fault("tail", ++g->exchanges_tail)) cmd[10] = sh.seq;
         sh.n_threads = sh.m_out;  // the resident workgroup materialises every entry (padding included)
         const u32 Sn = g->tail_S >> 2;
         if (!g->tail_solo && Sn < 4) {
@@ -1176,7 +1214,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
             lm_set_error("lm_gkr_round: the launch enqueued ahead does not match the round being asked for");
             return LM_E_INVALID;
         }
-        lm_mail_post(ctx, sh.mail_no, r0.v, r1.v);
+        if (!gkr_fault("ahead", ++g->exchanges_ahead)) lm_mail_post(ctx, sh.mail_no, r0.v, r1.v);
         if (sh.tail) {
             g->tail_live = true;
             g->tail_W = sh.tail_W, g->tail_S = sh.tail_S, g->tail_solo = sh.tail_solo;
@@ -1190,7 +1228,7 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     }
     // The launch after this one (two rounds on: F = 2) reads what this one leaves; enqueue it now, behind this one, when this one is a
     // launch (a live tail takes messages instead) and the layer has rounds left for it
-    if (!sh.tail && t + 2 < g->K && g->ahead_ok) {
+    if (!sh.tail && t + 2 < g->K && g->ahead_ok && !g->no_resident && gkr_launch_ahead_enabled(ctx)) {
         const u32 no = lm_mail_reserve(ctx);
         rc = gkr_shoot(ctx, g, t + 2, 2, F ? sh.dst : g->cur, sh.m_out, F ? sh.n_threads : g->arr_valid, ef_zero(), ef_zero(), no, &g->ahead_shot);
         if (rc) {
@@ -1286,6 +1324,41 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     memcpy(out_c0_c2, c0.v, 20);
     memcpy(out_c0_c2 + 5, c2.v, 20);
     g->round++;
+    return LM_OK;
+}
+
+// Fail soft.  A resident tail needs all its workgroups on the chip at once and a launch enqueued ahead holds its wave slots while it
+// waits: on a device shared with kernels this library knows nothing about (another tenant, a profiler, RCCL) either can be starved
+// until its own timeout, and the host then sees "sequence never published".  That is a scheduling hiccup, not a prover error
+// (errors are for invalid witnesses): the resident kernels are dismissed, the layer is re-run from its storage — which
+// no launch overwrites — with one launch per exchange and the challenges it has already received (same arithmetic, same sums: the
+// transcript does not notice), and the event is counted (lm_soft_fallbacks).  A second failure is reported.
+int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0_c2[10]) {
+    LM_REQUIRE(ctx && g && out_c0_c2 && g->round < g->K);
+    LM_REQUIRE((g->round == 0) == (prev_r == nullptr));
+    if (prev_r) g->history.push_back(host_ef(prev_r));
+    const bool resident_in_play = g->tail_live || g->ahead || (gkr_tail_enabled() && !g->no_resident) || (g->ahead_ok && !g->no_resident);
+    int rc = gkr_round_impl(ctx, g, prev_r, out_c0_c2);
+    if (rc != LM_E_DEVICE || g->no_resident || !resident_in_play) return rc;
+    static const bool soft = getenv("LM_GKR_NO_SOFT_FALLBACK") == nullptr;
+    if (!soft) return rc;
+    // (gkr_round_impl has dismissed the tail / the launch enqueued ahead and synchronised the stream on its error path)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return rc;  // a real device error: nothing to re-run on
+    g->no_resident = true;
+    ctx->soft_fallbacks++;
+    lm_mail_reset(ctx);
+    if (hipMemsetAsync(ctx->d_acc, 0, LM_ACC_WORDS * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
+        hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream) != hipSuccess)
+        return rc;
+    g->round = 0, g->cur = -1, g->m = 1ull << g->K, g->arr_valid = 0, g->fin_m = 0;
+    g->pending.clear();
+    g->la_valid = false;
+    const size_t n = g->history.size();  // the call that failed asked for round n
+    u32 scratch[10];
+    for (size_t i = 0; i <= n; i++) {
+        const int rc2 = gkr_round_impl(ctx, g, i ? g->history[i - 1].v : nullptr, i == n ? out_c0_c2 : scratch);
+        if (rc2) return rc2;
+    }
     return LM_OK;
 }
 

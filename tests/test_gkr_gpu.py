@@ -124,3 +124,47 @@ def test_gkr_schedule_variants_match_oracle(env_name, env_value):
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+_FAIL_SOFT_CHILD = """
+import numpy as np
+import leanmultisig_amd as lm
+from tests import oracle_binding as ob
+orc = ob.load()
+ctx = lm.Context(0)
+rng = np.random.default_rng(5)
+nums, dens = ob.gkr_instance(orc, rng, 15, 0.8)
+ref_proof, rq, rpt, rcl = ob.gkr_prove(orc, nums, dens)
+d_n, d_d = ctx.to_device(nums), ctx.ef_to_device_soa(dens)
+for rep in range(2):
+    pr = lm.Prover(ctx)
+    q, pt, cl = pr.prove_gkr_quotient(d_n, d_d, 15, active_len=int(0.8 * (1 << 15)))
+    assert np.array_equal(q, rq) and np.array_equal(pt, rpt) and np.array_equal(cl, rcl)
+    assert np.array_equal(pr.proof(), ref_proof), "proof differs after the fallback"
+print("FALLBACKS", ctx.soft_fallbacks())
+"""
+
+
+@pytest.mark.parametrize("fault", ["tail:1", "tail:6", "ahead:1", "ahead:4"])
+def test_gkr_fails_soft_when_a_resident_kernel_never_gets_its_message(fault):
+    """A resident tail / a launch enqueued ahead that is starved of its wave slots on a shared device looks to the host like a kernel whose
+    message never arrives: it gives up after its 3 s, nothing is published.  LM_GKR_FAULT drops the n-th message of that kind; lm_gkr_round
+    must dismiss the resident kernels, re-run the layer from its storage with one launch per exchange and deliver the SAME transcript —
+    an internal scheduling event (lm_soft_fallbacks), not a prover error."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LM_GKR_FAULT=fault, LM_GKR_AHEAD_ASSUME_ALONE="1")
+    r = subprocess.run([sys.executable, "-c", _FAIL_SOFT_CHILD], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "FALLBACKS 2" in r.stdout, r.stdout[-500:]   # one per proof: the fault counter is per GKR object
+
+
+def test_gkr_without_fault_never_falls_back(ctx, orc):
+    rng = np.random.default_rng(6)
+    nums, dens = ob.gkr_instance(orc, rng, 15, 1.0)
+    before = ctx.soft_fallbacks()
+    pr = lm.Prover(ctx)
+    pr.prove_gkr_quotient(ctx.to_device(nums), ctx.ef_to_device_soa(dens), 15)
+    assert ctx.soft_fallbacks() == before

@@ -96,3 +96,52 @@ def test_flipped_sibling_is_rejected_with_the_host_error(ctx, recursion):
     with pytest.raises(lm.LmError) as host:
         vm.execute(bc, pi2, wit2, n_threads=4)
     assert str(dev.value) == str(host.value) and "MemoryAlreadySet" in str(host.value)
+
+
+def test_recursion_n4_full_size_equals_oracle(ctx, orc):
+    """BASELINE configs[3] at FULL size (`recursion --n 4 --log-inv-rate 2`, src/main.rs:91-115): four leaves of 775 REAL signatures proved
+    by this library at rate 1/4 with the reference's production parameters, then the root step — `recursion()` of the in-VM verifier on
+    the four genuine child proofs — with production parameters as well: the device VM run must equal the oracle VM cell for cell with
+    every (child, query) loop on the device, and the root proof must equal the oracle PROVER's word for word and be accepted by both
+    verifiers (bench.py --shape whir-recursion is the timed twin of this test)."""
+    n_children, child_sigs, rate = 4, 775, 2
+    leaf = xa.build_program(19)
+    builder = lm.WhirBuilder.default(rate)
+    inst = dict(log_bytecode=leaf.log_size, ending_pc=leaf.ending_pc, bytecode_hash=leaf.hash(), bytecode=leaf.multilinear)
+    signer = xa.Xmss(compress=lambda x: ctx.poseidon16(x, compress=True))
+    children, n_vars = [], None
+    for c in range(n_children):
+        pi, wit, _ = xa.build_witness(leaf, child_sigs, np.random.default_rng(7000 + c), xmss=signer)
+        pr = lm.Prover(ctx)
+        vm.prove_execution_vm(ctx, pr, leaf, pi, wit, builder)
+        raw, claim, stmt = capi.verify_execution_raw(dict(inst, public_input=pi), pr, builder, with_statement=True)  # (the library's verifier accepts the child)
+        children.append((raw, claim, wv.parse_raw_proof(pr.proof())[1], stmt, pi))
+        assert n_vars in (None, claim.num_variables)
+        n_vars = claim.num_variables
+    assert n_vars == 25   # a 775-signature leaf at rate 1/4: stacked 2^25
+    cfg = lm.WhirConfig.new(builder, n_vars).to_dict()
+    bc = wv.build_program(cfg, n_children, log_size=19, statement=wv.Statement(children[0][3], children[0][1], public_input_len=8), air=True, head=True,
+                          evaluators=True)
+    S = bc.info["shape"]
+    pi, wit, _ = wv.build_witness(bc, children)
+    # the VM run: device == oracle
+    ex = vm.execute(bc, pi, wit, ctx=ctx)
+    d = run_info(ex)
+    assert d["vm_on_device"] and d["device_batches"] == 2 * S.n_rounds + 1 and d["host_batches"] == 0, d
+    run = ob.VmRun(orc, bc, pi, wit)
+    assert ex.n_cycles == run.pcs.size and ex.memory_len == run.memory.size
+    assert np.array_equal(ex.pcs(), run.pcs) and np.array_equal(ex.fps(), run.fps)
+    assert np.array_equal(ex.memory_defined(), run.defined) and np.array_equal(ex.memory(), run.memory)
+    assert ex.counts == run.counts and ex.n_poseidon_calls == run.n_poseidon_calls and ex.n_extension_rows == run.n_extension_rows
+    assert ex.n_cycles > 200_000 and ex.n_poseidon_calls > 30_000 and ex.n_extension_rows > 150_000   # (the shape profiles/r0x_bench_whir_recursion.json reports)
+    # the root proof: device == oracle prover, production parameters
+    pr = lm.Prover(ctx)
+    vm.prove_execution_vm(ctx, pr, bc, pi, wit, builder)
+    ww = run.trace(rate)
+    ok, err = lm.verify_execution(ww, pr.proof_bytes(compressed=True), builder, compressed=True)
+    assert ok, err
+    ob_builder = ob.whir_builder(log_inv_rate=rate)
+    ok, err = ob.verify_execution(orc, ww, pr.proof(), ob_builder)
+    assert ok, err
+    ob.set_threads(orc, 16)
+    assert np.array_equal(pr.proof(), ob.prove_execution(orc, ww, synth_witness.header(ww), ob_builder))

@@ -72,7 +72,7 @@ def build_vm_workload(ctx, rng, n_sigs, log_inv_rate, capacity, log_bytecode=19)
     cfg = lm.WhirConfig.new(lm_builder, n_vars)
     # aggregate_type_1 takes the (public key, signature) pairs in ANY order (it sorts them, type_1_aggregation.rs:232): the step gets them shuffled
     raw = vm.pack_xmss_signatures(info["sig"])[np.random.default_rng(5).permutation(n_sigs)]
-    w = dict(n_sigs=n_sigs, log_rows={t: int(tr.tables[t].log_rows) for t in range(3)}, log_memory=int(tr.log_memory), log_bytecode=bc.log_size,
+    w = dict(n_sigs=n_sigs, log_rows={t: int(tr.tables[t].log_rows) for t in range(3)}, log_memory=int(tr.log_memory), memory_words=int(ex.memory_len), log_bytecode=bc.log_size,
              ending_pc=bc.ending_pc, public_input=pi, bytecode_hash=bc.hash(), bytecode=bc.multilinear,
              counts=dict(poseidon=ex.n_poseidon_calls, extension_op=ex.n_extension_rows, cycles=ex.n_cycles, **ex.counts))
     return dict(w=w, tr=tr, keep=[dt, ex], cfg=cfg, cfgd=cfg.to_dict(), n_vars=n_vars, lm_builder=lm_builder, vm=dict(bc=bc, pi=pi, wit=wit, info=info, raw=raw, message=info["message"], slot=info["slot"]),
@@ -707,6 +707,10 @@ def main():
         if "counts" in ww:
             out["node_stats"].update(cycles=ww["counts"]["cycles"], memory=1 << ww["log_memory"], poseidons=ww["counts"]["poseidon"],
                                      dots=ww["counts"]["extension_op"])
+            if "memory_words" in ww:  # the words the run USED (the committed memory column pads them to `memory`)
+                out["node_stats"]["memory_words"] = ww["memory_words"]
+        # GKR layers re-run with one launch per exchange because a resident kernel never got its wave slots (lm_soft_fallbacks): 0 on a device of one's own
+        out["node_stats"]["tail_fallbacks"] = int(ctx.soft_fallbacks())
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         if phases:
             ph = np.asarray(phases).mean(axis=0)

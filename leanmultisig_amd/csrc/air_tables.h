@@ -509,6 +509,97 @@ KB_HD EF seg_finish(T s[16], ColFn col, const Extra& x) {
     return f.result();
 }
 
+// ---- sumcheck round 1 read through the first challenge (lm_air.hip: FoldCols) --------------------------------------------------
+// There a column value at the evaluation point is  a + t b  with BASE-FIELD a, b and t = the first challenge (the table after its
+// first fold, not materialised).  So the S-box layer of a segment's FIRST full round is a cubic in t with base coefficients,
+//     (a + t b)^3 = a^3 + 3 a^2 b t + 3 a b^2 t^2 + b^3 t^3 :
+// six base products instead of two extension products (50 multiply-adds), the MDS acts on its FOUR coefficient planes instead of
+// five, and the state enters the extension field only in front of the second S-box layer, s = c0 + c1 t + c2 t^2 + c3 t^3 (three
+// base-by-extension products per word).  Segment 2's constraints y_r^3 - q_r are cubics in t as well: their alpha-weighted sum is taken
+// coefficient by coefficient (base-by-extension multiply-adds, delayed reduction) and meets t, t^2, t^3 once per row pair.
+// Exact identities: the same field values as the extension-field evaluation (tests/test_air_gpu.py, proofs word-identical).
+struct Ab {
+    u32 a, b;
+};
+struct TPowers {
+    EF t1, t2, t3;
+};
+struct CubeCoeffs {
+    u32 c0, c1, c2, c3;
+};
+KB_HD CubeCoeffs cube_affine(u32 a, u32 b) {
+    const u32 a2 = kb::mul(a, a), b2 = kb::mul(b, b);
+    const u32 a2b = kb::mul(a2, b), ab2 = kb::mul(a, b2);
+    CubeCoeffs c;
+    c.c0 = kb::mul(a2, a);
+    c.c1 = kb::add(a2b, kb::dbl(a2b));
+    c.c2 = kb::add(ab2, kb::dbl(ab2));
+    c.c3 = kb::mul(b2, b);
+    return c;
+}
+template <int SEG, class AbFn>
+KB_HD void seg_first_affine(AbFn ab, const TPowers& tp, EF s[16]) {
+    constexpr int R = SegInfo<SEG>::round0;
+    u32 c0[16], c1[16], c2[16], c3[16];
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr u32 rc = R < 4 ? kb::kPoseidonHost.rc_init[R & 3][i] : kb::kPoseidonHost.rc_term[R & 3][i];
+        const Ab v = ab(SegInfo<SEG>::input_col + i);
+        const CubeCoeffs c = cube_affine(kb::add(v.a, rc), v.b);
+        c0[i] = c.c0, c1[i] = c.c1, c2[i] = c.c2, c3[i] = c.c3;
+    });
+    kb::mds_circ16(c0);
+    kb::mds_circ16(c1);
+    kb::mds_circ16(c2);
+    kb::mds_circ16(c3);
+    static_for<0, 16>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const u64 acc = (u64)c1[i] * tp.t1.v[k] + (u64)c2[i] * tp.t2.v[k] + (u64)c3[i] * tp.t3.v[k];  // < 3 p^2 < 2^64
+            s[i].v[k] = kb::reduce(kb::fold32(acc));
+        }
+        s[i].v[0] = kb::add(s[i].v[0], c0[i]);
+    });
+}
+// col(c): the extension-field value of column c (FoldCols::at); ab(c): its two base coefficients
+template <int SEG, class ColFn, class AbFn>
+KB_HD EF eval_poseidon16_segment_affine(ColFn col, AbFn ab, const TPowers& tp, const Extra& x) {
+    if constexpr (SEG == 2) {
+        u64 acc[4][5];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[m][k] = 0;
+        static_for<0, 20>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            const Ab y = ab(POS_VIRT_Y + r), q = ab(57 + r);
+            const CubeCoeffs c = cube_affine(y.a, y.b);
+            const u32 d[4] = {kb::sub(c.c0, q.a), kb::sub(c.c1, q.b), c.c2, c.c3};  // y_r^3 - partial_rounds[r], coefficient by coefficient
+            if constexpr (r >= 4 && (r - 4) % 3 == 0) {  // four products fit from zero, three after a fold
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int k = 0; k < 5; k++) acc[m][k] = kb::fold32(acc[m][k]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int k = 0; k < 5; k++) acc[m][k] += (u64)x.alpha_powers[40 + r].v[k] * d[m];
+        });
+        EF a[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[m].v[k] = kb::reduce(kb::fold32(acc[m][k]));
+        return kb::ef_add(kb::ef_add(a[0], kb::ef_mul(tp.t1, a[1])), kb::ef_add(kb::ef_mul(tp.t2, a[2]), kb::ef_mul(tp.t3, a[3])));
+    } else {
+        EF s[16];
+        seg_first_affine<SEG>(ab, tp, s);
+        return seg_finish<EF, SEG>(s, col, x);
+    }
+}
+
 // col(c) = column c at the evaluation point
 template <class T, int SEG, class ColFn>
 KB_HD EF eval_poseidon16_segment(ColFn col, const Extra& x) {

@@ -128,12 +128,38 @@ struct FoldCols {
     }
 };
 
+// FoldCols of the Poseidon table with the two base coefficients of a value on offer (air_tables.h: eval_poseidon16_segment_affine)
+struct FoldColsAff : FoldCols<false> {
+    air::TPowers tp;  // r, r^2, r^3
+    __device__ __forceinline__ air::Ab ab(u32 c, u64 j, u32 zm) const {
+        const u32* const* cp = cols;
+        asm volatile("" : "+s"(cp));
+        const uint4 v = *reinterpret_cast<const uint4*>(cp[c] + 4 * j);
+        air::Ab o;
+        o.a = lerp(v.x, v.z, zm);
+        o.b = lerp(sub(v.y, v.x), sub(v.w, v.z), zm);
+        return o;
+    }
+};
+
 template <class C>
 struct cols_lazy_fold {
     static constexpr bool value = false;
 };
 template <bool S>
 struct cols_lazy_fold<FoldCols<S>> {
+    static constexpr bool value = true;
+};
+template <>
+struct cols_lazy_fold<FoldColsAff> {
+    static constexpr bool value = true;
+};
+template <class C>
+struct cols_affine {
+    static constexpr bool value = false;
+};
+template <>
+struct cols_affine<FoldColsAff> {
     static constexpr bool value = true;
 };
 
@@ -233,6 +259,15 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         }
         auto col = [&](int c) { return val[c]; };
         return air::eval_poseidon16_segment<T, SEG>(col, x);
+    } else if constexpr (TABLE == air::T_POSEIDON16 && cols_affine<Cols>::value) {
+        // round 1 through the first challenge with the base coefficients of every value at hand (segment uniform per workgroup)
+        auto col = [&](int c) { return cols.template at<false>((u32)c, j, zm); };
+        auto ab = [&](int c) { return cols.ab((u32)c, j, zm); };
+        if (seg == 0) return air::eval_poseidon16_segment_affine<0>(col, ab, cols.tp, x);
+        if (seg == 1) return air::eval_poseidon16_segment_affine<1>(col, ab, cols.tp, x);
+        if (seg == 2) return air::eval_poseidon16_segment_affine<2>(col, ab, cols.tp, x);
+        if (seg == 3) return air::eval_poseidon16_segment_affine<3>(col, ab, cols.tp, x);
+        return air::eval_poseidon16_segment_affine<4>(col, ab, cols.tp, x);
     } else if constexpr (TABLE == air::T_POSEIDON16) {
         auto col = [&](int c) { return cols.template at<false>((u32)c, j, zm); };
         if constexpr (SEG >= 0) return air::eval_poseidon16_segment<T, SEG>(col, x);
@@ -749,6 +784,14 @@ static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const E
     }
     if constexpr (TABLE == air::T_POSEIDON16) {  // (lm_air_new: only that table's first fold stays unmaterialised)
         if (a->cur == -2) {
+            // LM_AIR_NO_AFFINE=1: round 1 on extension-field values throughout (A/B measurements)
+            static const bool affine = getenv("LM_AIR_NO_AFFINE") == nullptr;
+            if (affine && !air_coop_round(n_pairs, fin.pad_on != 0)) {
+                FoldColsAff c;
+                c.cols = a->d_base_cols, c.n_rows = 1ull << a->log_rows, c.n_flat = a->n_cols + a->n_virt, c.r = a->r1;
+                c.tp.t1 = a->r1, c.tp.t2 = ef_mul(a->r1, a->r1), c.tp.t3 = ef_mul(c.tp.t2, a->r1);
+                return launch_cols<TABLE, EF, FoldColsAff>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
+            }
             FoldCols<false> c{a->d_base_cols, 1ull << a->log_rows, a->n_cols + a->n_virt, a->r1};
             return launch_cols<TABLE, EF, FoldCols<false>>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
         }

@@ -115,6 +115,9 @@ struct lm_ctx {
     std::vector<float> wait_us;
     // GKR layers that were re-run with one launch per exchange because a resident kernel never got its wave slots (lm_gkr_round)
     u32 soft_fallbacks = 0;
+    // after a fallback the context keeps off resident kernels for a while (2 s, doubled by every further fallback up to 64 s, back to
+    // 2 s after a clean period): a device that starved one tail will starve the next, and each failed attempt costs its 3 s timeout
+    double no_resident_until_s = 0.0, no_resident_backoff_s = 0.0;
 };
 
 #define LM_LAUNCH(ctx, kernel, grid, block, shmem, ...) LM_LAUNCH_ON(ctx, (ctx)->stream, kernel, grid, block, shmem, __VA_ARGS__)
@@ -276,6 +279,7 @@ int lm_mail_abort(lm_ctx* ctx);
 void lm_mail_reset(lm_ctx* ctx);  // line and relay back to "no message, no dismissal" whatever the counters say (the stream must be idle)
 static inline const kb::u32* lm_mail_line(const lm_ctx* ctx) { return ctx->h_cmd + lm_ctx::CMD_LINE_WORDS * lm_ctx::MAIL_LINE; }
 size_t lm_ctx_live_count();  // contexts alive in this process
+int lm_gkr_foreign_processes(int device);  // live prover processes other than this one registered on the device (0 when there is no shared counter)
 void lm_gkr_register_process(int device);  // lm_gkr.hip: take this process's slot in the device's shared counter (lm_ctx_create)
 int lm_wait_result(lm_ctx* ctx, kb::u32 seq);
 // the same on flag word h_res[RES_FLAG + 1 + aux] (aux >= 0), published by work on aux_stream[aux]

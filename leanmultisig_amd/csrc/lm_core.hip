@@ -1,4 +1,5 @@
 // Context, memory helpers, twiddle tables, multilinear evaluation.
+#include <sys/prctl.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -486,6 +487,24 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
         const char* e = getenv("LM_WAIT_NAP_WAITERS");
         return e ? atoi(e) : 4;
     }();
+    // Hybrid wait (LM_WAIT_MODE=hybrid, or auto = default: when another prover PROCESS is registered on this device): a rank of a sharded
+    // job costs a core only while it has work.  The first ~20 us are polled as ever (most exchanges end there); a longer wait — a large
+    // kernel, or a GPU shared with other ranks — sleeps ~10 us at a time (timer slack 1 us) between polls.  Eight ranks on sixteen CPUs
+    // each spinning through 20 ms proofs starved each other's host work (host-busy per rank-step 5.6 -> 21-30 ms, profiles/r05_ranks_on_one_gpu.txt).
+    // A lone prover keeps spinning: its latency is the metric (LM_WAIT_MODE=spin forces that everywhere).
+    static const int wait_mode = [] {  // 0 spin, 1 hybrid, 2 auto
+        const char* e = getenv("LM_WAIT_MODE");
+        if (!e) return 2;
+        return e[0] == 's' ? 0 : e[0] == 'h' ? 1 : 2;
+    }();
+    bool hybrid = wait_mode == 1;
+    if (wait_mode == 2) {
+        // (re-evaluated every 64 waits: another process may come or go; the check walks 64 words of shared memory)
+        thread_local u32 tick = 0;
+        thread_local bool shared_device = false;
+        if ((tick++ & 63) == 0) shared_device = lm_gkr_foreign_processes(ctx->device) > 0;
+        hybrid = shared_device;
+    }
     static std::atomic<int> waiters{0};
     struct WaitScope {
         std::atomic<int>& w;
@@ -507,6 +526,15 @@ int lm_wait_result_aux(lm_ctx* ctx, int aux, u32 seq) {
             struct timespec ts = {0, 20000};
             nanosleep(&ts, nullptr);
             spins += 2000;  // (a nap is worth ~2000 polls of wall clock: the give-up point below stays where it was)
+        } else if (hybrid && spins >= 2000) {  // ~20 us of polling behind us
+            thread_local bool slack_set = false;
+            if (!slack_set) {
+                (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);  // this thread's sleeps may end 1 us late, not 50
+                slack_set = true;
+            }
+            struct timespec ts = {0, 8000};
+            nanosleep(&ts, nullptr);
+            spins += 1000;
         }
         if (spins > (1ull << 22)) {
             // Something is wrong or the kernel is long.  NOT hipStreamSynchronize: a resident kernel (k_gkr_tail) may own the stream

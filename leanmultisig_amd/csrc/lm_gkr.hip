@@ -14,6 +14,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include "lm_common.h"
 #include "lm_eqsplit.h"
 
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(GKR_TAIL_THREADS) void k_gkr_tail(const u32* __rest
 }
 
 namespace {
+double gkr_now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 EF host_ef(const u32* p) {
     EF r;
     memcpy(r.v, p, 20);
@@ -870,6 +872,7 @@ int lm_gkr_build(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, ui
 int lm_gkr_build_active(lm_ctx* ctx, const uint32_t* d_nums, const uint32_t* d_dens, uint32_t n_vars, uint64_t active_len, lm_gkr** out) {
     LM_REQUIRE(ctx && d_nums && d_dens && out && n_vars > 5 && n_vars <= 30 && active_len >= 1 && active_len <= (1ull << n_vars));
     lm_gkr* g = new lm_gkr();
+    g->no_resident = gkr_now_s() < ctx->no_resident_until_s;  // (a recent fallback on this context: lm_gkr_round)
     g->n_vars = n_vars;
     g->d_nums0 = d_nums;
     g->d_dens0 = d_dens;
@@ -1155,6 +1158,17 @@ static bool gkr_launch_ahead_enabled(lm_ctx* ctx) {
 // gate sees it from then on.  (The gate is evaluated per layer AND before every launch that is enqueued ahead.)
 }  // extern "C"
 void lm_gkr_register_process(int device) { (void)tail_counter(device); }
+int lm_gkr_foreign_processes(int device) {
+    TailCounter* c = tail_counter(device);
+    if (!c->sh) return 0;
+    const int me = (int)getpid();
+    int n = 0;
+    for (auto& sl : c->sh->slots) {
+        const int pid = sl.pid.load(std::memory_order_relaxed);
+        if (pid && pid != me && !(kill(pid, 0) != 0 && errno == ESRCH)) n++;
+    }
+    return n;
+}
 extern "C" {
 
 // LM_GKR_FAULT=tail:<n> / ahead:<n> (tests): the n-th message of that kind of this object is NOT sent — the resident kernel that waits for
@@ -1346,6 +1360,11 @@ int lm_gkr_round(lm_ctx* ctx, lm_gkr* g, const uint32_t* prev_r, uint32_t out_c0
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return rc;  // a real device error: nothing to re-run on
     g->no_resident = true;
     ctx->soft_fallbacks++;
+    {
+        const double now = gkr_now_s();
+        ctx->no_resident_backoff_s = now < ctx->no_resident_until_s + 10.0 && ctx->no_resident_backoff_s > 0 ? std::min(64.0, 2 * ctx->no_resident_backoff_s) : 2.0;
+        ctx->no_resident_until_s = now + ctx->no_resident_backoff_s;
+    }
     lm_mail_reset(ctx);
     if (hipMemsetAsync(ctx->d_acc, 0, LM_ACC_WORDS * sizeof(unsigned long long), ctx->stream) != hipSuccess ||
         hipMemsetAsync(ctx->d_sync + 1, 0, 4, ctx->stream) != hipSuccess)

@@ -158,7 +158,7 @@ def test_gkr_fails_soft_when_a_resident_kernel_never_gets_its_message(fault):
     env = dict(os.environ, LM_GKR_FAULT=fault, LM_GKR_AHEAD_ASSUME_ALONE="1")
     r = subprocess.run([sys.executable, "-c", _FAIL_SOFT_CHILD], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "FALLBACKS 2" in r.stdout, r.stdout[-500:]   # one per proof: the fault counter is per GKR object
+    assert "FALLBACKS 1" in r.stdout, r.stdout[-500:]   # the first proof falls back; the context then keeps off resident kernels for 2 s, so the second has none to lose
 
 
 def test_gkr_without_fault_never_falls_back(ctx, orc):

@@ -52,5 +52,6 @@ t0 = time.time()
 th = [threading.Thread(target=worker, args=(c,)) for c in range(C)]
 [t.start() for t in th]
 [t.join() for t in th]
-print(f"{C} provers x {N} proofs in {time.time() - t0:.1f} s: {len(bad)} proofs differ from the prover's first proof {bad[:5]}")
+print(f"{C} provers x {N} proofs in {time.time() - t0:.1f} s: {len(bad)} proofs differ from the prover's first proof {bad[:5]}; "
+      f"GKR layers re-run without resident kernels (lm_soft_fallbacks): {sum(c.soft_fallbacks() for c in ctxs)}")
 sys.exit(1 if bad else 0)

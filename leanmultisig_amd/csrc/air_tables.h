@@ -600,6 +600,216 @@ KB_HD EF eval_poseidon16_segment_affine(ColFn col, AbFn ab, const TPowers& tp, c
     }
 }
 
+// ---- the execution table in round 1, on polynomials in the first challenge -----------------------------------------------------
+// Same situation as above: every column value is a + t b with base-field a, b.  The 13 constraints have degree <= 5 in the columns,
+// so each is a polynomial of degree <= 5 in t with BASE coefficients: the evaluator below works on such polynomials (Pt<D>: D + 1 base
+// words; a product of degrees A and B is (A + 1)(B + 1) base multiply-adds with delayed reduction instead of 25 per extension
+// product), weights coefficient m of constraint k with alpha^k into one of six extension-field accumulators (5 multiply-adds per
+// coefficient, delayed reduction), and meets t, .., t^5 once per row pair:  sum_k alpha^k C_k = sum_m t^m (sum_k alpha^k c_km).
+// The bus value enters the same accumulators: (sum_i eq_i d_i + eq_15) beta + flag = sum_m t^m (sum_i (eq_i beta) d_im + flag_m) + eq_15 beta.
+// Constraint order and polynomials are eval_execution's (execution/air.rs:56-129); exact field identities throughout.
+template <int D>
+struct Pt {
+    u32 c[D + 1];
+};
+KB_HD Pt<1> pt_of(const Ab& v) {
+    Pt<1> r;
+    r.c[0] = v.a, r.c[1] = v.b;
+    return r;
+}
+template <int A, int B>
+KB_HD Pt<(A > B ? A : B)> pt_add(const Pt<A>& a, const Pt<B>& b) {
+    Pt<(A > B ? A : B)> r;
+    static_for<0, (A > B ? A : B) + 1>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        if constexpr (m <= A && m <= B)
+            r.c[m] = kb::add(a.c[m], b.c[m]);
+        else if constexpr (m <= A)
+            r.c[m] = a.c[m];
+        else
+            r.c[m] = b.c[m];
+    });
+    return r;
+}
+template <int A, int B>
+KB_HD Pt<(A > B ? A : B)> pt_sub(const Pt<A>& a, const Pt<B>& b) {
+    Pt<(A > B ? A : B)> r;
+    static_for<0, (A > B ? A : B) + 1>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        if constexpr (m <= A && m <= B)
+            r.c[m] = kb::sub(a.c[m], b.c[m]);
+        else if constexpr (m <= A)
+            r.c[m] = a.c[m];
+        else
+            r.c[m] = kb::neg(b.c[m]);
+    });
+    return r;
+}
+template <int A>
+KB_HD Pt<A> pt_one_minus(const Pt<A>& a) {  // 1 - a
+    Pt<A> r;
+    r.c[0] = kb::sub(kb::ONE, a.c[0]);
+    static_for<1, A + 1>([&](auto M) { r.c[decltype(M)::value] = kb::neg(a.c[decltype(M)::value]); });
+    return r;
+}
+template <int A>
+KB_HD Pt<A> pt_sub_one(const Pt<A>& a) {  // a - 1
+    Pt<A> r = a;
+    r.c[0] = kb::sub(a.c[0], kb::ONE);
+    return r;
+}
+template <int A>
+KB_HD Pt<A> pt_scale(const Pt<A>& a, u32 k) {
+    Pt<A> r;
+    static_for<0, A + 1>([&](auto M) { r.c[decltype(M)::value] = kb::mul(a.c[decltype(M)::value], k); });
+    return r;
+}
+// adds a * b into the 64-bit coefficient accumulators x[0 .. A + B]; n[m] counts the products x[m] holds (four fit from zero, three
+// after a fold: kb::fold32)
+template <int A, int B, int N>
+KB_HD void pt_mul_acc(const Pt<A>& a, const Pt<B>& b, u64 (&x)[N], int (&n)[N]) {
+    static_assert(A + B < N, "accumulator count");
+    static_for<0, A + 1>([&](auto I) {
+        static_for<0, B + 1>([&](auto J) {
+            constexpr int m = decltype(I)::value + decltype(J)::value;
+            if (n[m] == 4) {
+                x[m] = kb::fold32(x[m]);
+                n[m] = 1;
+            }
+            x[m] += (u64)a.c[decltype(I)::value] * b.c[decltype(J)::value];
+            n[m]++;
+        });
+    });
+}
+template <int D, int N>
+KB_HD Pt<D> pt_reduce(u64 (&x)[N], const int (&n)[N]) {
+    Pt<D> r;
+    static_for<0, D + 1>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        r.c[m] = kb::reduce(n[m] <= 2 ? x[m] : kb::fold32(x[m]));  // two products of reduced values stay below 2^32 p
+    });
+    return r;
+}
+template <int A, int B>
+KB_HD Pt<A + B> pt_mul(const Pt<A>& a, const Pt<B>& b) {
+    u64 x[A + B + 1];
+    int n[A + B + 1];
+#pragma unroll
+    for (int m = 0; m <= A + B; m++) x[m] = 0, n[m] = 0;
+    pt_mul_acc(a, b, x, n);
+    return pt_reduce<A + B>(x, n);
+}
+// a1 b1 + a2 b2 + a3 b3 (degree 1 each): nu_a, nu_b, nu_c
+KB_HD Pt<2> pt_dot3(const Pt<1>& a1, const Pt<1>& b1, const Pt<1>& a2, const Pt<1>& b2, const Pt<1>& a3, const Pt<1>& b3) {
+    u64 x[3] = {0, 0, 0};
+    int n[3] = {0, 0, 0};
+    pt_mul_acc(a1, b1, x, n);
+    pt_mul_acc(a2, b2, x, n);
+    pt_mul_acc(a3, b3, x, n);
+    return pt_reduce<2>(x, n);
+}
+struct ExecAffine {
+    EF tp[5];       // t, t^2, .., t^5
+    EF eq_beta[4];  // logup_eq[i] * bus_beta
+    EF eq15_beta;   // logup_eq[15] * bus_beta  (LOGUP_PRECOMPILE_DOMAINSEP = 1)
+};
+struct PtFolder {
+    const Extra& x;
+    u64 a[6][5];
+    int n[6];
+    KB_HD explicit PtFolder(const Extra& e) : x(e) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            n[m] = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[m][k] = 0;
+        }
+    }
+    KB_HD void room(int m) {
+        if (n[m] == 4) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[m][k] = kb::fold32(a[m][k]);
+            n[m] = 1;
+        }
+    }
+    template <int D>
+    KB_HD void weigh(const EF& w, const Pt<D>& v) {  // += w * v, coefficient by coefficient
+        static_for<0, D + 1>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            room(m);
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[m][k] += (u64)w.v[k] * v.c[m];
+            n[m]++;
+        });
+    }
+    template <int D>
+    KB_HD void assert_zero(int k, const Pt<D>& v) { weigh(x.alpha_powers[k], v); }
+    template <int D>
+    KB_HD void add_base(const Pt<D>& v) {  // += v (alpha^0 = 1: the flag of the bus value), plane 0 only
+        static_for<0, D + 1>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            room(m);
+            a[m][0] += (u64)v.c[m] * kb::ONE;  // (= v R: the final reduction divides by R again)
+            n[m]++;
+        });
+    }
+    KB_HD EF result(const ExecAffine& ex) const {
+        EF r;
+#pragma unroll
+        for (int k = 0; k < 5; k++) r.v[k] = kb::reduce(kb::fold32(a[0][k]));
+        r = kb::ef_add(r, ex.eq15_beta);
+        static_for<1, 6>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            EF c;
+#pragma unroll
+            for (int k = 0; k < 5; k++) c.v[k] = kb::reduce(kb::fold32(a[m][k]));
+            r = kb::ef_add(r, kb::ef_mul(ex.tp[m - 1], c));
+        });
+        return r;
+    }
+};
+KB_HD EF eval_execution_affine(const Ab* flat, const Ab* shift, const Extra& x, const ExecAffine& ex) {
+    const Pt<1> pc = pt_of(flat[0]), fp = pt_of(flat[1]), addr_a = pt_of(flat[2]), addr_b = pt_of(flat[3]), addr_c = pt_of(flat[4]);
+    const Pt<1> value_a = pt_of(flat[5]), value_b = pt_of(flat[6]), value_c = pt_of(flat[7]);
+    const Pt<1> operand_a = pt_of(flat[8]), operand_b = pt_of(flat[9]), operand_c = pt_of(flat[10]);
+    const Pt<1> flag_a = pt_of(flat[11]), flag_b = pt_of(flat[12]), flag_c = pt_of(flat[13]), flag_c_fp = pt_of(flat[14]), flag_ab_fp = pt_of(flat[15]);
+    const Pt<1> mul = pt_of(flat[16]), jump = pt_of(flat[17]), aux = pt_of(flat[18]), precompile_data = pt_of(flat[19]);
+    const Pt<1> pc_shift = pt_of(shift[0]), fp_shift = pt_of(shift[1]);
+    const Pt<1> omfa = pt_one_minus(pt_add(flag_a, flag_ab_fp)), omfb = pt_one_minus(pt_add(flag_b, flag_ab_fp)), omfc = pt_one_minus(pt_add(flag_c, flag_c_fp));
+    const Pt<1> fpa = pt_add(fp, operand_a), fpb = pt_add(fp, operand_b), fpc = pt_add(fp, operand_c);
+    const Pt<2> nu_a = pt_dot3(flag_a, operand_a, omfa, value_a, flag_ab_fp, fpa);
+    const Pt<2> nu_b = pt_dot3(flag_b, operand_b, omfb, value_b, flag_ab_fp, fpb);
+    const Pt<2> nu_c = pt_dot3(flag_c, operand_c, omfc, value_c, flag_c_fp, fpc);
+    const Pt<2> aux2 = pt_mul(aux, aux);
+    const Pt<2> add_ = pt_sub(pt_add(aux, aux), aux2);                       // 2 aux - aux^2
+    const Pt<2> deref = pt_scale(pt_sub(aux2, aux), mc((kb::P + 1) / 2));    // aux (aux - 1) / 2
+    const Pt<2> is_precompile = pt_one_minus(pt_add(pt_add(add_, mul), pt_add(deref, jump)));
+    PtFolder f(x);
+    // alpha^0: the bus value
+    f.weigh(ex.eq_beta[0], precompile_data);
+    f.weigh(ex.eq_beta[1], nu_a);
+    f.weigh(ex.eq_beta[2], nu_b);
+    f.weigh(ex.eq_beta[3], nu_c);
+    f.add_base(is_precompile);
+    f.assert_zero(1, pt_mul(omfa, pt_sub(addr_a, fpa)));
+    f.assert_zero(2, pt_mul(omfb, pt_sub(addr_b, fpb)));
+    f.assert_zero(3, pt_mul(omfc, pt_sub(addr_c, fpc)));
+    f.assert_zero(4, pt_mul(add_, pt_sub(nu_b, pt_add(nu_a, nu_c))));
+    f.assert_zero(5, pt_mul(mul, pt_sub(nu_b, pt_mul(nu_a, nu_c))));
+    f.assert_zero(6, pt_mul(deref, pt_sub(addr_b, pt_add(value_a, operand_b))));
+    f.assert_zero(7, pt_mul(deref, pt_sub(value_b, nu_c)));
+    const Pt<3> jc = pt_mul(jump, nu_a);
+    f.assert_zero(8, pt_mul(jc, pt_sub_one(nu_a)));
+    f.assert_zero(9, pt_mul(jc, pt_sub(pc_shift, nu_b)));
+    f.assert_zero(10, pt_mul(jc, pt_sub(fp_shift, nu_c)));
+    const Pt<3> njc = pt_one_minus(jc);
+    Pt<1> pc_next = pc;
+    pc_next.c[0] = kb::add(pc.c[0], kb::ONE);
+    f.assert_zero(11, pt_mul(njc, pt_sub(pc_shift, pc_next)));
+    f.assert_zero(12, pt_mul(njc, pt_sub(fp_shift, fp)));
+    return f.result(ex);
+}
+
 // col(c) = column c at the evaluation point
 template <class T, int SEG, class ColFn>
 KB_HD EF eval_poseidon16_segment(ColFn col, const Extra& x) {

@@ -142,6 +142,38 @@ struct FoldColsAff : FoldCols<false> {
     }
 };
 
+// The execution table after its first fold, not materialised, as the two base coefficients of every value (air_tables.h:
+// eval_execution_affine): the 20 flat columns from one 16-byte load, the two shift views from rows 4j+1 .. 4j+4.
+struct FoldColsExec {
+    const u32* const* cols;
+    u64 n_rows;  // of the BASE table
+    u32 n_flat;
+    air::ExecAffine ex;
+    __device__ __forceinline__ air::Ab ab(u32 c, u64 j, u32 zm) const {
+        u32 a0, a1, a2, a3;
+        if (c < n_flat) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cols[c] + 4 * j);
+            a0 = v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+        } else {  // shift view: row i of the view is row min(i + 1, n_rows - 1) of the column
+            const u32* p = cols[c - n_flat];
+            const u64 i = 4 * j;
+            a0 = p[i + 1], a1 = p[i + 2], a2 = p[i + 3], a3 = p[(i + 4 < n_rows) ? i + 4 : n_rows - 1];
+        }
+        air::Ab o;
+        o.a = lerp(a0, a2, zm);
+        o.b = lerp(sub(a1, a0), sub(a3, a2), zm);
+        return o;
+    }
+};
+template <class C>
+struct cols_exec_affine {
+    static constexpr bool value = false;
+};
+template <>
+struct cols_exec_affine<FoldColsExec> {
+    static constexpr bool value = true;
+};
+
 template <class C>
 struct cols_lazy_fold {
     static constexpr bool value = false;
@@ -277,6 +309,12 @@ __device__ __forceinline__ EF eval_table(const Cols& cols, u64 j, u32 zm, u32 se
         if (seg == 2) return air::eval_poseidon16_segment<T, 2>(col, x);
         if (seg == 3) return air::eval_poseidon16_segment<T, 3>(col, x);
         return air::eval_poseidon16_segment<T, 4>(col, x);
+    } else if constexpr (TABLE == air::T_EXECUTION && cols_exec_affine<Cols>::value) {
+        air::Ab flat[20], shift[2];
+        static_for<0, 20>([&](auto C) { flat[decltype(C)::value] = cols.ab(decltype(C)::value, j, zm); });
+        static_for<0, 2>([&](auto C) { shift[decltype(C)::value] = cols.ab(20 + decltype(C)::value, j, zm); });
+        (void)seg;
+        return air::eval_execution_affine(flat, shift, x, cols.ex);
     } else {
         constexpr int NF = air::n_columns(TABLE), NS = air::n_shift(TABLE);
         // (one copy of the loads per instantiation of the evaluator: a part of the ExtensionOp constraints leaves the columns it
@@ -796,6 +834,20 @@ static int launch_round(lm_ctx* ctx, lm_air* a, u64 n_pairs, u32 blocks, const E
             return launch_cols<TABLE, EF, FoldCols<false>>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
         }
     }
+    if constexpr (TABLE == air::T_EXECUTION) {  // (lm_air_new: its first fold stays unmaterialised too when round 1 runs on eval_execution_affine)
+        if (a->cur == -2) {
+            FoldColsExec c;
+            c.cols = a->d_base_cols, c.n_rows = 1ull << a->log_rows, c.n_flat = a->n_cols;
+            EF t = a->r1;
+            for (int m = 0; m < 5; m++) {
+                c.ex.tp[m] = t;
+                t = ef_mul(t, a->r1);
+            }
+            for (int i = 0; i < 4; i++) c.ex.eq_beta[i] = ef_mul(a->h_extra.logup_eq[i], a->h_extra.bus_beta);
+            c.ex.eq15_beta = ef_mul(a->h_extra.logup_eq[15], a->h_extra.bus_beta);
+            return launch_cols<TABLE, EF, FoldColsExec>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
+        }
+    }
     ExtCols c{a->ef[a->cur], 1ull << (a->log_rows - a->round)};  // (rows of the folded table: n_pairs may be the active prefix only)
     return launch_cols<TABLE, EF, ExtCols>(ctx, a, c, n_pairs, blocks, eq, partial, fin);
 }
@@ -871,7 +923,9 @@ int lm_air_new(lm_ctx* ctx, uint32_t table, const uint32_t* const* d_cols, uint3
     static const bool lazy = getenv("LM_AIR_NO_LAZY_FOLD") == nullptr;
     // The Poseidon table only: the ExtensionOp evaluation with its shift views compiles to 445 VGPRs over FoldCols (one wave per SIMD:
     // a 2^18-row table took 7 ms longer), and the execution table's first fold is small.
-    a->lazy_ok = lazy && log_rows >= 2 && table == air::T_POSEIDON16;
+    // The execution table joins when its round 1 runs on base coefficients (eval_execution_affine: LM_AIR_NO_AFFINE=1 switches that off).
+    static const bool affine = getenv("LM_AIR_NO_AFFINE") == nullptr;
+    a->lazy_ok = lazy && log_rows >= 2 && (table == air::T_POSEIDON16 || (table == air::T_EXECUTION && affine));
     for (const u32* cp : a->h_cols) a->lazy_ok = a->lazy_ok && (reinterpret_cast<uintptr_t>(cp) & 15) == 0;
     int rc;
     if ((rc = lm_stage_upload(ctx, (void*)a->d_base_cols, a->h_cols.data(), a->h_cols.size() * sizeof(u32*))) ||

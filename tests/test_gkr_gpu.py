@@ -145,7 +145,7 @@ print("FALLBACKS", ctx.soft_fallbacks())
 """
 
 
-@pytest.mark.parametrize("fault", ["tail:1", "tail:6", "ahead:1", "ahead:4"])
+@pytest.mark.parametrize("fault", ["tail:1", "tail:6", "ahead:1", "ahead:2"])
 def test_gkr_fails_soft_when_a_resident_kernel_never_gets_its_message(fault):
     """A resident tail / a launch enqueued ahead that is starved of its wave slots on a shared device looks to the host like a kernel whose
     message never arrives: it gives up after its 3 s, nothing is published.  LM_GKR_FAULT drops the n-th message of that kind; lm_gkr_round

@@ -17,6 +17,24 @@ __global__ void k_hog(unsigned long long ticks, unsigned* sink) {
     if (x == 0xdeadbeefu) *sink = x;
 }
 
+// the same with ~120 live VGPRs per lane: 1024 threads x 120 registers fill the register file of a CU — NOTHING else fits beside
+// such a workgroup (usage: 4th argument = 1).  248 of them leave 8 of the 256 CUs to everybody else.
+__global__ __launch_bounds__(1024) void k_hog_heavy(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned r[112];
+#pragma unroll
+    for (int i = 0; i < 112; i++) r[i] = threadIdx.x * 2654435761u + i;
+    while (wall_clock64() - t0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 112; i++) r[i] = r[i] * 1664525u + r[(i + 1) % 112];
+        __builtin_amdgcn_s_sleep(8);
+    }
+    unsigned x = 0;
+#pragma unroll
+    for (int i = 0; i < 112; i++) x ^= r[i];
+    if (x == 0xdeadbeefu) *sink = x;
+}
+
 int main(int argc, char** argv) {
     const int wgs = argc > 1 ? atoi(argv[1]) : 256;
     const double seconds = argc > 2 ? atof(argv[2]) : 30.0;
@@ -27,7 +45,10 @@ int main(int argc, char** argv) {
     double left = seconds;
     while (left > 0) {
         const double s = left > 2.0 ? 2.0 : left;
-        hipLaunchKernelGGL(k_hog, dim3(wgs), dim3(threads), 0, 0, (unsigned long long)(s * 1e8), sink);  // wall_clock64: 100 MHz
+        if (argc > 4 && atoi(argv[4]) == 1)
+            hipLaunchKernelGGL(k_hog_heavy, dim3(wgs), dim3(1024), 0, 0, (unsigned long long)(s * 1e8), sink);
+        else
+            hipLaunchKernelGGL(k_hog, dim3(wgs), dim3(threads), 0, 0, (unsigned long long)(s * 1e8), sink);  // wall_clock64: 100 MHz
         left -= s;
     }
     if (hipDeviceSynchronize() != hipSuccess) return 2;

@@ -2,7 +2,10 @@
 GPU prove the SAME leaf over and over from C host threads; proofs are deterministic, so every proof of a prover must equal
 its first one word for word, and EVERY proof is checked by lmh_verify_execution (a reordered publish would corrupt the
 transcript: the proof is rejected).  usage: python tools/stress_inflight.py [provers] [proofs each] [scale_log] [whole]
-whole = 1: every proof is the WHOLE function (lmh_prove_execution_vm: VM run with the parallel batch on the device, trace, proof)."""
+whole = 1: every proof is the WHOLE function (lmh_prove_execution_vm: VM run with the parallel batch on the device, trace, proof).
+hog = a command started (as a FOREIGN process: it knows nothing of this library) once the workloads are built and stopped when the
+proofs are done, e.g. "tools/ubench/hog 248 600 1024 1": 248 workgroups that fill a compute unit each, 8 CUs left to the provers — a
+16-workgroup resident GKR tail can then never be resident as a whole and must fail soft (lm_soft_fallbacks), not fail the proof."""
 import os
 import sys
 import threading
@@ -19,6 +22,7 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 WHOLE = len(sys.argv) > 4 and sys.argv[4] == "1"
+HOG = sys.argv[5] if len(sys.argv) > 5 else ""
 ctxs = [lm.Context(0) for _ in range(C)]
 ws = [bench.build_vm_workload(ctxs[c], np.random.default_rng(900 + c), max(2, bench.N_SIGS >> SCALE), 1, False, log_bytecode=19 if SCALE == 0 else None)
       for c in range(C)]
@@ -48,10 +52,19 @@ def worker(c):
         bad.append((c, -1, repr(e)))
 
 
+hog = None
+if HOG:
+    import shlex
+    import subprocess
+    hog = subprocess.Popen(shlex.split(HOG), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    time.sleep(1.0)   # its first kernel is resident
 t0 = time.time()
 th = [threading.Thread(target=worker, args=(c,)) for c in range(C)]
 [t.start() for t in th]
 [t.join() for t in th]
-print(f"{C} provers x {N} proofs in {time.time() - t0:.1f} s: {len(bad)} proofs differ from the prover's first proof {bad[:5]}; "
+if hog is not None:
+    hog.terminate()   # (this exact process)
+    hog.wait()
+print(("under `" + HOG + "`: " if HOG else "") + f"{C} provers x {N} proofs in {time.time() - t0:.1f} s: {len(bad)} proofs differ from the prover's first proof {bad[:5]}; "
       f"GKR layers re-run without resident kernels (lm_soft_fallbacks): {sum(c.soft_fallbacks() for c in ctxs)}")
 sys.exit(1 if bad else 0)

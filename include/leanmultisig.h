@@ -362,6 +362,10 @@ int lm_air_round_launch(lm_ctx* ctx, lm_air* a);
 int lm_air_round_wait(lm_ctx* ctx, lm_air* a, uint32_t* out_raw);
 int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[LM_EF_DIM]);
 int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out);
+/* lm_air_final_evals in two halves, like lm_air_round: _begin enqueues the session's publication on its own stream, _end collects it
+ * (the sessions of a batch: begin all, then end all). */
+int lm_air_final_evals_begin(lm_ctx* ctx, lm_air* a);
+int lm_air_final_evals_end(lm_ctx* ctx, lm_air* a, uint32_t* out);
 
 /* ---- proof-of-work ------------------------------------------------------------------------------------------------
  * FSProver::pow_grinding (crates/backend/fiat-shamir/src/prover.rs:120-177): smallest canonical w such that

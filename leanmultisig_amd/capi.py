@@ -99,6 +99,8 @@ _SIGS = {
     "lm_air_round_wait": (C.c_int, [vp, vp, vp]),
     "lm_air_bind": (C.c_int, [vp, vp, vp]),
     "lm_air_final_evals": (C.c_int, [vp, vp, vp]),
+    "lm_air_final_evals_begin": (C.c_int, [vp, vp]),
+    "lm_air_final_evals_end": (C.c_int, [vp, vp, vp]),
 }
 
 # include/leanmultisig_host.h

@@ -1016,6 +1016,10 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
         return code;
     };
     u32 n_rounds = 0, max_full_degree = 1;
+    std::vector<bool> launched(n_tables, false);
+    static const bool early_first = getenv("LM_AIR_NO_EARLY_FIRST") == nullptr;
+    u32 tallest = 0;
+    for (u32 i = 0; i < n_tables; i++) tallest = std::max(tallest, tables[i].log_rows);
     for (u32 i = 0; i < n_tables; i++) {
         const lm_air_table& t = tables[i];
         int rc = lm_air_new(ctx, t.table, t.d_cols, t.log_rows, t.eq_point, alpha, logup_eq16, bus_beta, &ss[i].h);
@@ -1026,6 +1030,12 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
                 return cleanup(LM_E_INVALID);
             }
             if ((rc = lm_air_set_active_rows(ss[i].h, t.non_padded_n_rows))) return cleanup(rc);
+        }
+        // the tallest table's first round is the first thing the batch waits for: it goes out the moment its session exists, beside the
+        // set-up of the other sessions (virtual columns, eq tables, uploads: ~60 us of stream time in front of it otherwise)
+        if (early_first && t.log_rows == tallest) {
+            if ((rc = lm_air_round_launch(ctx, ss[i].h))) return cleanup(rc);
+            launched[i] = true;
         }
         ss[i].n_vars = t.log_rows;
         ss[i].deg = lm_air_degree(ss[i].h);
@@ -1066,7 +1076,6 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     auto since = [](std::chrono::steady_clock::time_point a) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
-    std::vector<bool> launched(n_tables, false);
     std::vector<u32> launch_order(n_tables);
     for (u32 i = 0; i < n_tables; i++) launch_order[i] = i;
     std::stable_sort(launch_order.begin(), launch_order.end(), [&](u32 a, u32 b) { return tables[a].table > tables[b].table; });
@@ -1074,12 +1083,12 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
     // ones do: the base-field rounds of the tables that join late (Poseidon16: five launches, 0.42 ms on the default workload) are
     // enqueued at once, tallest table first, and run beside the rounds the tallest table does alone; their sums wait in the session's
     // slice of the pinned buffer until the session joins.  (LM_AIR_NO_EARLY_FIRST=1: launch when the session joins, for A/B.)
-    static const bool early_first = getenv("LM_AIR_NO_EARLY_FIRST") == nullptr;
     if (early_first) {
         std::vector<u32> by_height(n_tables);
         for (u32 i = 0; i < n_tables; i++) by_height[i] = i;
         std::stable_sort(by_height.begin(), by_height.end(), [&](u32 a, u32 b) { return ss[a].n_vars > ss[b].n_vars; });
         for (u32 i : by_height) {
+            if (launched[i]) continue;  // (enqueued right behind its lm_air_new, above)
             int rc = lm_air_round_launch(ctx, ss[i].h);
             if (rc) return cleanup(rc);
             launched[i] = true;
@@ -1175,9 +1184,13 @@ int lmh_prove_batched_air_sumcheck(lm_ctx* ctx, lmh_prover* p, const lm_air_tabl
                 n_rounds, total, t_wait, t_launch, total - t_wait - t_launch);
     }
     u32* oe = out_col_evals;
+    for (u32 i = 0; i < n_tables; i++) {  // (the three publications side by side, then collected in transcript order)
+        int rc = lm_air_final_evals_begin(ctx, ss[i].h);
+        if (rc) return cleanup(rc);
+    }
     for (u32 i = 0; i < n_tables; i++) {
         const u32 ne = lm_air_n_evals(ss[i].h);
-        int rc = lm_air_final_evals(ctx, ss[i].h, oe);
+        int rc = lm_air_final_evals_end(ctx, ss[i].h, oe);
         if (rc) return cleanup(rc);
         add_base(p, oe, (u64)ne * 5);  // add_extension_scalars(&col_evals)
         oe += (size_t)ne * 5;

@@ -38,6 +38,7 @@ struct lm_air {
     // one latency-bound workgroup — side by side they cost the longest of the three instead of the sum.
     u64 n_active = 0;                    // rows >= n_active are identical padding rows (lm_air_set_active_rows; default: all rows active)
     std::vector<EF> h_point;             // the eq point (host copy): tail sums of eq weights for the padded pairs
+    std::vector<u32> h_final;            // lm_air_final_evals_begin on a session without a stream of its own: the values, until _end
     int aux = 0;
     hipStream_t stream = nullptr;
     u32* d_sync = nullptr;               // this session's "writers done" counter (two words, zero between kernels)
@@ -856,8 +857,16 @@ extern "C" {
 
 void lm_air_free(lm_ctx* ctx, lm_air* a) {
     if (!a) return;
-    (void)hipStreamSynchronize(ctx->stream);  // the uploads of lm_air_new read from *a
-    if (a->stream) (void)hipStreamSynchronize(a->stream);  // the pool is ordered on ctx->stream: nothing of this session may still run
+    // Join WITHOUT a host synchronisation (two hipStreamSynchronize per session, three sessions: ~0.1 ms of idle GPU between the AIR
+    // sumcheck and the opening): the context's stream waits, on the device, for everything the session enqueued on its own stream.  The
+    // pool is ordered on ctx->stream, so the blocks returned below are handed out again only behind that point; the uploads of
+    // lm_air_new went through the staging ring (lm_stage_upload copies the host image before it returns), so *a may go at once.
+    if (a->stream && a->stream != ctx->stream) {
+        if (hipEventRecord(ctx->fork_event, a->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->fork_event, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(a->stream);
+        }
+    }
     lm_pool_free(ctx, a->d_sync);
     lm_pool_free(ctx, (void*)a->d_base_cols);
     lm_pool_free(ctx, a->d_virt);
@@ -1109,9 +1118,31 @@ int lm_air_bind(lm_ctx* ctx, lm_air* a, const uint32_t challenge[5]) {
 
 // final_column_evals (air_sumcheck.rs:294-296): (n_cols + n_shift) EF values after log_rows bindings
 int lm_air_final_evals(lm_ctx* ctx, lm_air* a, uint32_t* out) {
-    LM_REQUIRE(ctx && a && out && a->round == a->log_rows && a->cur >= 0);
-    // (n_cols + n_shift) * 5 <= 545 words: the aux slices of the result buffer start at 1024, 1024 words each
-    return lm_fetch_words(ctx, a->aux, a->ef[a->cur], (a->n_cols + a->n_shift) * 5, nullptr, 0, a->aux < 0 ? 1024u : 1024u * (1 + a->aux), out);
+    int rc = lm_air_final_evals_begin(ctx, a);
+    return rc ? rc : lm_air_final_evals_end(ctx, a, out);
+}
+// the same in two halves (the sessions of a batch publish side by side, one wait each instead of three round trips)
+int lm_air_final_evals_begin(lm_ctx* ctx, lm_air* a) {
+    LM_REQUIRE(ctx && a && a->round == a->log_rows && a->cur >= 0 && a->pending_seq == 0 && a->h_final.empty());
+    const u32 n = (a->n_cols + a->n_shift) * 5;
+    if (a->aux < 0) {  // LM_AIR_SINGLE_STREAM: the sessions share one flag word and one slice of the result buffer — fetched at once
+        a->h_final.resize(n);
+        return lm_fetch_words(ctx, -1, a->ef[a->cur], n, nullptr, 0, 1024u, a->h_final.data());
+    }
+    // n <= 545 words: the aux slices of the result buffer start at 1024, 1024 words each
+    return lm_fetch_words_begin(ctx, a->aux, a->ef[a->cur], n, nullptr, 0, 1024u * (1 + a->aux), &a->pending_seq);
+}
+int lm_air_final_evals_end(lm_ctx* ctx, lm_air* a, uint32_t* out) {
+    LM_REQUIRE(ctx && a && out && (a->pending_seq != 0 || !a->h_final.empty()));
+    const u32 n = (a->n_cols + a->n_shift) * 5;
+    if (!a->h_final.empty()) {
+        memcpy(out, a->h_final.data(), (size_t)n * 4);
+        a->h_final.clear();
+        return LM_OK;
+    }
+    const u32 seq = a->pending_seq;
+    a->pending_seq = 0;
+    return lm_fetch_words_end(ctx, a->aux, seq, 1024u * (1 + a->aux), n, out);
 }
 
 }  // extern "C"

@@ -326,6 +326,9 @@ int lm_stage_upload(lm_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 // device -> host for a few words without a copy command or a stream synchronise: one tiny kernel stores them (and n1 more
 // from a second source) into the pinned result buffer at `res_offset` and publishes; the host spins on the flag.
 int lm_fetch_words(lm_ctx* ctx, int aux, const kb::u32* d_src0, kb::u32 n0, const kb::u32* d_src1, kb::u32 n1, kb::u32 res_offset, kb::u32* out);
+// the same in two halves: several fetches on different streams are enqueued before the first one is awaited
+int lm_fetch_words_begin(lm_ctx* ctx, int aux, const kb::u32* d_src0, kb::u32 n0, const kb::u32* d_src1, kb::u32 n1, kb::u32 res_offset, kb::u32* seq_out);
+int lm_fetch_words_end(lm_ctx* ctx, int aux, kb::u32 seq, kb::u32 res_offset, kb::u32 n, kb::u32* out);
 // pooled device memory (see lm_ctx::pool_free); lm_pool_alloc returns hipErrorOutOfMemory on failure
 hipError_t lm_pool_alloc(lm_ctx* ctx, void** out, u64 bytes);
 void lm_pool_free(lm_ctx* ctx, void* p);

@@ -654,8 +654,8 @@ __global__ __launch_bounds__(256) void k_publish_words(const u32* __restrict__ s
     __syncthreads();
     if (threadIdx.x == 0) lm_publish_flag_word(flag_word, seq);
 }
-int lm_fetch_words(lm_ctx* ctx, int aux, const u32* d_src0, u32 n0, const u32* d_src1, u32 n1, u32 res_offset, u32* out) {
-    LM_REQUIRE(ctx && d_src0 && out && aux >= -1 && aux < lm_ctx::N_AUX && (u64)res_offset + n0 + n1 <= lm_ctx::RES_WORDS);
+int lm_fetch_words_begin(lm_ctx* ctx, int aux, const u32* d_src0, u32 n0, const u32* d_src1, u32 n1, u32 res_offset, u32* seq_out) {
+    LM_REQUIRE(ctx && d_src0 && seq_out && aux >= -1 && aux < lm_ctx::N_AUX && (u64)res_offset + n0 + n1 <= lm_ctx::RES_WORDS);
     hipStream_t stream = ctx->stream;
     if (aux >= 0) {
         int rc = lm_aux_stream(ctx, aux, &stream);
@@ -665,10 +665,20 @@ int lm_fetch_words(lm_ctx* ctx, int aux, const u32* d_src0, u32 n0, const u32* d
     LM_LAUNCH_ON(ctx, stream, k_publish_words, dim3(1), dim3(256), 0, d_src0, n0, d_src1, n1, ctx->h_res + res_offset,
                  ctx->h_res + lm_ctx::RES_FLAG + 1 + aux, seq);
     LM_HIP(hipGetLastError());
+    *seq_out = seq;
+    return LM_OK;
+}
+int lm_fetch_words_end(lm_ctx* ctx, int aux, u32 seq, u32 res_offset, u32 n, u32* out) {
+    LM_REQUIRE(ctx && out && (u64)res_offset + n <= lm_ctx::RES_WORDS);
     int rc = lm_wait_result_aux(ctx, aux, seq);
     if (rc) return rc;
-    memcpy(out, ctx->h_res + res_offset, (size_t)(n0 + n1) * 4);
+    memcpy(out, ctx->h_res + res_offset, (size_t)n * 4);
     return LM_OK;
+}
+int lm_fetch_words(lm_ctx* ctx, int aux, const u32* d_src0, u32 n0, const u32* d_src1, u32 n1, u32 res_offset, u32* out) {
+    u32 seq;
+    int rc = lm_fetch_words_begin(ctx, aux, d_src0, n0, d_src1, n1, res_offset, &seq);
+    return rc ? rc : lm_fetch_words_end(ctx, aux, seq, res_offset, n0 + n1, out);
 }
 
 int lm_scratch(lm_ctx* ctx, u64 words, u32** out) {

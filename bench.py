@@ -351,7 +351,7 @@ def load_profile(name, sha):
 
 
 VALU_PEAK_T = 256 * 4 * 32 * 2.4e9 / 1e12  # CUs x SIMD-32 units x lanes per cycle x clock = 78.6 T lane-ops/s (MI355X_MICROARCH.md)
-PROFILE_TAG = "r05"  # profiles/<tag>_{pmc,valu}_bench.json, <tag>_isa_mix.json: counter / ISA summaries of the current kernel sources (sha-guarded)
+PROFILE_TAG = "r06"  # profiles/<tag>_{pmc,valu}_bench.json, <tag>_isa_mix.json: counter / ISA summaries of the current kernel sources (sha-guarded)
 
 
 def sponge_ceiling():

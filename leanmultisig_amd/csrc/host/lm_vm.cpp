@@ -2355,6 +2355,14 @@ static int execute_impl(lm_ctx* ctx, const lmh_bytecode* bc, const uint32_t* pub
             }
         }
         bool device_failed = false;
+        // INVARIANT of re-arming (a batch per parallel loop where the reference arms one per run): the ExecutionResult is the SEQUENTIAL
+        // run's — pcs, fps, every defined cell, and the memory LENGTH, which feeds log_memory and the public memory and so the proof.  A
+        // batch resizes the memory to the end of its last call frame (runner.rs:404-407); a sequential run of the same loop ends at the
+        // last cell it SET.  For the one batch the reference runs, the resize is the reference's own behaviour; for every later one the
+        // length is put back (trim_to_defined, only when the batch grew the memory to exactly its frame end — a batch that did not grow it
+        // changed no length).  Nested batches, a batch inside a segment, or an error with more than one batch behind it repeat the run
+        // with the reference's arming, literally (below).  tests/test_vm.py::test_consecutive_parallel_batches_leave_the_sequential_
+        // memory_length and tools/vm_fuzz.py compare length, cells and logs with the sequential oracle VM.
         static const bool rearm_env = !(getenv("LM_VM_REARM") && getenv("LM_VM_REARM")[0] == '0');
         const bool rearm = allow_deferred && rearm_env;  // (the repeated run that reports an error is the reference's, literally)
         u64 skip_arm_pc = ~0ull;

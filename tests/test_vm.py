@@ -436,6 +436,96 @@ def test_parallel_batch(orc, n, threads):
     assert np.array_equal(m1[:k], m2[:k]) and not m1[k:].any() and not m2[k:].any()
 
 
+def two_loops_program(body_hashes=2, with_store=True):
+    """main calls TWO parallel loops in a row (the body of loop_program twice: n, then n2 iterations).  The reference batches the first
+    and runs the second sequentially (one batch per run, runner.rs:120-198,262-298); this runner batches both and must leave the memory
+    exactly as long as the sequential run does (lm_vm.cpp: trim_to_defined)."""
+    q = Program()
+    N, OUT, PERM, LF, N2, OUT2, PERM2, LF2 = 0, 1, 2, 3, 4, 5, 6, 7
+    q.add(K(0), K(0), M(20))
+    q.hint_witness("n", N)
+    q.hint_request_memory(OUT, M(N))
+    q.hint_request_memory(PERM, M(N))
+    q.hint_witness("perm", PERM, indirect=True)
+    q.hint_request_memory(LF, K(Label("@frame")))
+    q.deref(LF, 0, K(Label("after")))
+    q.deref(LF, 1, FP(0))
+    q.deref(LF, 2, K(0))
+    q.deref(LF, 3, M(N))
+    q.deref(LF, 4, M(OUT))
+    q.deref(LF, 5, M(PERM))
+    q.jump(K(1), K(Label("loop")), M(LF))
+    q.label("after")
+    q.hint_witness("n2", N2)
+    q.hint_request_memory(OUT2, M(N2))
+    q.hint_request_memory(PERM2, M(N2))
+    q.hint_witness("perm2", PERM2, indirect=True)
+    q.hint_request_memory(LF2, K(Label("@frame")))
+    q.deref(LF2, 0, K(Label("after2")))
+    q.deref(LF2, 1, FP(0))
+    q.deref(LF2, 2, K(0))
+    q.deref(LF2, 3, M(N2))
+    q.deref(LF2, 4, M(OUT2))
+    q.deref(LF2, 5, M(PERM2))
+    q.jump(K(1), K(Label("loopB")), M(LF2))
+    q.label("after2")
+    q.return_from_main(21)
+    q.starting_frame_memory = 32
+    I, END, OUTP, PERMP = 2, 3, 4, 5
+    d, inv, nz, omnz, t, idx, o, blk = 6, 7, 8, 9, 10, 11, 12, 13
+    h = 21
+    nxt = h + 8 * body_hashes
+    ip1 = nxt + 1
+    frame = ip1 + 1
+    for sfx in ("", "B"):   # two loop functions: a parallel loop is entered once per run (its armed batch belongs to one call frame)
+        q.hint_parallel_batch_start(4, M(END))
+        q.label("loop" + sfx)
+        q.add(M(d), M(END), M(I))
+        q.hint_inverse(M(d), inv)
+        q.mul(M(d), M(inv), M(nz))
+        q.add(M(omnz), M(nz), K(1))
+        q.mul(M(omnz), M(d), K(0))
+        q.jump(M(nz), K(Label("body" + sfx)), FP(0))
+        q.jump(K(1), M(0), M(1))
+        q.label("body" + sfx)
+        q.hint_witness("block", blk)
+        q.poseidon16(FP(blk), FP(blk), FP(h))
+        for k in range(1, body_hashes):
+            q.poseidon16(FP(h + 8 * (k - 1)), FP(blk), FP(h + 8 * k))
+        if with_store:
+            q.add(M(PERMP), M(I), M(t))
+            q.deref(t, 0, M(idx))
+            q.add(M(OUTP), M(idx), M(o))
+            q.deref(o, 0, M(I))
+        q.hint_request_memory(nxt, K(frame))
+        q.deref(nxt, 0, M(0))
+        q.deref(nxt, 1, M(1))
+        q.add(M(I), K(1), M(ip1))
+        q.deref(nxt, 2, M(ip1))
+        for a in (3, 4, 5):
+            q.deref(nxt, a, M(a))
+        q.jump(K(1), K(Label("loop" + sfx)), M(nxt))
+    q.labels["@frame"] = frame
+    return q
+
+
+@pytest.mark.parametrize("n,n2,with_store,threads", [(5, 7, True, 1), (5, 1, True, 2), (1, 1, True, 1), (9, 40, False, 4), (33, 2, False, 3), (4, 64, True, 8)])
+def test_consecutive_parallel_batches_leave_the_sequential_memory_length(orc, n, n2, with_store, threads):
+    """Round-5 advisor item: re-arming later parallel loops departs from the reference runner (which batches the first only); the
+    ExecutionResult must stay the SEQUENTIAL one — pcs, fps, every memory cell and the memory LENGTH (it feeds log_memory and the public
+    memory, hence the proof).  `both` compares all of them with the sequential oracle VM; the cases cover a second batch of one iteration
+    (no growth beyond its call frame), one that is shorter / longer than the first, loops without stores outside their frames, and
+    LM_VM_REARM=0's literal arming in a child run."""
+    rng = np.random.default_rng(100 * n + n2)
+    hints = {"n": [mont([n])], "perm": [mont(rng.permutation(n))], "n2": [mont([n2])], "perm2": [mont(rng.permutation(n2))],
+             "block": [ob.rand_field(rng, 8) for _ in range(n + n2)]}
+    ex, mem, defd, run, bc = both(orc, two_loops_program(with_store=with_store), hints, n_threads=threads)
+    assert ex.memory_len == run.memory.size and ex.n_poseidon_calls == 2 * (n + n2)
+    if with_store:
+        out2 = int(mem[FP0 + 5])
+        assert sorted(mem[out2:out2 + n2]) == list(range(n2))
+
+
 def test_parallel_batch_conflicting_deferred_write_fails(orc):
     n = 6
     rng = np.random.default_rng(0)

@@ -321,7 +321,7 @@ def cpu_baseline(orc, ob, ctx=None, witness="xmss", log_scale=0):
     return dict(value=N_SIGS / est_full, unit="xmss_sigs/s", cores=cores, kind="port", seconds=dt + t_vm, scale=1 << sh,
                 sample=f"oracle VM run + prove_execution (commit, logup GKR, AIR sumcheck, WHIR open; 124-bit parameters) on {what}: "
                        f"tables 2^{lr[0]}/2^{lr[2]}/2^{lr[1]}, memory 2^{w['log_memory']}, "
-                       f"prove {dt:.1f} s on {cores} OpenMP threads"
+                       f"prove {dt:.1f} s on {cores} OpenMP threads; runs AFTER the timed region (rank 0, N = 1): it is most of this run's wall clock and none of `value`"
                        + ("" if sh == 0 else f", scaled x{1 << sh}; the fixed-size PoW searches are over-counted by the scaling"))
 
 
@@ -648,6 +648,9 @@ def main():
                 "achieved": (alu["frac_issue_weighted_serialised"] * VALU_PEAK_T) if alu and alu.get("frac_issue_weighted_serialised") else None,
                 "peak": VALU_PEAK_T, "unit": "T issue-weighted VALU lane-ops/s",
                 "frac": alu.get("frac_issue_weighted_serialised") if alu else None,
+                # the ALGORITHMIC view beside it (utilisation counts instruction overhead as achieved): SURVEY §8(d)'s modular multiplications
+                # of the AIR sumchecks / the family's live time, against the multiply-add issue rate (details under `algorithmic`)
+                "frac_algorithmic": (21e9 * (int(w["tr"].tables[2].non_padded_n_rows) or (1 << ww["log_rows"][2])) / float(1 << 18)) * args.steps / (k_ms * 1e-3) / 1e12 / MAD_T if k_ms > 0 else None,
                 "frac_definition": "issue-weighted VALU lane-instructions of the k_air_round family per proof (SQ_INSTS_VALU x 64 x issue weight) / the family's "
                                    "kernel time with its launches serialised (the rocprofv3 counter pass) / 78.6 T lane-ops/s",
                 "frac_live_summed": alu["frac_issue_weighted"] if alu else None,

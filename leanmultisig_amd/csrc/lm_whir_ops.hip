@@ -30,17 +30,29 @@ struct WGroup {
     u32 fast_end;  // items [item_begin, fast_end) take the base-point path
 };
 
-// grid: (ceil(max_table/256), n_items, 2).  z = 0: T_hi over the first inner-k_lo coordinates, times the scalar;
-// z = 1: T_lo over the last k_lo coordinates.
+// grid: (blk_pre[n_items], 2): item k owns the workgroups [blk_pre[k], blk_pre[k + 1]) — as many as its longer table needs.  (As a
+// (ceil(max_table / 256), n_items) grid, the ~270 items of the opening's statement — two of them with 2^16-entry tables — were 138 k
+// workgroups of which 99 % left at once: 92 us of dispatch.)  y = 0: T_hi over the first inner - k_lo coordinates, times the scalar;
+// y = 1: T_lo over the last k_lo coordinates.
 __global__ __launch_bounds__(256) void k_weight_tables(const WItem* __restrict__ items, const u32* __restrict__ points,
-                                                       const u32* __restrict__ scalars, u32* __restrict__ arena) {
-    const WItem it = items[blockIdx.y];
+                                                       const u32* __restrict__ scalars, u32* __restrict__ arena,
+                                                       const u32* __restrict__ blk_pre, u32 n_items) {
+    u32 a = 0, b = n_items;  // the item whose range holds blockIdx.x (uniform: scalar loads, <= 12 steps)
+    while (b - a > 1) {
+        const u32 m = (a + b) >> 1;
+        if (blk_pre[m] <= blockIdx.x)
+            a = m;
+        else
+            b = m;
+    }
+    const u32 item = a;
+    const WItem it = items[item];
     const u32 k_lo = it.inner_n < W_KLO ? it.inner_n : W_KLO;
     const u32 k_hi = it.inner_n - k_lo;
-    const bool lo = blockIdx.z == 1;
+    const bool lo = blockIdx.y == 1;
     const u32 nb = lo ? k_lo : k_hi;
     const u32 len = 1u << nb;
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const u32 i = (blockIdx.x - blk_pre[item]) * 256 + threadIdx.x;
     if (i >= len) return;
     const u32* pt = points + (it.point_off + (lo ? k_hi : 0)) * 5;
     EF acc;
@@ -48,7 +60,7 @@ __global__ __launch_bounds__(256) void k_weight_tables(const WItem* __restrict__
         acc = ef_one();
     } else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc.v[k] = scalars[blockIdx.y * 5 + k];
+        for (int k = 0; k < 5; k++) acc.v[k] = scalars[item * 5 + k];
     }
     for (u32 j = 0; j < nb; j++) {
         EF p;
@@ -789,8 +801,15 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
               w_rest = (sizeof(WGroup) * rest.size() + 3) / 4;
     const u64 w_sc = (u64)n_items * 5, w_pts = n_point_coords * 5;
     auto al = [](u64 x) { return (x + 15) & ~15ull; };
+    // workgroups of k_weight_tables per item (prefix sums)
+    std::vector<u32> blk_pre(n_items + 1, 0);
+    for (u32 k = 0; k < n_items; k++) {
+        const u32 k_lo = hit[k].inner_n < W_KLO ? hit[k].inner_n : W_KLO;
+        const u32 longer = std::max(1u << (hit[k].inner_n - k_lo), 1u << k_lo);
+        blk_pre[k + 1] = blk_pre[k] + (longer + 255) / 256;
+    }
     const u64 o_items = 0, o_merged = al(o_items + w_items), o_rest = al(o_merged + w_merged), o_sc = al(o_rest + w_rest),
-              o_pts = al(o_sc + w_sc), o_arena = al(o_pts + w_pts);
+              o_pts = al(o_sc + w_sc), o_blk = al(o_pts + w_pts), o_arena = al(o_blk + n_items + 1);
     u32* s;
     int rc = lm_scratch(ctx, o_arena + arena_words, &s);
     if (rc) return rc;
@@ -809,11 +828,13 @@ static int weights_impl(lm_ctx* ctx, uint32_t* d_W, uint32_t n_vars, const lm_we
         if (!rest.empty()) memcpy(im + o_rest, rest.data(), sizeof(WGroup) * rest.size());
         memcpy(im + o_sc, hsc.data(), w_sc * 4);
         if (w_pts) memcpy(im + o_pts, points, w_pts * 4);
+        memcpy(im + o_blk, blk_pre.data(), (n_items + 1) * 4ull);
         LM_HIP(hipMemcpyAsync(s, im, o_arena * 4, hipMemcpyHostToDevice, ctx->stream));
         if (!pageable.empty()) LM_HIP(hipStreamSynchronize(ctx->stream));
     }
-    LM_LAUNCH(ctx, k_weight_tables, dim3((max_table + 255) / 256, n_items, 2), dim3(256), 0, (const WItem*)(s + o_items),
-              s + o_pts, s + o_sc, s + o_arena);
+    (void)max_table;
+    LM_LAUNCH(ctx, k_weight_tables, dim3(blk_pre[n_items], 2), dim3(256), 0, (const WItem*)(s + o_items), s + o_pts, s + o_sc, s + o_arena,
+              (const u32*)(s + o_blk), n_items);
     const bool dbg = getenv("LM_DEBUG_WEIGHTS") != nullptr;
     if (init) {
         if (dbg) fprintf(stderr, "# weights init launch: whole-domain items=%u, top-level regions=%zu\n",

@@ -95,6 +95,79 @@ def test_tampering_matches_the_oracle_verifier(orc, small):
     assert rejected >= 30  # (redundant siblings are pruned away before the proof travels: corrupting one changes nothing)
 
 
+def _mutations(rng, raw, n):
+    """n mutated copies of a raw proof blob: word edits of several kinds, swaps, block moves, truncations and extensions"""
+    P = 0x7F000001
+    T = int(raw[0])
+    for k in range(n):
+        bad = raw.copy()
+        kind = k % 8
+        pos = int(rng.integers(1, raw.size))
+        if kind == 0:
+            bad[pos] = (int(bad[pos]) + 1 + int(rng.integers(0, P - 2))) % P
+        elif kind == 1:
+            bad[pos] = 0 if bad[pos] else 1
+        elif kind == 2:
+            bad[pos] = P - 1 if int(bad[pos]) != P - 1 else P - 2
+        elif kind == 3:
+            q = int(rng.integers(1, raw.size))
+            if bad[pos] == bad[q]:
+                bad[pos] = (int(bad[pos]) + 1) % P
+            else:
+                bad[pos], bad[q] = bad[q], bad[pos]
+        elif kind == 4:  # a block of the transcript moved by one word
+            a = int(rng.integers(1, max(2, T - 8)))
+            bad[a:a + 8] = np.roll(bad[a:a + 8], 1)
+            if np.array_equal(bad, raw):
+                bad[a] = (int(bad[a]) + 1) % P
+        elif kind == 5:  # truncated
+            bad = bad[:raw.size - int(rng.integers(1, 16))]
+        elif kind == 6:  # extended with field words
+            bad = np.concatenate([bad, ob.rand_field(rng, int(rng.integers(1, 9)))]).astype(np.uint32)
+        else:            # the transcript length word itself
+            bad[0] = max(1, T + int(rng.integers(-3, 4)) or T + 1)
+        yield k, bad
+
+
+@pytest.mark.parametrize("which", ["small", "mixed"])
+def test_verifier_differential_fuzz_against_the_oracle_verifier(orc, small, which):
+    """lmh_verify_execution is load-bearing beyond accepting proofs (it rebuilds the raw transcripts and opening claims the recursion
+    program is fed), and only tests/test_verifier.py::test_tampering... compared it with anything: 50 single-word edits.  Here 2 x 240
+    mutations of eight kinds — field edits to small / large / swapped values, a rotated transcript block, truncation, extension, a changed
+    length word — on two instances (two rates, two programs): whatever parses must get the SAME verdict from the library's verifier and
+    from the oracle's (on the proof as it travels: pruned and restored), and no mutation may be accepted."""
+    if which == "small":
+        w, raw, ob_b, lm_b = small
+    else:
+        w = synth_witness.build_mixed(orc, np.random.default_rng(35))
+        w["log_inv_rate"] = 2
+        ob_b = ob.whir_builder(log_inv_rate=2, pow_bits=5, security=50)
+        lm_b = lm.WhirBuilder.default(2, security_level=50, pow_bits=5)
+        raw = ob.prove_execution(orc, w, synth_witness.header(w), ob_b)
+    sizes = _batch_sizes(w, lm_b)
+    ok, err = lm.verify_execution(w, lm.Prover.from_raw(raw, sizes), lm_b)
+    assert ok, err
+    rng = np.random.default_rng(36)
+    compared = unparsable = 0
+    for k, bad in _mutations(rng, raw, 240):
+        try:
+            pr = lm.Prover.from_raw(bad, sizes)
+        except lm.LmError:
+            unparsable += 1
+            continue
+        ok_lm, _ = lm.verify_execution(w, pr, lm_b)
+        try:
+            travelled = ob.restore_proof(orc, ob.prune_proof(orc, bad, sizes))
+            ok_orc, _ = ob.verify_execution(orc, w, travelled, ob_b)
+            same_as_original = travelled.size == raw.size and np.array_equal(travelled, raw)
+        except Exception:  # noqa: BLE001 — the oracle binding raises on unparsable blobs
+            ok_orc, same_as_original = False, False
+        assert ok_lm == ok_orc, (k, k % 8)
+        assert not ok_lm or same_as_original, (k, k % 8)   # accepted only when the edit fell on a sibling that pruning drops
+        compared += 1
+    assert compared >= 120, (compared, unparsable)
+
+
 def test_external_pin_fixture_of_real_signatures_is_accepted_by_the_library_verifier():
     """tests/golden/external_pin_xmss (tools/write_proof.py --xmss: a device proof of the aggregation program on 40 real XMSS signatures,
     VM run with the parallel batch on the device, default_whir_config) — what `make pin` feeds to the REFERENCE's verify_execution —

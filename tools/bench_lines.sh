@@ -2,7 +2,7 @@
 # The plain bench lines of a round (BASELINE configs and side measurements) -> gpurun_out/$1/.  Run AFTER the counter summaries
 # of the same sources have been published to profiles/ (tools/publish_profiles.sh): bench.py then reports traffic / alu from them.
 set -u
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

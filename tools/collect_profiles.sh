@@ -7,7 +7,7 @@
 #   pmc_fetch/, pmc_write/, pmc_valu/   FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate)
 #   *.json             plain bench lines for the BASELINE configs and side measurements
 set -u
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

@@ -101,6 +101,9 @@ unsafe extern "C" {
     pub fn lm_ctx_create(device: c_int, out: *mut *mut lm_ctx) -> c_int;
     pub fn lm_ctx_destroy(ctx: *mut lm_ctx);
     pub fn lm_last_error() -> *const c_char;
+    /// GKR layers this context re-ran with one launch per exchange because a resident kernel never got its wave slots on a shared
+    /// device: a scheduling event for NodeStats, never a `ProverError` (the proof is unchanged)
+    pub fn lm_soft_fallbacks(ctx: *const lm_ctx) -> u32;
     pub fn lm_malloc(ctx: *mut lm_ctx, n_words: u64, d_out: *mut *mut u32) -> c_int;
     pub fn lm_free(ctx: *mut lm_ctx, d_ptr: *mut u32) -> c_int;
     pub fn lm_upload(ctx: *mut lm_ctx, d_dst: *mut u32, src: *const u32, n_words: u64) -> c_int;
